@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REFERENCE
+implementation (read-only at /root/reference) on CPU.
+
+This script only runs in the build container (the reference never travels to
+the GPU box).  It does not copy any reference source: it imports the reference
+modules through the shims listed in SURVEY.md section 8c and records
+inputs/outputs as .npz data.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Shims (each forced by a specific reference line):
+  * fvcore.common.config.CfgNode stub      <- model/DDA_model/utils/experiment_manager.py:5
+  * os.path.isdir true for /scratch*,/cluster*  <- utils/constants.py:22-26
+  * chdir + sys.path                        <- utils/constants.py:172 (relative checkpoint dir)
+  * load_checkpoint(device="cpu")           <- model/popcorn.py:57,96 hard-code "cuda"
+  * nn.Module.cuda = identity               <- model/popcorn.py:97
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    fv = types.ModuleType("fvcore")
+    fvc = types.ModuleType("fvcore.common")
+    fvcc = types.ModuleType("fvcore.common.config")
+
+    class CfgNode(dict):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    fvcc.CfgNode = CfgNode
+    sys.modules["fvcore"] = fv
+    sys.modules["fvcore.common"] = fvc
+    sys.modules["fvcore.common.config"] = fvcc
+
+    real_isdir = os.path.isdir
+    os.path.isdir = lambda p: True if str(p).startswith(("/scratch", "/cluster")) else real_isdir(p)
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    import utils.constants  # noqa: F401
+    os.path.isdir = real_isdir
+
+    torch.nn.Module.cuda = lambda self, device=None: self
+    import model.DDA_model.utils.networks as networks
+    import model.popcorn as popcorn
+    real_load = networks.load_checkpoint
+    popcorn.load_checkpoint = lambda epoch, cfg, device: real_load(epoch, cfg, "cpu")
+    import model.get_model as get_model
+    import utils.losses as losses
+    import utils.metrics as metrics
+    return popcorn, networks, get_model, losses, metrics
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()   # copy: later in-place updates (clip, optimiser) must not alias
+
+
+def make_inputs(seed, B, H, W, region="disc"):
+    """Seeded synthetic, already-normalised model input + census-shaped mask."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 6, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    admin = torch.zeros(B, H, W)
+    census = torch.zeros(B, dtype=torch.int64)
+    for b in range(B):
+        cid = 7 + 3 * b
+        census[b] = cid
+        if region == "disc":
+            r = 0.30 * min(H, W) + 3 * b
+            disc = ((yy - H / 2 + 2 * b) ** 2 + (xx - W / 2 - b) ** 2) < r * r
+            admin[b] = torch.where(disc, torch.tensor(float(cid)), torch.tensor(float(cid + 1)))
+            admin[b, :3, :] = -1.0   # collate-style padding id
+        else:
+            admin[b] = float(cid)
+    y = torch.rand(B, generator=g) * 500.0
+    return x, admin, census, y
+
+
+def build_model(popcorn, seed=1600, biasinit=0.9407, pretrained=True):
+    torch.manual_seed(seed)
+    m = popcorn.POPCORN(input_channels=6, feature_extractor="DDA", occupancymodel=True,
+                        pretrained=pretrained, biasinit=biasinit, sentinelbuildings=True)
+    return m
+
+
+def g1_weights(popcorn):
+    ck = torch.load(os.path.join(REF, "model/DDA_model/checkpoints/networks/"
+                                 "fusionda_newAug8_16_checkpoint30_lossweight0.5.pt"),
+                    map_location="cpu", weights_only=False)
+    net = {k: np_(v) for k, v in ck["network"].items()}
+    np.savez_compressed(os.path.join(OUT, "g1_dda_checkpoint.npz"), step=np.int64(ck["step"]), **net)
+    m = build_model(popcorn)
+    head = {k: np_(v) for k, v in m.state_dict().items() if k.startswith("head.")}
+    keys = list(m.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    pnames = [n for n, _ in m.named_parameters()]
+    np.savez_compressed(os.path.join(OUT, "g1_head_seed1600.npz"), num_params=np.int64(m.num_params), **head)
+    with open(os.path.join(OUT, "g1_state_dict_keys.txt"), "w") as f:
+        for k in keys:
+            f.write(f"{k}\t{','.join(map(str, shapes[k]))}\t{'P' if k in pnames else 'B'}\n")
+    return m
+
+
+def g2_forward(popcorn, m):
+    out = {}
+    m.eval()
+    cases = [("b2_100", 11, 2, 100, 100), ("b1_131x77", 12, 1, 131, 77), ("b2_64", 13, 2, 64, 64)]
+    for name, seed, B, H, W in cases:
+        x, admin, census, y = make_inputs(seed, B, H, W)
+        out[f"{name}/input"] = np_(x)
+        out[f"{name}/admin_mask"] = np_(admin)
+        out[f"{name}/census_idx"] = np_(census)
+        for padding in (True, False):
+            for sparse in (True, False):
+                feats = {}
+                h = m.unetmodel.register_forward_hook(lambda mod, i, o: feats.__setitem__("f", o))
+                torch.manual_seed(1600)
+                inp = {"input": x.clone(), "admin_mask": admin.clone(), "census_idx": census.clone()}
+                with torch.no_grad():
+                    o = m(inp, train=False, padding=padding, sparse=sparse)
+                h.remove()
+                tag = f"{name}/pad{int(padding)}_sp{int(sparse)}"
+                out[f"{tag}/popcount"] = np_(o["popcount"])
+                out[f"{tag}/popdensemap"] = np_(o["popdensemap"])
+                out[f"{tag}/scale"] = np_(o["scale"])
+                out[f"{tag}/feat_shape"] = np.array(feats["f"].shape)
+                # keep the fixture small: a strided sample of the (padded) feature map + its checksum
+                out[f"{tag}/feat_sample"] = np_(feats["f"][:, :, ::7, ::5])
+                out[f"{tag}/feat_sum64"] = np.float64(feats["f"].double().sum().item())
+        out[f"{name}/building_counts"] = np_(inp["building_counts"])
+        # eval-style call without admin_mask (run_eval.py:109)
+        inp = {"input": x.clone()}
+        with torch.no_grad():
+            o = m(inp, padding=False)
+        out[f"{name}/noadmin/popcount"] = np_(o["popcount"])
+        out[f"{name}/noadmin/popdensemap"] = np_(o["popdensemap"])
+    np.savez_compressed(os.path.join(OUT, "g2_forward.npz"), **out)
+
+
+def g3_layers(popcorn, m):
+    """Per-layer activations of both streams of unetmodel on one small tile."""
+    out = {}
+    m.eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 6, 36, 28, generator=g)   # un-padded call straight into the DualStreamUNet
+    acts = {}
+    hooks = []
+    for name, mod in m.unetmodel.named_modules():
+        if isinstance(mod, (torch.nn.ReLU, torch.nn.MaxPool2d, torch.nn.ConvTranspose2d)) or name.endswith("out_conv"):
+            hooks.append(mod.register_forward_hook(lambda mod, i, o, name=name: acts.__setitem__(name, o.detach().clone())))
+    with torch.no_grad():
+        res = m.unetmodel(x, alpha=0, return_features=False)
+        feats = m.unetmodel(x, alpha=0, return_features=True)
+    for h in hooks:
+        h.remove()
+    out["input"] = np_(x)
+    out["features"] = np_(feats)
+    out["logits_sar"], out["logits_optical"], out["logits_fusion"] = np_(res[0]), np_(res[1]), np_(res[2])
+    for k, v in acts.items():
+        out["act/" + k] = np_(v)
+    np.savez_compressed(os.path.join(OUT, "g3_layers.npz"), **out)
+
+
+def g4_mask(popcorn, m):
+    out = {}
+    for name, seed, B, H, W in [("b2_100", 11, 2, 100, 100), ("b1_131x77", 12, 1, 131, 77), ("b2_40x52", 14, 2, 40, 52)]:
+        x, admin, census, y = make_inputs(seed, B, H, W)
+        g = torch.Generator().manual_seed(seed + 100)
+        bc = torch.rand(B, 1, H, W, generator=g)
+        bc[bc < 0.3] = 0.0   # exercise the (building > 0) term, unlike the sigmoid score
+        torch.manual_seed(1600)
+        mask, _ = m.get_sparsity_mask({"building_counts": bc, "admin_mask": admin, "census_idx": census})
+        torch.manual_seed(1600)
+        xi = torch.ones(H).multinomial(num_samples=min(60, H), replacement=False).sort()[0]
+        yi = torch.ones(W).multinomial(num_samples=min(60, W), replacement=False).sort()[0]
+        out[f"{name}/building_counts"] = np_(bc)
+        out[f"{name}/admin_mask"] = np_(admin)
+        out[f"{name}/census_idx"] = np_(census)
+        out[f"{name}/mask"] = np_(mask)
+        out[f"{name}/xindices"] = np_(xi)
+        out[f"{name}/yindices"] = np_(yi)
+    # empty-selection fallback (popcorn.py:374-375): region id absent -> mask stays the (empty) region
+    np.savez_compressed(os.path.join(OUT, "g4_mask.npz"), **out)
+
+
+def g5_train(popcorn, losses):
+    """Three optimisation steps of the reference recipe (run_train.py:82-90,201-238)."""
+    from torch.nn.utils import clip_grad_norm_
+    out = {}
+    m = build_model(popcorn, seed=1600, biasinit=0.9407, pretrained=True)
+    m.train()
+    head_name = ['head.6.weight', 'head.6.bias']
+    named = list(m.named_parameters())
+    p_decay = [p for n, p in named if n not in head_name and 'unetmodel' not in n]
+    p_unet = [p for n, p in named if n not in head_name and 'unetmodel' in n]
+    p_nodecay = [p for n, p in named if n in head_name and 'unetmodel' not in n]
+    opt = torch.optim.Adam([{'params': p_decay, 'weight_decay': 1e-5},
+                            {'params': p_unet, 'weight_decay': 1e-5},
+                            {'params': p_nodecay, 'weight_decay': 0.0}], lr=1e-4)
+    x, admin, census, y = make_inputs(31, 3, 100, 100)
+    out["input"], out["admin_mask"], out["census_idx"], out["y"] = np_(x), np_(admin), np_(census), np_(y)
+    loss_traj = []
+    for step in range(3):
+        torch.manual_seed(1700 + step)
+        sample = {"input": x.clone(), "admin_mask": admin.clone(), "census_idx": census.clone(), "y": y.clone()}
+        o = m(sample, train=True, padding=False, sparse=True)
+        loss, ld = losses.get_loss(o, sample, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0],
+                                   scale_regularization=0.01, tag="weak")
+        optim_loss = loss * 100.0
+        opt.zero_grad()
+        optim_loss.backward()
+        if step == 0:
+            out["step0/popcount"] = np_(o["popcount"])
+            out["step0/scale_sum64"] = np.float64(o["scale"].double().sum().item())
+            out["step0/nsel"] = np.int64(o["scale"].numel())
+            out["step0/loss"] = np.float32(loss.item())
+            gnames = []
+            for n, p in named:
+                if p.grad is not None:
+                    out["step0/grad/" + n] = np_(p.grad)
+                    gnames.append(n)
+            out["step0/grad_names"] = np.array(gnames)
+            for k, v in ld.items():
+                out["step0/lossdict/" + k.replace("/", "|")] = np.float64(v)
+        total_norm = clip_grad_norm_(m.parameters(), 0.01)
+        if step == 0:
+            out["step0/total_norm"] = np.float32(total_norm.item())
+        opt.step()
+        if step == 0:
+            for n, p in named:
+                if p.grad is not None:
+                    out["step0/param_after/" + n] = np_(p)
+        loss_traj.append(loss.item())
+    out["loss_traj"] = np.array(loss_traj, dtype=np.float32)
+    for n, p in named:
+        if p.grad is not None and n.startswith("head."):
+            out["step2/param_after/" + n] = np_(p)
+    np.savez_compressed(os.path.join(OUT, "g5_train.npz"), **out)
+
+
+def g6_loss_metrics(losses, metrics):
+    out = {}
+    g = torch.Generator().manual_seed(61)
+    pred = torch.rand(9, generator=g) * 300
+    y = torch.rand(9, generator=g) * 300
+    y[2] = 0.05   # below the mape threshold
+    scale = torch.rand(500, generator=g)
+    out["pred"], out["y"], out["scale"] = np_(pred), np_(y), np_(scale)
+    for lname in ["l1_loss", "log_l1_loss", "mse_loss", "log_mse_loss"]:
+        o = {"popcount": pred.clone(), "popdensemap": torch.zeros(1, 2, 2), "scale": scale.clone()}
+        loss, ld = losses.get_loss(o, {"y": y}, scale=scale, loss=[lname], lam=[1.0], scale_regularization=0.01, tag="weak")
+        out[f"get_loss/{lname}/loss"] = np.float32(loss.item())
+        for k, v in ld.items():
+            out[f"get_loss/{lname}/" + k.replace("/", "|")] = np.float64(v)
+    tm = metrics.get_test_metrics(pred, y, tag="coarse")
+    for k, v in tm.items():
+        out["test_metrics/" + k.replace("/", "|")] = np.float64(v.item())
+    np.savez_compressed(os.path.join(OUT, "g6_loss_metrics.npz"), **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    popcorn, networks, get_model, losses, metrics = import_reference()
+    m = g1_weights(popcorn)
+    g2_forward(popcorn, m)
+    g3_layers(popcorn, m)
+    g4_mask(popcorn, m)
+    g5_train(popcorn, losses)
+    g6_loss_metrics(losses, metrics)
+    args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
+                          pretrained=True, biasinit=0.9407, sentinelbuildings=True)
+    kw = get_model.get_model_kwargs(args, "POPCORN")
+    with open(os.path.join(OUT, "g1_model_kwargs.txt"), "w") as f:
+        f.write(repr(sorted(kw.items())) + "\n")
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * popcorn_hip.h -- C ABI of libpopcorn_hip.so: the MI355X (gfx950) kernels behind POPCORN's dense
+ * per-pixel CNN path.
+ *
+ * The reference (prs-eth/Popcorn) has no FFI: its boundary is the Python nn.Module API
+ * (model/get_model.py:19-61, model/popcorn.py:20-22,100-101) and all arithmetic is stock PyTorch ops.
+ * This header is the FFI a maintainer would bind *inside* that nn.Module: every
+ * entry point below cites the reference op it replaces.  Conventions:
+ *   - plain C, device pointers + sizes only, no torch types;
+ *   - every function enqueues on the hipStream_t passed as `void* stream` (0 = the null stream),
+ *     never synchronises, and returns 0 or a hipError_t / negative PC_E* code;
+ *   - tensors are fp32, NCHW, described by pc_src / pc_dst (strides in elements);
+ *   - pointers are borrowed for the duration of the enqueued work only.
+ */
+#ifndef POPCORN_HIP_H
+#define POPCORN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_ABI_VERSION 1
+
+/* error codes (negative; positive values are hipError_t) */
+#define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
+#define PC_ENOGPU (-2)     /* no HIP device */
+
+/* ---- tensor descriptors ------------------------------------------------------------------------- */
+
+/* how a conv loader maps conv-domain coordinates onto a source tensor */
+enum pc_src_mode {
+    PC_SRC_DIRECT  = 0,  /* src(y-oy, x-ox); zero outside the source extent (Up's zero F.pad,
+                            model/DDA_model/utils/networks.py:309-312) */
+    PC_SRC_POOL2   = 1,  /* max over the 2x2 window of a source at twice the resolution: nn.MaxPool2d(2) fused into
+                            the consumer (networks.py:289) */
+    PC_SRC_REFLECT = 2   /* reflect padding (oy rows on top, ox cols on the left) + channel gather through `chmap`:
+                            add_padding + channel reorder fused into the first conv (model/popcorn.py:231-258,130-134) */
+};
+
+typedef struct pc_src {
+    const float* ptr;    /* element (b=0, c=0, y=0, x=0) */
+    int32_t C;           /* channels taken from this source (0 = unused) */
+    int32_t H, W;        /* spatial extent of the source tensor */
+    int64_t bstride;     /* elements between consecutive batch items */
+    int64_t cstride;     /* elements between consecutive channels */
+    int32_t rstride;     /* elements between consecutive rows */
+    int32_t mode;        /* enum pc_src_mode */
+    int32_t oy, ox;      /* DIRECT: placement of the source origin in the conv domain; REFLECT: top/left pad */
+    int32_t chmap[4];    /* REFLECT only: conv channel c reads source channel chmap[c] */
+} pc_src;
+
+typedef struct pc_dst {
+    float* ptr;
+    int64_t bstride, cstride;
+    int32_t rstride;
+    int32_t _pad;
+} pc_dst;
+
+/* folded BatchNorm2d(eval) + conv bias of one layer: y = relu(conv * scale + shift) with
+   scale = gamma / sqrt(var + eps), shift = (bias - mean) * scale + beta   (networks.py:259-266) */
+typedef struct pc_bn {
+    const float* conv_bias;   /* [C] (may be NULL = 0) */
+    const float* gamma;       /* [C] (NULL = no BN: scale 1, shift = conv_bias) */
+    const float* beta;
+    const float* mean;
+    const float* var;
+    float eps;
+    int32_t _pad;
+} pc_bn;
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int pc_abi_version(void);
+/* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
+int pc_device_count(void);
+const char* pc_error_string(int code);
+
+/* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
+ * Input channels = a.C + b.C (torch.cat([skip, up]) fused, networks.py:318); conv domain H x W, batch B.
+ * w: [Cout][Cin][3][3].  Supported (Cin,Cout): (2,8) (4,8) (8,8) (16,8) (32,8) (8,16) (16,16). */
+int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, int relu,
+                           const pc_dst* out, int B, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- conv3x3 data gradient (autograd of the op above w.r.t. its input).
+ * g: gradient w.r.t. the conv output (already multiplied by relu-mask * bn-scale), Cg = forward Cout channels.
+ * Produces the gradient for forward input channels [c0, c0+Cn) of a forward weight w: [Cg][Cin_total][3][3].
+ * Epilogue (what the consumer of that gradient needs):
+ *   act == NULL                : out (=|+=) dgrad
+ *   act != NULL, pool == 0     : out (=|+=) dgrad * (act > 0) * act_bn.scale      (ReLU + frozen-BN backward of the
+ *                                producing layer, whose post-ReLU output is `act`)
+ *   act != NULL, pool == 1     : MaxPool2d(2) backward fused: dgrad lives at the pooled resolution; it is routed to the
+ *                                first arg-max of each 2x2 window of `act` (full resolution), times (act>0)*scale, and
+ *                                ACCUMULATED into out (full resolution).
+ */
+int pc_conv3x3_dgrad(const pc_src* g, const float* w, int Cin_total, int c0, int Cn,
+                     const pc_src* act, const pc_bn* act_bn, int pool, int accumulate,
+                     const pc_dst* out, int B, int H, int W, int Cg, void* stream);
+
+/* ---- conv3x3 weight/bias gradient.  x = forward input (a,b sources as in fwd), g as in dgrad.
+ * dw: [Cout][Cin][3][3], db: [Cout]; (=|+=).  ws: workspace of pc_conv3x3_wgrad_ws_bytes(). */
+int64_t pc_conv3x3_wgrad_ws_bytes(int Cin, int Cout);
+int pc_conv3x3_wgrad(const pc_src* a, const pc_src* b, const pc_src* g, float* dw, float* db, int accumulate,
+                     void* ws, int B, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- ConvTranspose2d(C, C, 2, stride 2), networks.py:302,306.  w: [Cin][Cout][2][2].  x: B x C x H x W -> out B x C x 2H x 2W */
+int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bias, const pc_dst* out, int B, int H, int W, int C,
+                    void* stream);
+/* data gradient, fused with the ReLU+BN backward of the layer that produced x (act = x's post-ReLU values) */
+int pc_convt2x2_dgrad(const pc_src* g, const float* w, const pc_src* act, const pc_bn* act_bn,
+                      const pc_dst* out, int B, int H, int W, int C, void* stream);
+int64_t pc_convt2x2_wgrad_ws_bytes(int C);
+int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, float* db, int accumulate, void* ws,
+                      int B, int H, int W, int C, void* stream);
+
+/* ---- fusion_out_conv (1x1, 16->1) + sigmoid + crop: create_building_score's tail, popcorn.py:301,317-320;
+ * networks.py:232,323-330.  feat: B x 16 x Hp x Wp, out: B x 1 x H x W taken at offset (py,px). */
+int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const float* bias, const pc_dst* out,
+                            int B, int H, int W, int py, int px, void* stream);
+
+/* ---- sparsity mask, popcorn.py:361-377 (non-sparse_unet branch).
+ * mask[b,y,x] = region & ((building>0) | (rowsel[y] & colsel[x])), region = (admin_mask == census_idx[b]);
+ * rowsel/colsel: uint8 [H]/[W] (the sorted multinomial draws, made on the host CPU generator like the reference).
+ * If the whole batch selects nothing the mask falls back to the region (popcorn.py:374-375).
+ * counts: int32[2] device scratch {nsel, nregion}. */
+int pc_sparsity_mask(const float* building, const float* admin_mask, const int64_t* census_idx,
+                     const uint8_t* rowsel, const uint8_t* colsel, int occupancymodel,
+                     uint8_t* mask, int32_t* counts, int B, int H, int W, void* stream);
+
+/* ---- the sparse head, popcorn.py:80-85,161-190,195-228:
+ * per selected pixel 16 -> 64 -> 64 -> 64 -> (channel 0 of 2) 1x1-conv MLP with ReLUs, scale = relu(out),
+ * popdensemap = scale * building, popcount[b] = sum over region pixels.  mask == NULL: dense head.
+ * admin_mask == NULL: popcount = plain sum (popcorn.py:189-190).
+ * feat: B x 16 x Hp x Wp read at crop offset (py,px) (revert_padding fused, popcorn.py:155).
+ * hw: the 8 head tensors {w0,b0,w2,b2,w4,b4,w6,b6}.  ws: pc_head_ws_bytes(). */
+int64_t pc_head_ws_bytes(int B, int H, int W);
+int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
+                const float* building, const float* admin_mask, const int64_t* census_idx,
+                float* scale_map, float* popdensemap, float* popcount, void* ws,
+                int B, int H, int W, void* stream);
+
+/* backward of pc_head_fwd.  Upstream gradients: g_popcount[B] and a constant g_scale added on every selected pixel
+ * with scale > 0 (the scale-regularisation term, utils/losses.py:74-76).  Produces the 8 head gradients
+ * (dhw, (=|+=)) and the gradient w.r.t. the padded feature map (zero outside the crop / unselected pixels). */
+int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
+                const float* building, const float* admin_mask, const int64_t* census_idx,
+                const float* g_popcount, const float* g_scale_dev, float* const* dhw, int accumulate,
+                const pc_dst* g_feat, int Hp, int Wp, void* ws, int B, int H, int W, void* stream);
+
+/* ---- compaction of scale[mask] in row-major (b,y,x) order (the boolean-index gather of popcorn.py:173).
+ * out must hold B*H*W floats; *n_out (device int32) receives Nsel. */
+int pc_compact_masked(const float* src, const uint8_t* mask, float* out, int32_t* n_out, void* ws, int64_t n,
+                      void* stream);
+int64_t pc_compact_ws_bytes(int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPCORN_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libpopcorn_hip.so (include/popcorn_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C popcorn_amd/csrc``.  There is NO CPU
+fallback: if the library is missing or a tensor is not on a HIP device, the ops raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpopcorn_hip.so")
+
+PC_SRC_DIRECT, PC_SRC_POOL2, PC_SRC_REFLECT = 0, 1, 2
+
+
+class PcSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32), ("mode", C.c_int32),
+                ("oy", C.c_int32), ("ox", C.c_int32), ("chmap", C.c_int32 * 4)]
+
+
+class PcDst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class PcBn(C.Structure):
+    _fields_ = [("conv_bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
+                ("var", C.c_void_p), ("eps", C.c_float), ("_pad", C.c_int32)]
+
+
+class PopcornHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises PopcornHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PopcornHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C popcorn_amd/csrc`).  popcorn_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pc_error_string.restype = C.c_char_p
+        for name in ("pc_conv3x3_wgrad_ws_bytes", "pc_convt2x2_wgrad_ws_bytes", "pc_head_ws_bytes",
+                     "pc_compact_ws_bytes", "pc_unet_ws_bytes"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_int64
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().pc_error_string(int(code)).decode()
+        raise PopcornHipError(f"{what}: libpopcorn_hip error {code}: {msg}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PopcornHipError("popcorn_amd ops run on a HIP device only (tensor is on %s); there is no CPU path"
+                                  % t.device)
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2, 3)) -> PcSrc:
+    """Descriptor of a (B, C, H, W) fp32 tensor (any batch/channel/row stride, unit x stride)."""
+    assert t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+    s = PcSrc()
+    s.ptr = t.data_ptr()
+    s.C = t.shape[1] if C_ is None else C_
+    s.H, s.W = t.shape[2], t.shape[3]
+    s.bstride, s.cstride, s.rstride = t.stride(0), t.stride(1), t.stride(2)
+    s.mode, s.oy, s.ox = mode, oy, ox
+    s.chmap[:] = list(chmap)
+    return s
+
+
+def dst(t: torch.Tensor) -> PcDst:
+    assert t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+    d = PcDst()
+    d.ptr = t.data_ptr()
+    d.bstride, d.cstride, d.rstride = t.stride(0), t.stride(1), t.stride(2)
+    return d
+
+
+def bn(conv_bias=None, gamma=None, beta=None, mean=None, var=None, eps=1e-5) -> PcBn:
+    b = PcBn()
+    b.conv_bias = 0 if conv_bias is None else conv_bias.data_ptr()
+    b.gamma = 0 if gamma is None else gamma.data_ptr()
+    b.beta = 0 if beta is None else beta.data_ptr()
+    b.mean = 0 if mean is None else mean.data_ptr()
+    b.var = 0 if var is None else var.data_ptr()
+    b.eps = eps
+    return b

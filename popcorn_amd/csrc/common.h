@@ -1,0 +1,60 @@
+// Shared device helpers for libpopcorn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "popcorn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PC_CHECK_LAUNCH()                         \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+// XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give every XCD a contiguous slice of the tile
+// space so that neighbouring tiles (which share halo rows and the same weights) hit the same private L2.
+// Bijective for any nwg (cdna_hip_programming.md T1).
+__device__ __forceinline__ int pc_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Per-channel folded BN: scale = gamma / sqrt(var + eps); shift = (bias - mean) * scale + beta.
+__device__ __forceinline__ void pc_bn_fold(const pc_bn& bn, int c, float& scale, float& shift) {
+    const float cb = bn.conv_bias ? bn.conv_bias[c] : 0.f;
+    if (bn.gamma) {
+        scale = bn.gamma[c] * (1.0f / sqrtf(bn.var[c] + bn.eps));
+        shift = (cb - bn.mean[c]) * scale + bn.beta[c];
+    } else {
+        scale = 1.f;
+        shift = cb;
+    }
+}
+
+__device__ __forceinline__ int pc_reflect(int i, int n) {
+    // F.pad(mode='reflect'): -1 -> 1, n -> n-2
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// Fetch conv-domain element (b, c, y, x) of a source; y/x may lie outside the conv domain [0,H)x[0,W) -> 0
+// (the conv's own zero padding).
+__device__ __forceinline__ float pc_fetch(const pc_src& s, int b, int c, int y, int x, int H, int W) {
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return 0.f;
+    if (s.mode == PC_SRC_DIRECT) {
+        const int ys = y - s.oy, xs = x - s.ox;
+        if ((unsigned)ys >= (unsigned)s.H || (unsigned)xs >= (unsigned)s.W) return 0.f;
+        return s.ptr[b * s.bstride + c * s.cstride + (int64_t)ys * s.rstride + xs];
+    } else if (s.mode == PC_SRC_POOL2) {
+        const float* p = s.ptr + b * s.bstride + c * s.cstride + (int64_t)(2 * y) * s.rstride + 2 * x;
+        // nn.MaxPool2d(2): floor mode, windows never cross the source extent for y < H/2, x < W/2
+        return fmaxf(fmaxf(p[0], p[1]), fmaxf(p[s.rstride], p[s.rstride + 1]));
+    } else {
+        const int ys = pc_reflect(y - s.oy, s.H), xs = pc_reflect(x - s.ox, s.W);
+        return s.ptr[b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + xs];
+    }
+}

@@ -1,0 +1,260 @@
+// conv3x3_wgrad.hip -- weight / bias gradient of the 3x3 pad-1 convolution on fp32 MFMA (gfx950).
+//
+// Replaces the autograd weight-gradient of nn.Conv2d(3, padding=1) (reference model/DDA_model/utils/networks.py:259,263;
+// 44 % of the reference's CPU train step).
+//
+// GEMM mapping (reduction over pixels rides on K):  D[(s,co)][(ci,v,dx)] += sum_x g[co][yp+s][x] * in[ci][yp+v-1][x+dx-1]
+//     M (16) = (s, co8): s = row of an output-row pair, 8 output channels      -> A[(s,co)][k] = g[co][yp+s][x0+k]
+//     N (16) = 16 consecutive columns of the (ci, v, dx) space, v = 0..3       -> B[k][(ci,v,dx)] = in[ci][yp+v-1][x0+k+dx-1]
+//     K (4)  = 4 consecutive x of the row pair
+// dW[co][ci][dy][dx] = D[(0,co)][(ci,dy,dx)] + D[(1,co)][(ci,dy+1,dx)]  (folded by the reduce kernel): 9 useful taps on
+// 12 columns = 75 % MFMA efficiency with M fully used even at Cout = 8.
+//
+// A workgroup stages a (CINC x 18 x 34) input halo tile and the (COUT x 16 x 32) gradient tile in LDS with strides
+// chosen so both fragment reads are bank-conflict free, accumulates over a persistent loop of tiles in registers,
+// and writes ONE partial per workgroup; a second kernel reduces the partials in a fixed order (deterministic --
+// no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 16;
+constexpr int IN_RS = 36;                    // == 4 mod 32
+constexpr int IN_CS = 18 * IN_RS + 8;        // 656 == 16 mod 32
+constexpr int G_RS = 34;                     // == 2 mod 32
+constexpr int G_CS = 16 * G_RS + 4;          // 548 == 4 mod 32
+constexpr int MAX_WG = 512;
+
+struct WgradArgs {
+    pc_src a, b, g;
+    float* partial;       // [nwg][E]
+    int ci0;              // first input channel of this launch's chunk (grid.y selects further chunks)
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int CINC, int COUT>
+struct WgradCfg {
+    static constexpr int NCOL = CINC * 12;
+    static constexpr int NBLK = (NCOL + 15) / 16;
+    static constexpr int MB = COUT / 8;
+    static constexpr int E = MB * NBLK * 256 + MB * 64;   // accumulators + bias partial sums
+    static constexpr int LDS_FLOATS = CINC * IN_CS + COUT * G_CS;
+};
+
+template <int CINC, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    constexpr int NBLK = Cfg::NBLK, MB = Cfg::MB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lin = lds;
+    float* lg = lds + CINC * IN_CS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int cbase = p.ci0 + chunk * CINC;
+
+    // per-lane fragment offsets
+    int boff[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        int ng = nb * 16 + li;
+        if (ng >= Cfg::NCOL) ng = Cfg::NCOL - 1;      // dead columns: any in-range address, never read back
+        const int ci = ng / 12, rem = ng % 12, v = rem / 3, dx = rem % 3;
+        boff[nb] = ci * IN_CS + v * IN_RS + dx + lk;
+    }
+    int aoff[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) aoff[mb] = (mb * 8 + (li & 7)) * G_CS + (li >> 3) * G_RS + lk;
+
+    f32x4 acc[MB][NBLK];
+    float bsum[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int CA = p.a.C;
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const int tile = pc_xcd_remap(t, p.ntiles);
+        const int tx = tile % p.tiles_x;
+        const int ty = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();
+        for (int idx = tid; idx < CINC * 18 * 34; idx += 256) {
+            const int c = idx % 34, r = (idx / 34) % 18, ci = idx / (34 * 18);
+            const int cg = cbase + ci;
+            const float v = cg < CA ? pc_fetch(p.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
+                                    : pc_fetch(p.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
+            lin[ci * IN_CS + r * IN_RS + c] = v;
+        }
+        for (int idx = tid; idx < COUT * 16 * 32; idx += 256) {
+            const int c = idx & 31, r = (idx >> 5) & 15, co = idx >> 9;
+            lg[co * G_CS + r * G_RS + c] = pc_fetch(p.g, b, co, y0 + r, x0 + c, p.H, p.W);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const int rp = 2 * wave + rpi;
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                float av[MB], bv[NBLK];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    av[mb] = lg[aoff[mb] + 2 * rp * G_RS + 4 * j];
+                    bsum[mb] += av[mb];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) bv[nb] = lin[boff[nb] + 2 * rp * IN_RS + 4 * j];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS (fixed order), one partial per workgroup
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::E;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+            *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
+        __syncthreads();
+        for (int e = tid; e < NBLK * 256; e += 256) {
+            const float s = ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e];
+            part[mb * NBLK * 256 + e] = s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
+    __syncthreads();
+    for (int e = tid; e < MB * 64; e += 256) {
+        const float s = ((lds[e] + lds[MB * 64 + e]) + lds[2 * MB * 64 + e]) + lds[3 * MB * 64 + e];
+        part[MB * NBLK * 256 + e] = s;
+    }
+}
+
+struct WreduceArgs {
+    const float* partial;
+    int nwg;              // partials per chunk
+    int nchunk;
+    float* dw;            // [COUT][CIN][3][3]
+    float* db;            // [COUT]
+    int Cin;
+    int accumulate;
+};
+
+// one thread-quad per output element: 4 slices over the workgroup partials, fixed-order combine.
+template <int CINC, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WreduceArgs p) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    constexpr int NBLK = Cfg::NBLK;
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int slice = tid >> 6, o = blockIdx.x * 64 + (tid & 63);
+    const int n_w = COUT * p.Cin * 9;
+    const int n_out = n_w + COUT;
+    float s = 0.f;
+    if (o < n_out) {
+        int e0, e1 = -1, chunk = 0;
+        if (o < n_w) {
+            const int tap = o % 9, ci = (o / 9) % p.Cin, co = o / (9 * p.Cin);
+            const int dy = tap / 3, dx = tap % 3;
+            chunk = ci / CINC;
+            const int cil = ci % CINC;
+            const int mb = co >> 3, c8 = co & 7;
+            // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
+            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
+            const int m0 = c8, m1 = 8 + c8;
+            e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+            e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+            const float* base = p.partial + (int64_t)chunk * p.nwg * Cfg::E;
+            for (int w = slice; w < p.nwg; w += 4) s += base[(int64_t)w * Cfg::E + e0] + base[(int64_t)w * Cfg::E + e1];
+        } else {
+            // bias: sum over the 8 lanes (s in 0..1, lk in 0..3) that carry channel co; chunk 0 only
+            const int co = o - n_w, mb = co >> 3, c8 = co & 7;
+            const float* base = p.partial;
+            for (int w = slice; w < p.nwg; w += 4) {
+                const float* q = base + (int64_t)w * Cfg::E + Cfg::MB * NBLK * 256 + mb * 64;
+                float t = 0.f;
+#pragma unroll
+                for (int lk = 0; lk < 4; ++lk) t += q[lk * 16 + c8] + q[lk * 16 + 8 + c8];
+                s += t;
+            }
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && o < n_out) {
+        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        float* dstp = o < n_w ? p.dw + o : p.db + (o - n_w);
+        if (o >= n_w && p.db == nullptr) return;
+        *dstp = p.accumulate ? *dstp + tot : tot;
+    }
+}
+
+template <int CINC, int COUT>
+int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, void* ws, hipStream_t stream) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const int nchunk = Cin / CINC;
+    int nwg = p.ntiles < MAX_WG / nchunk ? p.ntiles : MAX_WG / nchunk;
+    if (nwg < 1) nwg = 1;
+    p.partial = reinterpret_cast<float*>(ws);
+    p.ci0 = 0;
+    const size_t ldsb = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<CINC, COUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
+    PC_CHECK_LAUNCH();
+    WreduceArgs r{};
+    r.partial = p.partial; r.nwg = nwg; r.nchunk = nchunk; r.dw = dw; r.db = db; r.Cin = Cin; r.accumulate = accumulate;
+    const int n_out = COUT * Cin * 9 + COUT;
+    hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CINC, COUT>), dim3((n_out + 63) / 64), dim3(256), 0, stream, r);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+constexpr int cinc_of(int cin) { return cin < 16 ? cin : 16; }
+
+}  // namespace
+
+extern "C" int64_t pc_conv3x3_wgrad_ws_bytes(int Cin, int Cout) {
+    // nchunk * nwg <= MAX_WG partials of E floats; E <= 2*12*256 + 128
+    (void)Cin; (void)Cout;
+    return (int64_t)MAX_WG * (2 * 12 * 256 + 128) * sizeof(float);
+}
+
+extern "C" int pc_conv3x3_wgrad(const pc_src* a, const pc_src* b, const pc_src* g, float* dw, float* db, int accumulate,
+                                void* ws, int B, int H, int W, int Cin, int Cout, void* stream) {
+    if (!a || !g || !dw || !ws) return PC_EINVAL;
+    WgradArgs p{};
+    p.a = *a;
+    if (b) p.b = *b;
+    p.g = *g;
+    if (p.a.C + p.b.C != Cin || g->C != Cout) return PC_EINVAL;
+    p.B = B; p.H = H; p.W = W;
+    hipStream_t st = (hipStream_t)stream;
+#define PC_CASE(ci, co) \
+    if (Cin == ci && Cout == co) return launch_wgrad<cinc_of(ci), co>(p, Cin, dw, db, accumulate, ws, st);
+    PC_CASE(2, 8) PC_CASE(4, 8) PC_CASE(8, 8) PC_CASE(16, 8) PC_CASE(32, 8) PC_CASE(8, 16) PC_CASE(16, 16)
+#undef PC_CASE
+    return PC_EINVAL;
+}

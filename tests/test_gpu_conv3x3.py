@@ -1,0 +1,146 @@
+"""Kernel parity: HIP conv3x3 (+BN+ReLU, fused pool / concat / reflect loaders, dgrad epilogues) vs stock
+PyTorch-CPU fp32 ops (the oracle's building blocks).  Tolerance: 1e-5 abs on O(1) activations (fp32 MFMA is an
+exact fp32 fma chain; only the summation order differs from oneDNN)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _bn_params(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.2,
+            torch.rand(c, generator=g) + 0.3)
+
+
+def _ref_cbr(x, w, b, gamma, beta, mean, var, relu=True):
+    y = F.conv2d(x, w, b, padding=1)
+    y = F.batch_norm(y, mean, var, gamma, beta, training=False, eps=1e-5)
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("cin,cout", [(2, 8), (4, 8), (8, 8), (16, 8), (32, 8), (8, 16), (16, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 37, 53), (3, 16, 32)])
+def test_conv_fwd_direct(cin, cout, shape):
+    from popcorn_amd import ops
+    B, H, W = shape
+    x = _mk(B, cin, H, W, seed=1)
+    w = _mk(cout, cin, 3, 3, seed=2, scale=0.2)
+    b = _mk(cout, seed=3, scale=0.1)
+    gamma, beta, mean, var = _bn_params(cout, 4)
+    ref = _ref_cbr(x, w, b, gamma, beta, mean, var)
+    dev = "cuda"
+    out = ops.conv3x3_bn_relu(x.to(dev), w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+def test_conv_fwd_asymmetric_weights_catch_transpose():
+    """Single non-zero tap, asymmetric in (dy,dx) and (co,ci): catches any row/col or tap flip."""
+    from popcorn_amd import ops
+    x = _mk(1, 8, 20, 40, seed=5)
+    for (co, ci, dy, dx) in [(1, 6, 0, 2), (7, 0, 2, 0), (3, 3, 1, 0)]:
+        w = torch.zeros(8, 8, 3, 3)
+        w[co, ci, dy, dx] = 1.0
+        ref = F.conv2d(x, w, None, padding=1)
+        out = ops.conv3x3_bn_relu(x.cuda(), w.cuda(), None, relu=False)
+        torch.testing.assert_close(out.cpu(), ref, rtol=0, atol=1e-6)
+
+
+def test_conv_fwd_pool_and_concat_with_up_pad():
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    # pool fused: source 2x resolution (odd size -> floor)
+    xs = _mk(2, 8, 45, 67, seed=6)
+    w = _mk(16, 8, 3, 3, seed=7, scale=0.2)
+    b = _mk(16, seed=8, scale=0.1)
+    gamma, beta, mean, var = _bn_params(16, 9)
+    ref = _ref_cbr(F.max_pool2d(xs, 2), w, b, gamma, beta, mean, var)
+    out = ops.conv3x3_bn_relu(xs.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda(),
+                              a_mode=L.PC_SRC_POOL2)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+    # concat [skip(16), up(16)] with the up tensor smaller than the skip (Up's zero F.pad, networks.py:309-312)
+    skip = _mk(2, 16, 23, 35, seed=10)
+    upt = _mk(2, 16, 22, 34, seed=11)
+    w = _mk(8, 32, 3, 3, seed=12, scale=0.1)
+    b = _mk(8, seed=13, scale=0.1)
+    gamma, beta, mean, var = _bn_params(8, 14)
+    dy, dx = 1, 1
+    upp = F.pad(upt, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+    ref = _ref_cbr(torch.cat([skip, upp], 1), w, b, gamma, beta, mean, var)
+    out = ops.conv3x3_bn_relu(skip.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda(),
+                              b=upt.cuda(), b_offset=(dy // 2, dx // 2))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+def test_conv_fwd_reflect_reorder():
+    """add_padding(force) + channel reorder fused into the first conv (popcorn.py:243-245,130-134)."""
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    X = _mk(2, 6, 30, 41, seed=15)
+    Xp = F.pad(X, (14, 14, 14, 14), mode="reflect")
+    Xr = torch.cat([Xp[:, 4:6], torch.flip(Xp[:, :3], dims=(1,)), Xp[:, 3:4]], 1)
+    for lo, hi, chmap in [(0, 2, (4, 5, 0, 0)), (2, 6, (2, 1, 0, 3))]:
+        cin = hi - lo
+        w = _mk(8, cin, 3, 3, seed=16 + lo, scale=0.3)
+        b = _mk(8, seed=17, scale=0.1)
+        gamma, beta, mean, var = _bn_params(8, 18)
+        ref = _ref_cbr(Xr[:, lo:hi], w, b, gamma, beta, mean, var)
+        out = ops.conv3x3_bn_relu(X.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda(),
+                                  a_mode=L.PC_SRC_REFLECT, a_pad=(14, 14), chmap=chmap, out_hw=(58, 69), a_channels=cin)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin_total,c0,cn,cg", [(8, 0, 8, 8), (16, 8, 8, 8), (32, 0, 16, 8), (32, 16, 16, 8),
+                                                (8, 0, 8, 16), (16, 0, 16, 16)])
+def test_conv_dgrad_plain_and_masked(cin_total, c0, cn, cg):
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, H, W = 2, 29, 47
+    x = _mk(B, cin_total, H, W, seed=20).requires_grad_(True)
+    w = _mk(cg, cin_total, 3, 3, seed=21, scale=0.2)
+    g = _mk(B, cg, H, W, seed=22)
+    F.conv2d(x, w, None, padding=1).backward(g)
+    ref = x.grad[:, c0:c0 + cn]
+    out = torch.full((B, cn, H, W), 7.0, device="cuda")
+    ops.conv3x3_dgrad(g.cuda(), w.cuda(), c0, cn, out)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+    # masked (+accumulate): out += dgrad * (act>0) * gamma/sqrt(var+eps)
+    act = F.relu(_mk(B, cn, H, W, seed=23))
+    gamma, beta, mean, var = _bn_params(cn, 24)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    base = _mk(B, cn, H, W, seed=25)
+    ref2 = base + ref * (act > 0) * scale.view(1, -1, 1, 1)
+    out2 = base.clone().cuda()
+    bnd = L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())
+    keep = (gamma, beta, mean, var)
+    g_, b_, m_, v_ = (t.cuda() for t in keep)
+    bnd = L.bn(None, g_, b_, m_, v_)
+    ops.conv3x3_dgrad(g.cuda(), w.cuda(), c0, cn, out2, act=act.cuda(), act_bn=bnd, accumulate=True)
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=1e-5, atol=2e-5)
+
+
+def test_conv_dgrad_pool_scatter_matches_autograd():
+    """d1a-style: y = conv(maxpool(relu_bn_out)); gradient w.r.t. the pre-pool activation's conv output."""
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, Hs, Ws = 2, 38, 53
+    pre = _mk(B, 8, Hs, Ws, seed=30).requires_grad_(True)         # conv output of the producing layer (pre-BN)
+    gamma, beta, mean, var = _bn_params(8, 31)
+    act = F.relu(F.batch_norm(pre, mean, var, gamma, beta, training=False, eps=1e-5))
+    w = _mk(16, 8, 3, 3, seed=32, scale=0.2)
+    y = F.conv2d(F.max_pool2d(act, 2), w, None, padding=1)
+    g = _mk(*y.shape, seed=33)
+    y.backward(g)
+    base = _mk(B, 8, Hs, Ws, seed=34)
+    ref = base + pre.grad
+    out = base.clone().cuda()
+    g_, b_, m_, v_ = (t.cuda() for t in (gamma, beta, mean, var))
+    bnd = L.bn(None, g_, b_, m_, v_)
+    ops.conv3x3_dgrad(g.cuda(), w.cuda(), 0, 8, out, act=act.detach().cuda(), act_bn=bnd, pool=True, accumulate=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)

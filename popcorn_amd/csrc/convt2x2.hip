@@ -1,0 +1,301 @@
+// convt2x2.hip -- ConvTranspose2d(C, C, kernel 2, stride 2) forward / data-gradient / weight-gradient on fp32 MFMA.
+//
+// Replaces nn.ConvTranspose2d in the decoder's Up block (reference model/DDA_model/utils/networks.py:302,306):
+//     out[co][2i+a][2j+b] = bias[co] + sum_ci x[ci][i][j] * w[ci][co][a][b]
+// Stride == kernel, so it is a pure per-pixel GEMM: no halo, no LDS staging; fragments are loaded straight from
+// global memory (each input element is used by exactly one wave).
+//   fwd   : M = 16 consecutive input x,   K = ci,          N = (co,a,b)
+//   dgrad : M = 16 consecutive input x,   K = (co,a,b),    N = ci     (+ ReLU/BN backward of the producer fused)
+//   wgrad : M = ci,                       K = 4 input x,   N = (co,a,b)   (deterministic two-stage reduction)
+#include "common.h"
+
+namespace {
+
+struct CtArgs {
+    pc_src x;              // fwd: input;  dgrad: g (2H x 2W);  wgrad: input
+    pc_src g;              // wgrad: g (2H x 2W)
+    const float* w;        // [C][C][2][2]
+    const float* bias;     // fwd
+    const float* act;      // dgrad: post-ReLU activations of the layer that produced x (mask), same geometry as out
+    int64_t act_bstride, act_cstride;
+    int act_rstride;
+    pc_bn bn;              // dgrad: BN of that layer
+    pc_dst out;
+    float* partial;        // wgrad
+    int B, H, W;           // input resolution
+    int groups_x, ngroups;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtArgs p) {
+    constexpr int KS = C / 4, NBK = C / 4;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+    float bw[KS][NBK];
+    float binit[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const int ng = nb * 16 + li;
+        binit[nb] = p.bias ? p.bias[ng >> 2] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[ks][nb] = p.w[(4 * ks + lk) * 4 * C + ng];
+    }
+
+    for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
+        const int gx = grp % p.groups_x;
+        const int i = (grp / p.groups_x) % p.H;
+        const int b = grp / (p.groups_x * p.H);
+        const int j0 = gx * 16;
+        float av[KS];
+        const float* xp = p.x.ptr + b * p.x.bstride + (int64_t)i * p.x.rstride + j0 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = (j0 + li < p.W) ? xp[(4 * ks + lk) * p.x.cstride] : 0.f;
+        f32x4 acc[NBK];
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) acc[nb] = f32x4{binit[nb], binit[nb], binit[nb], binit[nb]};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[ks][nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+            const int ng = nb * 16 + li;
+            const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
+            float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + bb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + 4 * lk + r;
+                if (j < p.W) op[2 * j] = acc[nb][r];
+            }
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+    float bw[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) bw[co] = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
+    float e_scale = 1.f, e_shift = 0.f;
+    if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
+
+    for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
+        const int gx = grp % p.groups_x;
+        const int i = (grp / p.groups_x) % p.H;
+        const int b = grp / (p.groups_x * p.H);
+        const int j0 = gx * 16;
+        // A[pixel li][k = (a,b) = lk] of k-step co
+        const float* gp = p.x.ptr + b * p.x.bstride + (int64_t)(2 * i + (lk >> 1)) * p.x.rstride + 2 * (j0 + li) + (lk & 1);
+        const bool ok = j0 + li < p.W;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            const float av = ok ? gp[co * p.x.cstride] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[co], acc, 0, 0, 0);
+        }
+        if (li < C) {
+            const int j = j0 + 4 * lk;
+            float* op = p.out.ptr + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j;
+            const float* ap = p.act ? p.act + b * p.act_bstride + li * p.act_cstride + (int64_t)i * p.act_rstride + j : nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (j + r < p.W) {
+                    float o = acc[r];
+                    if (ap) o = ap[r] > 0.f ? o * e_scale : 0.f;
+                    op[r] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+struct CtWgradCfg {
+    static constexpr int NBK = C / 4;
+    static constexpr int E = NBK * 256 + NBK * 64;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtArgs p) {
+    constexpr int NBK = C / 4;
+    using Cfg = CtWgradCfg<C>;
+    __shared__ __attribute__((aligned(16))) float lds[4 * NBK * 256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + tid) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+    f32x4 acc[NBK];
+    float bsum[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) { acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[nb] = 0.f; }
+
+    // group = 16 consecutive input x of one row; 4 k-steps of 4 pixels each
+    for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
+        const int gx = grp % p.groups_x;
+        const int i = (grp / p.groups_x) % p.H;
+        const int b = grp / (p.groups_x * p.H);
+        const int j0 = gx * 16;
+        const float* xp = p.x.ptr + b * p.x.bstride + li * p.x.cstride + (int64_t)i * p.x.rstride;
+        float av[4], bv[4][NBK];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int j = j0 + 4 * ks + lk;
+            av[ks] = (li < C && j < p.W) ? xp[j] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+                const int ng = nb * 16 + li;
+                const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
+                bv[ks][nb] = j < p.W ? p.g.ptr[b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j + bb]
+                                     : 0.f;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+                bsum[nb] += bv[ks][nb];
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][nb], acc[nb], 0, 0, 0);
+            }
+    }
+
+    float* part = p.partial + (int64_t)blockIdx.x * Cfg::E;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * NBK + nb) * 64 + lane) * 4]) = acc[nb];
+    __syncthreads();
+    for (int e = tid; e < NBK * 256; e += 256)
+        part[e] = ((lds[e] + lds[NBK * 256 + e]) + lds[2 * NBK * 256 + e]) + lds[3 * NBK * 256 + e];
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) lds[(wave * NBK + nb) * 64 + lane] = bsum[nb];
+    __syncthreads();
+    for (int e = tid; e < NBK * 64; e += 256)
+        part[NBK * 256 + e] = ((lds[e] + lds[NBK * 64 + e]) + lds[2 * NBK * 64 + e]) + lds[3 * NBK * 64 + e];
+}
+
+struct CtReduceArgs {
+    const float* partial;
+    int nwg;
+    float* dw;
+    float* db;
+    int accumulate;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_wgrad_reduce_kernel(const CtReduceArgs p) {
+    constexpr int NBK = C / 4;
+    using Cfg = CtWgradCfg<C>;
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int slice = tid >> 6, o = blockIdx.x * 64 + (tid & 63);
+    constexpr int n_w = C * C * 4, n_out = n_w + C;
+    float s = 0.f;
+    if (o < n_w) {
+        const int ci = o / (4 * C), ng = o % (4 * C);     // dw[ci][co][a][b], ng = co*4 + a*2 + b
+        const int e = (((ng >> 4) * 64) + (ci >> 2) * 16 + (ng & 15)) * 4 + (ci & 3);
+        for (int w = slice; w < p.nwg; w += 4) s += p.partial[(int64_t)w * Cfg::E + e];
+    } else if (o < n_out) {
+        const int co = o - n_w;
+        for (int w = slice; w < p.nwg; w += 4) {
+            const float* q = p.partial + (int64_t)w * Cfg::E + NBK * 256;
+            float t = 0.f;
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const int ng = co * 4 + ab;
+#pragma unroll
+                for (int lk = 0; lk < 4; ++lk) t += q[(ng >> 4) * 64 + lk * 16 + (ng & 15)];
+            }
+            s += t;
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && o < n_out) {
+        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        float* dstp = o < n_w ? p.dw + o : p.db + (o - n_w);
+        if (o >= n_w && p.db == nullptr) return;
+        *dstp = p.accumulate ? *dstp + tot : tot;
+    }
+}
+
+constexpr int CT_MAX_WG = 512;
+
+int fill_groups(CtArgs& p) {
+    p.groups_x = (p.W + 15) / 16;
+    p.ngroups = p.B * p.H * p.groups_x;
+    int nwg = (p.ngroups + 3) / 4;
+    if (nwg > 2048) nwg = 2048;
+    return nwg < 1 ? 1 : nwg;
+}
+
+}  // namespace
+
+extern "C" int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bias, const pc_dst* out, int B, int H, int W,
+                               int C, void* stream) {
+    if (!x || !w || !out) return PC_EINVAL;
+    CtArgs p{};
+    p.x = *x; p.w = w; p.bias = bias; p.out = *out; p.B = B; p.H = H; p.W = W;
+    const int nwg = fill_groups(p);
+    if (C == 16) hipLaunchKernelGGL(convt2x2_fwd_kernel<16>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else if (C == 8) hipLaunchKernelGGL(convt2x2_fwd_kernel<8>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_convt2x2_dgrad(const pc_src* g, const float* w, const pc_src* act, const pc_bn* act_bn,
+                                 const pc_dst* out, int B, int H, int W, int C, void* stream) {
+    if (!g || !w || !out) return PC_EINVAL;
+    CtArgs p{};
+    p.x = *g; p.w = w; p.out = *out; p.B = B; p.H = H; p.W = W;
+    if (act) {
+        if (!act_bn) return PC_EINVAL;
+        p.act = act->ptr; p.act_bstride = act->bstride; p.act_cstride = act->cstride; p.act_rstride = act->rstride;
+        p.bn = *act_bn;
+    }
+    const int nwg = fill_groups(p);
+    if (C == 16) hipLaunchKernelGGL(convt2x2_dgrad_kernel<16>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else if (C == 8) hipLaunchKernelGGL(convt2x2_dgrad_kernel<8>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {
+    (void)C;
+    return (int64_t)CT_MAX_WG * (4 * 256 + 4 * 64) * sizeof(float);
+}
+
+extern "C" int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, float* db, int accumulate, void* ws,
+                                 int B, int H, int W, int C, void* stream) {
+    if (!x || !g || !dw || !ws) return PC_EINVAL;
+    CtArgs p{};
+    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W;
+    p.partial = reinterpret_cast<float*>(ws);
+    int nwg = fill_groups(p);
+    if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;
+    CtReduceArgs r{};
+    r.partial = p.partial; r.nwg = nwg; r.dw = dw; r.db = db; r.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) {
+        hipLaunchKernelGGL(convt2x2_wgrad_kernel<16>, dim3(nwg), dim3(256), 0, st, p);
+        PC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<16>, dim3((16 * 16 * 4 + 16 + 63) / 64), dim3(256), 0, st, r);
+    } else if (C == 8) {
+        hipLaunchKernelGGL(convt2x2_wgrad_kernel<8>, dim3(nwg), dim3(256), 0, st, p);
+        PC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<8>, dim3((8 * 8 * 4 + 8 + 63) / 64), dim3(256), 0, st, r);
+    } else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    return 0;
+}

@@ -55,3 +55,134 @@ def conv3x3_dgrad(g, w, c0, cn, out, act=None, act_bn=None, pool=False, accumula
                                     int(pool), int(accumulate), C.byref(d), B, H, W, Cg, L.stream_ptr())
     L.check(code, "pc_conv3x3_dgrad")
     return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (str(device), "ws")
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def conv3x3_wgrad(a, g, cout, dw=None, db=None, b=None, accumulate=False, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0),
+                  chmap=(0, 1, 2, 3), b_offset=(0, 0), a_channels=None):
+    """Weight/bias gradient of conv3x3 over x = cat[a, b] with output gradient g (already ReLU/BN-masked)."""
+    L.require_device(a, g)
+    B, Cg, H, W = g.shape
+    Ca = a.shape[1] if a_channels is None else a_channels
+    Cb = 0 if b is None else b.shape[1]
+    cin = Ca + Cb
+    sa = L.src(a, C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=chmap)
+    sb = L.src(b, oy=b_offset[0], ox=b_offset[1]) if b is not None else None
+    sg = L.src(g)
+    if dw is None:
+        dw = torch.empty(cout, cin, 3, 3, device=g.device, dtype=torch.float32)
+    if db is None:
+        db = torch.empty(cout, device=g.device, dtype=torch.float32)
+    ws = _workspace(L.lib().pc_conv3x3_wgrad_ws_bytes(cin, cout), g.device)
+    code = L.lib().pc_conv3x3_wgrad(C.byref(sa), C.byref(sb) if sb is not None else None, C.byref(sg), L.ptr(dw),
+                                    L.ptr(db), int(accumulate), L.ptr(ws), B, H, W, cin, cout, L.stream_ptr())
+    L.check(code, "pc_conv3x3_wgrad")
+    return dw, db
+
+
+def convt2x2(x, w, bias, out=None):
+    """ConvTranspose2d(C, C, 2, stride=2).  networks.py:302,306."""
+    L.require_device(x, w)
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, Cc, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    sx, d = L.src(x), L.dst(out)
+    L.check(L.lib().pc_convt2x2_fwd(C.byref(sx), L.ptr(w), L.ptr(bias), C.byref(d), B, H, W, Cc, L.stream_ptr()),
+            "pc_convt2x2_fwd")
+    return out
+
+
+def convt2x2_dgrad(g, w, out, act=None, act_bn=None):
+    L.require_device(g, w, out)
+    B, Cc, H, W = out.shape
+    sg, d = L.src(g), L.dst(out)
+    sa = L.src(act) if act is not None else None
+    L.check(L.lib().pc_convt2x2_dgrad(C.byref(sg), L.ptr(w), C.byref(sa) if sa is not None else None,
+                                      C.byref(act_bn) if act_bn is not None else None, C.byref(d), B, H, W, Cc,
+                                      L.stream_ptr()), "pc_convt2x2_dgrad")
+    return out
+
+
+def convt2x2_wgrad(x, g, dw=None, db=None, accumulate=False):
+    L.require_device(x, g)
+    B, Cc, H, W = x.shape
+    if dw is None:
+        dw = torch.empty(Cc, Cc, 2, 2, device=x.device, dtype=torch.float32)
+    if db is None:
+        db = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    ws = _workspace(L.lib().pc_convt2x2_wgrad_ws_bytes(Cc), x.device)
+    sx, sg = L.src(x), L.src(g)
+    L.check(L.lib().pc_convt2x2_wgrad(C.byref(sx), C.byref(sg), L.ptr(dw), L.ptr(db), int(accumulate), L.ptr(ws),
+                                      B, H, W, Cc, L.stream_ptr()), "pc_convt2x2_wgrad")
+    return dw, db
+
+
+def outconv_sigmoid_crop(feat, w, bias, H, W, py, px, out=None):
+    """fusion_out_conv (1x1, 16->1) + sigmoid + crop.  popcorn.py:301,317-320."""
+    L.require_device(feat, w, bias)
+    B = feat.shape[0]
+    if out is None:
+        out = torch.empty(B, 1, H, W, device=feat.device, dtype=torch.float32)
+    sf, d = L.src(feat), L.dst(out)
+    L.check(L.lib().pc_outconv_sigmoid_crop(C.byref(sf), L.ptr(w), L.ptr(bias), C.byref(d), B, H, W, py, px,
+                                            L.stream_ptr()), "pc_outconv_sigmoid_crop")
+    return out
+
+
+def sparsity_mask(building, admin_mask, census_idx, rowsel, colsel, occupancymodel=True):
+    """popcorn.py:361-377.  rowsel/colsel: uint8 device vectors.  Returns (mask uint8 (B,H,W), counts int32[2])."""
+    L.require_device(building, admin_mask, census_idx, rowsel, colsel)
+    B, H, W = admin_mask.shape
+    mask = torch.empty(B, H, W, dtype=torch.uint8, device=building.device)
+    counts = torch.empty(2, dtype=torch.int32, device=building.device)
+    L.check(L.lib().pc_sparsity_mask(L.ptr(building), L.ptr(admin_mask), L.ptr(census_idx), L.ptr(rowsel), L.ptr(colsel),
+                                     int(occupancymodel), L.ptr(mask), L.ptr(counts), B, H, W, L.stream_ptr()),
+            "pc_sparsity_mask")
+    return mask, counts
+
+
+def _hw_array(head_tensors):
+    arr = (C.c_void_p * 8)(*[t.data_ptr() for t in head_tensors])
+    return arr
+
+
+def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
+             want_scale=True):
+    """Sparse/dense head + occupancy product + census reduction.  popcorn.py:161-190.
+    head_tensors = [w0,b0,w2,b2,w4,b4,w6,b6].  Returns (scale_map, popdensemap, popcount)."""
+    L.require_device(feat, building, *head_tensors)
+    B = feat.shape[0]
+    dev = feat.device
+    scale_map = torch.empty(B, H, W, device=dev, dtype=torch.float32) if want_scale else None
+    popdense = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+    popcount = torch.empty(B, device=dev, dtype=torch.float32)
+    ws = _workspace(L.lib().pc_head_ws_bytes(B, H, W), dev)
+    sf = L.src(feat)
+    hw = _hw_array(head_tensors)
+    L.check(L.lib().pc_head_fwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
+                                L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(ws),
+                                B, H, W, L.stream_ptr()), "pc_head_fwd")
+    return scale_map, popdense, popcount
+
+
+def compact_masked(src, mask):
+    """src[mask] in row-major order (popcorn.py:173).  Returns (buffer of src.numel() floats, device int32 count)."""
+    L.require_device(src, mask)
+    n = src.numel()
+    out = torch.empty(n, device=src.device, dtype=torch.float32)
+    cnt = torch.empty(1, device=src.device, dtype=torch.int32)
+    ws = _workspace(L.lib().pc_compact_ws_bytes(n), src.device)
+    L.check(L.lib().pc_compact_masked(L.ptr(src), L.ptr(mask), L.ptr(out), L.ptr(cnt), L.ptr(ws), C.c_int64(n),
+                                      L.stream_ptr()), "pc_compact_masked")
+    return out, cnt

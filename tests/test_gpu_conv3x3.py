@@ -144,3 +144,44 @@ def test_conv_dgrad_pool_scatter_matches_autograd():
     bnd = L.bn(None, g_, b_, m_, v_)
     ops.conv3x3_dgrad(g.cuda(), w.cuda(), 0, 8, out, act=act.detach().cuda(), act_bn=bnd, pool=True, accumulate=True)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(2, 8), (4, 8), (8, 8), (16, 8), (32, 8), (8, 16), (16, 16)])
+@pytest.mark.parametrize("shape", [(3, 64, 64), (1, 37, 53), (40, 32, 32)])
+def test_conv_wgrad(cin, cout, shape):
+    from popcorn_amd import ops
+    B, H, W = shape
+    x = _mk(B, cin, H, W, seed=40)
+    w = _mk(cout, cin, 3, 3, seed=41, scale=0.2).requires_grad_(True)
+    bias = torch.zeros(cout, requires_grad=True)
+    g = _mk(B, cout, H, W, seed=42)
+    F.conv2d(x, w, bias, padding=1).backward(g)
+    dw, db = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
+    scale = w.grad.abs().max().item()
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=2e-6 * max(scale, 1.0))
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=1e-5, atol=2e-6 * max(bias.grad.abs().max().item(), 1.0))
+    # accumulate + determinism
+    dw2, db2 = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout, dw=dw.clone(), db=db.clone(), accumulate=True)
+    torch.testing.assert_close(dw2.cpu(), 2 * dw.cpu(), rtol=1e-6, atol=0)
+    dw3, db3 = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
+    assert torch.equal(dw3, dw) and torch.equal(db3, db)
+
+
+def test_conv_wgrad_fused_loaders():
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    xs = _mk(2, 8, 45, 67, seed=43)
+    w = _mk(16, 8, 3, 3, seed=44, scale=0.2).requires_grad_(True)
+    y = F.conv2d(F.max_pool2d(xs, 2), w, None, padding=1)
+    g = _mk(*y.shape, seed=45)
+    y.backward(g)
+    dw, _ = ops.conv3x3_wgrad(xs.cuda(), g.cuda(), 16, a_mode=L.PC_SRC_POOL2)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=1e-4)
+    skip = _mk(2, 16, 23, 35, seed=46)
+    upt = _mk(2, 16, 22, 34, seed=47)
+    w = _mk(8, 32, 3, 3, seed=48, scale=0.1).requires_grad_(True)
+    y = F.conv2d(torch.cat([skip, F.pad(upt, (0, 1, 0, 1))], 1), w, None, padding=1)
+    g = _mk(*y.shape, seed=49)
+    y.backward(g)
+    dw, _ = ops.conv3x3_wgrad(skip.cuda(), g.cuda(), 8, b=upt.cuda(), b_offset=(0, 0))
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=1e-4)

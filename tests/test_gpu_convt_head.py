@@ -1,0 +1,134 @@
+"""Kernel parity: ConvTranspose2d 2x2/s2 (fwd, dgrad, wgrad), building-score tail, sparsity mask, sparse head
+forward and ordered compaction -- HIP vs stock PyTorch-CPU ops / the oracle.  fp32 tolerance 1e-5 rel on O(1) data;
+mask / index paths bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _mk(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("C_", [8, 16])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 9, 21), (1, 40, 16)])
+def test_convt_fwd_dgrad_wgrad(C_, shape):
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, H, W = shape
+    x = _mk(B, C_, H, W, seed=1).requires_grad_(True)
+    w = _mk(C_, C_, 2, 2, seed=2, scale=0.3).requires_grad_(True)
+    bias = _mk(C_, seed=3, scale=0.1).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, bias, stride=2)
+    g = _mk(*y.shape, seed=4)
+    y.backward(g)
+    out = ops.convt2x2(x.detach().cuda(), w.detach().cuda(), bias.detach().cuda())
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-5, atol=1e-5)
+    gx = torch.empty(B, C_, H, W, device="cuda")
+    ops.convt2x2_dgrad(g.cuda(), w.detach().cuda(), gx)
+    torch.testing.assert_close(gx.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+    # fused ReLU/BN backward of the producer
+    act = F.relu(_mk(B, C_, H, W, seed=5))
+    gen = torch.Generator().manual_seed(6)
+    gamma, var = torch.rand(C_, generator=gen) + 0.5, torch.rand(C_, generator=gen) + 0.3
+    beta, mean = torch.zeros(C_), torch.zeros(C_)
+    keep = [t.cuda() for t in (gamma, beta, mean, var)]
+    bnd = L.bn(None, *keep)
+    ops.convt2x2_dgrad(g.cuda(), w.detach().cuda(), gx, act=act.cuda(), act_bn=bnd)
+    ref = x.grad * (act > 0) * (gamma / torch.sqrt(var + 1e-5)).view(1, -1, 1, 1)
+    torch.testing.assert_close(gx.cpu(), ref, rtol=1e-5, atol=1e-5)
+    dw, db = ops.convt2x2_wgrad(x.detach().cuda(), g.cuda())
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=2e-6 * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=1e-5, atol=2e-6 * max(1.0, bias.grad.abs().max().item()))
+    dw2, db2 = ops.convt2x2_wgrad(x.detach().cuda(), g.cuda())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_outconv_sigmoid_crop():
+    from popcorn_amd import ops
+    feat = _mk(2, 16, 58, 69, seed=7)
+    w = _mk(1, 16, 1, 1, seed=8, scale=0.4)
+    b = _mk(1, seed=9)
+    ref = torch.sigmoid(F.conv2d(feat, w, b))[:, :, 14:-14, 14:-14]
+    out = ops.outconv_sigmoid_crop(feat.cuda(), w.cuda(), b.cuda(), 30, 41, 14, 14)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["b2_100", "b1_131x77", "b2_40x52"])
+def test_sparsity_mask_bit_exact_vs_golden(name):
+    """Mask is an index path: bit-exact against the reference's own output (fixture g4)."""
+    from popcorn_amd import ops
+    g = np.load(os.path.join(G, "g4_mask.npz"))
+    bc = torch.from_numpy(g[f"{name}/building_counts"])
+    admin = torch.from_numpy(g[f"{name}/admin_mask"])
+    census = torch.from_numpy(g[f"{name}/census_idx"])
+    B, H, W = admin.shape
+    rowsel = torch.zeros(H, dtype=torch.uint8)
+    colsel = torch.zeros(W, dtype=torch.uint8)
+    rowsel[torch.from_numpy(g[f"{name}/xindices"])] = 1
+    colsel[torch.from_numpy(g[f"{name}/yindices"])] = 1
+    mask, counts = ops.sparsity_mask(bc.cuda(), admin.cuda(), census.cuda(), rowsel.cuda(), colsel.cuda())
+    ref = g[f"{name}/mask"]
+    assert np.array_equal(mask.cpu().numpy().astype(bool), ref)
+    assert counts[0].item() == int(ref.sum())
+    # empty selection -> falls back to the region (popcorn.py:374-375)
+    mask2, counts2 = ops.sparsity_mask(torch.zeros_like(bc).cuda(), admin.cuda(), census.cuda(),
+                                       torch.zeros(H, dtype=torch.uint8).cuda(), torch.zeros(W, dtype=torch.uint8).cuda())
+    region = (admin == census.view(-1, 1, 1)).numpy()
+    assert np.array_equal(mask2.cpu().numpy().astype(bool), region)
+    assert counts2[0].item() == int(region.sum())
+
+
+def test_compact_masked_order():
+    from popcorn_amd import ops
+    gen = torch.Generator().manual_seed(10)
+    for n in (1, 1000, 1024, 5000, 300007):
+        src = torch.randn(n, generator=gen)
+        mask = (torch.rand(n, generator=gen) < 0.37)
+        out, cnt = ops.compact_masked(src.cuda(), mask.to(torch.uint8).cuda())
+        k = cnt.item()
+        assert k == int(mask.sum())
+        assert torch.equal(out[:k].cpu(), src[mask])
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("shape", [(2, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
+def test_head_fwd_vs_oracle(sparse, shape):
+    from oracle import popcorn_oracle as O
+    from popcorn_amd import ops
+    B, H, W, Hp, Wp, py, px = shape
+    sd = O.load_golden_state(G)
+    feat = _mk(B, 16, Hp, Wp, seed=11)
+    gen = torch.Generator().manual_seed(12)
+    building = torch.rand(B, 1, H, W, generator=gen)
+    admin = (torch.rand(B, H, W, generator=gen) < 0.6).float() * 5.0
+    census = torch.full((B,), 5, dtype=torch.int64)
+    mask = (torch.rand(B, H, W, generator=gen) < 0.5) & (admin == 5.0)
+    headin = feat[:, :, py:py + H, px:px + W]
+    with torch.no_grad():
+        if sparse:
+            out = O.sparse_head_forward(sd, headin, mask)[:, 0]
+        else:
+            out = O.head_forward(sd, headin)[:, 0]
+        scale = F.relu(out)
+        pd = scale * building[:, 0]
+        pc = (pd * (admin == census.view(-1, 1, 1))).sum((1, 2))
+    ht = [sd[f"head.{i}.{n}"].cuda() for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+    s_map, pd_gpu, pc_gpu = ops.head_fwd(feat.cuda(), py, px, H, W, ht, building.cuda(),
+                                         mask=mask.to(torch.uint8).cuda() if sparse else None,
+                                         admin_mask=admin.cuda(), census_idx=census.cuda())
+    torch.testing.assert_close(s_map.cpu(), scale, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pd_gpu.cpu(), pd, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pc_gpu.cpu(), pc, rtol=2e-5, atol=1e-4)
+    # no admin mask: plain sum (popcorn.py:189-190)
+    _, _, pc2 = ops.head_fwd(feat.cuda(), py, px, H, W, ht, building.cuda())
+    with torch.no_grad():
+        ref2 = (F.relu(O.head_forward(sd, headin)[:, 0]) * building[:, 0]).sum((1, 2))
+    torch.testing.assert_close(pc2.cpu(), ref2, rtol=2e-5, atol=1e-4)

@@ -139,12 +139,17 @@ int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, cons
                 float* scale_map, float* popdensemap, float* popcount, void* ws,
                 int B, int H, int W, void* stream);
 
-/* backward of pc_head_fwd.  Upstream gradients: g_popcount[B] and a constant g_scale added on every selected pixel
- * with scale > 0 (the scale-regularisation term, utils/losses.py:74-76).  Produces the 8 head gradients
- * (dhw, (=|+=)) and the gradient w.r.t. the padded feature map (zero outside the crop / unselected pixels). */
+/* backward of pc_head_fwd (the forward chain is recomputed in registers).  Upstream gradients, all optional (NULL):
+ *   g_popcount[B]; g_popdense[B][H][W]; g_scale_map[B][H][W] (gradient w.r.t. scale = relu(out), e.g. the scattered
+ *   gradient of the compacted scale vector); g_scale_const: DEVICE scalar added on every selected pixel (the
+ *   scale-regularisation term scale_regularization * lam / Nsel, utils/losses.py:74-76).
+ * Produces the 8 head gradients dhw[i] (=|+=; entries may be NULL; head.6 row/bias 1 get exact zeros, as autograd
+ * gives for the unused second output channel) and the gradient w.r.t. the padded 16-channel feature map g_feat
+ * (contiguous B x 16 x Hp x Wp; zero outside the crop and on unselected pixels). */
 int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                 const float* building, const float* admin_mask, const int64_t* census_idx,
-                const float* g_popcount, const float* g_scale_dev, float* const* dhw, int accumulate,
+                const float* g_popcount, const float* g_popdense, const float* g_scale_map,
+                const float* g_scale_const, float* const* dhw, int accumulate,
                 const pc_dst* g_feat, int Hp, int Wp, void* ws, int B, int H, int W, void* stream);
 
 /* ---- compaction of scale[mask] in row-major (b,y,x) order (the boolean-index gather of popcorn.py:173).

@@ -172,6 +172,338 @@ __global__ void head_popcount_reduce_kernel(const float* partial, float* popcoun
     popcount[b] = t;
 }
 
+// ---- head backward ---------------------------------------------------------------------------------------------
+// Recomputes the forward chain in registers (cheaper than saving 3 x 64 hidden channels per pixel: 164 MB per
+// layer at B=64), then walks back:  g3 = W6^T g_out . relu'   ->  g2 = W4^T g3 . relu'  ->  g1 = W2^T g2 . relu'
+// -> g_x = W0^T g1, with the transposed-weight A fragments staged in LDS.  Because hidden units stay on M and
+// pixels on N, every intermediate keeps the forward's register layout.  The weight gradients dW = g . h^T contract
+// over pixels, which needs (hidden x pixel) matrices as A and B operands: each wave transposes g and h through a
+// private LDS scratch (row stride 18 floats: conflict-free fragment reads) and accumulates dW in registers over a
+// persistent loop of pixel groups.  One partial per workgroup, fixed-order second-stage reduction (deterministic).
+constexpr int LB_A1 = 0;                         // fwd fragments as in the forward kernel
+constexpr int LB_A2 = LB_A1 + 1024;
+constexpr int LB_A3 = LB_A2 + 4096;
+constexpr int LB_T3 = LB_A3 + 4096;              // [4 mi][16 ks][64]: lane(i,k) = W4[16mb+4k+r][16mi+i]
+constexpr int LB_T2 = LB_T3 + 4096;              // same for W2
+constexpr int LB_T1 = LB_T2 + 4096;              // [16 ks][64]:       lane(i=c,k) = W0[16mb+4k+r][c]
+constexpr int LB_B0 = LB_T1 + 1024;
+constexpr int LB_B2 = LB_B0 + 64;
+constexpr int LB_B4 = LB_B2 + 64;
+constexpr int LB_W6 = LB_B4 + 64;
+constexpr int LB_SCR = LB_W6 + 64 + 4;           // per wave: Gm[64][18] + Hm[64][18]
+constexpr int SCR_LD = 18;
+constexpr int SCR_WAVE = 2 * 64 * SCR_LD;
+constexpr int LB_END = LB_SCR + 4 * SCR_WAVE;
+// workgroup partial layout
+constexpr int PE_W4 = 0, PE_W2 = 4096, PE_W0 = 8192, PE_W6 = 9216, PE_B0 = 9280, PE_B2 = 9344, PE_B4 = 9408, PE_B6 = 9472;
+constexpr int PE_TOTAL = 9480;
+
+struct HeadBwdArgs {
+    HeadArgs f;
+    const float* g_popcount;     // [B] or NULL
+    const float* g_popdense;     // [B][H][W] or NULL
+    const float* g_scale_map;    // [B][H][W] or NULL
+    const float* g_scale_const;  // device scalar or NULL: added on every selected pixel
+    pc_dst g_feat;
+    float* partial;              // [nwg][PE_TOTAL]
+    int total_groups;
+};
+
+__device__ __forceinline__ float lane_sum16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+// dgrad through one 64x64 layer: out[mi] = sum_o W[o][16mi+i] * g[o]   (transposed fragments at t_off)
+__device__ __forceinline__ void head_dgrad64(const float* lds, int t_off, int lane, const f32x4 (&g)[4], f32x4 (&out)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) out[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ks = mb * 4 + r;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                out[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[t_off + (mi * 16 + ks) * 64 + lane], g[mb][r], out[mi], 0, 0, 0);
+        }
+}
+
+// scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a row-major [64][SCR_LD] matrix
+__device__ __forceinline__ void head_store_mat(float* m, int li, int lk, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[(16 * mb + 4 * lk + r) * SCR_LD + li] = v[mb][r];
+}
+
+// dW[o][i] += sum_px G[o][px] * Hm[i][px]   (64 x 64, 16 pixels = 4 k-steps)
+__device__ __forceinline__ void head_wgrad64(const float* gm, const float* hm, int li, int lk, f32x4 (&dw)[4][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float af[4], bf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            af[q] = gm[(16 * q + li) * SCR_LD + 4 * ks + lk];
+            bf[q] = hm[(16 * q + li) * SCR_LD + 4 * ks + lk];
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                dw[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bf[nb], dw[mb][nb], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const HeadArgs& p = a.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    head_stage_weights(lds, p);     // LB_A1..LB_A3 coincide with L_A1..L_A3
+    __syncthreads();                // its bias block (L_B0..) overlaps LB_T3: let it land before T3 is filled
+    for (int e = tid; e < 64 * 64; e += blockDim.x) {
+        const int l = e & 63, f = e >> 6, ks = f & 15, mi = f >> 4;
+        const int row = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);     // o
+        const int col = 16 * mi + (l & 15);                           // i
+        lds[LB_T3 + e] = p.w4[row * HID + col];
+        lds[LB_T2 + e] = p.w2[row * HID + col];
+    }
+    for (int e = tid; e < 16 * 64; e += blockDim.x) {
+        const int l = e & 63, ks = e >> 6;
+        const int row = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);
+        lds[LB_T1 + e] = p.w0[row * 16 + (l & 15)];
+    }
+    for (int e = tid; e < 64; e += blockDim.x) {
+        lds[LB_B0 + e] = p.b0[e];
+        lds[LB_B2 + e] = p.b2[e];
+        lds[LB_B4 + e] = p.b4[e];
+        lds[LB_W6 + e] = p.w6[e];
+    }
+    if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
+    __syncthreads();
+
+    float* gm = lds + LB_SCR + wave * SCR_WAVE;
+    float* hm = gm + 64 * SCR_LD;
+    const int HW = p.H * p.W;
+    const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
+
+    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4], db0[4], db2[4], db4[4];
+    float db6 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dW0[i] = dw6[i] = db0[i] = db2[i] = db4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int gg = blockIdx.x * 4 + wave; gg < a.total_groups; gg += gridDim.x * 4) {
+        const int b = gg / p.groups, g = gg - b * p.groups;
+        const int q = g * 16 + li;
+        const bool valid = q < HW;
+        const int64_t pix = (int64_t)b * HW + q;
+        const bool sel = valid && (p.mask ? p.mask[pix] != 0 : true);
+        if (!__any(sel)) continue;
+        const int y = valid ? q / p.W : 0, x = valid ? q - (q / p.W) * p.W : 0;
+        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = valid ? fp[(4 * j + lk) * p.feat.cstride] : 0.f;
+        // upstream gradient of relu(out) at this pixel
+        float gup = 0.f;
+        if (sel) {
+            const float bld = p.building[pix];
+            const bool region = p.admin ? (p.admin[pix] == (float)p.census[b]) : true;
+            gup = gsc;
+            if (a.g_popcount && region) gup += a.g_popcount[b] * bld;
+            if (a.g_popdense) gup += a.g_popdense[pix] * bld;
+            if (a.g_scale_map) gup += a.g_scale_map[pix];
+        }
+        // ---- forward recompute
+        f32x4 h1[4], h2[4], h3[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h1[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_B0 + 16 * mb + 4 * lk]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                h1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LB_A1 + (mb * 4 + j) * 64 + lane], xv[j], h1[mb], 0, 0, 0);
+        relu4(h1);
+        head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
+        relu4(h2);
+        head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
+        relu4(h3);
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float outv = s + lds[LB_W6 + 64];
+        const float gout = (sel && outv > 0.f) ? gup : 0.f;
+        if (!__any(gout != 0.f)) continue;
+
+        // ---- layer 4 (64 -> 1)
+        f32x4 g3[4], g2[4], g1[4];
+        if (lk == 0) db6 += gout;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                db4[mb][r] += g3[mb][r];
+            }
+        }
+        // ---- layer 3 (W4)
+        __builtin_amdgcn_wave_barrier();
+        head_store_mat(gm, li, lk, g3);
+        head_store_mat(hm, li, lk, h2);
+        __builtin_amdgcn_wave_barrier();
+        head_wgrad64(gm, hm, li, lk, dW4);
+        head_dgrad64(lds, LB_T3, lane, g3, g2);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+                db2[mb][r] += g2[mb][r];
+            }
+        // ---- layer 2 (W2)
+        __builtin_amdgcn_wave_barrier();
+        head_store_mat(gm, li, lk, g2);
+        head_store_mat(hm, li, lk, h1);
+        __builtin_amdgcn_wave_barrier();
+        head_wgrad64(gm, hm, li, lk, dW2);
+        head_dgrad64(lds, LB_T2, lane, g2, g1);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+                db0[mb][r] += g1[mb][r];
+            }
+        // ---- layer 1 (W0: 64 x 16)
+        __builtin_amdgcn_wave_barrier();
+        head_store_mat(gm, li, lk, g1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hm[(4 * j + lk) * SCR_LD + li] = xv[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float bf = hm[li * SCR_LD + 4 * ks + lk];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[(16 * mb + li) * SCR_LD + 4 * ks + lk], bf, dW0[mb], 0, 0, 0);
+        }
+        f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LB_T1 + (mb * 4 + r) * 64 + lane], g1[mb][r], gx, 0, 0, 0);
+        if (valid) {
+            float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = gx[r];
+        }
+    }
+
+    // ---- per-lane vectors: reduce over the 16 pixel lanes
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dw6[mb][r] = lane_sum16(dw6[mb][r]);
+            db0[mb][r] = lane_sum16(db0[mb][r]);
+            db2[mb][r] = lane_sum16(db2[mb][r]);
+            db4[mb][r] = lane_sum16(db4[mb][r]);
+        }
+    db6 = lane_sum16(db6);
+
+    // ---- cross-wave reduction (fixed order) -> one partial per workgroup
+    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
+    __syncthreads();
+#pragma unroll
+    for (int stage = 0; stage < 2; ++stage) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                *reinterpret_cast<f32x4*>(&lds[wave * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 256)
+            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
+        __syncthreads();
+    }
+    // small stuff: per wave [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1] -> stride 1344
+    {
+        float* w = lds + wave * 1344;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
+        if (li == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int h = 16 * mb + 4 * lk + r;
+                    w[1024 + h] = dw6[mb][r];
+                    w[1088 + h] = db0[mb][r];
+                    w[1152 + h] = db2[mb][r];
+                    w[1216 + h] = db4[mb][r];
+                }
+            if (lk == 0) w[1280] = db6;
+        }
+        __syncthreads();
+        for (int e = tid; e < 1281; e += 256) {
+            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
+            part[PE_W0 + e] = t;     // PE_W0.. contiguous: W0(1024) W6(64) B0 B2 B4 (64 each) B6(1)
+        }
+    }
+}
+
+struct HeadReduceArgs {
+    const float* partial;
+    int nwg;
+    float* dhw[8];
+    int accumulate;
+};
+
+// outputs: w0 (1024) b0 (64) w2 (4096) b2 (64) w4 (4096) b4 (64) w6 (128) b6 (2)  = 9538
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceArgs p) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, slice = tid >> 6;
+    const int o = blockIdx.x * 64 + (tid & 63);
+    int t = -1, idx = 0, e = -1;      // tensor id, index within tensor, partial element (-1 = structural zero)
+    if (o < 1024) { t = 0; idx = o; const int r = o >> 4, c = o & 15; e = PE_W0 + (((r >> 4) * 64) + ((r & 15) >> 2) * 16 + c) * 4 + (r & 3); }
+    else if (o < 1088) { t = 1; idx = o - 1024; e = PE_B0 + idx; }
+    else if (o < 5184) { t = 2; idx = o - 1088; const int r = idx >> 6, c = idx & 63;
+                         e = PE_W2 + ((((r >> 4) * 4 + (c >> 4)) * 64) + ((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3); }
+    else if (o < 5248) { t = 3; idx = o - 5184; e = PE_B2 + idx; }
+    else if (o < 9344) { t = 4; idx = o - 5248; const int r = idx >> 6, c = idx & 63;
+                         e = PE_W4 + ((((r >> 4) * 4 + (c >> 4)) * 64) + ((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3); }
+    else if (o < 9408) { t = 5; idx = o - 9344; e = PE_B4 + idx; }
+    else if (o < 9536) { t = 6; idx = o - 9408; e = idx < 64 ? PE_W6 + idx : -1; }
+    else if (o < 9538) { t = 7; idx = o - 9536; e = idx == 0 ? PE_B6 : -1; }
+    float s = 0.f;
+    if (t >= 0 && e >= 0)
+        for (int w = slice; w < p.nwg; w += 4) s += p.partial[(int64_t)w * PE_TOTAL + e];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && t >= 0 && p.dhw[t]) {
+        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        float* d = p.dhw[t] + idx;
+        *d = p.accumulate ? *d + tot : tot;
+    }
+}
+
 // ---- fusion_out_conv (1x1, 16->1) + sigmoid + crop ------------------------------------------------------------
 __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, const float* w, const float* bias,
                                                                    pc_dst out, int B, int H, int W, int py, int px) {
@@ -382,6 +714,50 @@ extern "C" int pc_compact_masked(const float* src, const uint8_t* mask, float* o
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nblocks, n_out);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(256), 0, st, src, mask, bc, out, n);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
+                           const float* building, const float* admin_mask, const int64_t* census_idx,
+                           const float* g_popcount, const float* g_popdense, const float* g_scale_map,
+                           const float* g_scale_const, float* const* dhw, int accumulate,
+                           const pc_dst* g_feat, int Hp, int Wp, void* ws, int B, int H, int W, void* stream) {
+    if (!feat || !hw || !building || !dhw || !g_feat || !ws) return PC_EINVAL;
+    if (admin_mask && !census_idx) return PC_EINVAL;
+    if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(g_feat->ptr, 0, (size_t)B * 16 * Hp * Wp * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    HeadBwdArgs a{};
+    HeadArgs& p = a.f;
+    p.feat = *feat; p.py = py; p.px = px;
+    p.w0 = hw[0]; p.b0 = hw[1]; p.w2 = hw[2]; p.b2 = hw[3]; p.w4 = hw[4]; p.b4 = hw[5]; p.w6 = hw[6]; p.b6 = hw[7];
+    p.mask = mask; p.building = building; p.admin = admin_mask; p.census = census_idx;
+    p.B = B; p.H = H; p.W = W;
+    p.groups = (H * W + 15) / 16;
+    a.g_popcount = g_popcount; a.g_popdense = g_popdense; a.g_scale_map = g_scale_map; a.g_scale_const = g_scale_const;
+    a.g_feat = *g_feat;
+    a.total_groups = B * p.groups;
+    // fwd partials live at the start of ws; the backward partials follow
+    const int64_t nchunk = (p.groups + 31) / 32 + 1;
+    a.partial = reinterpret_cast<float*>(ws) + B * nchunk;
+    int nwg = (a.total_groups + 3) / 4;
+    if (nwg > 256) nwg = 256;
+    if (nwg < 1) nwg = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
+    PC_CHECK_LAUNCH();
+    HeadReduceArgs r{};
+    r.partial = a.partial; r.nwg = nwg; r.accumulate = accumulate;
+    for (int i = 0; i < 8; ++i) r.dhw[i] = dhw[i];
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((9538 + 63) / 64), dim3(256), 0, st, r);
     PC_CHECK_LAUNCH();
     return 0;
 }

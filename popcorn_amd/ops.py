@@ -186,3 +186,25 @@ def compact_masked(src, mask):
     L.check(L.lib().pc_compact_masked(L.ptr(src), L.ptr(mask), L.ptr(out), L.ptr(cnt), L.ptr(ws), C.c_int64(n),
                                       L.stream_ptr()), "pc_compact_masked")
     return out, cnt
+
+
+def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
+             g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
+             g_feat=None):
+    """Backward of head_fwd.  Returns (list of 8 head grads, g_feat (B,16,Hp,Wp))."""
+    L.require_device(feat, building, *head_tensors)
+    B, _, Hp, Wp = feat.shape
+    dev = feat.device
+    if grads is None:
+        grads = [torch.empty_like(t) for t in head_tensors]
+    if g_feat is None:
+        g_feat = torch.empty(B, 16, Hp, Wp, device=dev, dtype=torch.float32)
+    ws = _workspace(L.lib().pc_head_ws_bytes(B, H, W), dev)
+    sf, d = L.src(feat), L.dst(g_feat)
+    hw = _hw_array(head_tensors)
+    dhw = (C.c_void_p * 8)(*[0 if t is None else t.data_ptr() for t in grads])
+    L.check(L.lib().pc_head_bwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
+                                L.ptr(census_idx), L.ptr(g_popcount), L.ptr(g_popdense), L.ptr(g_scale_map),
+                                L.ptr(g_scale_const), dhw, int(accumulate), C.byref(d), Hp, Wp, L.ptr(ws), B, H, W,
+                                L.stream_ptr()), "pc_head_bwd")
+    return grads, g_feat

@@ -132,3 +132,58 @@ def test_head_fwd_vs_oracle(sparse, shape):
     with torch.no_grad():
         ref2 = (F.relu(O.head_forward(sd, headin)[:, 0]) * building[:, 0]).sum((1, 2))
     torch.testing.assert_close(pc2.cpu(), ref2, rtol=2e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("shape", [(3, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
+def test_head_bwd_vs_oracle_autograd(sparse, shape):
+    """All four upstream-gradient routes at once; reference = torch autograd through the oracle head."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd import ops
+    B, H, W, Hp, Wp, py, px = shape
+    sd = O.load_golden_state(G)
+    names = [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+    work = dict(sd)
+    for n in names:
+        work[n] = sd[n].clone().requires_grad_(True)
+    feat = _mk(B, 16, Hp, Wp, seed=21).requires_grad_(True)
+    gen = torch.Generator().manual_seed(22)
+    building = torch.rand(B, 1, H, W, generator=gen)
+    admin = (torch.rand(B, H, W, generator=gen) < 0.6).float() * 5.0
+    census = torch.full((B,), 5, dtype=torch.int64)
+    mask = (torch.rand(B, H, W, generator=gen) < 0.5) & (admin == 5.0)
+    g_pc = torch.randn(B, generator=gen)
+    g_pd = torch.randn(B, H, W, generator=gen) * 0.1
+    g_sm = torch.randn(B, H, W, generator=gen) * 0.1
+    g_const = 0.37
+    headin = feat[:, :, py:py + H, px:px + W]
+    if sparse:
+        out = O.sparse_head_forward(work, headin, mask)[:, 0]
+        selmask = mask
+    else:
+        out = O.head_forward(work, headin)[:, 0]
+        selmask = torch.ones(B, H, W, dtype=torch.bool)
+    scale = F.relu(out)
+    pd = scale * building[:, 0]
+    pc = (pd * (admin == census.view(-1, 1, 1))).sum((1, 2))
+    loss = (pc * g_pc).sum() + (pd * g_pd).sum() + (scale * g_sm).sum() + g_const * scale[selmask].sum()
+    loss.backward()
+    ht = [sd[n].cuda() for n in names]
+    grads, g_feat = ops.head_bwd(feat.detach().cuda(), py, px, H, W, ht, building.cuda(),
+                                 mask=mask.to(torch.uint8).cuda() if sparse else None,
+                                 admin_mask=admin.cuda(), census_idx=census.cuda(), g_popcount=g_pc.cuda(),
+                                 g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
+                                 g_scale_const=torch.tensor([g_const], device="cuda"))
+    for n, gr in zip(names, grads):
+        ref = work[n].grad
+        tol = 3e-6 * max(1.0, ref.abs().max().item())
+        torch.testing.assert_close(gr.cpu(), ref, rtol=2e-5, atol=tol, msg=lambda m, n=n: f"{n}: {m}")
+    torch.testing.assert_close(g_feat.cpu(), feat.grad, rtol=2e-5, atol=1e-6)
+    # second output channel of head.6 gets exact zeros; run-to-run determinism
+    assert torch.all(grads[6][1] == 0) and grads[7][1].item() == 0.0
+    grads2, g_feat2 = ops.head_bwd(feat.detach().cuda(), py, px, H, W, ht, building.cuda(),
+                                   mask=mask.to(torch.uint8).cuda() if sparse else None,
+                                   admin_mask=admin.cuda(), census_idx=census.cuda(), g_popcount=g_pc.cuda(),
+                                   g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
+                                   g_scale_const=torch.tensor([g_const], device="cuda"))
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2)) and torch.equal(g_feat, g_feat2)

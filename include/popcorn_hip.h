@@ -75,6 +75,8 @@ int pc_abi_version(void);
 /* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
 int pc_device_count(void);
 const char* pc_error_string(int code);
+/* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn (lets a binding verify its struct layout) */
+int pc_sizeof(int which);
 
 /* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
  * Input channels = a.C + b.C (torch.cat([skip, up]) fused, networks.py:318); conv domain H x W, batch B.
@@ -145,12 +147,15 @@ int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, cons
  *   scale-regularisation term scale_regularization * lam / Nsel, utils/losses.py:74-76).
  * Produces the 8 head gradients dhw[i] (=|+=; entries may be NULL; head.6 row/bias 1 get exact zeros, as autograd
  * gives for the unused second output channel) and the gradient w.r.t. the padded 16-channel feature map g_feat
- * (contiguous B x 16 x Hp x Wp; zero outside the crop and on unselected pixels). */
+ * (contiguous B x 16 x Hp x Wp; zero outside the crop and on unselected pixels).  If feat_bn_sar/feat_bn_opt are given
+ * (BN of the layers that produced feature channels 0-7 / 8-15, networks.py:263-266) g_feat is additionally multiplied by
+ * (feat > 0) * bn_scale, i.e. it is the gradient w.r.t. those layers' conv outputs. */
 int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                 const float* building, const float* admin_mask, const int64_t* census_idx,
                 const float* g_popcount, const float* g_popdense, const float* g_scale_map,
                 const float* g_scale_const, float* const* dhw, int accumulate,
-                const pc_dst* g_feat, int Hp, int Wp, void* ws, int B, int H, int W, void* stream);
+                const pc_dst* g_feat, const pc_bn* feat_bn_sar, const pc_bn* feat_bn_opt,
+                int Hp, int Wp, void* ws, int B, int H, int W, void* stream);
 
 /* ---- compaction of scale[mask] in row-major (b,y,x) order (the boolean-index gather of popcorn.py:173).
  * out must hold B*H*W floats; *n_out (device int32) receives Nsel. */

@@ -17,3 +17,13 @@ extern "C" const char* pc_error_string(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
+
+// sizeof() of the ABI structs as the compiler laid them out: 0 = pc_src, 1 = pc_dst, 2 = pc_bn (binding self-check)
+extern "C" int pc_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(pc_src);
+        case 1: return (int)sizeof(pc_dst);
+        case 2: return (int)sizeof(pc_bn);
+        default: return -1;
+    }
+}

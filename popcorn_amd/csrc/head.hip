@@ -205,6 +205,8 @@ struct HeadBwdArgs {
     const float* g_scale_map;    // [B][H][W] or NULL
     const float* g_scale_const;  // device scalar or NULL: added on every selected pixel
     pc_dst g_feat;
+    pc_bn fbn[2];                // BN of the layers that produced feat channels 0-7 / 8-15 (fuse_feat_bn)
+    int fuse_feat_bn;            // 1: g_feat *= (feat > 0) * bn_scale  (ReLU + frozen-BN backward of those layers)
     float* partial;              // [nwg][PE_TOTAL]
     int total_groups;
 };
@@ -290,6 +292,16 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
     float* hm = gm + 64 * SCR_LD;
     const int HW = p.H * p.W;
     const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
+    float fscale[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        fscale[r] = 1.f;
+        if (a.fuse_feat_bn) {
+            const int c = 4 * lk + r;
+            float sh;
+            pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
+        }
+    }
 
     f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4], db0[4], db2[4], db4[4];
     float db6 = 0.f;
@@ -412,7 +424,15 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         if (valid) {
             float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = gx[r];
+            for (int r = 0; r < 4; ++r) {
+                float o = gx[r];
+                // xv[r'] holds feat channel 4*j + lk; channel 4*lk + r is held by lane group lk' = r at j = lk
+                if (a.fuse_feat_bn) {
+                    const float fv = fp[(4 * lk + r) * p.feat.cstride];
+                    o = fv > 0.f ? o * fscale[r] : 0.f;
+                }
+                op[(4 * lk + r) * a.g_feat.cstride] = o;
+            }
         }
     }
 
@@ -722,7 +742,8 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
                            const float* building, const float* admin_mask, const int64_t* census_idx,
                            const float* g_popcount, const float* g_popdense, const float* g_scale_map,
                            const float* g_scale_const, float* const* dhw, int accumulate,
-                           const pc_dst* g_feat, int Hp, int Wp, void* ws, int B, int H, int W, void* stream) {
+                           const pc_dst* g_feat, const pc_bn* feat_bn_sar, const pc_bn* feat_bn_opt,
+                           int Hp, int Wp, void* ws, int B, int H, int W, void* stream) {
     if (!feat || !hw || !building || !dhw || !g_feat || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
     if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
@@ -738,6 +759,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     p.groups = (H * W + 15) / 16;
     a.g_popcount = g_popcount; a.g_popdense = g_popdense; a.g_scale_map = g_scale_map; a.g_scale_const = g_scale_const;
     a.g_feat = *g_feat;
+    if (feat_bn_sar && feat_bn_opt) { a.fbn[0] = *feat_bn_sar; a.fbn[1] = *feat_bn_opt; a.fuse_feat_bn = 1; }
     a.total_groups = B * p.groups;
     // fwd partials live at the start of ws; the backward partials follow
     const int64_t nchunk = (p.groups + 31) / 32 + 1;

@@ -1,0 +1,270 @@
+"""POPCORN on MI355X: drop-in for the reference's ``model.popcorn.POPCORN`` (model/popcorn.py:13-377).
+
+Same constructor, same ``forward(inputs, train, padding, return_features, encoder_no_grad, unet_no_grad, sparse)``
+signature, same output dict, same state-dict keys, real ``nn.Parameter``s with ``.grad`` -- but every op on the path
+runs in the hand-written HIP kernels of libpopcorn_hip.so (popcorn_amd/engine.py).  The module refuses to run on CPU
+tensors: there is no stock-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import engine as E
+from .. import ops
+from . import networks
+
+STAGE1_FEATS = 8           # utils/constants.py:169
+
+
+def _burn_discriminator_rng():
+    """The reference constructs (and then discards) an ``ownDiscriminator(8, 2)`` inside every DualStreamUNet
+    (networks.py:44,179,49-66).  Its default initialisation consumes the global RNG *before* the head is built, so a
+    given ``torch.manual_seed`` only reproduces the reference's head weights if the same draws are made here."""
+    for cin, cout in ((8, 64), (64, 128), (128, 256), (256, 512)):
+        nn.Conv2d(cin, cout, kernel_size=3, stride=2, padding=1)
+    for cin, cout in ((512, 256), (256, 128), (128, 64), (64, 2)):
+        nn.ConvTranspose2d(cin, cout, kernel_size=3, stride=2, padding=1, output_padding=1)
+
+
+def _new_dualstream(device="cpu"):
+    net = networks.DualStreamUNet()
+    _burn_discriminator_rng()
+    from safetensors.torch import load_file
+    net.load_state_dict(load_file(networks.CHECKPOINT), strict=False)
+    return net.to(device)
+
+
+def pad_geometry(H, W, force):
+    """add_padding (popcorn.py:231-258) as numbers: (top, bottom, left, right)."""
+    if force:
+        return 14, 14, 14, 14
+    pt = pb = pl = pr = 0
+    if H % 32 != 0:
+        pt = (64 - H % 64) // 2
+        pb = (64 - H % 64) - pt
+    if W % 32 != 0:
+        pl = (64 - W % 64) // 2
+        pr = (64 - W % 64) - pl
+    return pt, pb, pl, pr
+
+
+class POPCORN(nn.Module):
+    def __init__(self, input_channels, feature_extractor="DDA", occupancymodel=False, pretrained=False, biasinit=0.75,
+                 sentinelbuildings=False):
+        super().__init__()
+        self.occupancymodel = occupancymodel
+        self.sentinelbuildings = sentinelbuildings
+        self.feature_extractor = feature_extractor
+        self.p = 14
+        self.p2d = (self.p,) * 4
+        self.parent = None
+        self.S1, self.S2 = True, True
+        if input_channels == 0:
+            self.S1, self.S2 = False, False
+        elif input_channels == 2:
+            self.S1, self.S2 = True, False
+        elif input_channels == 4:
+            self.S1, self.S2 = False, True
+        if not (self.S1 and self.S2):
+            raise NotImplementedError("popcorn_amd implements the dual-stream S1+S2 configuration (input_channels=6); "
+                                      "single-modality variants (popcorn.py:136-145) are not built yet")
+
+        self.unetmodel = _new_dualstream()                                   # popcorn.py:57
+        if not pretrained:                                                   # popcorn.py:59-66
+            for m in self.unetmodel.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                elif isinstance(m, nn.BatchNorm2d):
+                    nn.init.constant_(m.weight, 1)
+                    nn.init.constant_(m.bias, 0)
+        head_input_dim = self.S1 * STAGE1_FEATS + self.S2 * STAGE1_FEATS
+        self.unetmodel.num_params = sum(p.numel() for p in self.unetmodel.parameters() if p.requires_grad)
+        h = 64
+        self.head = nn.Sequential(                                           # popcorn.py:80-85
+            nn.Conv2d(head_input_dim, h, kernel_size=1, padding=0), nn.ReLU(inplace=True),
+            nn.Conv2d(h, h, kernel_size=1, padding=0), nn.ReLU(inplace=True),
+            nn.Conv2d(h, h, kernel_size=1, padding=0), nn.ReLU(inplace=True),
+            nn.Conv2d(h, 2, kernel_size=1, padding=0))
+        self.head[-1].bias.data = biasinit * torch.ones(2)                   # popcorn.py:88
+        self.num_params = sum(p.numel() for p in self.head.parameters() if p.requires_grad) + self.unetmodel.num_params
+        self.building_extractor = _new_dualstream()                          # popcorn.py:96
+        self._engines = None
+
+    # ------------------------------------------------------------------------------------------- engine plumbing
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._engines = None           # .cuda()/.to() re-create tensors: drop cached device pointers
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._engines = None
+        return r
+
+    def invalidate_cache(self):
+        self._engines = None
+
+    @staticmethod
+    def _tensor_table(net):
+        t = dict(net.named_parameters())
+        t.update(dict(net.named_buffers()))
+        return t
+
+    def engines(self):
+        if self._engines is None:
+            self._engines = (E.UNetEngine(self._tensor_table(self.unetmodel)),
+                             E.UNetEngine(self._tensor_table(self.building_extractor)))
+        return self._engines
+
+    def head_tensors(self):
+        return [getattr(self.head[i], n) for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+
+    def trainable(self):
+        """(names, parameters) that receive gradients, in a fixed order: 48 U-Net tensors + 8 head tensors."""
+        names = E.trainable_names("unetmodel.") + [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+        table = dict(self.named_parameters())
+        return names, [table[n] for n in names]
+
+    # ------------------------------------------------------------------------------------------------- pieces
+    def add_padding(self, data, force=True):
+        """Kept for API compatibility (popcorn.py:231-258); the engine fuses this into its first conv."""
+        raise RuntimeError("add_padding is fused into the first HIP conv; use pad_geometry()")
+
+    def create_building_score(self, inputs):
+        """popcorn.py:279-322."""
+        X = inputs["input"]
+        L.require_device(X)
+        self.building_extractor.eval()
+        self.unetmodel.freeze_bn_layers()
+        with torch.no_grad():
+            return self.engines()[1].building_score(X.contiguous(), self.p)
+
+    def get_sparsity_mask(self, inputs, sparse_unet=False):
+        """popcorn.py:361-377 (non-sparse_unet branch).  The two ``multinomial`` draws come from the CPU global
+        generator exactly as in the reference (so a seeded run selects the same grid); the mask itself is built on
+        the device.  Returns (bool mask (B,H,W), None)."""
+        if sparse_unet:
+            raise NotImplementedError("sparse_unet branch (popcorn.py:371-396) is unused by the reference's callers")
+        mask, _ = self._sparsity_mask_u8(inputs)
+        return mask.bool(), None
+
+    def _sparsity_mask_u8(self, inputs):
+        admin = inputs["admin_mask"]
+        B, H, W = admin.shape
+        sub = 60
+        xi = torch.ones(H).multinomial(num_samples=min(sub, H), replacement=False)
+        yi = torch.ones(W).multinomial(num_samples=min(sub, W), replacement=False)
+        sel = torch.zeros(H + W, dtype=torch.uint8)
+        sel[xi] = 1
+        sel[H + yi] = 1
+        sel = sel.to(admin.device, non_blocking=True)
+        bc = inputs["building_counts"]
+        return ops.sparsity_mask(bc.contiguous(), admin.contiguous().float(), inputs["census_idx"].contiguous(),
+                                 sel[:H], sel[H:], self.occupancymodel)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, inputs, train=False, padding=True, return_features=True, encoder_no_grad=False,
+                unet_no_grad=False, sparse=False):
+        X = inputs["input"]
+        L.require_device(X)
+        if X.dim() != 4:
+            raise ValueError("Input tensor must have shape (batch_size, channels, height, width)")
+        X = X.contiguous().float()
+        B, _, H, W = X.shape
+        if "building_counts" not in inputs.keys() or self.sentinelbuildings:
+            inputs["building_counts"] = self.create_building_score(inputs)
+        building = inputs["building_counts"].contiguous()
+        mask = None
+        if sparse:
+            mask, _ = self._sparsity_mask_u8(inputs)
+        self.unetmodel.freeze_bn_layers()
+        pt, pb, pl, pr = pad_geometry(H, W, padding)
+        geom = (pt, pl, H + pt + pb, W + pl + pr)
+        admin = inputs["admin_mask"].contiguous().float() if "admin_mask" in inputs.keys() else None
+        census = inputs["census_idx"].contiguous() if admin is not None else None
+        if not self.occupancymodel:
+            # popcorn.py:179-181: popdensemap = relu(out), no building product
+            building = torch.ones_like(building)
+
+        names, params = self.trainable()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if unet_no_grad:
+            self.unetmodel.eval()
+        if need_grad:
+            popcount, popdense, scale = _PopcornFn.apply(self, X, building, mask, admin, census, geom, sparse,
+                                                         encoder_no_grad, unet_no_grad, *params)
+        else:
+            popcount, popdense, scale = _forward_nograd(self, X, building, mask, admin, census, geom, sparse)
+        aux = {"scale": scale if self.occupancymodel else None}
+        return {"popcount": popcount, "popdensemap": popdense, **aux}
+
+
+def _forward_core(model, X, building, mask, admin, census, geom, sparse, save):
+    pt, pl, Hp, Wp = geom
+    B, _, H, W = X.shape
+    eng = model.engines()[0]
+    feats, saved = eng.forward(X, pt, pl, Hp, Wp, save=save)
+    ht = model.head_tensors()
+    scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, ht, building, mask=mask, admin_mask=admin,
+                                                 census_idx=census)
+    if sparse:
+        buf, cnt = ops.compact_masked(scale_map, mask)
+        scale = buf[: int(cnt.item())]          # Nsel sizes the returned tensor (the reference's boolean index syncs too)
+    else:
+        scale = scale_map
+    return feats, saved, scale, popdense, popcount
+
+
+def _forward_nograd(model, X, building, mask, admin, census, geom, sparse):
+    with torch.no_grad():
+        _, _, scale, popdense, popcount = _forward_core(model, X, building, mask, admin, census, geom, sparse, save=False)
+    return popcount, popdense, scale
+
+
+class _PopcornFn(torch.autograd.Function):
+    """One autograd node for unetmodel + head + occupancy product + census reduction."""
+
+    @staticmethod
+    def forward(ctx, model, X, building, mask, admin, census, geom, sparse, encoder_no_grad, unet_no_grad, *params):
+        feats, saved, scale, popdense, popcount = _forward_core(model, X, building, mask, admin, census, geom, sparse,
+                                                                save=not unet_no_grad)
+        ctx.model, ctx.saved, ctx.feats = model, saved, feats
+        ctx.aux = (X, building, mask, admin, census, geom, sparse, encoder_no_grad, unet_no_grad)
+        return popcount, popdense, scale
+
+    @staticmethod
+    def backward(ctx, g_popcount, g_popdense, g_scale):
+        model = ctx.model
+        X, building, mask, admin, census, geom, sparse, encoder_no_grad, unet_no_grad = ctx.aux
+        pt, pl, Hp, Wp = geom
+        B, _, H, W = X.shape
+        names, params = model.trainable()
+        eng = model.engines()[0]
+        g_scale_map = None
+        if g_scale is not None:
+            if sparse:
+                g_scale_map = torch.zeros(B, H, W, device=X.device, dtype=torch.float32)
+                g_scale_map[mask.bool()] = g_scale.contiguous().float()
+            else:
+                g_scale_map = g_scale.contiguous().float()
+        grads = {n: torch.empty_like(p) for n, p in zip(names, params)}
+        hgrads = [grads[n] for n in names[-8:]]
+        _, G = ops.head_bwd(ctx.feats, pt, pl, H, W, model.head_tensors(), building, mask=mask, admin_mask=admin,
+                            census_idx=census,
+                            g_popcount=None if g_popcount is None else g_popcount.contiguous().float(),
+                            g_popdense=None if g_popdense is None else g_popdense.contiguous().float(),
+                            g_scale_map=g_scale_map, grads=hgrads,
+                            feat_bn=None if unet_no_grad else eng.feat_bn())
+        if unet_no_grad:
+            out = [None] * 48 + hgrads
+        else:
+            eng.backward(ctx.saved, G, grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
+            out = []
+            for n in names[:48]:
+                is_enc = any(("." + E.CONVS[t][0] + ".") in n for t in E.ENCODER)
+                out.append(None if (encoder_no_grad and is_enc) else grads[n])
+            out += hgrads
+        ctx.saved = None
+        return (None,) * 10 + tuple(out)

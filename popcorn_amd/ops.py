@@ -12,10 +12,9 @@ import torch
 from . import _lib as L
 
 
-def conv3x3_bn_relu(a, w, bias, gamma=None, beta=None, mean=None, var=None, eps=1e-5, relu=True, b=None,
-                    a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), chmap=(0, 1, 2, 3), out=None, out_hw=None,
-                    b_offset=(0, 0), a_channels=None):
-    """Conv2d(3x3, pad 1)(cat[a, b]) -> BN(eval) -> ReLU.  networks.py:259-266,318.
+def conv3x3_raw(a, w, bnd, relu=True, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), chmap=(0, 1, 2, 3), out=None,
+                out_hw=None, b_offset=(0, 0), a_channels=None):
+    """Conv2d(3x3, pad 1)(cat[a, b]) -> BN(eval) -> ReLU with a prebuilt pc_bn descriptor.  networks.py:259-266,318.
 
     a_mode POOL2: a is at twice the resolution (MaxPool2d(2) fused).  a_mode REFLECT: a is reflect-padded by
     a_pad=(top,left) up to out_hw and its channels gathered through chmap."""
@@ -34,12 +33,15 @@ def conv3x3_bn_relu(a, w, bias, gamma=None, beta=None, mean=None, var=None, eps=
     sb = L.src(b, oy=b_offset[0], ox=b_offset[1]) if b is not None else None
     if out is None:
         out = torch.empty(B, Cout, H, W, device=a.device, dtype=torch.float32)
-    bnd = L.bn(bias, gamma, beta, mean, var, eps)
     d = L.dst(out)
     code = L.lib().pc_conv3x3_bn_relu_fwd(C.byref(sa), C.byref(sb) if sb is not None else None, L.ptr(w), C.byref(bnd),
                                           int(relu), C.byref(d), B, H, W, Ca + Cb, Cout, L.stream_ptr())
     L.check(code, "pc_conv3x3_bn_relu_fwd")
     return out
+
+
+def conv3x3_bn_relu(a, w, bias, gamma=None, beta=None, mean=None, var=None, eps=1e-5, relu=True, **kw):
+    return conv3x3_raw(a, w, L.bn(bias, gamma, beta, mean, var, eps), relu=relu, **kw)
 
 
 def conv3x3_dgrad(g, w, c0, cn, out, act=None, act_bn=None, pool=False, accumulate=False):
@@ -190,7 +192,7 @@ def compact_masked(src, mask):
 
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
-             g_feat=None):
+             g_feat=None, feat_bn=None):
     """Backward of head_fwd.  Returns (list of 8 head grads, g_feat (B,16,Hp,Wp))."""
     L.require_device(feat, building, *head_tensors)
     B, _, Hp, Wp = feat.shape
@@ -205,6 +207,7 @@ def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     dhw = (C.c_void_p * 8)(*[0 if t is None else t.data_ptr() for t in grads])
     L.check(L.lib().pc_head_bwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
                                 L.ptr(census_idx), L.ptr(g_popcount), L.ptr(g_popdense), L.ptr(g_scale_map),
-                                L.ptr(g_scale_const), dhw, int(accumulate), C.byref(d), Hp, Wp, L.ptr(ws), B, H, W,
-                                L.stream_ptr()), "pc_head_bwd")
+                                L.ptr(g_scale_const), dhw, int(accumulate), C.byref(d),
+                                C.byref(feat_bn[0]) if feat_bn else None, C.byref(feat_bn[1]) if feat_bn else None,
+                                Hp, Wp, L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_bwd")
     return grads, g_feat

@@ -1,0 +1,159 @@
+"""Model-level parity on the GPU: POPCORN.forward (HIP) vs the golden vectors produced by the reference itself
+(g2 forward, g5 train step) and vs the CPU oracle on fresh seeded inputs.  Tolerances (north_star): forward
+<= 1e-4 relative in fp32; mask / Nsel index paths bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407,
+                sentinelbuildings=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", ["b2_100", "b1_131x77", "b2_64"])
+@pytest.mark.parametrize("padding", [True, False])
+@pytest.mark.parametrize("sparse", [True, False])
+def test_forward_vs_reference_golden(model, name, padding, sparse):
+    g = np.load(os.path.join(G, "g2_forward.npz"))
+    inp = {"input": torch.from_numpy(g[f"{name}/input"]).cuda(),
+           "admin_mask": torch.from_numpy(g[f"{name}/admin_mask"]).cuda(),
+           "census_idx": torch.from_numpy(g[f"{name}/census_idx"]).cuda()}
+    model.eval()
+    torch.manual_seed(1600)
+    with torch.no_grad():
+        o = model(inp, train=False, padding=padding, sparse=sparse)
+    tag = f"{name}/pad{int(padding)}_sp{int(sparse)}"
+    np.testing.assert_allclose(inp["building_counts"].cpu().numpy(), g[f"{name}/building_counts"], rtol=0, atol=1e-5)
+    assert rel_err(o["popdensemap"].cpu().numpy(), g[f"{tag}/popdensemap"]) < 1e-4
+    assert rel_err(o["popcount"].cpu().numpy(), g[f"{tag}/popcount"]) < 1e-4
+    assert o["scale"].shape == g[f"{tag}/scale"].shape                  # Nsel: index path, exact
+    assert rel_err(o["scale"].cpu().numpy(), g[f"{tag}/scale"]) < 1e-4
+    # feature map (padded domain) through the engine directly
+    from popcorn_amd.model.popcorn import pad_geometry
+    H, W = inp["input"].shape[2:]
+    pt, pb, pl, pr = pad_geometry(H, W, padding)
+    feats, _ = model.engines()[0].forward(inp["input"], pt, pl, H + pt + pb, W + pl + pr)
+    assert tuple(feats.shape) == tuple(g[f"{tag}/feat_shape"])
+    np.testing.assert_allclose(feats[:, :, ::7, ::5].cpu().numpy(), g[f"{tag}/feat_sample"], rtol=0, atol=3e-5)
+    assert abs(feats.double().sum().item() - float(g[f"{tag}/feat_sum64"])) < 1e-5 * abs(float(g[f"{tag}/feat_sum64"])) + 1e-2
+
+
+@pytest.mark.parametrize("name", ["b2_100", "b1_131x77"])
+def test_forward_noadmin_eval_call(model, name):
+    g = np.load(os.path.join(G, "g2_forward.npz"))
+    inp = {"input": torch.from_numpy(g[f"{name}/input"]).cuda()}
+    with torch.no_grad():
+        o = model(inp, padding=False)
+    assert rel_err(o["popcount"].cpu().numpy(), g[f"{name}/noadmin/popcount"]) < 1e-4
+    assert rel_err(o["popdensemap"].cpu().numpy(), g[f"{name}/noadmin/popdensemap"]) < 1e-4
+
+
+def test_layer_activations_vs_reference_golden(model):
+    """Per-layer bisecting aid (fixture g3): un-padded 36x28 tile straight through both streams."""
+    g = np.load(os.path.join(G, "g3_layers.npz"))
+    X6 = torch.from_numpy(g["input"])                       # already in [VV,VH,B,G,R,NIR] order
+    # engine expects the dataset order [R,G,B,NIR,VV,VH]: invert the reorder
+    X = torch.cat([X6[:, 4:5], X6[:, 3:4], X6[:, 2:3], X6[:, 5:6], X6[:, 0:2]], 1).cuda()
+    eng = model.engines()[0]
+    feats, saved = eng.forward(X, 0, 0, 36, 28, save=True)
+    np.testing.assert_allclose(feats.cpu().numpy(), g["features"], rtol=0, atol=2e-5)
+    ref = {"a1": "inc.conv.conv.2", "a2": "inc.conv.conv.5", "b1": "down_seq.down1.mpconv.1.conv.2",
+           "b2": "down_seq.down1.mpconv.1.conv.5", "c1": "down_seq.down2.mpconv.1.conv.2",
+           "c2": "down_seq.down2.mpconv.1.conv.5", "u2": "up_seq.up2.up", "e1": "up_seq.up2.conv.conv.2",
+           "e2": "up_seq.up2.conv.conv.5", "u1": "up_seq.up1.up", "f1": "up_seq.up1.conv.conv.2"}
+    for s in ("sar_stream", "optical_stream"):
+        for k, r in ref.items():
+            np.testing.assert_allclose(saved[s][k].cpu().numpy(), g[f"act/{s}.{r}"], rtol=0, atol=2e-5, err_msg=f"{s}.{k}")
+
+
+def test_train_step_vs_reference_golden(model):
+    """Reference recipe (run_train.py:201-238) through the drop-in module + torch autograd + torch Adam: loss,
+    all 56 gradients, clipped norm and post-Adam parameters vs fixture g5."""
+    from torch.nn.utils import clip_grad_norm_
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.utils.losses import get_loss
+    g = np.load(os.path.join(G, "g5_train.npz"))
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407,
+                sentinelbuildings=True).cuda()
+    m.train()
+    head_name = ["head.6.weight", "head.6.bias"]
+    named = list(m.named_parameters())
+    opt = torch.optim.Adam([
+        {"params": [p for n, p in named if n not in head_name and "unetmodel" not in n], "weight_decay": 1e-5},
+        {"params": [p for n, p in named if n not in head_name and "unetmodel" in n], "weight_decay": 1e-5},
+        {"params": [p for n, p in named if n in head_name and "unetmodel" not in n], "weight_decay": 0.0}], lr=1e-4)
+    sample0 = {k: torch.from_numpy(g[k]).cuda() for k in ("input", "admin_mask", "census_idx", "y")}
+    traj = []
+    for step in range(3):
+        torch.manual_seed(1700 + step)
+        sample = dict(sample0)
+        o = m(sample, train=True, padding=False, sparse=True)
+        loss, ld = get_loss(o, sample, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01,
+                            tag="weak")
+        opt.zero_grad()
+        (loss * 100.0).backward()
+        if step == 0:
+            assert o["scale"].numel() == int(g["step0/nsel"])
+            assert rel_err(o["popcount"].detach().cpu().numpy(), g["step0/popcount"]) < 1e-4
+            got = {n for n, p in named if p.grad is not None}
+            assert got == set(g["step0/grad_names"].tolist())
+            for n, p in named:
+                if p.grad is not None:
+                    ref = g["step0/grad/" + n]
+                    e = np.abs(p.grad.cpu().numpy() - ref).max()
+                    assert e <= 2e-4 * max(np.abs(ref).max(), 1e-3), (n, e, np.abs(ref).max())
+            for k in [k for k in g.files if k.startswith("step0/lossdict/")]:
+                kk = k[len("step0/lossdict/"):].replace("|", "/")
+                assert abs(ld[kk] - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), kk
+        total = clip_grad_norm_(m.parameters(), 0.01)
+        if step == 0:
+            assert abs(total.item() - float(g["step0/total_norm"])) < 2e-4 * float(g["step0/total_norm"])
+        opt.step()
+        if step == 0:
+            for n, p in named:
+                if p.grad is not None:
+                    np.testing.assert_allclose(p.detach().cpu().numpy(), g["step0/param_after/" + n], rtol=0, atol=1e-6)
+        traj.append(loss.item())
+    np.testing.assert_allclose(np.array(traj), g["loss_traj"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("flags", [dict(encoder_no_grad=True), dict(unet_no_grad=True, encoder_no_grad=True)])
+def test_grad_truncation_modes_vs_oracle(model, flags):
+    """limit1/limit2 regimes (run_train.py:191-198): encoder under no_grad / whole U-Net under no_grad."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd.utils.losses import get_loss
+    g = np.load(os.path.join(G, "g5_train.npz"))
+    sample = {k: torch.from_numpy(g[k]) for k in ("input", "admin_mask", "census_idx", "y")}
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(5)
+    _, _, ref_grads, _ = O.train_step_grads(sd, dict(sample), **flags)
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(5)
+    s = {k: v.cuda() for k, v in sample.items()}
+    o = model(s, train=True, padding=False, sparse=True, **flags)
+    loss, _ = get_loss(o, s, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01, tag="weak")
+    (loss * 100.0).backward()
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_grads)
+    for n, r in ref_grads.items():
+        e = (got[n].cpu() - r).abs().max().item()
+        assert e <= 2e-4 * max(r.abs().max().item(), 1e-3), (n, e)
+    model.zero_grad()

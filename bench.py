@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- training throughput of the POPCORN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched once per GPU by torch.distributed.run)
+
+One "step" = one full optimisation step of the reference recipe (run_train.py:186-238) on a batch of synthetic
+15-band 100x100 tiles already resident in HBM: band select + normalise -> frozen building-extractor U-Net ->
+sparsity mask -> trainable dual-stream U-Net forward -> sparse head -> log-L1 loss + scale regulariser -> backward
+(head, U-Net dgrad/wgrad) -> [N > 1: one RCCL all-reduce of the flat gradient] -> clip_grad_norm_(0.01) -> Adam.
+fp32 throughout (fp32 MFMA).  Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
+kernel, timed live with events) and, at N = 1, `cpu_baseline` (the CPU oracle = "port", timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_TRAIN_PER_TILE = 1_732_423_680          # SURVEY.md section 8d / BASELINE.md section 2 (all 10^4 px selected)
+FP32_MATRIX_PEAK = 157.3e12                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step (BASELINE config: 64)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    return ap.parse_args()
+
+
+def dominant_kernel_roofline(torch, model, B, reps=20):
+    """The dominant kernel class of the step is the 3x3 conv on 8-channel 128x128 maps (fwd / dgrad / wgrad all map
+    to the same MFMA structure); its largest single launch is the forward conv 8->8 at 128x128 over the batch.
+    Timed live: `reps` back-to-back launches between two events on the launch stream.
+    Algorithmic flops per launch = 2 * 9 * Cin * Cout * H * W * B (9,437,184 MAC / tile)."""
+    from popcorn_amd import ops
+    eng = model.engines()[0]
+    lay = eng.layers[("optical_stream", "inc2")]
+    x = torch.randn(B, 8, 128, 128, device="cuda")
+    out = torch.empty_like(x)
+    for _ in range(3):
+        ops.conv3x3_raw(x, lay.w, lay.bn, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv3x3_raw(x, lay.w, lay.bn, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    dur = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * 9 * 8 * 8 * 128 * 128 * B
+    achieved = flops / dur / 1e12
+    return {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<8,8,fwd> (8->8 ch, 128x128, fp32 MFMA 16x16x4)",
+            "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": None,
+            "launch_us": round(dur * 1e6, 2), "alg_flop_per_launch": flops,
+            "alg_bytes_per_launch": 2.0 * 4 * 8 * 128 * 128 * B}
+
+
+def cpu_baseline(torch, sd, cpu_batch, iters):
+    """The oracle (CPU restatement of the reference path, oracle/popcorn_oracle.py) timed on the host cores on a
+    bounded sample of the same workload: `iters` train steps (fwd + loss + bwd + clip + Adam) at B=cpu_batch."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    batch = make_raw_batch(cpu_batch, 100, 100, seed=1600)
+    sample = {"input": select_normalize_reference(batch["raw"]), "admin_mask": batch["admin_mask"],
+              "census_idx": batch["census_idx"], "y": batch["y"]}
+    params, state = dict(sd), {}
+
+    def one():
+        loss, out, grads, _ = O.train_step_grads(params, dict(sample))
+        _, clipped = O.clip_grad_norm(grads, 0.01)
+        params.update(O.adam_step(params, clipped, state, lr=1e-4, weight_decay=1e-5))
+
+    one()                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(cpu_batch * iters / dt, 2), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} train steps x B={cpu_batch} synthetic 100x100 tiles (oracle, torch-CPU fp32, "
+                      f"{cores} threads), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from popcorn_amd.distributed import FlatReducer, init_from_env
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd import ops
+    from popcorn_amd.model import Args, get_model_kwargs, model_dict
+    from popcorn_amd.train import FusedTrainStep
+
+    rank, local_rank, world = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B = args.batch
+
+    # rwa recipe (README.md:187): -S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407
+    margs = Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True, pretrained=True,
+                 biasinit=0.9407, sentinelbuildings=True)
+    torch.manual_seed(1600)
+    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    trainer = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,),
+                             scale_regularization=0.01, lam_weak=100.0, reducer=FlatReducer(),
+                             use_graph=not args.no_graph)
+    batch = make_raw_batch(B, 100, 100, seed=1600 + rank, device=dev)           # resident in HBM before timing
+    sample = {"admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}
+    x = torch.empty(B, 6, 100, 100, device=dev)
+
+    def step():
+        ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6, out=x)
+        sample["input"] = x
+        return trainer.step(sample)
+
+    torch.manual_seed(1600 + rank)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss[0].item())
+    if not (loss_val == loss_val) or abs(loss_val) == float("inf"):
+        raise SystemExit(f"non-finite loss {loss_val}")
+
+    if rank == 0:
+        tiles = B * world * args.steps
+        value = tiles / dt
+        res = {
+            "metric": "training patches/s (15-band 100x100)", "value": round(value, 1), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config[1]/[2]: batch={B} synthetic S1+S2 100x100 tiles per GPU, full train step "
+                                   "(building extractor + DDA dual-stream U-Net + sparse head fwd/bwd, log-L1 loss, "
+                                   "clip 0.01, Adam, rwa flags), every pixel of every tile selected",
+                       "global_batch": B * world, "tile": "15x100x100 -> 6x100x100 (128x128 internal)",
+                       "parallelism": f"dp{world}", "graph": not args.no_graph},
+            "final_loss": round(loss_val, 6),
+            "step_tflops": round(value * FLOP_TRAIN_PER_TILE / 1e12, 3),
+            "step_frac_of_fp32_mfma_peak": round(value * FLOP_TRAIN_PER_TILE / (FP32_MATRIX_PEAK * world), 4),
+        }
+        res["roofline"] = dominant_kernel_roofline(torch, model, B)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_batch, args.cpu_iters)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,12 +134,14 @@ int pc_sparsity_mask(const float* building, const float* admin_mask, const int64
  * popdensemap = scale * building, popcount[b] = sum over region pixels.  mask == NULL: dense head.
  * admin_mask == NULL: popcount = plain sum (popcorn.py:189-190).
  * feat: B x 16 x Hp x Wp read at crop offset (py,px) (revert_padding fused, popcorn.py:155).
- * hw: the 8 head tensors {w0,b0,w2,b2,w4,b4,w6,b6}.  ws: pc_head_ws_bytes(). */
+ * hw: the 8 head tensors {w0,b0,w2,b2,w4,b4,w6,b6}.  ws: pc_head_ws_bytes().
+ * stats (optional, device double[2]) receives {Nsel, sum(scale)}: Nsel = nsel_counts[0] (the int32 count written by
+ * pc_sparsity_mask) or B*H*W for the dense head -- the inputs of the scale regulariser (utils/losses.py:74). */
 int64_t pc_head_ws_bytes(int B, int H, int W);
 int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                 const float* building, const float* admin_mask, const int64_t* census_idx,
-                float* scale_map, float* popdensemap, float* popcount, void* ws,
-                int B, int H, int W, void* stream);
+                float* scale_map, float* popdensemap, float* popcount, double* stats,
+                const int32_t* nsel_counts, void* ws, int B, int H, int W, void* stream);
 
 /* backward of pc_head_fwd (the forward chain is recomputed in registers).  Upstream gradients, all optional (NULL):
  *   g_popcount[B]; g_popdense[B][H][W]; g_scale_map[B][H][W] (gradient w.r.t. scale = relu(out), e.g. the scattered
@@ -162,6 +164,33 @@ int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, cons
 int pc_compact_masked(const float* src, const uint8_t* mask, float* out, int32_t* n_out, void* ws, int64_t n,
                       void* stream);
 int64_t pc_compact_ws_bytes(int64_t n);
+
+/* ---- training-step scalars ------------------------------------------------------------------------- */
+
+/* Population loss + scale regulariser and their gradients, utils/losses.py:49-76 + autograd.
+ * lam4 = weights of {l1_loss, log_l1_loss, mse_loss, log_mse_loss} (host array of 4); the batch mean is taken with
+ * inv_B = 1 / (world_size * B) so that the SUM of all ranks' gradients equals the single-process gradient.
+ * stats: device double[2] {Nsel, sum(scale)} from pc_head_fwd (all-reduced across ranks in data-parallel runs).
+ * loss_out[2] = {loss, regulariser};  g_popcount[B] = d(lam_weak*loss)/d popcount;  *g_scale_const = lam_weak *
+ * scale_regularization / Nsel (the constant gradient of the regulariser on every selected pixel). */
+int pc_loss_fwd_bwd(const float* popcount, const float* y, const double* stats, const float* lam4,
+                    float scale_regularization, float lam_weak, float inv_B, int B,
+                    float* loss_out, float* g_popcount, float* g_scale_const, void* stream);
+
+/* L2 norm of a flat gradient buffer (torch.nn.utils.clip_grad_norm_'s total_norm, run_train.py:233-234); deterministic. */
+int pc_grad_norm(const float* g, int n, float* norm_out, void* stream);
+
+/* clip_grad_norm_(max_norm) + torch.optim.Adam step over flat buffers (run_train.py:82-90,233-238).  Weight decay
+ * (L2, added to the gradient) applies to elements [0, n_decay) only.  hyper_dev: device float[1] {lr};
+ * step_dev: device int32 step counter, incremented by the call.  max_norm <= 0 or norm_dev == NULL: no clipping. */
+int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
+                      float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                      const float* norm_dev, int32_t* step_dev, void* stream);
+
+/* Band selection + per-band (x - mean) / std: data/PopulationDataset.py:566-568 + utils/utils.py:105-127.
+ * raw: B x Craw x H x W; out: B x 6 x H x W; band6/mean6/std6: host arrays of 6. */
+int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,
+                        float* out, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ struct HeadArgs {
     const int64_t* census;
     float* scale_map;
     float* popdense;
-    float* partial;        // [B][nchunk]
+    float* partial;        // [B][nchunk][2]  {popcount partial, scale-sum partial}
     int B, H, W;
     int groups, nchunk, groups_per_wave;
 };
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     const int b = blockIdx.y;
     const int HW = p.H * p.W;
     const float cid = p.census ? (float)p.census[b] : 0.f;
-    float pc_sum = 0.f;
+    float pc_sum = 0.f, sc_sum = 0.f;
 
     const int g_begin = (blockIdx.x * 4 + wave) * p.groups_per_wave;
     int g_end = g_begin + p.groups_per_wave;
@@ -150,26 +150,57 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
             p.popdense[pix] = pd;
             const bool region = p.admin ? (p.admin[pix] == cid) : true;
             pc_sum += region ? pd : 0.f;
+            sc_sum += scale;
         }
     }
     // deterministic per-workgroup partial: lanes 0..15 of each wave hold the sums
     __syncthreads();
     float* red = lds;   // weights no longer needed
-    if (lk == 0) red[wave * 16 + li] = pc_sum;
+    if (lk == 0) { red[wave * 16 + li] = pc_sum; red[64 + wave * 16 + li] = sc_sum; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 2) {
         float t = 0.f;
-        for (int i = 0; i < 64; ++i) t += red[i];
-        p.partial[(int64_t)b * p.nchunk + blockIdx.x] = t;
+        for (int i = 0; i < 64; ++i) t += red[tid * 64 + i];
+        p.partial[((int64_t)b * p.nchunk + blockIdx.x) * 2 + tid] = t;
     }
 }
 
-__global__ void head_popcount_reduce_kernel(const float* partial, float* popcount, int B, int nchunk) {
+// popcount[b] = sum of the sample's partials (fixed order).  stats (optional, double[2]) = {Nsel, sum of scale over
+// the batch}: the two scalars the scale-regularisation term needs (utils/losses.py:74) -- and the only two numbers a
+// data-parallel run has to exchange before the backward pass.
+__global__ void head_popcount_reduce_kernel(const float* partial, float* popcount, int B, int nchunk, double* stats,
+                                            const int32_t* nsel_counts, double dense_count) {
+    __shared__ double ssum[64];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float t = 0.f;
-    for (int c = 0; c < nchunk; ++c) t += partial[(int64_t)b * nchunk + c];
-    popcount[b] = t;
+    double sc = 0.0;
+    if (b < B) {
+        float t = 0.f, u = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            t += partial[((int64_t)b * nchunk + c) * 2];
+            u += partial[((int64_t)b * nchunk + c) * 2 + 1];
+        }
+        popcount[b] = t;
+        sc = (double)u;
+    }
+    if (stats) {          // launched as ONE block when stats are requested
+        for (int bb = b + blockDim.x; bb < B; bb += blockDim.x) {
+            float t = 0.f, u = 0.f;
+            for (int c = 0; c < nchunk; ++c) {
+                t += partial[((int64_t)bb * nchunk + c) * 2];
+                u += partial[((int64_t)bb * nchunk + c) * 2 + 1];
+            }
+            popcount[bb] = t;
+            sc += (double)u;
+        }
+        ssum[threadIdx.x] = sc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < (int)blockDim.x; ++i) tot += ssum[i];
+            stats[0] = nsel_counts ? (double)nsel_counts[0] : dense_count;
+            stats[1] = tot;
+        }
+    }
 }
 
 // ---- head backward ---------------------------------------------------------------------------------------------
@@ -659,13 +690,13 @@ extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
     const int groups = (H * W + 15) / 16;
     const int64_t nchunk = (groups + 31) / 32 + 1;
     // fwd partials [B][nchunk]; the backward needs workgroup partials of the 9.5k weight gradients
-    return (int64_t)B * nchunk * sizeof(float) + 512 * 12288 * (int64_t)sizeof(float);
+    return (int64_t)B * nchunk * 2 * sizeof(float) + 512 * 12288 * (int64_t)sizeof(float);
 }
 
 extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                            const float* building, const float* admin_mask, const int64_t* census_idx,
-                           float* scale_map, float* popdensemap, float* popcount, void* ws,
-                           int B, int H, int W, void* stream) {
+                           float* scale_map, float* popdensemap, float* popcount, double* stats,
+                           const int32_t* nsel_counts, void* ws, int B, int H, int W, void* stream) {
     if (!feat || !hw || !building || !popdensemap || !popcount || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
     HeadArgs p{};
@@ -681,7 +712,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3((B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B, p.nchunk);
+    hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
+                       p.nchunk, stats, nsel_counts, (double)B * H * W);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -763,7 +795,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     a.total_groups = B * p.groups;
     // fwd partials live at the start of ws; the backward partials follow
     const int64_t nchunk = (p.groups + 31) / 32 + 1;
-    a.partial = reinterpret_cast<float*>(ws) + B * nchunk;
+    a.partial = reinterpret_cast<float*>(ws) + B * nchunk * 2;
     int nwg = (a.total_groups + 3) / 4;
     if (nwg > 256) nwg = 256;
     if (nwg < 1) nwg = 1;

@@ -1,0 +1,178 @@
+// train_ops.hip -- the O(batch) / O(parameters) kernels of a training step: loss forward+backward, global gradient
+// norm, fused clip + Adam, and the loader-side band select + normalise.
+//
+// Replaces (reference): utils/losses.py:49-76 (population loss + scale regulariser) and its autograd;
+// torch.nn.utils.clip_grad_norm_ + optim.Adam (run_train.py:82-90,233-238); utils/utils.py:105-127 (apply_normalize)
+// + the band selection of data/PopulationDataset.py:566-568.
+#include "common.h"
+
+namespace {
+
+// ---- loss ---------------------------------------------------------------------------------------------------------
+// loss = sum_k lam[k] * L_k(popcount, y) + sreg * sum(scale) / Nsel, with L_k in {l1, log_l1, mse, log_mse} taken as
+// a mean over the GLOBAL batch (inv_B = 1 / (world * B)), so that summing every rank's gradient reproduces the
+// single-process gradient exactly.  Outputs d(lam_weak * loss)/d popcount[b] and the constant
+// d(lam_weak * loss)/d scale on selected pixels.
+struct LossArgs {
+    const float* popcount; const float* y; const double* stats;
+    float lam[4]; float sreg, lam_weak, inv_B; int B;
+    float* loss_out;        // [2]: {optimisation loss (local part of the batch mean + regulariser), regulariser}
+    float* g_popcount; float* g_scale_const;
+};
+
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+        const float pc = a.popcount[b], y = a.y[b];
+        const float d = pc - y;
+        const float lp = logf(pc + 1.f), ly = logf(y + 1.f);
+        const float dl = lp - ly;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float sgl = dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f);
+        const float l = a.lam[0] * fabsf(d) + a.lam[1] * fabsf(dl) + a.lam[2] * d * d + a.lam[3] * dl * dl;
+        const float g = a.lam[0] * sg + a.lam[1] * sgl / (pc + 1.f) + a.lam[2] * 2.f * d + a.lam[3] * 2.f * dl / (pc + 1.f);
+        a.g_popcount[b] = a.lam_weak * a.inv_B * g;
+        acc += (double)l;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nsel = a.stats ? a.stats[0] : 0.0, ssum = a.stats ? a.stats[1] : 0.0;
+        const double reg = (a.sreg > 0.f && nsel > 0.0) ? (double)a.sreg * ssum / nsel : 0.0;
+        a.loss_out[0] = (float)(red[0] * (double)a.inv_B + reg);
+        a.loss_out[1] = (float)reg;
+        *a.g_scale_const = (a.sreg > 0.f && nsel > 0.0) ? (float)((double)a.lam_weak * (double)a.sreg / nsel) : 0.f;
+    }
+}
+
+// ---- gradient norm (deterministic two-level tree over a flat buffer) ---------------------------------------------------
+__global__ __launch_bounds__(1024) void grad_norm_kernel(const float* g, int n, float* norm_out) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *norm_out = (float)sqrt(red[0]);
+}
+
+// ---- clip + Adam over the flat parameter buffer --------------------------------------------------------------------
+// torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected, eps outside the sqrt), with the
+// clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)) folded in.  Elements [0, n_decay) get weight decay, the
+// tail (head.6.*) does not (run_train.py:82-90).  hyper (device): {lr}.  step (device int32) is incremented here so a
+// captured graph advances the bias correction on every replay.
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    int n, n_decay;
+    const float* hyper; float wd, beta1, beta2, eps, max_norm;
+    const float* norm; int32_t* step;
+};
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(const AdamArgs a) {
+    __shared__ float sh[3];
+    if (threadIdx.x == 0) {
+        const int t = *a.step + 1;
+        const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
+        const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+        sh[0] = (float)((double)a.hyper[0] / bc1);          // step size
+        sh[1] = (float)sqrt(bc2);
+        float coef = 1.f;
+        if (a.max_norm > 0.f && a.norm) {
+            coef = a.max_norm / (*a.norm + 1e-6f);
+            coef = coef > 1.f ? 1.f : coef;
+        }
+        sh[2] = coef;
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2s = sh[1], coef = sh[2];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) {
+        float g = a.g[i] * coef;
+        const float p = a.p[i];
+        if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p, g);
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / bc2s + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+    }
+}
+
+__global__ void adam_step_inc_kernel(int32_t* step) { *step += 1; }
+
+// ---- band select + normalise -------------------------------------------------------------------------------------------
+// raw tile (B, Craw, H, W) -> model input (B, 6, H, W) = [(raw[band[c]] - mean[c]) / std[c]]
+struct SelNormArgs { const float* raw; float* out; int band[6]; float mean[6], stdv[6]; int Craw; int64_t hw, n; };
+
+__global__ __launch_bounds__(256) void select_normalize_kernel(const SelNormArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i % a.hw;
+        const int c = (int)((i / a.hw) % 6);
+        const int64_t b = i / (a.hw * 6);
+        a.out[i] = (a.raw[(b * a.Craw + a.band[c]) * a.hw + pix] - a.mean[c]) / a.stdv[c];
+    }
+}
+
+}  // namespace
+
+extern "C" int pc_loss_fwd_bwd(const float* popcount, const float* y, const double* stats, const float* lam4,
+                               float scale_regularization, float lam_weak, float inv_B, int B,
+                               float* loss_out, float* g_popcount, float* g_scale_const, void* stream) {
+    if (!popcount || !y || !lam4 || !loss_out || !g_popcount || !g_scale_const) return PC_EINVAL;
+    LossArgs a{};
+    a.popcount = popcount; a.y = y; a.stats = stats;
+    for (int i = 0; i < 4; ++i) a.lam[i] = lam4[i];
+    a.sreg = scale_regularization; a.lam_weak = lam_weak; a.inv_B = inv_B; a.B = B;
+    a.loss_out = loss_out; a.g_popcount = g_popcount; a.g_scale_const = g_scale_const;
+    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_grad_norm(const float* g, int n, float* norm_out, void* stream) {
+    if (!g || !norm_out) return PC_EINVAL;
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, norm_out);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
+                                 float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                                 const float* norm_dev, int32_t* step_dev, void* stream) {
+    if (!p || !g || !m || !v || !hyper_dev || !step_dev) return PC_EINVAL;
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_decay = n_decay; a.hyper = hyper_dev; a.wd = weight_decay;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.norm = norm_dev; a.step = step_dev;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    PC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,
+                                   float* out, int B, int H, int W, void* stream) {
+    if (!raw || !band6 || !mean6 || !std6 || !out) return PC_EINVAL;
+    SelNormArgs a{};
+    a.raw = raw; a.out = out; a.Craw = Craw; a.hw = (int64_t)H * W; a.n = (int64_t)B * 6 * H * W;
+    for (int i = 0; i < 6; ++i) {
+        if (band6[i] < 0 || band6[i] >= Craw) return PC_EINVAL;
+        a.band[i] = band6[i]; a.mean[i] = mean6[i]; a.stdv[i] = std6[i];
+    }
+    int grid = (int)((a.n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(select_normalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    PC_CHECK_LAUNCH();
+    return 0;
+}

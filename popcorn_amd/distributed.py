@@ -1,0 +1,69 @@
+"""Single-node data parallelism: one process per GPU, torch.distributed (backend 'nccl' = RCCL over xGMI).
+
+The reference has no distributed code; this is the build's own design for BASELINE configs 4-5:
+
+  * tiles are independent samples -> each rank draws its own B_local tiles; no data-path collective in the forward;
+  * the only couplings are the batch mean of the loss and the mean over *all selected pixels* of the scale
+    regulariser (utils/losses.py:53,74).  Each rank therefore normalises by the GLOBAL batch size and the GLOBAL
+    Nsel, which needs one 16-byte all-reduce of {Nsel, sum(scale)} before the backward pass;
+  * gradients: ONE sum-all-reduce of the flat 39,298-element fp32 gradient buffer (157 KB) per step -- never
+    per-tensor.  At this size a ring over 8 GPUs is latency-bound (~275 KB per GPU, ~2 us of xGMI time), so one
+    collective on a pre-flattened buffer is the right shape; bucketing would only add launches.
+    Because every rank already used the global normalisers, SUM (not mean) reproduces the single-process gradient;
+  * clip_grad_norm_ and Adam then run identically on every rank on the reduced buffer.
+
+The same code runs on the gloo backend with CPU tensors (tests/test_distributed_cpu.py).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (as set by torch.distributed.run).
+    Returns (rank, local_rank, world).  No-op for world == 1."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class FlatReducer:
+    """Sum-all-reduce of the flat gradient buffer and of the 2-scalar loss statistics."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def reduce_stats(self, stats: torch.Tensor):
+        """stats: float64[2] {Nsel, sum(scale)} -> global sums (in place)."""
+        if self.world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        return stats
+
+    def reduce_grads(self, flat: torch.Tensor):
+        """flat fp32 gradient buffer -> sum over ranks (in place).  One collective per step."""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def global_batch(self, local_batch: int) -> int:
+        return local_batch * self.world
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """Round-robin assignment of independent work items (tiles / sliding windows) to ranks."""
+    return list(range(rank, n_items, world))

@@ -160,7 +160,7 @@ def _hw_array(head_tensors):
 
 
 def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
-             want_scale=True):
+             want_scale=True, stats=None, nsel_counts=None):
     """Sparse/dense head + occupancy product + census reduction.  popcorn.py:161-190.
     head_tensors = [w0,b0,w2,b2,w4,b4,w6,b6].  Returns (scale_map, popdensemap, popcount)."""
     L.require_device(feat, building, *head_tensors)
@@ -173,8 +173,8 @@ def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     sf = L.src(feat)
     hw = _hw_array(head_tensors)
     L.check(L.lib().pc_head_fwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
-                                L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(ws),
-                                B, H, W, L.stream_ptr()), "pc_head_fwd")
+                                L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(stats),
+                                L.ptr(nsel_counts), L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_fwd")
     return scale_map, popdense, popcount
 
 
@@ -211,3 +211,37 @@ def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
                                 C.byref(feat_bn[0]) if feat_bn else None, C.byref(feat_bn[1]) if feat_bn else None,
                                 Hp, Wp, L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_bwd")
     return grads, g_feat
+
+
+def select_normalize(raw, band6, mean6, std6, out=None):
+    """Band selection + (x - mean) / std.  PopulationDataset.py:566-568 + utils/utils.py:105-127."""
+    L.require_device(raw)
+    B, Craw, H, W = raw.shape
+    assert raw.is_contiguous() and raw.dtype == torch.float32
+    if out is None:
+        out = torch.empty(B, 6, H, W, device=raw.device, dtype=torch.float32)
+    L.check(L.lib().pc_select_normalize(L.ptr(raw), Craw, (C.c_int * 6)(*band6), (C.c_float * 6)(*mean6),
+                                        (C.c_float * 6)(*std6), L.ptr(out), B, H, W, L.stream_ptr()),
+            "pc_select_normalize")
+    return out
+
+
+def loss_fwd_bwd(popcount, y, stats, lam4, scale_regularization, lam_weak, inv_B, loss_out, g_popcount, g_scale_const):
+    L.require_device(popcount, y)
+    L.check(L.lib().pc_loss_fwd_bwd(L.ptr(popcount), L.ptr(y), L.ptr(stats), (C.c_float * 4)(*lam4),
+                                    C.c_float(scale_regularization), C.c_float(lam_weak), C.c_float(inv_B),
+                                    popcount.numel(), L.ptr(loss_out), L.ptr(g_popcount), L.ptr(g_scale_const),
+                                    L.stream_ptr()), "pc_loss_fwd_bwd")
+
+
+def grad_norm(flat, norm_out):
+    L.require_device(flat)
+    L.check(L.lib().pc_grad_norm(L.ptr(flat), flat.numel(), L.ptr(norm_out), L.stream_ptr()), "pc_grad_norm")
+
+
+def adam_clip_step(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm, step):
+    L.require_device(p, g, m, v)
+    L.check(L.lib().pc_adam_clip_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), n_decay, L.ptr(hyper),
+                                      C.c_float(weight_decay), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                                      C.c_float(max_norm), L.ptr(norm), L.ptr(step), L.stream_ptr()),
+            "pc_adam_clip_step")

@@ -1,0 +1,212 @@
+"""Fused training step: the build's counterpart of the reference's inner training loop
+(run_train.py:186-238: forward(train, padding=False, sparse=True) -> get_loss -> x lam_weak -> backward ->
+clip_grad_norm_(0.01) -> Adam step -> zero_grad), with everything on the device and nothing synchronising:
+
+    building score (frozen U-Net) -> sparsity mask -> U-Net forward -> sparse head (+ {Nsel, sum scale})
+    -> [DP: all-reduce 2 scalars] -> loss fwd+bwd kernel -> head backward -> U-Net backward into ONE flat gradient
+    buffer -> [DP: one all-reduce] -> gradient norm -> fused clip + Adam over the flat parameter buffer.
+
+The 56 trainable tensors (39,298 elements) are re-homed as views of one flat buffer, so the optimiser and the
+all-reduce are single kernels / a single collective.  The static-shape step can be captured into HIP graphs
+(``use_graph=True``) and replayed with no per-launch host cost.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .distributed import FlatReducer
+from .model.popcorn import pad_geometry
+
+LOSS_INDEX = {"l1_loss": 0, "log_l1_loss": 1, "mse_loss": 2, "log_mse_loss": 3}
+HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
+
+
+class FusedTrainStep:
+    def __init__(self, model, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, gradient_clip=0.01,
+                 loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01, lam_weak=100.0,
+                 reducer: FlatReducer | None = None, use_graph=False):
+        self.model = model
+        self.names, params = model.trainable()
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise L.PopcornHipError("FusedTrainStep needs the model on a HIP device (no CPU path)")
+        self.device = dev
+        assert self.names[-2:] == list(HEAD_NO_DECAY)
+        sizes = [p.numel() for p in params]
+        self.n = sum(sizes)
+        self.n_decay = self.n - sizes[-1] - sizes[-2]
+        self.flat_p = torch.empty(self.n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.grads = {}
+        off = 0
+        for n_, p in zip(self.names, params):
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view_as(p)          # parameters become views of the flat buffer
+            self.grads[n_] = self.flat_g[off:off + k].view_as(p)
+            off += k
+        model.invalidate_cache()
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.hyper = torch.tensor([lr], device=dev, dtype=torch.float32)
+        self.lr = lr
+        self.wd, self.betas, self.eps, self.clip = weight_decay, betas, eps, gradient_clip
+        self.lam4 = [0.0] * 4
+        for lo, la in zip(loss, lam):
+            if lo in LOSS_INDEX:
+                self.lam4[LOSS_INDEX[lo]] += la
+        self.sreg, self.lam_weak = scale_regularization, lam_weak
+        self.reducer = reducer or FlatReducer()
+        self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
+        self.loss_out = torch.zeros(2, device=dev, dtype=torch.float32)
+        self.g_scale_const = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.use_graph = use_graph
+        self._graphs = None
+        self._static = None
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        """StepLR-style schedule hook (run_train.py:93,141): takes effect on the next step, also under graph replay."""
+        self.lr = lr
+        self.hyper.fill_(lr)
+
+    def attach_grads(self):
+        """Expose the flat gradient views as ``param.grad`` (for logging / wandb.watch-style consumers)."""
+        table = dict(self.model.named_parameters())
+        for n_ in self.names:
+            table[n_].grad = self.grads[n_]
+
+    # ---- the three stream-ordered sections -------------------------------------------------------------------------
+    def _forward(self, s, sel, encoder_no_grad, unet_no_grad):
+        m = self.model
+        X = s["input"]
+        B, _, H, W = X.shape
+        eng_u, eng_b = m.engines()
+        building = eng_b.building_score(X, m.p)
+        s["building_counts"] = building
+        if not m.occupancymodel:
+            building = torch.ones_like(building)
+        mask, counts = ops.sparsity_mask(s["building_counts"], s["admin_mask"], s["census_idx"], sel[:H], sel[H:],
+                                         m.occupancymodel)
+        pt, pb, pl, pr = pad_geometry(H, W, False)
+        feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
+        scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
+                                                     admin_mask=s["admin_mask"], census_idx=s["census_idx"],
+                                                     stats=self.stats, nsel_counts=counts)
+        self._ctx = (feats, saved, building, mask, (pt, pl), (B, H, W))
+        self.last = {"popcount": popcount, "popdensemap": popdense, "scale_map": scale_map, "mask": mask}
+
+    def _backward(self, s, encoder_no_grad, unet_no_grad):
+        m = self.model
+        feats, saved, building, mask, (pt, pl), (B, H, W) = self._ctx
+        g_pc = torch.empty(B, device=self.device, dtype=torch.float32)
+        inv_B = 1.0 / self.reducer.global_batch(B)
+        ops.loss_fwd_bwd(self.last["popcount"], s["y"], self.stats, self.lam4, self.sreg, self.lam_weak, inv_B,
+                         self.loss_out, g_pc, self.g_scale_const)
+        eng_u = m.engines()[0]
+        hgrads = [self.grads[n_] for n_ in self.names[-8:]]
+        _, G = ops.head_bwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask, admin_mask=s["admin_mask"],
+                            census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=hgrads,
+                            feat_bn=None if unet_no_grad else eng_u.feat_bn())
+        if unet_no_grad:
+            self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()
+        else:
+            if encoder_no_grad:
+                self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()
+            eng_u.backward(saved, G, self.grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
+        self._ctx = None
+
+    def _update(self):
+        if self.clip and self.clip > 0:
+            ops.grad_norm(self.flat_g, self.norm)
+        ops.adam_clip_step(self.flat_p, self.flat_g, self.m, self.v, self.n_decay, self.hyper, self.wd, self.betas[0],
+                           self.betas[1], self.eps, self.clip or 0.0, self.norm, self.step_count)
+
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _draw_selection(H, W):
+        """The two CPU-generator multinomial draws of get_sparsity_mask (popcorn.py:366-369)."""
+        sub = 60
+        xi = torch.ones(H).multinomial(num_samples=min(sub, H), replacement=False)
+        yi = torch.ones(W).multinomial(num_samples=min(sub, W), replacement=False)
+        sel = torch.zeros(H + W, dtype=torch.uint8)
+        sel[xi] = 1
+        sel[H + yi] = 1
+        return sel
+
+    def step(self, sample, encoder_no_grad=False, unet_no_grad=False):
+        """One optimisation step on ``sample`` = {input (B,6,H,W) normalised, admin_mask, census_idx, y}.  Returns the
+        device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
+        B, _, H, W = sample["input"].shape
+        sel_host = self._draw_selection(H, W)
+        if not self.use_graph:
+            s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
+            s["admin_mask"] = s["admin_mask"].float()
+            sel = sel_host.to(self.device, non_blocking=True)
+            self._forward(s, sel, encoder_no_grad, unet_no_grad)
+            self.reducer.reduce_stats(self.stats)
+            self._backward(s, encoder_no_grad, unet_no_grad)
+            self.reducer.reduce_grads(self.flat_g)
+            self._update()
+            return self.loss_out
+        return self._graph_step(sample, sel_host, encoder_no_grad, unet_no_grad)
+
+    def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
+        key = (tuple(sample["input"].shape), encoder_no_grad, unet_no_grad)
+        if self._graphs is None or self._graphs[0] != key:
+            self._capture(sample, sel_host, key)
+        _, st, sel, graphs = self._graphs
+        for k in ("input", "admin_mask", "census_idx", "y"):
+            st[k].copy_(sample[k], non_blocking=True)
+        sel.copy_(sel_host, non_blocking=True)
+        if self.reducer.world == 1:
+            graphs[0].replay()
+        else:
+            graphs[0].replay()
+            self.reducer.reduce_stats(self.stats)
+            graphs[1].replay()
+            self.reducer.reduce_grads(self.flat_g)
+            graphs[2].replay()
+        return self.loss_out
+
+    def _capture(self, sample, sel_host, key):
+        _, enc_ng, unet_ng = key
+        st = {k: sample[k].detach().clone().contiguous() for k in ("input", "admin_mask", "census_idx", "y")}
+        st["admin_mask"] = st["admin_mask"].float()
+        sel = sel_host.to(self.device)
+        # warm-up on a side stream (first-launch attribute calls, workspace allocation), state restored afterwards
+        snap = (self.flat_p.clone(), self.m.clone(), self.v.clone(), self.step_count.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._forward(st, sel, enc_ng, unet_ng)
+                self._backward(st, enc_ng, unet_ng)
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.flat_p.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
+        graphs = []
+        if self.reducer.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward(st, sel, enc_ng, unet_ng)
+                self._backward(st, enc_ng, unet_ng)
+                self._update()
+            graphs = [g]
+        else:
+            g0, g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0):
+                self._forward(st, sel, enc_ng, unet_ng)
+            pool = g0.pool()
+            with torch.cuda.graph(g1, pool=pool):
+                self._backward(st, enc_ng, unet_ng)
+            with torch.cuda.graph(g2, pool=pool):
+                self._update()
+            graphs = [g0, g1, g2]
+        self._graphs = (key, st, sel, graphs)

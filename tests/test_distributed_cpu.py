@@ -1,0 +1,110 @@
+"""Data-parallel host logic on the gloo backend (world_size 2, CPU): the product's FlatReducer + global-normaliser
+rule reproduce the single-process gradient exactly (up to fp32 summation order).  The per-rank arithmetic here is
+the CPU oracle (checker); what is under test is popcorn_amd.distributed."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sample(B=4, H=48, W=40):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 6, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    admin = torch.zeros(B, H, W)
+    census = torch.arange(3, 3 + B, dtype=torch.int64)
+    for b in range(B):
+        r = 10 + 3 * b                                   # unequal region sizes -> unequal Nsel per rank
+        admin[b] = torch.where(((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < r * r, float(census[b]), 0.0)
+    y = torch.rand(B, generator=g) * 300
+    return {"input": x, "admin_mask": admin, "census_idx": census, "y": y}
+
+
+def _local_grads(sd, s, inv_B, nsel_global, lam_weak=100.0, sreg=0.01):
+    """Per-rank backward with GLOBAL normalisers (popcorn_amd/distributed.py docstring)."""
+    from oracle import popcorn_oracle as O
+    names = O.trainable_names(sd)
+    work = dict(sd)
+    for n in names:
+        work[n] = sd[n].detach().clone().requires_grad_(True)
+    torch.manual_seed(9)
+    out = O.popcorn_forward(work, s, padding=False, sparse=True)
+    y_pred = out["popcount"]
+    loss = (torch.log(y_pred + 1) - torch.log(s["y"] + 1)).abs().sum() * inv_B + sreg * out["scale"].abs().sum() / nsel_global
+    (loss * lam_weak).backward()
+    return names, [work[n].grad if work[n].grad is not None else torch.zeros_like(work[n]) for n in names]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import popcorn_oracle as O
+    from popcorn_amd.distributed import FlatReducer, init_from_env, shard_indices
+    r, lr, w = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dist.is_initialized()
+    sd = O.load_golden_state(G)
+    full = _sample()
+    idx = shard_indices(full["input"].shape[0], rank, world)
+    s = {k: v[idx] for k, v in full.items()}
+    red = FlatReducer()
+    # forward statistics: {Nsel, sum(scale)} -> one 16-byte all-reduce
+    with torch.no_grad():
+        torch.manual_seed(9)
+        o = O.popcorn_forward(dict(sd), dict(s), padding=False, sparse=True)
+    stats = torch.tensor([float(o["scale"].numel()), float(o["scale"].abs().sum())], dtype=torch.float64)
+    red.reduce_stats(stats)
+    inv_B = 1.0 / red.global_batch(len(idx))
+    names, grads = _local_grads(sd, dict(s), inv_B, stats[0].item())
+    flat = torch.cat([g.reshape(-1) for g in grads]).float()
+    red.reduce_grads(flat)                                # ONE collective for all 56 tensors
+    if rank == 0:
+        q.put((stats.numpy(), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_reproduces_single_process_gradient():
+    from oracle import popcorn_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    stats, flat = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sd = O.load_golden_state(G)
+    full = _sample()
+    torch.manual_seed(9)
+    loss, out, grads, _ = O.train_step_grads(sd, dict(full))
+    assert stats[0] == out["scale"].numel()
+    assert abs(stats[1] - out["scale"].abs().sum().item()) < 1e-3 * max(1.0, stats[1])
+    names = O.trainable_names(sd)
+    ref = torch.cat([grads[n].reshape(-1) for n in names]).numpy()
+    assert flat.shape == ref.shape == (39298,)
+    scale = np.abs(ref).max()
+    assert np.abs(flat - ref).max() <= 1e-4 * scale, (np.abs(flat - ref).max(), scale)
+
+
+def test_shard_indices_partition():
+    from popcorn_amd.distributed import shard_indices
+    for n, w in ((10, 4), (3, 8), (208, 8)):
+        parts = [shard_indices(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))

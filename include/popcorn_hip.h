@@ -84,6 +84,16 @@ int pc_sizeof(int which);
 int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, int relu,
                            const pc_dst* out, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* Grouped form: up to PC_MAX_GROUP independent problems of identical geometry (B,H,W,Cin,Cout, loader modes) in ONE
+ * launch -- e.g. the SAR and optical streams of a layer, or the frozen building extractor next to the trainable U-Net
+ * (the four share every layer shape).  Cuts launch count and fills the chip on the 32x32 layers. */
+#define PC_MAX_GROUP 4
+typedef struct pc_conv_fwd_desc {
+    const pc_src* a; const pc_src* b; const float* w; const pc_bn* bn; const pc_dst* out;
+} pc_conv_fwd_desc;
+int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,
+                                 void* stream);
+
 /* ---- conv3x3 data gradient (autograd of the op above w.r.t. its input).
  * g: gradient w.r.t. the conv output (already multiplied by relu-mask * bn-scale), Cg = forward Cout channels.
  * Produces the gradient for forward input channels [c0, c0+Cn) of a forward weight w: [Cg][Cin_total][3][3].
@@ -98,6 +108,14 @@ int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, con
 int pc_conv3x3_dgrad(const pc_src* g, const float* w, int Cin_total, int c0, int Cn,
                      const pc_src* act, const pc_bn* act_bn, int pool, int accumulate,
                      const pc_dst* out, int B, int H, int W, int Cg, void* stream);
+
+typedef struct pc_conv_dgrad_desc {
+    const pc_src* g; const float* w; const pc_src* act; const pc_bn* act_bn; const pc_dst* out;
+} pc_conv_dgrad_desc;
+int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Cin_total, int c0, int Cn, int pool,
+                           int accumulate, int B, int H, int W, int Cg, void* stream);
+/* ablation switches for tools/ablate_conv.py (0,0 = normal operation) */
+void pc_debug_conv(int dbg, int max_grid);
 
 /* ---- conv3x3 weight/bias gradient.  x = forward input (a,b sources as in fwd), g as in dgrad.
  * dw: [Cout][Cin][3][3], db: [Cout]; (=|+=).  ws: workspace of pc_conv3x3_wgrad_ws_bytes(). */

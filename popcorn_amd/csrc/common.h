@@ -12,6 +12,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// Division by a launch-invariant divisor without the ~40-instruction VALU sequence the compiler emits for a runtime
+// integer divide (there is no hardware integer divide; in the persistent tile loops those sequences were ~1000
+// instructions per stage per wave -- tools/ablate_conv.py).  q = umulhi(n, ceil(2^32 / d)) is exact for n * d < 2^32.
+struct pc_fastdiv {
+    uint32_t d, m;
+};
+static inline pc_fastdiv pc_make_fastdiv(uint32_t d) {
+    pc_fastdiv f;
+    f.d = d ? d : 1;
+    f.m = f.d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + f.d - 1) / f.d);
+    return f;
+}
+__device__ __forceinline__ uint32_t pc_div(uint32_t n, const pc_fastdiv& f) { return f.d == 1 ? n : __umulhi(n, f.m); }
+
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give every XCD a contiguous slice of the tile
 // space so that neighbouring tiles (which share halo rows and the same weights) hit the same private L2.
 // Bijective for any nwg (cdna_hip_programming.md T1).

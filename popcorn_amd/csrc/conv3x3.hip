@@ -11,155 +11,259 @@
 // so 9 useful taps ride on 12 K-slots: 75 % MFMA efficiency at Cout = 8 (a plain im2col with N = Cout = 8 wastes half
 // of every MFMA) and no padding waste in N for any Cout that is a multiple of 8.
 //
-// Data movement: a workgroup (4 waves) owns a 32 x 16 output tile; the (CHUNK x 18 x 34) input halo tile is staged
+// Data movement: a workgroup (4 waves) owns a 32 x 16 output tile; the (CHUNK x 18 x 40) input halo tile is staged
 // in LDS with row stride 48 (= 16 mod 32 banks), which makes the A-operand read -- lane (i = x, k = row) ->
 // lds[ci][2*rp + k][x + dx] -- bank-conflict free.  Weights live in registers as ready-made B fragments for the
-// whole kernel; workgroups are persistent over tiles (XCD-aware tile order) so they are fetched once.
+// whole kernel; workgroups are persistent over tiles (XCD-aware tile order).
+//
+// The tile loop is a software pipeline: every 16-lane group owns one (channel, row-range) of the halo tile and moves
+// its rows as aligned 16-byte segments; the loads of tile t+1 are issued into registers before the MFMA phase of tile
+// t and written to LDS after it, so HBM latency hides under MFMA inside one workgroup.  The first version spent ~1200
+// mostly scalar/branch instructions per tile per wave on loader index arithmetic and was instruction-issue bound at
+// 4x the MFMA time (profiles/r1_v0, tools/ablate_conv.py); the hot path below is ~10 VALU per 16-byte segment.
+//
+// Up to PC_MAX_GROUP independent problems of identical geometry (e.g. the SAR and optical streams, or the frozen
+// building extractor next to the trainable U-Net) share one launch: blockIdx.y selects the problem.
 #include "common.h"
+#include "tile_loader.h"
+
+static int g_conv_dbg = 0, g_conv_max_grid = 0;
+extern "C" void pc_debug_conv(int dbg, int max_grid) { g_conv_dbg = dbg; g_conv_max_grid = max_grid; }
 
 namespace {
 
 constexpr int TW = 32, TH = 16;          // output tile
-constexpr int LROWS = TH + 2, LCOLS = TW + 2;
 constexpr int RS = 48;                   // LDS row stride  (== 16 mod 32)
-constexpr int CS = LROWS * RS;           // LDS channel stride
+constexpr int COL0 = 4;                  // LDS column of tile x0 (left halo at COL0-1): keeps float4 stores aligned
+constexpr int MAXG = PC_MAX_GROUP;       // problems per launch
 
-struct ConvArgs {
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+enum { LD_GENERIC = 0, LD_DIRECT = 1, LD_POOL = 2 };
+
+struct ConvProb {
     pc_src a, b;          // input sources (channels a.C then b.C)
     const float* w;       // weights
-    int w_co_stride;      // element stride between output channels in w
-    int w_ci_stride;      // element stride between input channels in w
-    int w_flip;           // 1: tap index 8 - t (dgrad)
     pc_bn bn;             // FWD: this layer's BN; DGRAD: BN of the layer that produced `act`
-    int relu;             // FWD
     const float* act;     // DGRAD: post-ReLU activations of the producer (NULL = plain)
     int64_t act_bstride, act_cstride;
     int act_rstride;
-    int pool;             // DGRAD: max-pool backward scatter into a 2x resolution output
-    int accumulate;       // DGRAD: out += instead of out =
-    int outH, outW;       // DGRAD+pool: extent of the full-resolution output
+    int fast_a, fast_b;   // pc_src_fast_mode of the two sources (generic loader)
     pc_dst out;
-    int B, H, W;
-    int tiles_x, tiles_y, ntiles;
 };
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+struct ConvArgs {
+    ConvProb pr[MAXG];
+    int w_co_stride;      // element stride between output channels in w
+    int w_ci_stride;      // element stride between input channels in w
+    int w_flip;           // 1: tap index 8 - t (dgrad)
+    int relu;             // FWD
+    int pool;             // DGRAD: max-pool backward scatter into a 2x resolution output
+    int accumulate;       // DGRAD: out += instead of out =
+    int vec_ok;           // outputs (and act) are 16-byte aligned with W % 4 == 0: vector epilogue allowed
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;
+    pc_fastdiv div_tx, div_tpi;   // by tiles_x, by tiles per image
+    int dbg;              // ablation switches (tools/ablate_conv.py): 1 skip loader, 2 skip MFMA, 4 skip stores
+};
 
-template <int CIN, int COUT, int MODE>
+// Wave-private strips.  Each wave owns a 32 x 4 output strip (4 MFMA units), stages its own (CHUNK x 6 x 40) halo
+// strip in a private LDS region and runs its own software pipeline -- there is NO workgroup barrier in the loop: DS
+// operations of one wave execute in order, so "ds_write strip t+1" behind "ds_read strip t" needs no synchronisation.
+// Waves therefore drift apart and the hardware interleaves one wave's MFMA phase with the others' loads, LDS writes
+// and epilogue stores.  (The workgroup-tile version kept all waves of a CU in lock-step through its two barriers per
+// tile: MFMA pipe 42 % busy with waves parked in issue stalls, total time == sum of the phases; tools/ablate_conv.py.)
+// The price is a 6/4 instead of 18/16 row halo, served by L2.
+constexpr int SROWS = 6;                 // input rows of a 4-row strip
+constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS region
+
+template <int CIN, int COUT, int MODE, int LD>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 16 ? CIN : 16;
     constexpr int NCHUNK = CIN / CHUNK;
     constexpr int NB = COUT / 8;
+    constexpr bool STAGED = LD != LD_GENERIC;
+    constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
+    const ConvProb& q = p.pr[blockIdx.y];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;      // A: (i, k);  B: (k, n = li);  D: (n = li, rows 4*lk + r)
     const int s_row = li >> 3, col = li & 7;
+    if (p.dbg & 8) return;
 
     // ---- B fragments: bw[ci][dx][nb] = w[co = nb*8+col][ci][dy = lk - s_row][dx]
+    // The (strided, possibly transposed) weight slice is first copied into LDS by the whole workgroup with coalesced,
+    // independent loads -- one memory round trip -- and the per-lane fragments are then gathered from LDS.
     float bw[CIN][3][NB];
     {
+        for (int e = tid; e < COUT * CIN * 9; e += 256) {
+            const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+            lds[e] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+        }
+        __syncthreads();
         const int dy = lk - s_row;
+        const bool valid = dy >= 0 && dy <= 2;
+        const int dyc = valid ? dy : 0;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    float v = 0.f;
-                    if (dy >= 0 && dy <= 2) {
-                        int tap = dy * 3 + dx;
-                        if (p.w_flip) tap = 8 - tap;
-                        v = p.w[(nb * 8 + col) * p.w_co_stride + ci * p.w_ci_stride + tap];
-                    }
-                    bw[ci][dx][nb] = v;
+                    const float v = lds[((nb * 8 + col) * CIN + ci) * 9 + dyc * 3 + dx];
+                    bw[ci][dx][nb] = valid ? v : 0.f;
                 }
+        __syncthreads();   // the weight image is dead: waves may now overwrite their LDS regions
     }
     // ---- per-lane epilogue constants for co = nb*8 + col
     float e_scale[NB], e_shift[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        if (MODE == MODE_FWD || p.act != nullptr) pc_bn_fold(p.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
+        if (MODE == MODE_FWD || q.act != nullptr) pc_bn_fold(q.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
         else { e_scale[nb] = 1.f; e_shift[nb] = 0.f; }
     }
+    const float* const act = q.act;
+    float* const outp = q.out.ptr;
+    const int64_t o_bs = q.out.bstride, o_cs = q.out.cstride, a_bs = q.act_bstride, a_cs = q.act_cstride;
+    const int o_rs = q.out.rstride, a_rs = q.act_rstride;
 
-    const int CA = p.a.C;
-    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-        const int tile = pc_xcd_remap(t, p.ntiles);
-        const int tx = tile % p.tiles_x;
-        const int ty = (tile / p.tiles_x) % p.tiles_y;
-        const int b = tile / (p.tiles_x * p.tiles_y);
-        const int x0 = tx * TW, y0 = ty * TH;
+    float* const wl = lds + wave * (CHUNK * CSW);        // this wave's LDS region
 
-        f32x4 acc[4][NB];
+    // ---- staged loader: lane = (row r of the 6-row strip, 16-byte segment seg of the 40-float row)
+    const int l_r = lane / 10, l_seg = lane - l_r * 10;
+    const bool l_act = lane < 60;
+    const int CA = q.a.C;
+    const float* const a_ptr = q.a.ptr;
+    const float* const b_ptr = q.b.ptr;
+    const int64_t a_cstr = q.a.cstride, b_cstr = q.b.cstride;
+    const int64_t my_bs = q.a.bstride;
+    const int my_rs = q.a.rstride;                       // launch_conv guarantees identical layouts for both sources
+    // Loads are issued UNCONDITIONALLY (out-of-image segments read a clamped, always-valid address) and the validity
+    // mask is applied when the registers are written to LDS: a predicated load is if-converted into load + select,
+    // i.e. an s_waitcnt right behind the load and no overlap with the MFMA phase.
+    f32x4 R[NIT];
+    bool rvalid = false;
+    auto issue = [&](int ch, int b, int y0, int x0) {
+        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
+        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
+        rvalid = ok;
+        if (LD == LD_DIRECT) {
+            const int64_t off = ok ? b * my_bs + (int64_t)y * my_rs + xg : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-        for (int ch = 0; ch < NCHUNK; ++ch) {
-            __syncthreads();   // previous readers of the LDS tile are done
-            for (int idx = tid; idx < CHUNK * LROWS * LCOLS; idx += 256) {
-                const int c = idx % LCOLS;
-                const int r = (idx / LCOLS) % LROWS;
-                const int ci = idx / (LCOLS * LROWS);
-                const int cg = ch * CHUNK + ci;
-                const float v = cg < CA ? pc_fetch(p.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
-                                        : pc_fetch(p.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-                lds[ci * CS + r * RS + c] = v;
+            for (int it = 0; it < NIT; ++it) {
+                const int cg = ch * CHUNK + it;
+                const float* cp = cg < CA ? a_ptr + cg * a_cstr : b_ptr + (cg - CA) * b_cstr;
+                R[it] = *reinterpret_cast<const f32x4*>(cp + off);
             }
-            __syncthreads();
+        } else if (LD == LD_POOL) {
+            const int64_t off = ok ? b * my_bs + (int64_t)(2 * y) * my_rs + 2 * xg : 0;
+            const int rs1 = ok ? my_rs : 0;
 #pragma unroll
-            for (int ci = 0; ci < CHUNK; ++ci) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    float av[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int rp = 2 * wave + (u >> 1), xb = u & 1;
-                        av[u] = lds[ci * CS + (2 * rp + lk) * RS + xb * 16 + li + dx];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[ch * CHUNK + ci][dx][nb],
-                                                                              acc[u][nb], 0, 0, 0);
-                }
+            for (int it = 0; it < NIT; ++it) {
+                const float* s0 = a_ptr + (ch * CHUNK + it) * a_cstr + off;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + rs1), b1 = *reinterpret_cast<const f32x4*>(s0 + rs1 + 4);
+                f32x4 v;
+                v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
+                v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
+                v[2] = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1]));
+                v[3] = fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]));
+                R[it] = v;
             }
         }
+    };
+    auto commit = [&]() {
+        if (l_act) {
+            float* d = wl + l_r * RS + 4 * l_seg;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                *reinterpret_cast<f32x4*>(d + it * CSW) = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto load_generic = [&](int ch, int b, int y0, int x0) {
+        for (int idx = lane; idx < CHUNK * SROWS * 34; idx += 64) {
+            const int c = idx % 34, r = (idx / 34) % SROWS, ci = idx / (34 * SROWS);
+            const int cg = ch * CHUNK + ci;
+            const float v = cg < CA ? pc_fetch(q.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
+                                    : pc_fetch(q.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
+            wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
+        }
+    };
 
-        // ---- epilogue: lane holds (co = nb*8+col, y = y0 + 2*rp + s_row, x = x0 + xb*16 + 4*lk + r), r = 0..3
+    // strips: tile-major so that the 4 waves of a workgroup take the 4 strips of one 32 x 16 tile (shared halo rows
+    // hit in L1/L2); workgroups walk the tiles in the XCD-aware order.
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nstages = my_tiles * NCHUNK;
+    auto strip_coords = [&](int stage, int& b, int& y0, int& x0) {
+        const int t = blockIdx.x + (stage / NCHUNK) * gridDim.x;
+        const int tile = pc_xcd_remap(t, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+
+    // deferred epilogue: the results of strip t are stored while strip t+1 is in its MFMA phase
+    f32x4 pacc[4][NB];
+    int eb = 0, ey0 = 0, ex0 = 0;
+    bool have_prev = false;
+    auto epilogue = [&]() {
+        // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + (u&1)*16 + 4*lk + r), r = 0..3
+        if (ey0 >= p.H) return;
+        const bool full = p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W) && !p.pool;
+        if (full) {
+            // interior strip, aligned tensors: no bounds checks, 16-byte accesses only
+            float* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0 + 4 * lk;
+            const float* ab = act ? act + eb * a_bs + col * a_cs + (int64_t)(ey0 + s_row) * a_rs + ex0 + 4 * lk : nullptr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 v = pacc[u][nb];
+                    float* op = ob + nb * 8 * o_cs + (int64_t)((u >> 1) * 2) * o_rs + (u & 1) * 16;
+                    if (MODE == MODE_FWD) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float o = v[r] * e_scale[nb] + e_shift[nb];
+                            v[r] = p.relu ? fmaxf(o, 0.f) : o;
+                        }
+                    } else {
+                        if (ab) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + nb * 8 * a_cs + (int64_t)((u >> 1) * 2) * a_rs + (u & 1) * 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb] : 0.f;
+                        }
+                        if (p.accumulate) {
+                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(op);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(op) = v;
+                }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int rp = 2 * wave + (u >> 1), xb = u & 1;
-            const int y = y0 + 2 * rp + s_row;
-            const int x = x0 + xb * 16 + 4 * lk;
+            const int y = ey0 + 2 * (u >> 1) + s_row;
+            const int x = ex0 + (u & 1) * 16 + 4 * lk;
             if (y >= p.H || x >= p.W) continue;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = nb * 8 + col;
-                f32x4 v = acc[u][nb];
+                const f32x4 v = pacc[u][nb];
                 if (MODE == MODE_FWD) {
+                    float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float o = v[r] * e_scale[nb] + e_shift[nb];
-                        v[r] = p.relu ? fmaxf(o, 0.f) : o;
-                    }
-                    float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)y * p.out.rstride + x;
-                    if (x + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
-                        *reinterpret_cast<f32x4*>(op) = v;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (x + r < p.W) op[r] = v[r];
+                        const float o = v[r] * e_scale[nb] + e_shift[nb];
+                        if (x + r < p.W) op[r] = p.relu ? fmaxf(o, 0.f) : o;
                     }
                 } else if (!p.pool) {
-                    float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)y * p.out.rstride + x;
-                    const float* ap = p.act ? p.act + b * p.act_bstride + co * p.act_cstride + (int64_t)y * p.act_rstride + x
-                                            : nullptr;
+                    float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
+                    const float* ap = act ? act + eb * a_bs + co * a_cs + (int64_t)y * a_rs + x : nullptr;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (x + r < p.W) {
@@ -171,10 +275,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                     }
                 } else {
                     // MaxPool2d(2) backward: (y,x) is a pooled coordinate; route to the first arg-max of the window.
-                    const float* a0 = p.act + b * p.act_bstride + co * p.act_cstride + (int64_t)(2 * y) * p.act_rstride;
-                    const float* a1 = a0 + p.act_rstride;
-                    float* o0 = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * y) * p.out.rstride;
-                    float* o1 = o0 + p.out.rstride;
+                    const float* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs;
+                    const float* a1 = a0 + a_rs;
+                    float* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs;
+                    float* o1 = o0 + o_rs;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int xx = x + r;
@@ -195,92 +299,226 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 }
             }
         }
+    };
+
+    int b = 0, y0 = 0, x0 = 0;
+    if (nstages > 0) {
+        strip_coords(0, b, y0, x0);
+        if (STAGED && !(p.dbg & 1)) issue(0, b, y0, x0);
     }
+    f32x4 acc[4][NB];
+    for (int stage = 0; stage < nstages; ++stage) {
+        const int ch = stage % NCHUNK;
+        if (!(p.dbg & 1)) {
+            if (STAGED) commit();
+            else load_generic(ch, b, y0, x0);
+        }
+        int nb_ = b, ny0 = y0, nx0 = x0;
+        if (stage + 1 < nstages) {
+            if ((stage + 1) % NCHUNK == 0) strip_coords(stage + 1, nb_, ny0, nx0);
+            if (STAGED && !(p.dbg & 1)) issue((stage + 1) % NCHUNK, nb_, ny0, nx0);
+        }
+        if (have_prev) {
+            if (!(p.dbg & 4)) epilogue();
+            have_prev = false;
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!(p.dbg & 2)) {
+#pragma unroll
+            for (int chc = 0; chc < NCHUNK; ++chc) {
+                if (chc != ch) continue;
+                const float* lrow = wl + lk * RS + (COL0 - 1) + li;
+#pragma unroll
+                for (int ci = 0; ci < CHUNK; ++ci) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        float av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) av[u] = lrow[ci * CSW + (u >> 1) * 2 * RS + (u & 1) * 16 + dx];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[chc * CHUNK + ci][dx][nb],
+                                                                                  acc[u][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (ch == NCHUNK - 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) pacc[u][nb] = acc[u][nb];
+            eb = b; ey0 = y0; ex0 = x0;
+            have_prev = true;
+        }
+        b = nb_; y0 = ny0; x0 = nx0;
+    }
+    if (have_prev && !(p.dbg & 4)) epilogue();
 }
 
+template <int CIN, int COUT, int MODE, int LD>
+int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
+    constexpr int CHUNK = CIN < 16 ? CIN : 16;
+    size_t lds = (size_t)4 * CHUNK * CSW * sizeof(float);
+    if (lds < (size_t)COUT * CIN * 9 * sizeof(float)) lds = (size_t)COUT * CIN * 9 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    // persistent workgroups: about 3 per CU in total, split over the grouped problems
+    int max_grid = g_conv_max_grid > 0 ? g_conv_max_grid : 768 / nprob;
+    if (max_grid < 128) max_grid = 128;
+    const int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+bool same_layout(const pc_src& a, const pc_src& b) { return b.C == 0 || (a.bstride == b.bstride && a.rstride == b.rstride); }
+
 template <int CIN, int COUT, int MODE>
-int launch_conv(ConvArgs& p, hipStream_t stream) {
+int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 16 ? CIN : 16;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
-    const size_t lds = (size_t)CHUNK * CS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    p.div_tx = pc_make_fastdiv(p.tiles_x);
+    p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
+    p.dbg = g_conv_dbg;
+    // loader choice: all problems of the group must qualify for a staged loader
+    bool direct = CHUNK >= 8, pool = CHUNK >= 8;
+    bool vec = (p.W % 4) == 0;
+    for (int i = 0; i < nprob; ++i) {
+        ConvProb& q = p.pr[i];
+        q.fast_a = pc_src_fast_mode(q.a, p.H, p.W);
+        q.fast_b = pc_src_fast_mode(q.b, p.H, p.W);
+        const bool lay = same_layout(q.a, q.b);
+        direct = direct && q.fast_a == 1 && (q.b.C == 0 || q.fast_b == 1) && lay && (CIN <= 16 || q.a.C == 16);
+        pool = pool && q.fast_a == 2 && q.b.C == 0;
+        vec = vec && (q.out.rstride % 4 == 0) && (q.out.cstride % 4 == 0) && (q.out.bstride % 4 == 0) &&
+              ((reinterpret_cast<uintptr_t>(q.out.ptr) & 15) == 0);
+        if (q.act) vec = vec && (q.act_rstride % 4 == 0) && (q.act_cstride % 4 == 0) && (q.act_bstride % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(q.act) & 15) == 0);
     }
-    const int max_grid = 256 * 4;
-    const int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE>), dim3(grid), dim3(256), lds, stream, p);
-    PC_CHECK_LAUNCH();
-    return 0;
+    p.vec_ok = vec ? 1 : 0;
+    if constexpr (CHUNK >= 8) {
+        if (direct) return launch_conv_ld<CIN, COUT, MODE, LD_DIRECT>(p, nprob, stream);
+        if constexpr (CIN <= 16) {
+            if (pool) return launch_conv_ld<CIN, COUT, MODE, LD_POOL>(p, nprob, stream);
+        }
+    }
+    return launch_conv_ld<CIN, COUT, MODE, LD_GENERIC>(p, nprob, stream);
 }
 
 template <int MODE>
-int dispatch_conv(ConvArgs& p, int Cin, int Cout, hipStream_t stream) {
+int dispatch_conv(ConvArgs& p, int nprob, int Cin, int Cout, hipStream_t stream) {
 #define PC_CASE(ci, co) \
-    if (Cin == ci && Cout == co) return launch_conv<ci, co, MODE>(p, stream);
+    if (Cin == ci && Cout == co) return launch_conv<ci, co, MODE>(p, nprob, stream);
     PC_CASE(2, 8) PC_CASE(4, 8) PC_CASE(8, 8) PC_CASE(16, 8) PC_CASE(32, 8) PC_CASE(8, 16) PC_CASE(16, 16)
 #undef PC_CASE
     return PC_EINVAL;
 }
 
-pc_src empty_src() {
-    pc_src s{};
-    return s;
+int fill_fwd(ConvProb& q, const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, const pc_dst* out, int Cin) {
+    if (!a || !w || !bn || !out) return PC_EINVAL;
+    q.a = *a;
+    if (b) q.b = *b;
+    if (q.a.C + q.b.C != Cin) return PC_EINVAL;
+    q.w = w;
+    q.bn = *bn;
+    q.out = *out;
+    return 0;
+}
+
+int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_src* act, const pc_bn* act_bn, int pool,
+               const pc_dst* out, int Cg) {
+    if (!g || !w || !out || g->C != Cg) return PC_EINVAL;
+    if (pool && !act) return PC_EINVAL;
+    q.a = *g;
+    // forward weight w[cg][Cin_total][3][3]; as a conv over g producing input channel (c0 + co):
+    //   weight(out = co, in = cg, tap) = w[cg][c0 + co][8 - tap]
+    q.w = w + (int64_t)c0 * 9;
+    if (act) {
+        if (!act_bn) return PC_EINVAL;
+        q.bn = *act_bn;
+        q.act = act->ptr;
+        q.act_bstride = act->bstride;
+        q.act_cstride = act->cstride;
+        q.act_rstride = act->rstride;
+    }
+    q.out = *out;
+    return 0;
 }
 
 }  // namespace
 
 extern "C" int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, int relu,
                                       const pc_dst* out, int B, int H, int W, int Cin, int Cout, void* stream) {
-    if (!a || !w || !bn || !out) return PC_EINVAL;
     ConvArgs p{};
-    p.a = *a;
-    p.b = b ? *b : empty_src();
-    if (p.a.C + p.b.C != Cin) return PC_EINVAL;
-    p.w = w;
+    const int rc = fill_fwd(p.pr[0], a, b, w, bn, out, Cin);
+    if (rc) return rc;
     p.w_co_stride = Cin * 9;
     p.w_ci_stride = 9;
-    p.w_flip = 0;
-    p.bn = *bn;
     p.relu = relu;
-    p.out = *out;
     p.B = B; p.H = H; p.W = W;
-    return dispatch_conv<MODE_FWD>(p, Cin, Cout, (hipStream_t)stream);
+    return dispatch_conv<MODE_FWD>(p, 1, Cin, Cout, (hipStream_t)stream);
+}
+
+extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,
+                                            void* stream) {
+    if (n < 1 || n > MAXG || !d) return PC_EINVAL;
+    ConvArgs p{};
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
+        if (rc) return rc;
+    }
+    p.w_co_stride = Cin * 9;
+    p.w_ci_stride = 9;
+    p.relu = relu;
+    p.B = B; p.H = H; p.W = W;
+    return dispatch_conv<MODE_FWD>(p, n, Cin, Cout, (hipStream_t)stream);
 }
 
 extern "C" int pc_conv3x3_dgrad(const pc_src* g, const float* w, int Cin_total, int c0, int Cn,
                                 const pc_src* act, const pc_bn* act_bn, int pool, int accumulate,
                                 const pc_dst* out, int B, int H, int W, int Cg, void* stream) {
-    if (!g || !w || !out || g->C != Cg) return PC_EINVAL;
-    if (pool && !act) return PC_EINVAL;
     ConvArgs p{};
-    p.a = *g;
-    p.b = empty_src();
-    // forward weight w[cg][Cin_total][3][3]; as a conv over g producing input channel (c0 + co):
-    //   weight(out = co, in = cg, tap) = w[cg][c0 + co][8 - tap]
-    p.w = w + (int64_t)c0 * 9;
+    const int rc = fill_dgrad(p.pr[0], g, w, c0, act, act_bn, pool, out, Cg);
+    if (rc) return rc;
     p.w_co_stride = 9;
     p.w_ci_stride = Cin_total * 9;
     p.w_flip = 1;
-    if (act) {
-        if (!act_bn) return PC_EINVAL;
-        p.bn = *act_bn;
-        p.act = act->ptr;
-        p.act_bstride = act->bstride;
-        p.act_cstride = act->cstride;
-        p.act_rstride = act->rstride;
-        p.outH = act->H;
-        p.outW = act->W;
-    }
     p.pool = pool;
     p.accumulate = accumulate;
-    p.out = *out;
     p.B = B; p.H = H; p.W = W;
-    return dispatch_conv<MODE_DGRAD>(p, Cg, Cn, (hipStream_t)stream);
+    return dispatch_conv<MODE_DGRAD>(p, 1, Cg, Cn, (hipStream_t)stream);
+}
+
+extern "C" int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Cin_total, int c0, int Cn, int pool,
+                                      int accumulate, int B, int H, int W, int Cg, void* stream) {
+    if (n < 1 || n > MAXG || !d) return PC_EINVAL;
+    ConvArgs p{};
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_dgrad(p.pr[i], d[i].g, d[i].w, c0, d[i].act, d[i].act_bn, pool, d[i].out, Cg);
+        if (rc) return rc;
+        if ((d[i].act != nullptr) != (d[0].act != nullptr)) return PC_EINVAL;
+    }
+    p.w_co_stride = 9;
+    p.w_ci_stride = Cin_total * 9;
+    p.w_flip = 1;
+    p.pool = pool;
+    p.accumulate = accumulate;
+    p.B = B; p.H = H; p.W = W;
+    return dispatch_conv<MODE_DGRAD>(p, n, Cg, Cn, (hipStream_t)stream);
 }

@@ -15,12 +15,14 @@
 // and writes ONE partial per workgroup; a second kernel reduces the partials in a fixed order (deterministic --
 // no atomics).
 #include "common.h"
+#include "tile_loader.h"
 
 namespace {
 
 constexpr int TW = 32, TH = 16;
-constexpr int IN_RS = 36;                    // == 4 mod 32
-constexpr int IN_CS = 18 * IN_RS + 8;        // 656 == 16 mod 32
+constexpr int IN_RS = 40;                    // == 8 mod 32: the 4 input rows v of a k-step land 8 banks apart
+constexpr int IN_CS = 18 * IN_RS + 20;       // 740 == 4 mod 32: the (at most) two channels of an N-block interleave
+constexpr int IN_COL0 = 4;                   // LDS column of tile x0 (16-byte aligned interior for ds_write_b128)
 constexpr int G_RS = 34;                     // == 2 mod 32
 constexpr int G_CS = 16 * G_RS + 4;          // 548 == 4 mod 32
 constexpr int MAX_WG = 512;
@@ -31,6 +33,8 @@ struct WgradArgs {
     int ci0;              // first input channel of this launch's chunk (grid.y selects further chunks)
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
+    pc_fastdiv div_tx, div_tpi;
+    int fast_a, fast_b, fast_g;
 };
 
 template <int CINC, int COUT>
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
         int ng = nb * 16 + li;
         if (ng >= Cfg::NCOL) ng = Cfg::NCOL - 1;      // dead columns: any in-range address, never read back
         const int ci = ng / 12, rem = ng % 12, v = rem / 3, dx = rem % 3;
-        boff[nb] = ci * IN_CS + v * IN_RS + dx + lk;
+        boff[nb] = ci * IN_CS + v * IN_RS + (IN_COL0 - 1) + dx + lk;
     }
     int aoff[MB];
 #pragma unroll
@@ -78,24 +82,29 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
         for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const int CA = p.a.C;
     for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
         const int tile = pc_xcd_remap(t, p.ntiles);
-        const int tx = tile % p.tiles_x;
-        const int ty = (tile / p.tiles_x) % p.tiles_y;
-        const int b = tile / (p.tiles_x * p.tiles_y);
-        const int x0 = tx * TW, y0 = ty * TH;
+        const int b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        const int x0 = (rem - ty * p.tiles_x) * TW, y0 = ty * TH;
         __syncthreads();
-        for (int idx = tid; idx < CINC * 18 * 34; idx += 256) {
-            const int c = idx % 34, r = (idx / 34) % 18, ci = idx / (34 * 18);
-            const int cg = cbase + ci;
-            const float v = cg < CA ? pc_fetch(p.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
-                                    : pc_fetch(p.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-            lin[ci * IN_CS + r * IN_RS + c] = v;
-        }
-        for (int idx = tid; idx < COUT * 16 * 32; idx += 256) {
-            const int c = idx & 31, r = (idx >> 5) & 15, co = idx >> 9;
-            lg[co * G_CS + r * G_RS + c] = pc_fetch(p.g, b, co, y0 + r, x0 + c, p.H, p.W);
+        pc_load_halo_tile<CINC, IN_RS, IN_CS, IN_COL0, true>(lin, p.a, p.b, p.fast_a, p.fast_b, cbase, b, y0, x0, p.H, p.W, tid);
+        // gradient tile: COUT x 16 rows x 32 cols, no halo; 8 lanes x float4 per row
+        for (int job = tid >> 3; job < COUT * 16; job += 32) {
+            const int co = job >> 4, r = job & 15, l8 = tid & 7;
+            const int y = y0 + r, x = x0 + 4 * l8;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.fast_g) {
+                if (y < p.H && x < p.W)
+                    v = *reinterpret_cast<const f32x4*>(p.g.ptr + b * p.g.bstride + co * p.g.cstride + (int64_t)y * p.g.rstride + x);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pc_fetch(p.g, b, co, y, x + e, p.H, p.W);
+            }
+            float* d = lg + co * G_CS + r * G_RS + 4 * l8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = v[e];
         }
         __syncthreads();
 #pragma unroll
@@ -154,49 +163,59 @@ struct WreduceArgs {
     int accumulate;
 };
 
-// one thread-quad per output element: 4 slices over the workgroup partials, fixed-order combine.
+// 16 outputs x 16 slices per block: every thread sums nwg/16 workgroup partials with 4 independent loads in flight,
+// then the 16 slices combine in a fixed order (deterministic).  (The first version used 4 slices and a serial
+// dependent loop: 40 us per call for a 2 KB result -- profiles/r1_v0.)
 template <int CINC, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WreduceArgs p) {
     using Cfg = WgradCfg<CINC, COUT>;
     constexpr int NBLK = Cfg::NBLK;
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const int slice = tid >> 6, o = blockIdx.x * 64 + (tid & 63);
+    const int slice = tid >> 4, o = blockIdx.x * 16 + (tid & 15);
     const int n_w = COUT * p.Cin * 9;
     const int n_out = n_w + COUT;
-    float s = 0.f;
-    if (o < n_out) {
-        int e0, e1 = -1, chunk = 0;
-        if (o < n_w) {
-            const int tap = o % 9, ci = (o / 9) % p.Cin, co = o / (9 * p.Cin);
-            const int dy = tap / 3, dx = tap % 3;
-            chunk = ci / CINC;
-            const int cil = ci % CINC;
-            const int mb = co >> 3, c8 = co & 7;
-            // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
-            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
-            const int m0 = c8, m1 = 8 + c8;
-            e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
-            e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
-            const float* base = p.partial + (int64_t)chunk * p.nwg * Cfg::E;
-            for (int w = slice; w < p.nwg; w += 4) s += base[(int64_t)w * Cfg::E + e0] + base[(int64_t)w * Cfg::E + e1];
-        } else {
-            // bias: sum over the 8 lanes (s in 0..1, lk in 0..3) that carry channel co; chunk 0 only
-            const int co = o - n_w, mb = co >> 3, c8 = co & 7;
-            const float* base = p.partial;
-            for (int w = slice; w < p.nwg; w += 4) {
-                const float* q = base + (int64_t)w * Cfg::E + Cfg::MB * NBLK * 256 + mb * 64;
-                float t = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (o < n_w) {
+        const int tap = o % 9, ci = (o / 9) % p.Cin, co = o / (9 * p.Cin);
+        const int dy = tap / 3, dx = tap % 3;
+        const int chunk = ci / CINC, cil = ci % CINC;
+        const int mb = co >> 3, c8 = co & 7;
+        // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
+        const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
+        const int m0 = c8, m1 = 8 + c8;
+        const int e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+        const int e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+        const float* base = p.partial + (int64_t)chunk * p.nwg * Cfg::E;
+        int w = slice;
+        for (; w + 48 < p.nwg; w += 64) {
+            const float* q0 = base + (int64_t)w * Cfg::E;
+            const float* q1 = q0 + (int64_t)16 * Cfg::E;
+            const float* q2 = q0 + (int64_t)32 * Cfg::E;
+            const float* q3 = q0 + (int64_t)48 * Cfg::E;
+            s0 += q0[e0] + q0[e1];
+            s1 += q1[e0] + q1[e1];
+            s2 += q2[e0] + q2[e1];
+            s3 += q3[e0] + q3[e1];
+        }
+        for (; w < p.nwg; w += 16) s0 += base[(int64_t)w * Cfg::E + e0] + base[(int64_t)w * Cfg::E + e1];
+    } else if (o < n_out) {
+        // bias: sum over the 8 lanes (s in 0..1, lk in 0..3) that carry channel co; chunk 0 only
+        const int co = o - n_w, mb = co >> 3, c8 = co & 7;
+        for (int w = slice; w < p.nwg; w += 16) {
+            const float* q = p.partial + (int64_t)w * Cfg::E + Cfg::MB * NBLK * 256 + mb * 64;
+            float t = 0.f;
 #pragma unroll
-                for (int lk = 0; lk < 4; ++lk) t += q[lk * 16 + c8] + q[lk * 16 + 8 + c8];
-                s += t;
-            }
+            for (int lk = 0; lk < 4; ++lk) t += q[lk * 16 + c8] + q[lk * 16 + 8 + c8];
+            s0 += t;
         }
     }
-    red[tid] = s;
+    red[tid] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (tid < 64 && o < n_out) {
-        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    if (tid < 16 && o < n_out) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
         float* dstp = o < n_w ? p.dw + o : p.db + (o - n_w);
         if (o >= n_w && p.db == nullptr) return;
         *dstp = p.accumulate ? *dstp + tot : tot;
@@ -209,11 +228,16 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.div_tx = pc_make_fastdiv(p.tiles_x);
+    p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     const int nchunk = Cin / CINC;
     int nwg = p.ntiles < MAX_WG / nchunk ? p.ntiles : MAX_WG / nchunk;
     if (nwg < 1) nwg = 1;
     p.partial = reinterpret_cast<float*>(ws);
     p.ci0 = 0;
+    p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);
+    p.fast_b = pc_src_fast_mode(p.b, p.H, p.W);
+    p.fast_g = pc_src_fast_mode(p.g, p.H, p.W) == 1;
     const size_t ldsb = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -227,7 +251,7 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     WreduceArgs r{};
     r.partial = p.partial; r.nwg = nwg; r.nchunk = nchunk; r.dw = dw; r.db = db; r.Cin = Cin; r.accumulate = accumulate;
     const int n_out = COUT * Cin * 9 + COUT;
-    hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CINC, COUT>), dim3((n_out + 63) / 64), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CINC, COUT>), dim3((n_out + 15) / 16), dim3(256), 0, stream, r);
     PC_CHECK_LAUNCH();
     return 0;
 }

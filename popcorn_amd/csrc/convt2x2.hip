@@ -24,6 +24,7 @@ struct CtArgs {
     float* partial;        // wgrad
     int B, H, W;           // input resolution
     int groups_x, ngroups;
+    pc_fastdiv div_gx, div_gimg;   // by groups_x, by groups per image
 };
 
 template <int C>
@@ -45,9 +46,10 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtArgs p) {
     }
 
     for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
-        const int gx = grp % p.groups_x;
-        const int i = (grp / p.groups_x) % p.H;
-        const int b = grp / (p.groups_x * p.H);
+        const int b = (int)pc_div((uint32_t)grp, p.div_gimg);
+        const int rem = grp - b * p.groups_x * p.H;
+        const int i = (int)pc_div((uint32_t)rem, p.div_gx);
+        const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
         float av[KS];
         const float* xp = p.x.ptr + b * p.x.bstride + (int64_t)i * p.x.rstride + j0 + li;
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtArgs p) {
     if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
 
     for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
-        const int gx = grp % p.groups_x;
-        const int i = (grp / p.groups_x) % p.H;
-        const int b = grp / (p.groups_x * p.H);
+        const int b = (int)pc_div((uint32_t)grp, p.div_gimg);
+        const int rem = grp - b * p.groups_x * p.H;
+        const int i = (int)pc_div((uint32_t)rem, p.div_gx);
+        const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
         // A[pixel li][k = (a,b) = lk] of k-step co
         const float* gp = p.x.ptr + b * p.x.bstride + (int64_t)(2 * i + (lk >> 1)) * p.x.rstride + 2 * (j0 + li) + (lk & 1);
@@ -142,9 +145,10 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtArgs p) {
 
     // group = 16 consecutive input x of one row; 4 k-steps of 4 pixels each
     for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
-        const int gx = grp % p.groups_x;
-        const int i = (grp / p.groups_x) % p.H;
-        const int b = grp / (p.groups_x * p.H);
+        const int b = (int)pc_div((uint32_t)grp, p.div_gimg);
+        const int rem = grp - b * p.groups_x * p.H;
+        const int i = (int)pc_div((uint32_t)rem, p.div_gx);
+        const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
         const float* xp = p.x.ptr + b * p.x.bstride + li * p.x.cstride + (int64_t)i * p.x.rstride;
         float av[4], bv[4][NBK];
@@ -197,16 +201,21 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_reduce_kernel(const CtRedu
     using Cfg = CtWgradCfg<C>;
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const int slice = tid >> 6, o = blockIdx.x * 64 + (tid & 63);
+    const int slice = tid >> 4, o = blockIdx.x * 16 + (tid & 15);     // 16 outputs x 16 slices
     constexpr int n_w = C * C * 4, n_out = n_w + C;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
     if (o < n_w) {
         const int ci = o / (4 * C), ng = o % (4 * C);     // dw[ci][co][a][b], ng = co*4 + a*2 + b
         const int e = (((ng >> 4) * 64) + (ci >> 2) * 16 + (ng & 15)) * 4 + (ci & 3);
-        for (int w = slice; w < p.nwg; w += 4) s += p.partial[(int64_t)w * Cfg::E + e];
+        int w = slice;
+        for (; w + 16 < p.nwg; w += 32) {
+            s0 += p.partial[(int64_t)w * Cfg::E + e];
+            s1 += p.partial[(int64_t)(w + 16) * Cfg::E + e];
+        }
+        for (; w < p.nwg; w += 16) s0 += p.partial[(int64_t)w * Cfg::E + e];
     } else if (o < n_out) {
         const int co = o - n_w;
-        for (int w = slice; w < p.nwg; w += 4) {
+        for (int w = slice; w < p.nwg; w += 16) {
             const float* q = p.partial + (int64_t)w * Cfg::E + NBK * 256;
             float t = 0.f;
 #pragma unroll
@@ -215,13 +224,15 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_reduce_kernel(const CtRedu
 #pragma unroll
                 for (int lk = 0; lk < 4; ++lk) t += q[(ng >> 4) * 64 + lk * 16 + (ng & 15)];
             }
-            s += t;
+            s0 += t;
         }
     }
-    red[tid] = s;
+    red[tid] = s0 + s1;
     __syncthreads();
-    if (tid < 64 && o < n_out) {
-        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    if (tid < 16 && o < n_out) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
         float* dstp = o < n_w ? p.dw + o : p.db + (o - n_w);
         if (o >= n_w && p.db == nullptr) return;
         *dstp = p.accumulate ? *dstp + tot : tot;
@@ -233,6 +244,8 @@ constexpr int CT_MAX_WG = 512;
 int fill_groups(CtArgs& p) {
     p.groups_x = (p.W + 15) / 16;
     p.ngroups = p.B * p.H * p.groups_x;
+    p.div_gx = pc_make_fastdiv(p.groups_x);
+    p.div_gimg = pc_make_fastdiv(p.groups_x * p.H);
     int nwg = (p.ngroups + 3) / 4;
     if (nwg > 2048) nwg = 2048;
     return nwg < 1 ? 1 : nwg;
@@ -290,11 +303,11 @@ extern "C" int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, fl
     if (C == 16) {
         hipLaunchKernelGGL(convt2x2_wgrad_kernel<16>, dim3(nwg), dim3(256), 0, st, p);
         PC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<16>, dim3((16 * 16 * 4 + 16 + 63) / 64), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<16>, dim3((16 * 16 * 4 + 16 + 15) / 16), dim3(256), 0, st, r);
     } else if (C == 8) {
         hipLaunchKernelGGL(convt2x2_wgrad_kernel<8>, dim3(nwg), dim3(256), 0, st, p);
         PC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<8>, dim3((8 * 8 * 4 + 8 + 63) / 64), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<8>, dim3((8 * 8 * 4 + 8 + 15) / 16), dim3(256), 0, st, r);
     } else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;

@@ -43,6 +43,7 @@ struct HeadArgs {
     float* partial;        // [B][nchunk][2]  {popcount partial, scale-sum partial}
     int B, H, W;
     int groups, nchunk, groups_per_wave;
+    pc_fastdiv div_w, div_groups;
 };
 
 // Fill the LDS weight image.  Fragment (lane = k*16 + i) of k-step ks, m-block mb:  W[16*mb + i][col(ks, k)]
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         const bool sel = valid && (p.mask ? p.mask[pix] != 0 : true);
         float outv = 0.f;
         if (__any(sel)) {
-            const int y = valid ? q / p.W : 0, x = valid ? q - (q / p.W) * p.W : 0;
+            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
             const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
             float xv[4];
 #pragma unroll
@@ -344,13 +345,13 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
     }
 
     for (int gg = blockIdx.x * 4 + wave; gg < a.total_groups; gg += gridDim.x * 4) {
-        const int b = gg / p.groups, g = gg - b * p.groups;
+        const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
         const int q = g * 16 + li;
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
         const bool sel = valid && (p.mask ? p.mask[pix] != 0 : true);
         if (!__any(sel)) continue;
-        const int y = valid ? q / p.W : 0, x = valid ? q - (q / p.W) * p.W : 0;
+        const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
         const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
         float xv[4];
 #pragma unroll
@@ -563,8 +564,9 @@ __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, 
 #pragma unroll
     for (int c = 0; c < 16; ++c) wv[c] = w[c];
     const float bv = bias[0];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
+        const unsigned row = i / (unsigned)W;
+        const int x = (int)(i - row * (unsigned)W), y = (int)(row % (unsigned)H), b = (int)(row / (unsigned)H);
         const float* fp = feat.ptr + b * feat.bstride + (int64_t)(py + y) * feat.rstride + px + x;
         float s = bv;
 #pragma unroll
@@ -579,8 +581,9 @@ __global__ __launch_bounds__(256) void sparsity_mask_kernel(const float* buildin
                                                             uint8_t* mask, int32_t* counts, int B, int H, int W) {
     const int64_t n = (int64_t)B * H * W;
     int nsel = 0, nreg = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
+        const unsigned row = i / (unsigned)W;
+        const int x = (int)(i - row * (unsigned)W), y = (int)(row % (unsigned)H), b = (int)(row / (unsigned)H);
         const bool region = admin[i] == (float)census[b];
         // popcorn.py:365-372: ((building>0)*region | grid) & region  [occupancymodel]   /   region | grid) & region
         const bool base = occ ? (building[i] > 0.f) : true;
@@ -602,8 +605,8 @@ __global__ __launch_bounds__(256) void sparsity_mask_fallback_kernel(const float
                                                                      int32_t* counts, int B, int H, int W) {
     if (counts[0] != 0) return;
     const int64_t n = (int64_t)B * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / ((int64_t)W * H));
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
+        const int b = (int)(i / (unsigned)(W * H));
         mask[i] = admin[i] == (float)census[b] ? 1 : 0;
     }
 }
@@ -707,6 +710,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     p.partial = reinterpret_cast<float*>(ws);
     p.B = B; p.H = H; p.W = W;
     p.groups = (H * W + 15) / 16;
+    p.div_w = pc_make_fastdiv(W);
+    p.div_groups = pc_make_fastdiv(p.groups);
     p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
@@ -789,6 +794,8 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     p.mask = mask; p.building = building; p.admin = admin_mask; p.census = census_idx;
     p.B = B; p.H = H; p.W = W;
     p.groups = (H * W + 15) / 16;
+    p.div_w = pc_make_fastdiv(W);
+    p.div_groups = pc_make_fastdiv(p.groups);
     a.g_popcount = g_popcount; a.g_popdense = g_popdense; a.g_scale_map = g_scale_map; a.g_scale_const = g_scale_const;
     a.g_feat = *g_feat;
     if (feat_bn_sar && feat_bn_opt) { a.fbn[0] = *feat_bn_sar; a.fbn[1] = *feat_bn_opt; a.fuse_feat_bn = 1; }

@@ -153,6 +153,187 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ---- wave-private variant (aligned DIRECT / POOL2 sources) -------------------------------------------------------------
+// Same GEMM mapping, but every wave owns a 32 x 4 strip and its own pipeline (no workgroup barrier in the loop, see
+// conv3x3.hip): the (CINC x 6 x 40) input strip is register-staged into a private LDS region one strip ahead, and the
+// gradient strip is not staged at all -- with the K ordering x(j,k) = x0 + {0,16,8,24}[k] + j a lane's A operands for
+// the 8 k-steps of a row pair are 8 consecutive floats, i.e. two 16-byte global loads straight into registers.
+constexpr int WIN_RS = 44;                   // == 12 mod 32: rows v = 0..3 land on banks {0,12,24,4} (+dx, +16 for k)
+constexpr int WIN_CSW = 6 * WIN_RS;          // 264
+
+template <int CINC, int COUT, int LD>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradArgs p) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    constexpr int NBLK = Cfg::NBLK, MB = Cfg::MB;
+    constexpr int NIT = CINC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int cbase = p.ci0 + chunk * CINC;
+    float* const wl = lds + wave * (CINC * WIN_CSW);
+
+    const int koff = ((lk & 1) << 4) | ((lk >> 1) << 3);          // {0,16,8,24}
+    int boff[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        int ng = nb * 16 + li;
+        if (ng >= Cfg::NCOL) ng = Cfg::NCOL - 1;      // dead columns: any in-range address, never read back
+        const int ci = ng / 12, rem = ng % 12, v = rem / 3, dx = rem % 3;
+        boff[nb] = ci * WIN_CSW + v * WIN_RS + (IN_COL0 - 1) + dx + koff;
+    }
+
+    // ---- input-strip loader: lane = (row r of 6, 16-byte segment of the 40-float row)
+    const int l_r = lane / 10, l_seg = lane - l_r * 10;
+    const bool l_act = lane < 60;
+    const int CA = p.a.C;
+    const int64_t in_bs = p.a.bstride;
+    const int in_rs = p.a.rstride;
+    f32x4 R[NIT];
+    bool rvalid = false;
+    // ---- gradient strip: lane (i = (s, co8), k): rows y0 + 2*rpi + s, 8 floats at x0 + koff
+    const int g_s = li >> 3, g_c = li & 7;
+    f32x4 G[2][MB][2];
+    unsigned gvalid = 0;      // bit (rpi*2 + half)
+
+    auto issue = [&](int b, int y0, int x0) {
+        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
+        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
+        rvalid = ok;
+        if (LD == 1) {
+            const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cg = cbase + it;
+                const float* cp = cg < CA ? p.a.ptr + cg * p.a.cstride : p.b.ptr + (cg - CA) * p.b.cstride;
+                R[it] = *reinterpret_cast<const f32x4*>(cp + off);
+            }
+        } else {
+            const int64_t off = ok ? b * in_bs + (int64_t)(2 * y) * in_rs + 2 * xg : 0;
+            const int rs1 = ok ? in_rs : 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float* s0 = p.a.ptr + (cbase + it) * p.a.cstride + off;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + rs1), b1 = *reinterpret_cast<const f32x4*>(s0 + rs1 + 4);
+                f32x4 v;
+                v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
+                v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
+                v[2] = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1]));
+                v[3] = fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]));
+                R[it] = v;
+            }
+        }
+        unsigned gm = 0;
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const int yy = y0 + 2 * rpi + g_s;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int xx = x0 + koff + 4 * h;
+                const bool gok = yy < p.H && xx < p.W;
+                gm |= gok ? 1u << (rpi * 2 + h) : 0u;
+                const int64_t goff = gok ? b * p.g.bstride + (int64_t)yy * p.g.rstride + xx : 0;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    G[rpi][mb][h] = *reinterpret_cast<const f32x4*>(p.g.ptr + (mb * 8 + g_c) * p.g.cstride + goff);
+            }
+        }
+        gvalid = gm;
+    };
+    auto commit = [&]() {
+        if (l_act) {
+            float* d = wl + l_r * WIN_RS + 4 * l_seg;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                *reinterpret_cast<f32x4*>(d + it * WIN_CSW) = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x4 acc[MB][NBLK];
+    float bsum[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) {
+        strip_coords(0, b, y0, x0);
+        issue(b, y0, x0);
+    }
+    for (int k = 0; k < my_tiles; ++k) {
+        commit();
+        // A operands of this strip (masked), then prefetch the next strip
+        float av[2][MB][8];
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool gok = (gvalid >> (rpi * 2 + h)) & 1u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[rpi][mb][h * 4 + e] = gok ? G[rpi][mb][h][e] : 0.f;
+                }
+        if (k + 1 < my_tiles) {
+            strip_coords(k + 1, b, y0, x0);
+            issue(b, y0, x0);
+        }
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float bv[NBLK];
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) bv[nb] = wl[boff[nb] + 2 * rpi * WIN_RS + j];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    bsum[mb] += av[rpi][mb][j];
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rpi][mb][j], bv[nb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS (fixed order), one partial per workgroup
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::E;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+            *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
+        __syncthreads();
+        for (int e = tid; e < NBLK * 256; e += 256) {
+            const float s = ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e];
+            part[mb * NBLK * 256 + e] = s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
+    __syncthreads();
+    for (int e = tid; e < MB * 64; e += 256) {
+        const float s = ((lds[e] + lds[MB * 64 + e]) + lds[2 * MB * 64 + e]) + lds[3 * MB * 64 + e];
+        part[MB * NBLK * 256 + e] = s;
+    }
+}
+
 struct WreduceArgs {
     const float* partial;
     int nwg;              // partials per chunk
@@ -246,7 +427,37 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
+    const bool lay = p.b.C == 0 || (p.a.bstride == p.b.bstride && p.a.rstride == p.b.rstride);
+    const bool direct = p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g;
+    const bool pool = p.fast_a == 2 && p.b.C == 0 && p.fast_g;
+    bool launched = false;
+    if constexpr (CINC >= 8) {
+        if (direct || pool) {
+            size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
+            const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
+            if (lw < lred) lw = lred;
+            static bool attr_w[2] = {false, false};
+            if (direct) {
+                if (!attr_w[0]) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+                    if (e != hipSuccess) return (int)e;
+                    attr_w[0] = true;
+                }
+                hipLaunchKernelGGL((conv3x3_wgrad_wave_kernel<CINC, COUT, 1>), dim3(nwg, nchunk), dim3(256), lw, stream, p);
+            } else {
+                if (!attr_w[1]) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+                    if (e != hipSuccess) return (int)e;
+                    attr_w[1] = true;
+                }
+                hipLaunchKernelGGL((conv3x3_wgrad_wave_kernel<CINC, COUT, 2>), dim3(nwg, nchunk), dim3(256), lw, stream, p);
+            }
+            launched = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
     PC_CHECK_LAUNCH();
     WreduceArgs r{};
     r.partial = p.partial; r.nwg = nwg; r.nchunk = nchunk; r.dw = dw; r.db = db; r.Cin = Cin; r.accumulate = accumulate;

@@ -592,11 +592,16 @@ __global__ __launch_bounds__(256) void sparsity_mask_kernel(const float* buildin
         nsel += m;
         nreg += region;
     }
-    // integer counts: order-independent, atomics are exact
+    // integer counts: order-independent, atomics are exact.  One atomic pair per BLOCK (a per-wave atomic on two words
+    // serialised 16 k atomics: 188 us for a 640 k-pixel batch, profiles/r1_v0).
+    __shared__ int red[2][4];
     for (int off = 32; off > 0; off >>= 1) { nsel += __shfl_down(nsel, off); nreg += __shfl_down(nreg, off); }
-    if ((threadIdx.x & 63) == 0) {
-        if (nsel) atomicAdd(&counts[0], nsel);
-        if (nreg) atomicAdd(&counts[1], nreg);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nsel; red[1][threadIdx.x >> 6] = nreg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (a) atomicAdd(&counts[0], a);
+        if (b2) atomicAdd(&counts[1], b2);
     }
 }
 
@@ -745,7 +750,7 @@ extern "C" int pc_sparsity_mask(const float* building, const float* admin_mask, 
     if (e != hipSuccess) return (int)e;
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(sparsity_mask_kernel, dim3(grid), dim3(256), 0, st, building, admin_mask, census_idx, rowsel, colsel,
                        occupancymodel, mask, counts, B, H, W);

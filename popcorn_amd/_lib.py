@@ -32,6 +32,19 @@ class PcBn(C.Structure):
                 ("var", C.c_void_p), ("eps", C.c_float), ("_pad", C.c_int32)]
 
 
+class PcConvFwdDesc(C.Structure):
+    _fields_ = [("a", C.POINTER(PcSrc)), ("b", C.POINTER(PcSrc)), ("w", C.c_void_p), ("bn", C.POINTER(PcBn)),
+                ("out", C.POINTER(PcDst))]
+
+
+class PcConvDgradDesc(C.Structure):
+    _fields_ = [("g", C.POINTER(PcSrc)), ("w", C.c_void_p), ("act", C.POINTER(PcSrc)), ("act_bn", C.POINTER(PcBn)),
+                ("out", C.POINTER(PcDst))]
+
+
+PC_MAX_GROUP = 4
+
+
 class PopcornHipError(RuntimeError):
     pass
 

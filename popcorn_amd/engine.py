@@ -102,44 +102,8 @@ class UNetEngine:
     def forward(self, X, pad_top, pad_left, Hp, Wp, save=False, feats=None):
         """X: (B,6,H,W) in the dataset's channel order [R,G,B,NIR,VV,VH]; the conv domain is the reflect-padded
         (Hp,Wp) image.  Returns (features (B,16,Hp,Wp), saved activations or None)."""
-        L.require_device(X)
-        B = X.shape[0]
-        if pad_top >= X.shape[2] or pad_left >= X.shape[3] or Hp - X.shape[2] - pad_top >= X.shape[2] \
-                or Wp - X.shape[3] - pad_left >= X.shape[3]:
-            raise ValueError("reflect padding must be smaller than the input (same restriction as F.pad reflect)")
-        if Hp < 4 or Wp < 4:
-            raise ValueError("input too small for two 2x2 poolings")
-        dev = X.device
-        H1, W1, = Hp // 2, Wp // 2
-        H2, W2 = H1 // 2, W1 // 2
-        if feats is None:
-            feats = torch.empty(B, 16, Hp, Wp, device=dev, dtype=torch.float32)
-        saved = {} if save else None
-        E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
-        for s, chmap, cin, f0 in STREAMS:
-            ly = lambda t: self.layers[(s, t)]  # noqa: E731
-            a1 = ops.conv3x3_raw(X, ly("inc1").w, ly("inc1").bn, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left),
-                                 chmap=chmap, out_hw=(Hp, Wp), a_channels=cin, out=E(8, Hp, Wp))
-            a2 = ops.conv3x3_raw(a1, ly("inc2").w, ly("inc2").bn, out=E(8, Hp, Wp))
-            b1 = ops.conv3x3_raw(a2, ly("d1a").w, ly("d1a").bn, a_mode=L.PC_SRC_POOL2, out=E(16, H1, W1))
-            b2 = ops.conv3x3_raw(b1, ly("d1b").w, ly("d1b").bn, out=E(16, H1, W1))
-            c1 = ops.conv3x3_raw(b2, ly("d2a").w, ly("d2a").bn, a_mode=L.PC_SRC_POOL2, out=E(16, H2, W2))
-            c2 = ops.conv3x3_raw(c1, ly("d2b").w, ly("d2b").bn, out=E(16, H2, W2))
-            u2 = ops.convt2x2(c2, ly("up2t").w, ly("up2t").b)
-            o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
-            e1 = ops.conv3x3_raw(b2, ly("up2a").w, ly("up2a").bn, b=u2, b_offset=o2, out=E(8, H1, W1))
-            e2 = ops.conv3x3_raw(e1, ly("up2b").w, ly("up2b").bn, out=E(8, H1, W1))
-            u1 = ops.convt2x2(e2, ly("up1t").w, ly("up1t").b)
-            o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
-            f1 = ops.conv3x3_raw(a2, ly("up1a").w, ly("up1a").bn, b=u1, b_offset=o1, out=E(8, Hp, Wp))
-            ops.conv3x3_raw(f1, ly("up1b").w, ly("up1b").bn, out=feats[:, f0:f0 + 8])
-            if save:
-                saved[s] = dict(a1=a1, a2=a2, b1=b1, b2=b2, c1=c1, c2=c2, u2=u2, e1=e1, e2=e2, u1=u1, f1=f1, o1=o1, o2=o2)
-        if save:
-            saved["X"] = X
-            saved["geom"] = (pad_top, pad_left, Hp, Wp)
-            saved["feats"] = feats
-        return feats, saved
+        f, s = forward_multi([self], X, pad_top, pad_left, Hp, Wp, [save], [feats])
+        return f[0], s[0]
 
     def building_score(self, X, pad=14):
         """create_building_score (popcorn.py:279-322): reflect-pad 14, frozen U-Net, fusion_out_conv, sigmoid, crop."""
@@ -155,7 +119,9 @@ class UNetEngine:
     def backward(self, saved, G, grads, accumulate=False, encoder_no_grad=False, prefix=""):
         """G: (B,16,Hp,Wp) gradient w.r.t. the conv outputs of the two up1b layers (i.e. already multiplied by
         relu-mask * bn-scale -- the head-backward epilogue does that).  Writes dW/db into ``grads[prefix+name]``
-        (= or += per ``accumulate``).  encoder_no_grad: networks.py:124-132 semantics."""
+        (= or += per ``accumulate``).  encoder_no_grad: networks.py:124-132 semantics.
+        Data-gradient launches are grouped over the two streams (same shapes); weight-gradient launches are per
+        stream (each owns its partial-sum workspace)."""
         X = saved["X"]
         pad_top, pad_left, Hp, Wp = saved["geom"]
         B = X.shape[0]
@@ -163,57 +129,153 @@ class UNetEngine:
         H1, W1 = Hp // 2, Wp // 2
         H2, W2 = H1 // 2, W1 // 2
         E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
+        S = [s for s, _, _, _ in STREAMS]
+        A = {s: saved[s] for s in S}
+        ly = lambda s, t: self.layers[(s, t)]  # noqa: E731
+
+        def wg(s, tag, a, g, **kw):
+            lay = ly(s, tag)
+            ops.conv3x3_wgrad(a, g, lay.w.shape[0], dw=grads[prefix + lay.wname], db=grads[prefix + lay.bname],
+                              accumulate=accumulate, **kw)
+
+        def wgt(s, tag, x, g):
+            lay = ly(s, tag)
+            ops.convt2x2_wgrad(x, g, dw=grads[prefix + lay.wname], db=grads[prefix + lay.bname], accumulate=accumulate)
+
+        def dg(tag, gs, outs, c0, cn, acts=None, act_tag=None, pool=False, acc=False):
+            """grouped data-gradient of layer `tag` over both streams"""
+            probs = []
+            for s in S:
+                pr = {"g": gs[s], "w": ly(s, tag).w, "out": outs[s]}
+                if acts is not None:
+                    pr["act"] = acts[s]
+                    pr["act_bn"] = ly(s, act_tag).bn_nobias
+                probs.append(pr)
+            ops.conv3x3_dgrad_group(probs, c0, cn, pool=pool, accumulate=acc)
+            return outs
+
+        G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in STREAMS}
+        for s in S:
+            wg(s, "up1b", A[s]["f1"], G_f2[s])
+        G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
+        for s in S:
+            wg(s, "up1a", A[s]["a2"], G_f1[s], b=A[s]["u1"], b_offset=A[s]["o1"])
+        if not encoder_no_grad:
+            G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
+        g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
+        G_e2 = {}
+        for s in S:
+            oy, ox = A[s]["o1"]
+            g_u1v = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
+            wgt(s, "up1t", A[s]["e2"], g_u1v)
+            G_e2[s] = ops.convt2x2_dgrad(g_u1v, ly(s, "up1t").w, E(8, H1, W1), act=A[s]["e2"], act_bn=ly(s, "up2b").bn_nobias)
+        for s in S:
+            wg(s, "up2b", A[s]["e1"], G_e2[s])
+        G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
+        for s in S:
+            wg(s, "up2a", A[s]["b2"], G_e1[s], b=A[s]["u2"], b_offset=A[s]["o2"])
+        if not encoder_no_grad:
+            G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+        g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
+        G_c2 = {}
+        for s in S:
+            oy, ox = A[s]["o2"]
+            g_u2v = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
+            wgt(s, "up2t", A[s]["c2"], g_u2v)
+            if not encoder_no_grad:
+                G_c2[s] = ops.convt2x2_dgrad(g_u2v, ly(s, "up2t").w, E(16, H2, W2), act=A[s]["c2"],
+                                             act_bn=ly(s, "d2b").bn_nobias)
+        if encoder_no_grad:
+            return
+        # encoder
+        for s in S:
+            wg(s, "d2b", A[s]["c1"], G_c2[s])
+        G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
+        for s in S:
+            wg(s, "d2a", A[s]["b2"], G_c1[s], a_mode=L.PC_SRC_POOL2)
+        dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
+        for s in S:
+            wg(s, "d1b", A[s]["b1"], G_b2[s])
+        G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
+        for s in S:
+            wg(s, "d1a", A[s]["a2"], G_b1[s], a_mode=L.PC_SRC_POOL2)
+        dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
+        for s in S:
+            wg(s, "inc2", A[s]["a1"], G_a2[s])
+        G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
         for s, chmap, cin, f0 in STREAMS:
-            A = saved[s]
-            ly = lambda t: self.layers[(s, t)]  # noqa: E731
+            wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
 
-            def wg(tag, a, g, **kw):
-                lay = ly(tag)
-                ops.conv3x3_wgrad(a, g, lay.w.shape[0], dw=grads[prefix + lay.wname],
-                                  db=grads[prefix + lay.bname], accumulate=accumulate, **kw)
 
-            def wgt(tag, x, g):
-                lay = ly(tag)
-                ops.convt2x2_wgrad(x, g, dw=grads[prefix + lay.wname], db=grads[prefix + lay.bname],
-                                   accumulate=accumulate)
+def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None):
+    """Forward of several DualStreamUNets (e.g. the frozen building extractor and the trainable U-Net) on the same
+    input and geometry, layer by layer, with ONE launch per layer for all (network, stream) pairs: 4x fewer
+    launches than per-stream execution and 4x more workgroups per launch on the 32x32 layers.
+    Returns ([features], [saved-or-None])."""
+    L.require_device(X)
+    B = X.shape[0]
+    if pad_top >= X.shape[2] or pad_left >= X.shape[3] or Hp - X.shape[2] - pad_top >= X.shape[2] \
+            or Wp - X.shape[3] - pad_left >= X.shape[3]:
+        raise ValueError("reflect padding must be smaller than the input (same restriction as F.pad reflect)")
+    if Hp < 4 or Wp < 4:
+        raise ValueError("input too small for two 2x2 poolings")
+    dev = X.device
+    H1, W1 = Hp // 2, Wp // 2
+    H2, W2 = H1 // 2, W1 // 2
+    nE = len(engines)
+    if feats_list is None:
+        feats_list = [None] * nE
+    feats = [f if f is not None else torch.empty(B, 16, Hp, Wp, device=dev, dtype=torch.float32) for f in feats_list]
+    E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
+    keys = [(e, s) for e in range(nE) for s, _, _, _ in STREAMS]
+    ly = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
 
-            G_f2 = G[:, f0:f0 + 8]
-            # up1b
-            wg("up1b", A["f1"], G_f2)
-            G_f1 = ops.conv3x3_dgrad(G_f2, ly("up1b").w, 0, 8, E(8, Hp, Wp), act=A["f1"], act_bn=ly("up1a").bn_nobias)
-            # up1a over cat[a2, pad(u1)]
-            wg("up1a", A["a2"], G_f1, b=A["u1"], b_offset=A["o1"])
-            if not encoder_no_grad:
-                G_a2 = ops.conv3x3_dgrad(G_f1, ly("up1a").w, 0, 8, E(8, Hp, Wp), act=A["a2"], act_bn=ly("inc2").bn_nobias)
-            g_u1 = ops.conv3x3_dgrad(G_f1, ly("up1a").w, 8, 8, E(8, Hp, Wp))
-            oy, ox = A["o1"]
-            g_u1v = g_u1[:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
-            wgt("up1t", A["e2"], g_u1v)
-            G_e2 = ops.convt2x2_dgrad(g_u1v, ly("up1t").w, E(8, H1, W1), act=A["e2"], act_bn=ly("up2b").bn_nobias)
-            # up2b, up2a
-            wg("up2b", A["e1"], G_e2)
-            G_e1 = ops.conv3x3_dgrad(G_e2, ly("up2b").w, 0, 8, E(8, H1, W1), act=A["e1"], act_bn=ly("up2a").bn_nobias)
-            wg("up2a", A["b2"], G_e1, b=A["u2"], b_offset=A["o2"])
-            if not encoder_no_grad:
-                G_b2 = ops.conv3x3_dgrad(G_e1, ly("up2a").w, 0, 16, E(16, H1, W1), act=A["b2"], act_bn=ly("d1b").bn_nobias)
-            g_u2 = ops.conv3x3_dgrad(G_e1, ly("up2a").w, 16, 16, E(16, H1, W1))
-            oy, ox = A["o2"]
-            g_u2v = g_u2[:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
-            wgt("up2t", A["c2"], g_u2v)
-            if encoder_no_grad:
-                continue
-            G_c2 = ops.convt2x2_dgrad(g_u2v, ly("up2t").w, E(16, H2, W2), act=A["c2"], act_bn=ly("d2b").bn_nobias)
-            # encoder
-            wg("d2b", A["c1"], G_c2)
-            G_c1 = ops.conv3x3_dgrad(G_c2, ly("d2b").w, 0, 16, E(16, H2, W2), act=A["c1"], act_bn=ly("d2a").bn_nobias)
-            wg("d2a", A["b2"], G_c1, a_mode=L.PC_SRC_POOL2)
-            ops.conv3x3_dgrad(G_c1, ly("d2a").w, 0, 16, G_b2, act=A["b2"], act_bn=ly("d1b").bn_nobias, pool=True,
-                              accumulate=True)
-            wg("d1b", A["b1"], G_b2)
-            G_b1 = ops.conv3x3_dgrad(G_b2, ly("d1b").w, 0, 16, E(16, H1, W1), act=A["b1"], act_bn=ly("d1a").bn_nobias)
-            wg("d1a", A["a2"], G_b1, a_mode=L.PC_SRC_POOL2)
-            ops.conv3x3_dgrad(G_b1, ly("d1a").w, 0, 8, G_a2, act=A["a2"], act_bn=ly("inc2").bn_nobias, pool=True,
-                              accumulate=True)
-            wg("inc2", A["a1"], G_a2)
-            G_a1 = ops.conv3x3_dgrad(G_a2, ly("inc2").w, 0, 8, E(8, Hp, Wp), act=A["a1"], act_bn=ly("inc1").bn_nobias)
-            wg("inc1", X, G_a1, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
+    def conv(tag, ins, c, h, w, outs=None, bs=None, **kw):
+        outs = outs or {k: E(c, h, w) for k in keys}
+        probs = []
+        for k in keys:
+            pr = {"a": ins[k], "w": ly(k, tag).w, "bn": ly(k, tag).bn, "out": outs[k]}
+            if bs is not None:
+                pr["b"] = bs[k]
+            probs.append(pr)
+        ops.conv3x3_fwd_group(probs, **kw)
+        return outs
+
+    # first layer: reflect padding + channel gather fused; Cin differs per stream -> one launch per stream kind
+    a1 = {}
+    for s, chmap, cin, f0 in STREAMS:
+        ks = [k for k in keys if k[1] == s]
+        probs = []
+        for k in ks:
+            a1[k] = E(8, Hp, Wp)
+            probs.append({"a": X, "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k], "chmap": chmap})
+        ops.conv3x3_fwd_group(probs, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), out_hw=(Hp, Wp), a_channels=cin)
+    a2 = conv("inc2", a1, 8, Hp, Wp)
+    b1 = conv("d1a", a2, 16, H1, W1, a_mode=L.PC_SRC_POOL2)
+    b2 = conv("d1b", b1, 16, H1, W1)
+    c1 = conv("d2a", b2, 16, H2, W2, a_mode=L.PC_SRC_POOL2)
+    c2 = conv("d2b", c1, 16, H2, W2)
+    u2 = {k: ops.convt2x2(c2[k], ly(k, "up2t").w, ly(k, "up2t").b) for k in keys}
+    o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
+    e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
+    e2 = conv("up2b", e1, 8, H1, W1)
+    u1 = {k: ops.convt2x2(e2[k], ly(k, "up1t").w, ly(k, "up1t").b) for k in keys}
+    o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
+    f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
+    f0s = {s: f0 for s, _, _, f0 in STREAMS}
+    conv("up1b", f1, 8, Hp, Wp, outs={k: feats[k[0]][:, f0s[k[1]]:f0s[k[1]] + 8] for k in keys})
+    saved = []
+    for e in range(nE):
+        if not saves[e]:
+            saved.append(None)
+            continue
+        sv = {}
+        for s, _, _, _ in STREAMS:
+            k = (e, s)
+            sv[s] = dict(a1=a1[k], a2=a2[k], b1=b1[k], b2=b2[k], c1=c1[k], c2=c2[k], u2=u2[k], e1=e1[k], e2=e2[k],
+                         u1=u1[k], f1=f1[k], o1=o1, o2=o2)
+        sv["X"] = X
+        sv["geom"] = (pad_top, pad_left, Hp, Wp)
+        sv["feats"] = feats[e]
+        saved.append(sv)
+    return feats, saved

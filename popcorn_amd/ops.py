@@ -40,6 +40,62 @@ def conv3x3_raw(a, w, bnd, relu=True, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 
     return out
 
 
+def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), out_hw=None, a_channels=None,
+                      b_offset=(0, 0)):
+    """Grouped form of conv3x3_raw: ``problems`` = list (<= 4) of dicts {a, w, bn, out, b (optional), chmap (optional)}
+    with identical geometry; one launch (blockIdx.y = problem)."""
+    n = len(problems)
+    assert 1 <= n <= L.PC_MAX_GROUP
+    a0, w0 = problems[0]["a"], problems[0]["w"]
+    L.require_device(a0, w0)
+    B = a0.shape[0]
+    Ca = a0.shape[1] if a_channels is None else a_channels
+    Cb = 0 if problems[0].get("b") is None else problems[0]["b"].shape[1]
+    Cout = w0.shape[0]
+    if a_mode == L.PC_SRC_POOL2:
+        H, W = a0.shape[2] // 2, a0.shape[3] // 2
+    elif a_mode == L.PC_SRC_REFLECT:
+        H, W = out_hw
+    else:
+        H, W = a0.shape[2], a0.shape[3]
+    keep = []
+    descs = (L.PcConvFwdDesc * n)()
+    for i, pr in enumerate(problems):
+        sa = L.src(pr["a"], C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=pr.get("chmap", (0, 1, 2, 3)))
+        sb = L.src(pr["b"], oy=b_offset[0], ox=b_offset[1]) if pr.get("b") is not None else None
+        d = L.dst(pr["out"])
+        keep += [sa, sb, d]
+        descs[i].a = C.pointer(sa)
+        descs[i].b = C.pointer(sb) if sb is not None else None
+        descs[i].w = pr["w"].data_ptr()
+        descs[i].bn = C.pointer(pr["bn"])
+        descs[i].out = C.pointer(d)
+    L.check(L.lib().pc_conv3x3_bn_relu_fwd_group(n, descs, int(relu), B, H, W, Ca + Cb, Cout, L.stream_ptr()),
+            "pc_conv3x3_bn_relu_fwd_group")
+
+
+def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):
+    """Grouped conv3x3_dgrad: problems = list of dicts {g, w, out, act (optional), act_bn (optional)}."""
+    n = len(problems)
+    assert 1 <= n <= L.PC_MAX_GROUP
+    g0, w0 = problems[0]["g"], problems[0]["w"]
+    L.require_device(g0, w0)
+    B, Cg, H, W = g0.shape
+    keep = []
+    descs = (L.PcConvDgradDesc * n)()
+    for i, pr in enumerate(problems):
+        sg, d = L.src(pr["g"]), L.dst(pr["out"])
+        sa = L.src(pr["act"]) if pr.get("act") is not None else None
+        keep += [sg, d, sa]
+        descs[i].g = C.pointer(sg)
+        descs[i].w = pr["w"].data_ptr()
+        descs[i].act = C.pointer(sa) if sa is not None else None
+        descs[i].act_bn = C.pointer(pr["act_bn"]) if pr.get("act_bn") is not None else None
+        descs[i].out = C.pointer(d)
+    L.check(L.lib().pc_conv3x3_dgrad_group(n, descs, w0.shape[1], c0, cn, int(pool), int(accumulate), B, H, W, Cg,
+                                           L.stream_ptr()), "pc_conv3x3_dgrad_group")
+
+
 def conv3x3_bn_relu(a, w, bias, gamma=None, beta=None, mean=None, var=None, eps=1e-5, relu=True, **kw):
     return conv3x3_raw(a, w, L.bn(bias, gamma, beta, mean, var, eps), relu=relu, **kw)
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import engine as E
 from . import ops
 from .distributed import FlatReducer
 from .model.popcorn import pad_geometry
@@ -87,14 +88,21 @@ class FusedTrainStep:
         X = s["input"]
         B, _, H, W = X.shape
         eng_u, eng_b = m.engines()
-        building = eng_b.building_score(X, m.p)
+        pt, pb, pl, pr = pad_geometry(H, W, False)
+        fused = (pt, pb, pl, pr) == (m.p, m.p, m.p, m.p)      # e.g. 100x100 tiles: both networks see the same 128x128 domain
+        if fused:
+            (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
+                                                       [False, not unet_no_grad])
+            building = ops.outconv_sigmoid_crop(f_b, eng_b.fusion_w, eng_b.fusion_b, H, W, pt, pl)
+        else:
+            building = eng_b.building_score(X, m.p)
         s["building_counts"] = building
         if not m.occupancymodel:
             building = torch.ones_like(building)
         mask, counts = ops.sparsity_mask(s["building_counts"], s["admin_mask"], s["census_idx"], sel[:H], sel[H:],
                                          m.occupancymodel)
-        pt, pb, pl, pr = pad_geometry(H, W, False)
-        feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
+        if not fused:
+            feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
                                                      admin_mask=s["admin_mask"], census_idx=s["census_idx"],
                                                      stats=self.stats, nsel_counts=counts)

@@ -210,6 +210,27 @@ int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n
 int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,
                         float* out, int B, int H, int W, void* stream);
 
+/* ---- census aggregation + sliding-window stitching ----------------------- */
+
+/* Region totals: sums[id] = sum of pred over pixels with boundary == id, id in [0, num_ids) (other ids, e.g. the -1
+ * fill, are ignored); counts[id] (optional) = pixel count.  One pass instead of the per-census-row bbox-crop loop of
+ * convert_popmap_to_census (data/PopulationDataset.py:705-712).  fp64 accumulation; pred/boundary 16-byte aligned. */
+int pc_census_sum(const float* pred, const int32_t* boundary, int64_t n, int num_ids, double* sums, int32_t* counts,
+                  void* stream);
+/* Dasymetric adjustment, adjust_map_to_census (PopulationDataset.py:823-852): pred[i] *= pop[id] / float(sums[id]) for
+ * regions with a census entry (has_entry[id] != 0, NULL = all) and a non-zero total. */
+int pc_census_adjust(float* pred, const int32_t* boundary, int64_t n, int num_ids, const double* sums, const float* pop,
+                     const uint8_t* has_entry, void* stream);
+/* One sliding window of an M-member ensemble into the (H,W) device accumulators (run_eval.py:108-135): interior pixels
+ * only (border of `overlap` excluded, PopulationDataset.py:656-672), window origin (yl,xl) = img_coords.
+ * popdense/scale: [M][ps_y][ps_x] (scale may be NULL). */
+int pc_stitch_accumulate(const float* popdense, const float* scale, int M, int ps_y, int ps_x, int overlap, int yl, int xl,
+                         float* out_sum, float* out_sq, float* scale_sum, float* scale_sq, int16_t* count, int H, int W,
+                         void* stream);
+/* run_eval.py:140-154: where count > 1: sum -> mean, sq -> unbiased std; pixels visited once keep their raw values. */
+int pc_stitch_finalize(float* out_sum, float* out_sq, float* scale_sum, float* scale_sq, const int16_t* count, int64_t n,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,6 +266,46 @@ def g6_loss_metrics(losses, metrics):
     np.savez_compressed(os.path.join(OUT, "g6_loss_metrics.npz"), **out)
 
 
+def g7_dataset_helpers():
+    """Pure-torch helpers of data/PopulationDataset.py, importable with a rasterio stub: get_patch_indices (:294-334),
+    _create_mask (:656-672) and Population_Dataset_collate_fn (:885-958)."""
+    for name in ("rasterio", "rasterio.warp", "rasterio.windows", "rasterio.features", "rasterio.transform", "rasterio.crs",
+                 "rasterio.enums"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["rasterio.warp"].transform_geom = None
+    sys.modules["rasterio.windows"].Window = object
+    sys.modules["rasterio"].windows = sys.modules["rasterio.windows"]
+    import data.PopulationDataset as PD
+    out = {}
+
+    class Dummy:
+        pass
+
+    for (h, w) in [(5000, 4100), (2048 + 2 * 1792 + 300, 2300), (2049, 2049)]:
+        for fs in (False, True):
+            d = Dummy()
+            d.img_shape = (h, w)
+            d.fourseasons = fs
+            idx = PD.Population_Dataset.get_patch_indices(d, 2048, 128)
+            out[f"patch_indices/{h}x{w}/fs{int(fs)}"] = idx.numpy().copy()
+    d = Dummy()
+    out["create_mask/20x30_o4"] = PD.Population_Dataset._create_mask(d, 20, 30, 4).copy()
+    # collate: irregular shapes
+    g = torch.Generator().manual_seed(71)
+    batch = []
+    for i, (hh, ww) in enumerate([(7, 5), (4, 9), (6, 6)]):
+        batch.append({"S2": torch.randn(4, hh, ww, generator=g), "S1": torch.randn(2, hh, ww, generator=g),
+                      "admin_mask": torch.randint(0, 5, (hh, ww), generator=g).float(), "y": torch.tensor(float(10 + i)),
+                      "img_coords": (i, 2 * i), "valid_coords": (i, i), "season": i % 4,
+                      "census_idx": torch.tensor([i + 3])})
+        for k in ("S2", "S1", "admin_mask"):
+            out[f"collate/in{i}/{k}"] = np_(batch[-1][k])
+    res = PD.Population_Dataset_collate_fn(batch)
+    for k in ("S2", "S1", "admin_mask", "y", "season", "census_idx"):
+        out[f"collate/out/{k}"] = np_(res[k])
+    np.savez_compressed(os.path.join(OUT, "g7_dataset_helpers.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     popcorn, networks, get_model, losses, metrics = import_reference()
@@ -275,6 +315,7 @@ def main():
     g4_mask(popcorn, m)
     g5_train(popcorn, losses)
     g6_loss_metrics(losses, metrics)
+    g7_dataset_helpers()
     args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
                           pretrained=True, biasinit=0.9407, sentinelbuildings=True)
     kw = get_model.get_model_kwargs(args, "POPCORN")

@@ -1,0 +1,303 @@
+"""Entry-point counterparts of the reference's ``run_train.py`` / ``run_eval.py`` (same flag names and defaults as
+arguments/train.py:10-60 and arguments/eval.py:4-26; argparse instead of configargparse, JSONL instead of wandb).
+
+Order of operations of the training loop is the reference's (run_train.py:146-269):
+  to_device -> normalise (+ augment) -> limit1/2/3 gating -> forward(train, padding=False, sparse=True) -> get_loss ->
+  x lam_weak -> backward -> clip_grad_norm_(gradient_clip) -> Adam step -> zero_grad; StepLR per epoch; checkpoint dict
+  {'model','epoch','iter','optimizer','scheduler'} in ``<save_dir>/experiment_*/last_model.pth`` (:445-456).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .data import stats
+from .data.collate import Population_Dataset_collate_fn, augment_geometric
+from .data.dataset import SyntheticTestRaster, SyntheticWeaksupDataset
+from .distributed import FlatReducer, init_from_env
+from .model import get_model_kwargs, model_dict
+
+
+def train_parser():
+    p = argparse.ArgumentParser(description="Training Population Estimation (MI355X)")
+    p.add_argument("-r", "--resume", type=str)
+    p.add_argument("-treg", "--target_regions", nargs="+", default=["pri2017"])
+    p.add_argument("-tregtrain", "--target_regions_train", nargs="+", default=["pri2017"])
+    p.add_argument("-S1", "--Sentinel1", action="store_true")
+    p.add_argument("-S2", "--Sentinel2", action="store_true")
+    p.add_argument("-NIR", "--NIR", action="store_true")
+    p.add_argument("-wb", "--weak_batch_size", type=int, default=2)
+    p.add_argument("-wvb", "--weak_val_batch_size", type=int, default=1)
+    p.add_argument("-pret", "--pretrained", action="store_true")
+    p.add_argument("-m", "--model", type=str, default="POPCORN")
+    p.add_argument("-binit", "--biasinit", type=float, default=0.75)
+    p.add_argument("-occmodel", "--occupancymodel", action="store_true")
+    p.add_argument("-binp", "--buildinginput", action="store_true")
+    p.add_argument("-sinp", "--segmentationinput", action="store_true")
+    p.add_argument("-senbuilds", "--sentinelbuildings", action="store_true")
+    p.add_argument("-fe", "--feature_extractor", type=str, default="DDA")
+    p.add_argument("-e", "--num_epochs", type=int, default=100)
+    p.add_argument("-lr", "--learning_rate", type=float, default=1e-4)
+    p.add_argument("-l", "--loss", nargs="+", default=["log_l1_loss"])
+    p.add_argument("-sreg", "--scale_regularization", default=0.01, type=float)
+    p.add_argument("-la", "--lam", nargs="+", type=float, default=[1.0])
+    p.add_argument("-lw", "--lam_weak", type=float, default=100.0)
+    p.add_argument("-lim1", "--limit1", type=int, default=9000000)
+    p.add_argument("-lim2", "--limit2", type=int, default=9000000)
+    p.add_argument("-lim3", "--limit3", type=int, default=13000000)
+    p.add_argument("-wd", "--weightdecay", type=float, default=0.0)
+    p.add_argument("-lrs", "--lr_step", type=int, default=5)
+    p.add_argument("-lrg", "--lr_gamma", type=float, default=0.75)
+    p.add_argument("-gc", "--gradient_clip", type=float, default=0.01)
+    p.add_argument("--save_dir", default="outputs")
+    p.add_argument("-w", "--num_workers", type=int, default=0)
+    p.add_argument("-lt", "--logstep_train", type=int, default=25)
+    p.add_argument("-val", "--val_every_n_epochs", type=int, default=2)
+    p.add_argument("--seed", type=int, default=1600)
+    p.add_argument("--save-model", default="both", choices=["last", "best", "no", "both"])
+    p.add_argument("-mws", "--max_weak_samples", type=int, default=None)
+    # build-specific
+    p.add_argument("--synthetic_regions", type=int, default=64, help="size of the synthetic weaksup dataset")
+    p.add_argument("--fixed_hw", type=int, nargs=2, default=None, help="fixed crop size (enables HIP-graph replay)")
+    p.add_argument("--torch_optimizer", action="store_true",
+                   help="reference recipe through torch autograd + torch.optim.Adam instead of the fused HIP step")
+    p.add_argument("--max_steps", type=int, default=None)
+    return p
+
+
+def eval_parser():
+    p = argparse.ArgumentParser(description="Ensemble evaluation (MI355X)")
+    p.add_argument("-r", "--resume", nargs="+", type=str, default=[])
+    p.add_argument("-treg", "--target_regions", nargs="+", default=["pri2017"])
+    p.add_argument("-S1", "--Sentinel1", action="store_true")
+    p.add_argument("-S2", "--Sentinel2", action="store_true")
+    p.add_argument("-NIR", "--NIR", action="store_true")
+    p.add_argument("-m", "--model", type=str, default="POPCORN")
+    p.add_argument("-binit", "--biasinit", type=float, default=0.75)
+    p.add_argument("-occmodel", "--occupancymodel", action="store_true")
+    p.add_argument("-senbuilds", "--sentinelbuildings", action="store_true")
+    p.add_argument("-pret", "--pretrained", action="store_true")
+    p.add_argument("-fe", "--feature_extractor", type=str, default="DDA")
+    p.add_argument("--fourseasons", action="store_true")
+    p.add_argument("--save_dir", default="outputs")
+    p.add_argument("--seed", type=int, default=1610)
+    p.add_argument("--raster_hw", type=int, nargs=2, default=[2304, 2560])
+    p.add_argument("--patchsize", type=int, default=2048)
+    p.add_argument("--overlap", type=int, default=128)
+    p.add_argument("--ensemble", type=int, default=1, help="members to instantiate when no --resume checkpoints are given")
+    return p
+
+
+def seed_all(seed):
+    """utils/utils.py:50-59."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+
+def new_log(folder, args=None):
+    """utils/utils.py:62-73."""
+    os.makedirs(folder, exist_ok=True)
+    n_exp = len(os.listdir(folder))
+    randn = round((time.time() * 1000000) % 1000)
+    exp = os.path.join(folder, f"experiment_{n_exp}_{randn}")
+    os.makedirs(exp, exist_ok=True)
+    if args is not None:
+        with open(os.path.join(exp, "args.csv"), "w") as fh:
+            fh.write("key,value\n")
+            for k, v in vars(args).items():
+                fh.write(f"{k},{v}\n")
+    return exp
+
+
+def normalize_sample(sample, device):
+    """to_cuda_inplace + apply_normalize + concat [S2, S1] (utils/utils.py:22-43,105-127,171) on the device."""
+    s2, s1 = sample["S2"].to(device, non_blocking=True), sample["S1"].to(device, non_blocking=True)
+    raw = torch.cat([s2, s1], 1).contiguous().float()
+    x = ops.select_normalize(raw, (0, 1, 2, 3, 4, 5), stats.MEAN6, stats.STD6)
+    out = {"input": x, "admin_mask": sample["admin_mask"].to(device).float().contiguous(),
+           "census_idx": sample["census_idx"].to(device).contiguous(), "y": sample["y"].to(device).float().contiguous()}
+    return out
+
+
+class Trainer:
+    def __init__(self, args):
+        self.args = args
+        self.rank, self.local_rank, self.world = init_from_env()
+        if not torch.cuda.is_available():
+            raise SystemExit("popcorn_amd training needs a HIP device (no CPU path)")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.exp = new_log(os.path.join(args.save_dir, "So2Sat"), args) if self.rank == 0 else None
+        seed_all(args.seed)
+        ds = SyntheticWeaksupDataset(args.synthetic_regions, seed=args.seed, fixed_hw=args.fixed_hw)
+        sampler = None
+        if self.world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
+                                                                      shuffle=True, seed=args.seed, drop_last=True)
+        self.loader = torch.utils.data.DataLoader(ds, batch_size=args.weak_batch_size, num_workers=args.num_workers,
+                                                  shuffle=sampler is None, sampler=sampler,
+                                                  collate_fn=Population_Dataset_collate_fn, drop_last=True)
+        self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)
+        seed_all(args.seed + 2)
+        self.reducer = FlatReducer()
+        self.info = {"epoch": 0, "iter": 0, "sampleitr": 0}
+        if args.torch_optimizer:
+            head_name = ["head.6.weight", "head.6.bias"]                     # run_train.py:82-90
+            named = list(self.model.named_parameters())
+            self.optimizer = torch.optim.Adam([
+                {"params": [p for n, p in named if n not in head_name and "unetmodel" not in n], "weight_decay": args.weightdecay},
+                {"params": [p for n, p in named if n not in head_name and "unetmodel" in n], "weight_decay": args.weightdecay},
+                {"params": [p for n, p in named if n in head_name and "unetmodel" not in n], "weight_decay": 0.0}],
+                lr=args.learning_rate)
+            self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=args.lr_step, gamma=args.lr_gamma)
+            self.fused = None
+        else:
+            from .train import FusedTrainStep
+            self.fused = FusedTrainStep(self.model, lr=args.learning_rate, weight_decay=args.weightdecay,
+                                        gradient_clip=args.gradient_clip, loss=args.loss, lam=args.lam,
+                                        scale_regularization=args.scale_regularization, lam_weak=args.lam_weak,
+                                        reducer=self.reducer, use_graph=args.fixed_hw is not None)
+        if args.resume:
+            self.resume(args.resume)
+
+    # ---- checkpoint (run_train.py:445-476) --------------------------------------------------------------------------
+    def save_model(self, prefix="last"):
+        if self.rank != 0:
+            return None
+        path = os.path.join(self.exp, f"{prefix}_model.pth")
+        if self.fused is not None:
+            opt = {"fused_adam": {"m": self.fused.m.cpu(), "v": self.fused.v.cpu(), "step": self.fused.step_count.cpu(),
+                                  "lr": self.fused.lr}}
+            sched = {"lr": self.fused.lr}
+        else:
+            opt, sched = self.optimizer.state_dict(), self.scheduler.state_dict()
+        torch.save({"model": self.model.state_dict(), "epoch": self.info["epoch"], "iter": self.info["iter"],
+                    "optimizer": opt, "scheduler": sched}, path)
+        return path
+
+    def resume(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["model"])
+        self.info["epoch"], self.info["iter"] = ck["epoch"], ck["iter"]
+        if self.fused is not None and "fused_adam" in ck["optimizer"]:
+            fa = ck["optimizer"]["fused_adam"]
+            self.fused.m.copy_(fa["m"]); self.fused.v.copy_(fa["v"]); self.fused.step_count.copy_(fa["step"])
+            self.fused.set_lr(fa["lr"])
+        elif self.fused is None:
+            self.optimizer.load_state_dict(ck["optimizer"])
+            self.scheduler.load_state_dict(ck["scheduler"])
+
+    # ---- loop ------------------------------------------------------------------------------------------------------
+    def train_step(self, sample):
+        a = self.args
+        s = normalize_sample(sample, self.device)
+        s["input"], s["admin_mask"] = augment_geometric(s["input"], s["admin_mask"])
+        num_pix = s["input"].shape[0] * s["input"].shape[2] * s["input"].shape[3]
+        enc_ng = unet_ng = False                                           # run_train.py:191-198
+        if num_pix > a.limit1:
+            enc_ng = True
+            if num_pix > a.limit2:
+                unet_ng = True
+                if num_pix > a.limit3:
+                    return None
+        if self.fused is not None:
+            return self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0]
+        from torch.nn.utils import clip_grad_norm_
+        from .utils.losses import get_loss
+        out = self.model(s, train=True, padding=False, sparse=True, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
+        loss, _ = get_loss(out, s, scale=out["scale"], loss=a.loss, lam=a.lam, scale_regularization=a.scale_regularization,
+                           tag="weak")
+        if torch.isnan(loss) or torch.isinf(loss):
+            raise Exception("detected NaN/Inf loss..")
+        self.optimizer.zero_grad()
+        (loss * a.lam_weak).backward()
+        if a.gradient_clip > 0.0:
+            clip_grad_norm_(self.model.parameters(), a.gradient_clip)
+        self.optimizer.step()
+        return loss.detach()
+
+    def train(self):
+        a = self.args
+        log = open(os.path.join(self.exp, "train_log.jsonl"), "a") if self.rank == 0 else None
+        lr = a.learning_rate * (a.lr_gamma ** (self.info["epoch"] // a.lr_step))
+        t0 = time.time()
+        for epoch in range(self.info["epoch"], a.num_epochs):
+            self.model.train()
+            losses = []
+            for i, sample in enumerate(self.loader):
+                loss = self.train_step(sample)
+                if loss is not None:
+                    losses.append(loss)
+                self.info["iter"] += 1
+                self.info["sampleitr"] += a.weak_batch_size
+                if (i + 1) % a.logstep_train == 0 and log:
+                    mean = torch.stack(losses[-a.logstep_train:]).mean().item()
+                    log.write(json.dumps({"iter": self.info["iter"], "epoch": epoch, "loss": mean, "lr": lr}) + "\n")
+                    log.flush()
+                if a.max_steps and self.info["iter"] >= a.max_steps:
+                    break
+            self.info["epoch"] = epoch + 1
+            if a.save_model in ("last", "both"):
+                self.save_model("last")
+            if a.lr_gamma != 1.0:                                          # StepLR(step_size=lr_step, gamma), run_train.py:93,141
+                lr = a.learning_rate * (a.lr_gamma ** ((epoch + 1) // a.lr_step))
+                if self.fused is not None:
+                    self.fused.set_lr(lr)
+                else:
+                    self.scheduler.step()
+            if a.max_steps and self.info["iter"] >= a.max_steps:
+                break
+        if self.rank == 0:
+            print(f"Training finished in {time.time() - t0:.1f} s, {self.info['iter']} iterations; logs in {self.exp}")
+        return losses
+
+
+def run_train(argv=None):
+    args = train_parser().parse_args(argv)
+    t = Trainer(args)
+    t.train()
+    return t
+
+
+def run_eval(argv=None):
+    from . import eval as E
+    from .utils.metrics import get_test_metrics
+    args = eval_parser().parse_args(argv)
+    rank, local_rank, world = init_from_env()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    seed_all(args.seed)
+    models = []
+    n = max(len(args.resume), args.ensemble)
+    for j in range(n):
+        m = model_dict[args.model](**get_model_kwargs(args, args.model)).to(dev)
+        if j < len(args.resume):
+            m.load_state_dict(torch.load(args.resume[j], map_location="cpu", weights_only=False)["model"])   # run_eval.py:243-257
+        models.append(m.eval())
+    data = SyntheticTestRaster(args.raster_hw[0], args.raster_hw[1], seasons=4 if args.fourseasons else 1, device=dev)
+    reducer = FlatReducer()
+    t0 = time.time()
+    out, out_std, scale, scale_std = E.evaluate_raster(models, data.raster, args.patchsize, args.overlap, args.fourseasons,
+                                                       reducer, rank)
+    res = {}
+    cp, cg = E.convert_popmap_to_census(out, data.boundary, data.census_idx, data.census_pop)
+    res.update({k: float(v) for k, v in get_test_metrics(cp, cg, tag="MainCensus_synthetic_fine").items()})
+    adj = E.adjust_map_to_census(out.clone(), data.boundary, data.census_idx, data.census_pop)
+    cp, cg = E.convert_popmap_to_census(adj, data.boundary, data.census_idx, data.census_pop)
+    res.update({k: float(v) for k, v in get_test_metrics(cp, cg, tag="AdjCensus_synthetic_fine").items()})
+    torch.cuda.synchronize()
+    if rank == 0:
+        res["seconds"] = time.time() - t0
+        print(json.dumps(res))
+    return res

@@ -157,3 +157,38 @@ def test_grad_truncation_modes_vs_oracle(model, flags):
         e = (got[n].cpu() - r).abs().max().item()
         assert e <= 2e-4 * max(r.abs().max().item(), 1e-3), (n, e)
     model.zero_grad()
+
+
+def test_run_train_cli_loss_decreases_and_resume(tmp_path):
+    """Counterpart of run_train.py end to end (fused HIP step, variable-size synthetic regions) + checkpoint resume."""
+    from popcorn_amd.cli import Trainer, train_parser
+    argv = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-3 -e 2 --synthetic_regions 16 "
+            f"-wb 4 --save_dir {tmp_path} -lt 2").split()
+    t = Trainer(train_parser().parse_args(argv))
+    first = t.train_step(next(iter(t.loader))).item()
+    losses = t.train()
+    assert torch.isfinite(torch.stack(losses)).all()
+    ck = os.path.join(t.exp, "last_model.pth")
+    assert os.path.exists(ck)
+    d = torch.load(ck, weights_only=False)
+    assert set(d) == {"model", "epoch", "iter", "optimizer", "scheduler"} and d["epoch"] == 2      # run_train.py:445-456
+    t2 = Trainer(train_parser().parse_args(argv + ["-r", ck]))
+    for (k1, v1), (k2, v2) in zip(t.model.state_dict().items(), t2.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+    assert torch.equal(t.fused.m.cpu(), t2.fused.m.cpu()) and t2.info["epoch"] == 2
+    assert first == first
+
+
+def test_torch_optimizer_path_equals_fused_path(tmp_path):
+    """The drop-in module + torch autograd + torch.optim.Adam and the fused HIP step take the same optimisation step."""
+    from popcorn_amd.cli import Trainer, train_parser
+    base = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 --synthetic_regions 8 -wb 4 "
+            f"--save_dir {tmp_path}").split()
+    ta = Trainer(train_parser().parse_args(base))
+    tb = Trainer(train_parser().parse_args(base + ["--torch_optimizer"]))
+    sample = next(iter(ta.loader))
+    for t in (ta, tb):
+        torch.manual_seed(11)
+        t.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()})
+    for (k1, v1), (k2, v2) in zip(ta.model.state_dict().items(), tb.model.state_dict().items()):
+        torch.testing.assert_close(v1, v2, rtol=0, atol=2e-6, msg=lambda m, k=k1: f"{k}: {m}")

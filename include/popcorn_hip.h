@@ -123,6 +123,22 @@ int64_t pc_conv3x3_wgrad_ws_bytes(int Cin, int Cout);
 int pc_conv3x3_wgrad(const pc_src* a, const pc_src* b, const pc_src* g, float* dw, float* db, int accumulate,
                      void* ws, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* Deferred form: stage 1 only (one partial per workgroup into ws, *nwg_out = number of partials); the second stage of
+ * many layers is then done by ONE pc_wgrad_reduce_batch launch.  Each deferred call needs its own ws slice. */
+int pc_conv3x3_wgrad_partial(const pc_src* a, const pc_src* b, const pc_src* g, void* ws, int B, int H, int W,
+                             int Cin, int Cout, int* nwg_out, void* stream);
+int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B, int H, int W, int C, int* nwg_out,
+                              void* stream);
+typedef struct pc_wgrad_reduce_desc {
+    const float* partial;   /* ws of the deferred call */
+    float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */
+    int32_t nwg, Cin, Cout; /* convT: Cin = Cout = C */
+    int32_t kind;           /* 0: conv3x3, 1: convT 2x2 */
+    int32_t accumulate;
+    int32_t _pad;
+} pc_wgrad_reduce_desc;
+int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void* stream);
+
 /* ---- ConvTranspose2d(C, C, 2, stride 2), networks.py:302,306.  w: [Cin][Cout][2][2].  x: B x C x H x W -> out B x C x 2H x 2W */
 int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bias, const pc_dst* out, int B, int H, int W, int C,
                     void* stream);

@@ -42,6 +42,11 @@ class PcConvDgradDesc(C.Structure):
                 ("out", C.POINTER(PcDst))]
 
 
+class PcWgradReduceDesc(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
+                ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
 PC_MAX_GROUP = 4
 
 

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const Wreduce
 }
 
 template <int CINC, int COUT>
-int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, void* ws, hipStream_t stream) {
+int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, void* ws, hipStream_t stream,
+                 int* nwg_out = nullptr) {
     using Cfg = WgradCfg<CINC, COUT>;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
@@ -459,6 +460,10 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     }
     if (!launched) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
     PC_CHECK_LAUNCH();
+    if (nwg_out) {            // deferred: the caller batches the reductions of many layers into one launch
+        *nwg_out = nwg;
+        return 0;
+    }
     WreduceArgs r{};
     r.partial = p.partial; r.nwg = nwg; r.nchunk = nchunk; r.dw = dw; r.db = db; r.Cin = Cin; r.accumulate = accumulate;
     const int n_out = COUT * Cin * 9 + COUT;
@@ -469,12 +474,143 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
 
 constexpr int cinc_of(int cin) { return cin < 16 ? cin : 16; }
 
+// ---- batched second stage: the reductions of ALL layers of a backward pass in one launch ---------------------------------
+// (24 conv + 4 transposed-conv reductions per step were 8-12 us each: launch + latency bound; profiles/r1_v3.)
+constexpr int RB_MAX = 32;
+struct RbEntry {
+    const float* partial; float* dw; float* db;
+    int nwg, Cin, Cout, kind, accumulate;     // kind 0: conv3x3, 1: convT 2x2 (C = Cin)
+};
+struct RbArgs { RbEntry e[RB_MAX]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a) {
+    const RbEntry& q = a.e[blockIdx.y];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int slice = tid >> 4, o = blockIdx.x * 16 + (tid & 15);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n_w, n_out;
+    if (q.kind == 0) {
+        const int CINC = q.Cin < 16 ? q.Cin : 16;
+        const int NBLK = (CINC * 12 + 15) / 16, MB = q.Cout / 8;
+        const int E = MB * NBLK * 256 + MB * 64;
+        n_w = q.Cout * q.Cin * 9;
+        n_out = n_w + q.Cout;
+        if (o < n_w) {
+            const int tap = o % 9, ci = (o / 9) % q.Cin, co = o / (9 * q.Cin);
+            const int dy = tap / 3, dx = tap % 3;
+            const int chunk = ci / CINC, cil = ci % CINC;
+            const int mb = co >> 3, c8 = co & 7;
+            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+            const int e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+            const float* base = q.partial + (int64_t)chunk * q.nwg * E;
+            int w = slice;
+            for (; w + 48 < q.nwg; w += 64) {
+                const float* q0 = base + (int64_t)w * E;
+                const float* q1 = q0 + (int64_t)16 * E;
+                const float* q2 = q0 + (int64_t)32 * E;
+                const float* q3 = q0 + (int64_t)48 * E;
+                s0 += q0[e0] + q0[e1];
+                s1 += q1[e0] + q1[e1];
+                s2 += q2[e0] + q2[e1];
+                s3 += q3[e0] + q3[e1];
+            }
+            for (; w < q.nwg; w += 16) s0 += base[(int64_t)w * E + e0] + base[(int64_t)w * E + e1];
+        } else if (o < n_out) {
+            const int co = o - n_w, mb = co >> 3, c8 = co & 7;
+            for (int w = slice; w < q.nwg; w += 16) {
+                const float* pq = q.partial + (int64_t)w * E + MB * NBLK * 256 + mb * 64;
+                float t = 0.f;
+#pragma unroll
+                for (int lk = 0; lk < 4; ++lk) t += pq[lk * 16 + c8] + pq[lk * 16 + 8 + c8];
+                s0 += t;
+            }
+        }
+    } else {
+        const int C = q.Cin, NBK = C / 4, E = NBK * 256 + NBK * 64;
+        n_w = C * C * 4;
+        n_out = n_w + C;
+        if (o < n_w) {
+            const int ci = o / (4 * C), ng = o % (4 * C);
+            const int e = (((ng >> 4) * 64) + (ci >> 2) * 16 + (ng & 15)) * 4 + (ci & 3);
+            int w = slice;
+            for (; w + 16 < q.nwg; w += 32) {
+                s0 += q.partial[(int64_t)w * E + e];
+                s1 += q.partial[(int64_t)(w + 16) * E + e];
+            }
+            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * E + e];
+        } else if (o < n_out) {
+            const int co = o - n_w;
+            for (int w = slice; w < q.nwg; w += 16) {
+                const float* pq = q.partial + (int64_t)w * E + NBK * 256;
+                float t = 0.f;
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) {
+                    const int ng = co * 4 + ab;
+#pragma unroll
+                    for (int lk = 0; lk < 4; ++lk) t += pq[(ng >> 4) * 64 + lk * 16 + (ng & 15)];
+                }
+                s0 += t;
+            }
+        }
+    }
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < 16 && o < n_out) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
+        float* dstp = o < n_w ? q.dw + o : q.db + (o - n_w);
+        if (o >= n_w && q.db == nullptr) return;
+        *dstp = q.accumulate ? *dstp + tot : tot;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t pc_conv3x3_wgrad_ws_bytes(int Cin, int Cout) {
     // nchunk * nwg <= MAX_WG partials of E floats; E <= 2*12*256 + 128
     (void)Cin; (void)Cout;
     return (int64_t)MAX_WG * (2 * 12 * 256 + 128) * sizeof(float);
+}
+
+extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void* stream) {
+    if (n < 0 || (n > 0 && !d)) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += RB_MAX) {
+        RbArgs a{};
+        const int m = n - base < RB_MAX ? n - base : RB_MAX;
+        int max_out = 0;
+        for (int i = 0; i < m; ++i) {
+            const pc_wgrad_reduce_desc& s = d[base + i];
+            if (!s.partial || !s.dw || s.nwg < 1) return PC_EINVAL;
+            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate};
+            const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : s.Cin * s.Cin * 4 + s.Cin;
+            if (n_out > max_out) max_out = n_out;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((max_out + 15) / 16, m), dim3(256), 0, st, a);
+        PC_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int pc_conv3x3_wgrad_partial(const pc_src* a, const pc_src* b, const pc_src* g, void* ws, int B, int H, int W,
+                                        int Cin, int Cout, int* nwg_out, void* stream) {
+    if (!a || !g || !ws || !nwg_out) return PC_EINVAL;
+    WgradArgs p{};
+    p.a = *a;
+    if (b) p.b = *b;
+    p.g = *g;
+    if (p.a.C + p.b.C != Cin || g->C != Cout) return PC_EINVAL;
+    p.B = B; p.H = H; p.W = W;
+    hipStream_t st = (hipStream_t)stream;
+#define PC_CASE(ci, co) \
+    if (Cin == ci && Cout == co) return launch_wgrad<cinc_of(ci), co>(p, Cin, nullptr, nullptr, 0, ws, st, nwg_out);
+    PC_CASE(2, 8) PC_CASE(4, 8) PC_CASE(8, 8) PC_CASE(16, 8) PC_CASE(32, 8) PC_CASE(8, 16) PC_CASE(16, 16)
+#undef PC_CASE
+    return PC_EINVAL;
 }
 
 extern "C" int pc_conv3x3_wgrad(const pc_src* a, const pc_src* b, const pc_src* g, float* dw, float* db, int accumulate,

@@ -289,6 +289,23 @@ extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {
     return (int64_t)CT_MAX_WG * (4 * 256 + 4 * 64) * sizeof(float);
 }
 
+extern "C" int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B, int H, int W, int C, int* nwg_out,
+                                         void* stream) {
+    if (!x || !g || !ws || !nwg_out) return PC_EINVAL;
+    CtArgs p{};
+    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W;
+    p.partial = reinterpret_cast<float*>(ws);
+    int nwg = fill_groups(p);
+    if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) hipLaunchKernelGGL(convt2x2_wgrad_kernel<16>, dim3(nwg), dim3(256), 0, st, p);
+    else if (C == 8) hipLaunchKernelGGL(convt2x2_wgrad_kernel<8>, dim3(nwg), dim3(256), 0, st, p);
+    else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    *nwg_out = nwg;
+    return 0;
+}
+
 extern "C" int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, float* db, int accumulate, void* ws,
                                  int B, int H, int W, int C, void* stream) {
     if (!x || !g || !dw || !ws) return PC_EINVAL;

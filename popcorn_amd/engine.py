@@ -133,14 +133,15 @@ class UNetEngine:
         A = {s: saved[s] for s in S}
         ly = lambda s, t: self.layers[(s, t)]  # noqa: E731
 
+        wb = ops.WgradBatch(dev, accumulate)      # first stages now, ONE batched reduction at the end
+
         def wg(s, tag, a, g, **kw):
             lay = ly(s, tag)
-            ops.conv3x3_wgrad(a, g, lay.w.shape[0], dw=grads[prefix + lay.wname], db=grads[prefix + lay.bname],
-                              accumulate=accumulate, **kw)
+            wb.conv3x3(a, g, lay.w.shape[0], grads[prefix + lay.wname], grads[prefix + lay.bname], **kw)
 
         def wgt(s, tag, x, g):
             lay = ly(s, tag)
-            ops.convt2x2_wgrad(x, g, dw=grads[prefix + lay.wname], db=grads[prefix + lay.bname], accumulate=accumulate)
+            wb.convt2x2(x, g, grads[prefix + lay.wname], grads[prefix + lay.bname])
 
         def dg(tag, gs, outs, c0, cn, acts=None, act_tag=None, pool=False, acc=False):
             """grouped data-gradient of layer `tag` over both streams"""
@@ -186,6 +187,7 @@ class UNetEngine:
                 G_c2[s] = ops.convt2x2_dgrad(g_u2v, ly(s, "up2t").w, E(16, H2, W2), act=A[s]["c2"],
                                              act_bn=ly(s, "d2b").bn_nobias)
         if encoder_no_grad:
+            wb.finish()
             return
         # encoder
         for s in S:
@@ -205,6 +207,7 @@ class UNetEngine:
         G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
         for s, chmap, cin, f0 in STREAMS:
             wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
+        wb.finish()
 
 
 def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None):

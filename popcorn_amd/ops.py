@@ -301,3 +301,66 @@ def adam_clip_step(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, 
                                       C.c_float(weight_decay), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
                                       C.c_float(max_norm), L.ptr(norm), L.ptr(step), L.stream_ptr()),
             "pc_adam_clip_step")
+
+
+class WgradBatch:
+    """Collects the first-stage (per-workgroup partial) weight-gradient launches of a backward pass and finishes them
+    with ONE batched reduction launch.  Each layer gets its own slice of a persistent workspace."""
+
+    _ws = {}
+
+    def __init__(self, device, accumulate=False):
+        self.device = device
+        self.accumulate = accumulate
+        self.entries = []
+        self.slot_bytes = int(max(L.lib().pc_conv3x3_wgrad_ws_bytes(32, 8), L.lib().pc_convt2x2_wgrad_ws_bytes(16)))
+        self.slot = 0
+
+    def _slice(self):
+        key = str(self.device)
+        need = (self.slot + 1) * self.slot_bytes
+        buf = WgradBatch._ws.get(key)
+        if buf is None or buf.numel() < need:
+            nbuf = torch.empty(max(need, 32 * self.slot_bytes), dtype=torch.uint8, device=self.device)
+            WgradBatch._ws[key] = buf = nbuf
+        ptr_ = buf.data_ptr() + self.slot * self.slot_bytes
+        self.slot += 1
+        return ptr_
+
+    def conv3x3(self, a, g, cout, dw, db, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), chmap=(0, 1, 2, 3),
+                b_offset=(0, 0), a_channels=None):
+        B, Cg, H, W = g.shape
+        Ca = a.shape[1] if a_channels is None else a_channels
+        Cb = 0 if b is None else b.shape[1]
+        sa = L.src(a, C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=chmap)
+        sb = L.src(b, oy=b_offset[0], ox=b_offset[1]) if b is not None else None
+        sg = L.src(g)
+        ws = self._slice()
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_conv3x3_wgrad_partial(C.byref(sa), C.byref(sb) if sb is not None else None, C.byref(sg),
+                                                 C.c_void_p(ws), B, H, W, Ca + Cb, cout, C.byref(nwg), L.stream_ptr()),
+                "pc_conv3x3_wgrad_partial")
+        self.entries.append((ws, dw, db, nwg.value, Ca + Cb, cout, 0))
+
+    def convt2x2(self, x, g, dw, db):
+        B, Cc, H, W = x.shape
+        sx, sg = L.src(x), L.src(g)
+        ws = self._slice()
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_convt2x2_wgrad_partial(C.byref(sx), C.byref(sg), C.c_void_p(ws), B, H, W, Cc, C.byref(nwg),
+                                                  L.stream_ptr()), "pc_convt2x2_wgrad_partial")
+        self.entries.append((ws, dw, db, nwg.value, Cc, Cc, 1))
+
+    def finish(self):
+        n = len(self.entries)
+        if n == 0:
+            return
+        d = (L.PcWgradReduceDesc * n)()
+        for i, (ws, dw, db, nwg, cin, cout, kind) in enumerate(self.entries):
+            d[i].partial = ws
+            d[i].dw = dw.data_ptr()
+            d[i].db = 0 if db is None else db.data_ptr()
+            d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate = nwg, cin, cout, kind, int(self.accumulate)
+        L.check(L.lib().pc_wgrad_reduce_batch(n, d, L.stream_ptr()), "pc_wgrad_reduce_batch")
+        self.entries = []
+        self.slot = 0

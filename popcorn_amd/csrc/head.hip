@@ -46,17 +46,21 @@ struct HeadArgs {
     pc_fastdiv div_w, div_groups;
 };
 
-// Fill the LDS weight image.  Fragment (lane = k*16 + i) of k-step ks, m-block mb:  W[16*mb + i][col(ks, k)]
+// Fill the LDS weight image.  A fragments are packed so that one lane's operands for 4 consecutive K-steps are 16
+// contiguous bytes: [m-block][k-group][lane][4] -> one ds_read_b128 feeds four MFMAs (a quarter of the LDS
+// instructions of a per-K-step ds_read_b32; with one wave per SIMD in the backward kernel every LDS instruction
+// sits on the MFMA issue path).
+//   layer 1 (W0 64x16):  [mb][lane][j]            = W0[16*mb + i][4*j + k]
+//   64x64 layers:        [mb2][mb][lane][r]       = W[16*mb2 + i][16*mb + 4*k + r]      (lane = k*16 + i)
 __device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p) {
     const int tid = threadIdx.x;
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
-        const int lane = e & 63, f = e >> 6, ks = f & 3, mb = f >> 2;
-        lds[L_A1 + e] = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * ks + (lane >> 4)];
+        const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
+        lds[L_A1 + e] = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)];
     }
     for (int e = tid; e < 64 * 64; e += blockDim.x) {
-        const int lane = e & 63, f = e >> 6, ks = f & 15, mb2 = f >> 4;
-        // k-step ks = (mb, r): hidden input index 16*mb + 4*k + r
-        const int col = 16 * (ks >> 2) + 4 * (lane >> 4) + (ks & 3);
+        const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8, mb = f & 3, mb2 = f >> 2;
+        const int col = 16 * mb + 4 * (lane >> 4) + r;
         const int row = 16 * mb2 + (lane & 15);
         lds[L_A2 + e] = p.w2[row * HID + col];
         lds[L_A3 + e] = p.w4[row * HID + col];
@@ -76,15 +80,28 @@ __device__ __forceinline__ void head_layer64(const float* lds, int a_off, int b_
 #pragma unroll
     for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4; ++mb) {
+        f32x4 a4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ks = mb * 4 + r;
+        for (int mb2 = 0; mb2 < 4; ++mb2) a4[mb2] = *reinterpret_cast<const f32x4*>(&lds[a_off + ((mb2 * 4 + mb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mb2 = 0; mb2 < 4; ++mb2)
-                acc[mb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[a_off + (mb2 * 16 + ks) * 64 + lane], h[mb][r],
-                                                                acc[mb2], 0, 0, 0);
-        }
+                acc[mb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb2][r], h[mb][r], acc[mb2], 0, 0, 0);
+    }
+}
+
+// first layer (16 -> 64): h[mb] = b0 + W0 * x
+__device__ __forceinline__ void head_layer1(const float* lds, int a_off, int b_off, int lane, int lk, const float (&xv)[4],
+                                            f32x4 (&h)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        h[mb] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb + 4 * lk]);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&lds[a_off + (mb * 64 + lane) * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], xv[j], h[mb], 0, 0, 0);
+    }
 }
 
 __device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
@@ -121,13 +138,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[j] = valid ? fp[(4 * j + lk) * p.feat.cstride] : 0.f;
             f32x4 h[4], acc[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(&lds[L_B0 + 16 * mb + 4 * lk]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    h[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L_A1 + (mb * 4 + j) * 64 + lane], xv[j], h[mb], 0, 0, 0);
+            head_layer1(lds, L_A1, L_B0, lane, lk, xv, h);
             relu4(h);
             head_layer64(lds, L_A2, L_B2, lane, lk, h, acc);
             relu4(acc);
@@ -223,7 +234,7 @@ constexpr int LB_B2 = LB_B0 + 64;
 constexpr int LB_B4 = LB_B2 + 64;
 constexpr int LB_W6 = LB_B4 + 64;
 constexpr int LB_SCR = LB_W6 + 64 + 4;           // per wave: Gm[64][18] + Hm[64][18]
-constexpr int SCR_LD = 18;
+constexpr int SCR_LD = 20;    // multiple of 4 (ds_read_b128) and 5 x 16 B: the 16 rows of a fragment hit 16 distinct slots
 constexpr int SCR_WAVE = 2 * 64 * SCR_LD;
 constexpr int LB_END = LB_SCR + 4 * SCR_WAVE;
 // workgroup partial layout
@@ -251,45 +262,48 @@ __device__ __forceinline__ float lane_sum16(float v) {
     return v;
 }
 
-// dgrad through one 64x64 layer: out[mi] = sum_o W[o][16mi+i] * g[o]   (transposed fragments at t_off)
+// dgrad through one 64x64 layer: out[mi] = sum_o W[o][16mi+i] * g[o]   (transposed fragments at t_off, float4-packed)
 __device__ __forceinline__ void head_dgrad64(const float* lds, int t_off, int lane, const f32x4 (&g)[4], f32x4 (&out)[4]) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) out[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4; ++mb) {
+        f32x4 a4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ks = mb * 4 + r;
+        for (int mi = 0; mi < 4; ++mi) a4[mi] = *reinterpret_cast<const f32x4*>(&lds[t_off + ((mi * 4 + mb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                out[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[t_off + (mi * 16 + ks) * 64 + lane], g[mb][r], out[mi], 0, 0, 0);
-        }
+                out[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi][r], g[mb][r], out[mi], 0, 0, 0);
+    }
 }
 
-// scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a row-major [64][SCR_LD] matrix
+// scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a [64][SCR_LD] matrix whose columns are
+// permuted so that the 4 K-steps (pixels 4*ks + k, ks = 0..3) of a lane are contiguous: column(px) = (px & 3)*4 + (px >> 2)
 __device__ __forceinline__ void head_store_mat(float* m, int li, int lk, const f32x4 (&v)[4]) {
+    const int c = (li & 3) * 4 + (li >> 2);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[(16 * mb + 4 * lk + r) * SCR_LD + li] = v[mb][r];
+        for (int r = 0; r < 4; ++r) m[(16 * mb + 4 * lk + r) * SCR_LD + c] = v[mb][r];
 }
 
-// dW[o][i] += sum_px G[o][px] * Hm[i][px]   (64 x 64, 16 pixels = 4 k-steps)
+// dW[o][i] += sum_px G[o][px] * Hm[i][px]   (64 x 64, 16 pixels = 4 k-steps; one ds_read_b128 per 16-row block)
 __device__ __forceinline__ void head_wgrad64(const float* gm, const float* hm, int li, int lk, f32x4 (&dw)[4][4]) {
+    f32x4 af[4], bf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        float af[4], bf[4];
+    for (int q = 0; q < 4; ++q) {
+        af[q] = *reinterpret_cast<const f32x4*>(&gm[(16 * q + li) * SCR_LD + 4 * lk]);
+        bf[q] = *reinterpret_cast<const f32x4*>(&hm[(16 * q + li) * SCR_LD + 4 * lk]);
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            af[q] = gm[(16 * q + li) * SCR_LD + 4 * ks + lk];
-            bf[q] = hm[(16 * q + li) * SCR_LD + 4 * ks + lk];
-        }
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                dw[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bf[nb], dw[mb][nb], 0, 0, 0);
-    }
+                dw[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dw[mb][nb], 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
@@ -300,15 +314,15 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
     head_stage_weights(lds, p);     // LB_A1..LB_A3 coincide with L_A1..L_A3
     __syncthreads();                // its bias block (L_B0..) overlaps LB_T3: let it land before T3 is filled
     for (int e = tid; e < 64 * 64; e += blockDim.x) {
-        const int l = e & 63, f = e >> 6, ks = f & 15, mi = f >> 4;
-        const int row = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);     // o
+        const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
+        const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
         const int col = 16 * mi + (l & 15);                           // i
         lds[LB_T3 + e] = p.w4[row * HID + col];
         lds[LB_T2 + e] = p.w2[row * HID + col];
     }
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
-        const int l = e & 63, ks = e >> 6;
-        const int row = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);
+        const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
+        const int row = 16 * mb + 4 * (l >> 4) + r;
         lds[LB_T1 + e] = p.w0[row * 16 + (l & 15)];
     }
     for (int e = tid; e < 64; e += blockDim.x) {
@@ -353,9 +367,12 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         if (!__any(sel)) continue;
         const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
         const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
-        float xv[4];
+        float xv[4], fvv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = valid ? fp[(4 * j + lk) * p.feat.cstride] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            xv[j] = valid ? fp[(4 * j + lk) * p.feat.cstride] : 0.f;
+            fvv[j] = (valid && a.fuse_feat_bn) ? fp[(4 * lk + j) * p.feat.cstride] : 1.f;   // issued with xv: not on the tail
+        }
         // upstream gradient of relu(out) at this pixel
         float gup = 0.f;
         if (sel) {
@@ -368,13 +385,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         }
         // ---- forward recompute
         f32x4 h1[4], h2[4], h3[4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h1[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_B0 + 16 * mb + 4 * lk]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                h1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LB_A1 + (mb * 4 + j) * 64 + lane], xv[j], h1[mb], 0, 0, 0);
+        head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
         relu4(h1);
         head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
         relu4(h2);
@@ -437,22 +448,30 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         // ---- layer 1 (W0: 64 x 16)
         __builtin_amdgcn_wave_barrier();
         head_store_mat(gm, li, lk, g1);
+        {
+            const int c = (li & 3) * 4 + (li >> 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hm[(4 * j + lk) * SCR_LD + li] = xv[j];
+            for (int j = 0; j < 4; ++j) hm[(4 * j + lk) * SCR_LD + c] = xv[j];
+        }
         __builtin_amdgcn_wave_barrier();
+        {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&hm[li * SCR_LD + 4 * lk]);
+            f32x4 af[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const float bf = hm[li * SCR_LD + 4 * ks + lk];
+            for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const f32x4*>(&gm[(16 * mb + li) * SCR_LD + 4 * lk]);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[(16 * mb + li) * SCR_LD + 4 * ks + lk], bf, dW0[mb], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[ks], dW0[mb], 0, 0, 0);
         }
         f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(&lds[LB_T1 + (mb * 64 + lane) * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LB_T1 + (mb * 4 + r) * 64 + lane], g1[mb][r], gx, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
+        }
         if (valid) {
             float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
 #pragma unroll
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
                 float o = gx[r];
                 // xv[r'] holds feat channel 4*j + lk; channel 4*lk + r is held by lane group lk' = r at j = lk
                 if (a.fuse_feat_bn) {
-                    const float fv = fp[(4 * lk + r) * p.feat.cstride];
+                    const float fv = fvv[r];
                     o = fv > 0.f ? o * fscale[r] : 0.f;
                 }
                 op[(4 * lk + r) * a.g_feat.cstride] = o;

@@ -78,7 +78,7 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 
 template <int CIN, int COUT, int MODE, int LD>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
-    constexpr int CHUNK = CIN < 16 ? CIN : 16;
+    constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
     constexpr int NB = COUT / 8;
     constexpr bool STAGED = LD != LD_GENERIC;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 
 template <int CIN, int COUT, int MODE, int LD>
 int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
-    constexpr int CHUNK = CIN < 16 ? CIN : 16;
+    constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     size_t lds = (size_t)4 * CHUNK * CSW * sizeof(float);
     if (lds < (size_t)COUT * CIN * 9 * sizeof(float)) lds = (size_t)COUT * CIN * 9 * sizeof(float);
     static bool attr_set = false;
@@ -388,7 +388,7 @@ bool same_layout(const pc_src& a, const pc_src& b) { return b.C == 0 || (a.bstri
 
 template <int CIN, int COUT, int MODE>
 int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
-    constexpr int CHUNK = CIN < 16 ? CIN : 16;
+    constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;

@@ -71,9 +71,15 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     dur = e0.elapsed_time(e1) * 1e-3 / reps       # includes the 42 MB memset + the 10 us reduce kernel of the call
     flops = 56064.0 * nsel
     achieved = flops / dur / 1e12
+    traffic = None                              # HBM bytes per launch from the committed PMC pass (cannot be read live)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_head_bwd.json")) as fh:
+            traffic = json.load(fh)["traffic_bytes"] if (B, H, W) == (64, 100, 100) else None
+    except OSError:
+        pass
     return {"bound": "mfma", "kernel": "head_bwd_kernel (sparse head backward, fp32 MFMA 16x16x4; + memset + reduce)",
             "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": None,
+            "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "alg_flop_per_launch": flops, "units_per_launch": nsel,
             "unit_def": "selected pixel, 56,064 flop"}
 

@@ -150,7 +150,8 @@ int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, float* db, in
                       int B, int H, int W, int C, void* stream);
 
 /* ---- fusion_out_conv (1x1, 16->1) + sigmoid + crop: create_building_score's tail, popcorn.py:301,317-320;
- * networks.py:232,323-330.  feat: B x 16 x Hp x Wp, out: B x 1 x H x W taken at offset (py,px). */
+ * networks.py:232,323-330.  feat: B x C x Hp x Wp with C = 16 (fusion_out_conv) or 8 (sar_out_conv / optical_out_conv of the
+ * single-modality variants, networks.py:217-228), out: B x 1 x H x W taken at offset (py,px). */
 int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const float* bias, const pc_dst* out,
                             int B, int H, int W, int py, int px, void* stream);
 

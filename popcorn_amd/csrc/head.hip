@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, 
     const int64_t n = (int64_t)B * H * W;
     float wv[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wv[c] = w[c];
+    for (int c = 0; c < 16; ++c) wv[c] = c < feat.C ? w[c] : 0.f;       // C = 16 (fusion_out_conv) or 8 (sar/optical_out_conv)
     const float bv = bias[0];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)W;
@@ -589,7 +589,8 @@ __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, 
         const float* fp = feat.ptr + b * feat.bstride + (int64_t)(py + y) * feat.rstride + px + x;
         float s = bv;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s = fmaf(fp[c * feat.cstride], wv[c], s);
+        for (int c = 0; c < 16; ++c)
+            if (c < feat.C) s = fmaf(fp[c * feat.cstride], wv[c], s);
         out.ptr[b * out.bstride + (int64_t)y * out.rstride + x] = 1.f / (1.f + expf(-s));
     }
 }
@@ -749,7 +750,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
 
 extern "C" int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const float* bias, const pc_dst* out,
                                        int B, int H, int W, int py, int px, void* stream) {
-    if (!feat || !w || !bias || !out || feat->C != 16) return PC_EINVAL;
+    if (!feat || !w || !bias || !out || (feat->C != 16 && feat->C != 8)) return PC_EINVAL;
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;

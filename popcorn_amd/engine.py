@@ -44,11 +44,13 @@ CONVTS = {"up2t": "up_seq.up2.up", "up1t": "up_seq.up1.up"}
 ENCODER = ("inc1", "inc2", "d1a", "d1b", "d2a", "d2b")
 
 
-def trainable_names(prefix="unetmodel."):
+def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream")):
     """The 48 U-Net tensors that receive a gradient in the reference train step (conv / convT weights + biases of
     both streams; BN affine frozen, out-convs unused).  SURVEY.md section 8a row 18."""
     names = []
     for s, _, _, _ in STREAMS:
+        if s not in streams:
+            continue
         for tag in ("inc1", "inc2", "d1a", "d1b", "d2a", "d2b"):
             names += [f"{prefix}{s}.{CONVS[tag][0]}.weight", f"{prefix}{s}.{CONVS[tag][0]}.bias"]
         names += [f"{prefix}{s}.{CONVTS['up2t']}.weight", f"{prefix}{s}.{CONVTS['up2t']}.bias"]
@@ -80,16 +82,25 @@ class UNetEngine:
     """Executes one DualStreamUNet on the HIP kernels.  ``tensors``: name -> tensor, names relative to the
     DualStreamUNet module (e.g. 'sar_stream.inc.conv.conv.0.weight').  Tensors are referenced, not copied."""
 
-    def __init__(self, tensors):
+    def __init__(self, tensors, streams=("sar_stream", "optical_stream"), chmaps=None):
+        """streams: which U-Net streams run (single-modality variants of popcorn.py:136-145 run one); chmaps: optional
+        {stream: source-channel map} overriding the 6-channel default (a 2-channel S1 or 4-channel S2 input)."""
+        self.streams = [st for st in STREAMS if st[0] in streams]
+        if chmaps:
+            self.streams = [(n, tuple(chmaps.get(n, cm)), ci, f0) for n, cm, ci, f0 in self.streams]
         self.layers = {}
-        for s, _, _, _ in STREAMS:
+        for s, _, _, _ in self.streams:
             for tag, (ck, bk) in CONVS.items():
                 self.layers[(s, tag)] = _Layer(tensors, f"{s}.{ck}", f"{s}.{bk}")
             for tag, ck in CONVTS.items():
                 self.layers[(s, tag)] = _Layer(tensors, f"{s}.{ck}", None)
         self.fusion_w = tensors.get("fusion_out_conv.conv.weight")
         self.fusion_b = tensors.get("fusion_out_conv.conv.bias")
-        dev = self.layers[("sar_stream", "inc1")].w.device
+        self.single_out = None
+        if len(self.streams) == 1:        # logits of the only stream: sar_out_conv / optical_out_conv (networks.py:217-228)
+            pre = "sar_out_conv" if self.streams[0][0] == "sar_stream" else "optical_out_conv"
+            self.single_out = (tensors[pre + ".conv.weight"], tensors[pre + ".conv.bias"])
+        dev = self.layers[(self.streams[0][0], "inc1")].w.device
         if dev.type != "cuda":
             raise L.PopcornHipError(f"popcorn_amd engine needs parameters on a HIP device, got {dev}; there is no CPU path")
         self.device = dev
@@ -109,11 +120,17 @@ class UNetEngine:
         """create_building_score (popcorn.py:279-322): reflect-pad 14, frozen U-Net, fusion_out_conv, sigmoid, crop."""
         B, _, H, W = X.shape
         feats, _ = self.forward(X, pad, pad, H + 2 * pad, W + 2 * pad, save=False)
+        if self.single_out is not None:
+            f0 = self.streams[0][3]
+            return ops.outconv_sigmoid_crop(feats[:, f0:f0 + 8], self.single_out[0], self.single_out[1], H, W, pad, pad)
         return ops.outconv_sigmoid_crop(feats, self.fusion_w, self.fusion_b, H, W, pad, pad)
 
     def feat_bn(self):
         """BN descriptors of the two layers that produce the feature map (for the head-backward epilogue)."""
-        return (self.layers[("sar_stream", "up1b")].bn_nobias, self.layers[("optical_stream", "up1b")].bn_nobias)
+        plain = L.bn()       # missing stream: its feature channels are identically zero, any scale will do
+        names = [st[0] for st in self.streams]
+        return (self.layers[("sar_stream", "up1b")].bn_nobias if "sar_stream" in names else plain,
+                self.layers[("optical_stream", "up1b")].bn_nobias if "optical_stream" in names else plain)
 
     # ----------------------------------------------------------------------------------------------- backward
     def backward(self, saved, G, grads, accumulate=False, encoder_no_grad=False, prefix=""):
@@ -129,7 +146,7 @@ class UNetEngine:
         H1, W1 = Hp // 2, Wp // 2
         H2, W2 = H1 // 2, W1 // 2
         E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
-        S = [s for s, _, _, _ in STREAMS]
+        S = [s for s, _, _, _ in self.streams]
         A = {s: saved[s] for s in S}
         ly = lambda s, t: self.layers[(s, t)]  # noqa: E731
 
@@ -155,7 +172,7 @@ class UNetEngine:
             ops.conv3x3_dgrad_group(probs, c0, cn, pool=pool, accumulate=acc)
             return outs
 
-        G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in STREAMS}
+        G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
         for s in S:
             wg(s, "up1b", A[s]["f1"], G_f2[s])
         G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
@@ -205,7 +222,7 @@ class UNetEngine:
         for s in S:
             wg(s, "inc2", A[s]["a1"], G_a2[s])
         G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
-        for s, chmap, cin, f0 in STREAMS:
+        for s, chmap, cin, f0 in self.streams:
             wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
         wb.finish()
 
@@ -228,9 +245,13 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
     nE = len(engines)
     if feats_list is None:
         feats_list = [None] * nE
-    feats = [f if f is not None else torch.empty(B, 16, Hp, Wp, device=dev, dtype=torch.float32) for f in feats_list]
+    # single-stream engines leave the other 8 feature channels at zero
+    mk = torch.empty if len(engines[0].streams) == 2 else torch.zeros
+    feats = [f if f is not None else mk(B, 16, Hp, Wp, device=dev, dtype=torch.float32) for f in feats_list]
     E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
-    keys = [(e, s) for e in range(nE) for s, _, _, _ in STREAMS]
+    streams = engines[0].streams
+    assert all([st[0] for st in e.streams] == [st[0] for st in streams] for e in engines)
+    keys = [(e, s) for e in range(nE) for s, _, _, _ in streams]
     ly = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
 
     def conv(tag, ins, c, h, w, outs=None, bs=None, **kw):
@@ -246,7 +267,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
 
     # first layer: reflect padding + channel gather fused; Cin differs per stream -> one launch per stream kind
     a1 = {}
-    for s, chmap, cin, f0 in STREAMS:
+    for s, chmap, cin, f0 in streams:
         ks = [k for k in keys if k[1] == s]
         probs = []
         for k in ks:
@@ -265,7 +286,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
     u1 = {k: ops.convt2x2(e2[k], ly(k, "up1t").w, ly(k, "up1t").b) for k in keys}
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
     f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
-    f0s = {s: f0 for s, _, _, f0 in STREAMS}
+    f0s = {s: f0 for s, _, _, f0 in streams}
     conv("up1b", f1, 8, Hp, Wp, outs={k: feats[k[0]][:, f0s[k[1]]:f0s[k[1]] + 8] for k in keys})
     saved = []
     for e in range(nE):
@@ -273,7 +294,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
             saved.append(None)
             continue
         sv = {}
-        for s, _, _, _ in STREAMS:
+        for s, _, _, _ in streams:
             k = (e, s)
             sv[s] = dict(a1=a1[k], a2=a2[k], b1=b1[k], b2=b2[k], c1=c1[k], c2=c2[k], u2=u2[k], e1=e1[k], e2=e2[k],
                          u1=u1[k], f1=f1[k], o1=o1, o2=o2)

@@ -67,9 +67,10 @@ class POPCORN(nn.Module):
             self.S1, self.S2 = True, False
         elif input_channels == 4:
             self.S1, self.S2 = False, True
-        if not (self.S1 and self.S2):
-            raise NotImplementedError("popcorn_amd implements the dual-stream S1+S2 configuration (input_channels=6); "
-                                      "single-modality variants (popcorn.py:136-145) are not built yet")
+        if not (self.S1 or self.S2):
+            raise NotImplementedError("input_channels=0 (no Sentinel modality) has no features to feed the head; the "
+                                      "reference fails on it too (torch.cat of an empty list, networks.py:210)")
+        self._streams = tuple(n for n, on in (("sar_stream", self.S1), ("optical_stream", self.S2)) if on)
 
         self.unetmodel = _new_dualstream()                                   # popcorn.py:57
         if not pretrained:                                                   # popcorn.py:59-66
@@ -91,6 +92,7 @@ class POPCORN(nn.Module):
         self.num_params = sum(p.numel() for p in self.head.parameters() if p.requires_grad) + self.unetmodel.num_params
         self.building_extractor = _new_dualstream()                          # popcorn.py:96
         self._engines = None
+        self._w0_pad = None
 
     # ------------------------------------------------------------------------------------------- engine plumbing
     def _apply(self, fn, *a, **k):
@@ -114,16 +116,46 @@ class POPCORN(nn.Module):
 
     def engines(self):
         if self._engines is None:
-            self._engines = (E.UNetEngine(self._tensor_table(self.unetmodel)),
-                             E.UNetEngine(self._tensor_table(self.building_extractor)))
+            # a 2-channel (S1) / 4-channel (S2) input: the stream's channels are picked straight from it
+            chmaps = None if (self.S1 and self.S2) else {"sar_stream": (0, 1, 0, 0), "optical_stream": (2, 1, 0, 3)}
+            self._engines = (E.UNetEngine(self._tensor_table(self.unetmodel), self._streams, chmaps),
+                             E.UNetEngine(self._tensor_table(self.building_extractor), self._streams, chmaps))
         return self._engines
 
+    @property
+    def feat_offset(self):
+        """first feature channel of the (only) active stream inside the 16-channel feature map"""
+        return 0 if self.S1 else 8
+
     def head_tensors(self):
-        return [getattr(self.head[i], n) for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+        """[w0,b0,w2,b2,w4,b4,w6,b6] as the head kernels expect them (w0: 64 x 16).  Single-modality models have a
+        64 x 8 first layer (popcorn.py:68-69): it is embedded at the active stream's feature channels of a zero-padded
+        64 x 16 image; the other 8 feature channels are identically zero."""
+        t = [getattr(self.head[i], n) for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+        if self.S1 and self.S2:
+            return t
+        w0 = t[0]
+        if self._w0_pad is None or self._w0_pad.device != w0.device:
+            self._w0_pad = torch.zeros(64, 16, 1, 1, device=w0.device, dtype=torch.float32)
+        with torch.no_grad():
+            self._w0_pad[:, self.feat_offset:self.feat_offset + 8].copy_(w0)
+        t[0] = self._w0_pad
+        return t
+
+    def head_grad_targets(self, hgrads):
+        """Gradient buffers to hand to the head-backward kernel for parameter gradients ``hgrads`` + a fix-up to call
+        afterwards (single modality: the kernel fills a 64 x 16 image whose active half is copied into hgrads[0])."""
+        if self.S1 and self.S2:
+            return hgrads, (lambda: None)
+        pad = torch.empty(64, 16, 1, 1, device=hgrads[0].device, dtype=torch.float32)
+        k = [pad] + list(hgrads[1:])
+        f0 = self.feat_offset
+        return k, (lambda: hgrads[0].copy_(pad[:, f0:f0 + 8]))
 
     def trainable(self):
-        """(names, parameters) that receive gradients, in a fixed order: 48 U-Net tensors + 8 head tensors."""
-        names = E.trainable_names("unetmodel.") + [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+        """(names, parameters) that receive gradients, in a fixed order: 24 U-Net tensors per active stream + 8 head
+        tensors (56 for the S1+S2 model)."""
+        names = E.trainable_names("unetmodel.", self._streams) + [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
         table = dict(self.named_parameters())
         return names, [table[n] for n in names]
 
@@ -251,18 +283,21 @@ class _PopcornFn(torch.autograd.Function):
                 g_scale_map = g_scale.contiguous().float()
         grads = {n: torch.empty_like(p) for n, p in zip(names, params)}
         hgrads = [grads[n] for n in names[-8:]]
+        khgrads, fix = model.head_grad_targets(hgrads)
         _, G = ops.head_bwd(ctx.feats, pt, pl, H, W, model.head_tensors(), building, mask=mask, admin_mask=admin,
                             census_idx=census,
                             g_popcount=None if g_popcount is None else g_popcount.contiguous().float(),
                             g_popdense=None if g_popdense is None else g_popdense.contiguous().float(),
-                            g_scale_map=g_scale_map, grads=hgrads,
+                            g_scale_map=g_scale_map, grads=khgrads,
                             feat_bn=None if unet_no_grad else eng.feat_bn())
+        fix()
+        n_unet = len(names) - 8
         if unet_no_grad:
-            out = [None] * 48 + hgrads
+            out = [None] * n_unet + hgrads
         else:
             eng.backward(ctx.saved, G, grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
             out = []
-            for n in names[:48]:
+            for n in names[:n_unet]:
                 is_enc = any(("." + E.CONVS[t][0] + ".") in n for t in E.ENCODER)
                 out.append(None if (encoder_no_grad and is_enc) else grads[n])
             out += hgrads

@@ -118,9 +118,11 @@ class FusedTrainStep:
                          self.loss_out, g_pc, self.g_scale_const)
         eng_u = m.engines()[0]
         hgrads = [self.grads[n_] for n_ in self.names[-8:]]
+        khgrads, fix = m.head_grad_targets(hgrads)
         _, G = ops.head_bwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask, admin_mask=s["admin_mask"],
-                            census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=hgrads,
+                            census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=khgrads,
                             feat_bn=None if unet_no_grad else eng_u.feat_bn())
+        fix()
         if unet_no_grad:
             self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()
         else:

@@ -306,6 +306,41 @@ def g7_dataset_helpers():
     np.savez_compressed(os.path.join(OUT, "g7_dataset_helpers.npz"), **out)
 
 
+def g8_single_modality(popcorn, losses):
+    """S1-only (input_channels=2) and S2-only (input_channels=4) variants, popcorn.py:48-54,136-145,301-314:
+    forward + one backward on a small tile."""
+    out = {}
+    for ic in (2, 4):
+        torch.manual_seed(1600)
+        m = popcorn.POPCORN(input_channels=ic, feature_extractor="DDA", occupancymodel=True, pretrained=True,
+                            biasinit=0.9407, sentinelbuildings=True)
+        m.train()
+        for k, v in m.state_dict().items():
+            if k.startswith("head."):
+                out[f"ic{ic}/{k}"] = np_(v)
+        x6, admin, census, y = make_inputs(80 + ic, 2, 48, 40)
+        x = x6[:, :ic].contiguous()
+        out[f"ic{ic}/input"], out[f"ic{ic}/admin_mask"], out[f"ic{ic}/census_idx"], out[f"ic{ic}/y"] = np_(x), np_(admin), np_(census), np_(y)
+        torch.manual_seed(5)
+        sample = {"input": x.clone(), "admin_mask": admin.clone(), "census_idx": census.clone(), "y": y.clone()}
+        o = m(sample, train=True, padding=False, sparse=True)
+        loss, _ = losses.get_loss(o, sample, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01, tag="weak")
+        (loss * 100.0).backward()
+        out[f"ic{ic}/popcount"], out[f"ic{ic}/popdensemap"], out[f"ic{ic}/scale"] = np_(o["popcount"]), np_(o["popdensemap"]), np_(o["scale"])
+        out[f"ic{ic}/building_counts"] = np_(sample["building_counts"])
+        out[f"ic{ic}/loss"] = np.float32(loss.item())
+        gn = []
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                gn.append(n)
+                out[f"ic{ic}/grad/{n}"] = np_(p.grad)
+        out[f"ic{ic}/grad_names"] = np.array(gn)
+        with torch.no_grad():
+            o2 = m({"input": x.clone()}, padding=True)
+        out[f"ic{ic}/dense_pad1/popdensemap"] = np_(o2["popdensemap"])
+    np.savez_compressed(os.path.join(OUT, "g8_single_modality.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     popcorn, networks, get_model, losses, metrics = import_reference()
@@ -316,6 +351,7 @@ def main():
     g5_train(popcorn, losses)
     g6_loss_metrics(losses, metrics)
     g7_dataset_helpers()
+    g8_single_modality(popcorn, losses)
     args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
                           pretrained=True, biasinit=0.9407, sentinelbuildings=True)
     kw = get_model.get_model_kwargs(args, "POPCORN")

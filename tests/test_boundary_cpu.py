@@ -106,7 +106,9 @@ def test_cpu_tensors_fail_loudly_no_fallback():
     with pytest.raises(RuntimeError):
         m.unetmodel.sar_stream.inc(torch.zeros(1, 2, 8, 8))      # parameter containers have no torch forward
     with pytest.raises(NotImplementedError):
-        _build(input_channels=2)
+        _build(input_channels=0)
+    m2 = _build(input_channels=2)                      # S1-only: 8 head inputs (popcorn.py:68-69)
+    assert m2.head[0].weight.shape == (64, 8, 1, 1) and len(m2.trainable()[0]) == 32
 
 
 def test_pad_geometry_matches_reference_rule():

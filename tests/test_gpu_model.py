@@ -192,3 +192,44 @@ def test_torch_optimizer_path_equals_fused_path(tmp_path):
         t.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()})
     for (k1, v1), (k2, v2) in zip(ta.model.state_dict().items(), tb.model.state_dict().items()):
         torch.testing.assert_close(v1, v2, rtol=0, atol=2e-6, msg=lambda m, k=k1: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("ic", [2, 4])
+def test_single_modality_vs_reference_golden(ic):
+    """S1-only (input_channels=2) / S2-only (4) variants, popcorn.py:48-54,136-145,301-314: forward, loss and all 32
+    gradients vs fixture g8; plus the fused training step on the same sample."""
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    from popcorn_amd.utils.losses import get_loss
+    g = np.load(os.path.join(G, "g8_single_modality.npz"))
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=ic, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407,
+                sentinelbuildings=True).cuda()
+    for k in g.files:
+        if k.startswith(f"ic{ic}/head."):
+            assert np.array_equal(m.state_dict()[k[len(f"ic{ic}/"):]].cpu().numpy(), g[k])     # same seeded init
+    m.train()
+    s = {k: torch.from_numpy(g[f"ic{ic}/{k}"]).cuda() for k in ("input", "admin_mask", "census_idx", "y")}
+    torch.manual_seed(5)
+    o = m(dict(s), train=True, padding=False, sparse=True)
+    loss, _ = get_loss(o, s, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01, tag="weak")
+    (loss * 100.0).backward()
+    assert abs(loss.item() - float(g[f"ic{ic}/loss"])) < 1e-4
+    assert rel_err(o["popdensemap"].detach().cpu().numpy(), g[f"ic{ic}/popdensemap"]) < 1e-4
+    assert o["scale"].shape == g[f"ic{ic}/scale"].shape
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(g[f"ic{ic}/grad_names"].tolist())
+    for n, gr in got.items():
+        r = g[f"ic{ic}/grad/{n}"]
+        assert np.abs(gr.cpu().numpy() - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3), n
+    with torch.no_grad():
+        o2 = m({"input": s["input"]}, padding=True)
+    assert rel_err(o2["popdensemap"].cpu().numpy(), g[f"ic{ic}/dense_pad1/popdensemap"]) < 1e-4
+    # fused path: same gradients
+    tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5)
+    torch.manual_seed(5)
+    l2 = tr.step(dict(s))
+    assert abs(l2[0].item() - float(g[f"ic{ic}/loss"])) < 1e-4
+    for n in got:
+        r = g[f"ic{ic}/grad/{n}"]
+        assert np.abs(tr.grads[n].cpu().numpy() - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3), n

@@ -152,3 +152,24 @@ def test_census_sums_known_answer():
     s = O.census_sums(p, b, 7)
     for i in range(7):
         assert abs(s[i] - p[b == i].astype(np.float64).sum()) < 1e-9
+
+
+@pytest.mark.parametrize("ic", [2, 4])
+def test_single_modality_g8(sd, ic):
+    """S1-only / S2-only variants (popcorn.py:48-54,136-145): oracle vs reference fixture."""
+    g = np.load(os.path.join(G, "g8_single_modality.npz"))
+    sd2 = dict(sd)
+    for k in g.files:
+        if k.startswith(f"ic{ic}/head."):
+            sd2[k[len(f"ic{ic}/"):]] = torch.from_numpy(g[k])
+    sample = {"input": torch.from_numpy(g[f"ic{ic}/input"]), "admin_mask": torch.from_numpy(g[f"ic{ic}/admin_mask"]),
+              "census_idx": torch.from_numpy(g[f"ic{ic}/census_idx"]), "y": torch.from_numpy(g[f"ic{ic}/y"])}
+    torch.manual_seed(5)
+    loss, out, grads, _ = O.train_step_grads(sd2, dict(sample))
+    assert abs(loss.item() - float(g[f"ic{ic}/loss"])) < 1e-5
+    assert rel_err(out["popdensemap"].numpy(), g[f"ic{ic}/popdensemap"]) < 1e-5
+    ref_names = set(g[f"ic{ic}/grad_names"].tolist())
+    assert {n for n, v in grads.items() if v is not None} == ref_names
+    for n in ref_names:
+        r = g[f"ic{ic}/grad/{n}"]
+        assert np.abs(grads[n].numpy() - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3), n

@@ -1,0 +1,79 @@
+"""Data-parallel training on the device: two ranks (gloo backend, both on the one GPU of the test box -- RCCL needs one
+GPU per rank) run FusedTrainStep on the two halves of a batch, eagerly and with the split HIP graphs; the updated
+parameters must equal a single-process step on the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(B, seed=3):
+    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    b = make_raw_batch(B, 64, 48, seed=seed, region="disc")
+    return {"input": select_normalize_reference(b["raw"]), "admin_mask": b["admin_mask"], "census_idx": b["census_idx"],
+            "y": b["y"]}
+
+
+def _run(rank, world, port, use_graph, q):
+    import torch.distributed as dist
+    from popcorn_amd.distributed import FlatReducer
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    tr = FusedTrainStep(m, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01, reducer=FlatReducer(), use_graph=use_graph)
+    full = _make(4)
+    idx = list(range(rank, 4, world))
+    s = {k: v[idx].cuda() for k, v in full.items()}
+    losses = []
+    for step in range(3):
+        torch.manual_seed(100 + step)            # same selection grid on every rank
+        l = tr.step(s)
+        losses.append(l[0].item())
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((tr.flat_p.cpu().numpy().tolist(), losses))    # plain lists: no shared-memory handles that die with the child
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch(world, use_graph):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_fused_step_equals_single_process(use_graph):
+    p1, l1 = _launch(1, use_graph)
+    p2, l2 = _launch(2, use_graph)
+    # rank 0 reports only its local part of the batch-mean loss; parameters are what must agree
+    p1, p2 = torch.tensor(p1), torch.tensor(p2)
+    scale = p1.abs().max().item()
+    assert (p1 - p2).abs().max().item() <= 2e-5 * scale, (p1 - p2).abs().max().item()
+    assert all(abs(a) < 1e6 for a in l2)

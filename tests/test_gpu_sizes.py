@@ -1,0 +1,146 @@
+"""Parity at BASELINE.json's sizes and at the edges of the input domain (HIP vs the CPU oracle on the same seeded
+inputs; fp32, <= 1e-4 relative; index paths exact)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import popcorn_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    return m, sd
+
+
+def test_config2_batch64_forward_parity(pair):
+    """BASELINE config[1]: batch=64 synthetic S1+S2 100x100 tiles, full DDA_model + sparse-head forward, vs CPU."""
+    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    m, sd = pair
+    b = make_raw_batch(64, 100, 100, seed=1600, region="disc")
+    x = select_normalize_reference(b["raw"])
+    cpu = {"input": x, "admin_mask": b["admin_mask"], "census_idx": b["census_idx"]}
+    torch.manual_seed(7)
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, dict(cpu), padding=False, sparse=True)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        out = m({k: v.cuda() for k, v in cpu.items()}, padding=False, sparse=True)
+    assert out["scale"].numel() == ref["scale"].numel()
+    assert rel_err(out["popdensemap"].cpu(), ref["popdensemap"]) < 1e-4
+    assert rel_err(out["popcount"].cpu(), ref["popcount"]) < 1e-4
+    assert rel_err(out["scale"].cpu(), ref["scale"]) < 1e-4
+
+
+def test_config1_single_tile_eval_call(pair):
+    """BASELINE config[0]: one 100x100 tile, eval-style call (run_eval.py:109)."""
+    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    m, sd = pair
+    x = select_normalize_reference(make_raw_batch(1, 100, 100, seed=5)["raw"])
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, {"input": x}, padding=False)
+        out = m({"input": x.cuda()}, padding=False)
+    assert rel_err(out["popdensemap"].cpu(), ref["popdensemap"]) < 1e-4
+    assert rel_err(out["popcount"].cpu(), ref["popcount"]) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 64), (2, 33, 47), (1, 96, 160), (1, 29, 31), (1, 512, 384)])
+@pytest.mark.parametrize("padding", [True, False])
+def test_ragged_and_aligned_shapes(pair, shape, padding):
+    """Sizes that are / are not multiples of 32 (add_padding's two branches, popcorn.py:246-256), odd sizes (Up's zero
+    pad, networks.py:309-312), a 512x384 window."""
+    m, sd = pair
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(B, 6, H, W, generator=g)
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, {"input": x}, padding=padding)
+        out = m({"input": x.cuda()}, padding=padding)
+    assert rel_err(out["popdensemap"].cpu(), ref["popdensemap"]) < 1e-4
+    assert rel_err(out["scale"].cpu(), ref["scale"]) < 1e-4
+
+
+def test_empty_and_absent_regions(pair):
+    """A census id that does not occur in admin_mask: the selection is empty, the fallback mask (popcorn.py:374-375) is
+    empty too -> popcount 0, scale has 0 elements, gradients are exact zeros; no NaN from the 1/Nsel term."""
+    from popcorn_amd.train import FusedTrainStep
+    from popcorn_amd.model import POPCORN
+    m, sd = pair
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 6, 64, 48, generator=g)
+    admin = torch.full((2, 64, 48), 3.0)
+    admin[1, :10] = -1.0
+    census = torch.tensor([3, 99])                       # sample 1: absent id
+    torch.manual_seed(2)
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, {"input": x, "admin_mask": admin, "census_idx": census}, padding=False, sparse=True)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        out = m({"input": x.cuda(), "admin_mask": admin.cuda(), "census_idx": census.cuda()}, padding=False, sparse=True)
+    assert out["scale"].numel() == ref["scale"].numel()
+    assert out["popcount"][1].item() == 0.0 and ref["popcount"][1].item() == 0.0
+    assert rel_err(out["popcount"].cpu(), ref["popcount"]) < 1e-4
+    # whole batch empty
+    census2 = torch.tensor([77, 99])
+    torch.manual_seed(2)
+    with torch.no_grad():
+        out2 = m({"input": x.cuda(), "admin_mask": admin.cuda(), "census_idx": census2.cuda()}, padding=False, sparse=True)
+    assert out2["scale"].numel() == 0 and torch.all(out2["popcount"] == 0) and torch.all(out2["popdensemap"] == 0)
+    torch.manual_seed(1600)
+    m2 = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    tr = FusedTrainStep(m2, lr=1e-4)
+    before = tr.flat_p.clone()
+    loss = tr.step({"input": x.cuda(), "admin_mask": admin.cuda(), "census_idx": census2.cuda(), "y": torch.tensor([5.0, 7.0]).cuda()})
+    assert torch.isfinite(loss).all() and torch.isfinite(tr.flat_p).all()
+    assert torch.all(tr.flat_g == 0) and torch.equal(tr.flat_p, before)
+
+
+def test_non_occupancy_model_and_given_building_counts():
+    """occupancymodel=False (popdensemap = relu(out), popcorn.py:179-181) and sentinelbuildings=False with
+    building_counts supplied by the dataset (popcorn.py:112)."""
+    from popcorn_amd.model import POPCORN
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 6, 64, 64, generator=g)
+    bc = torch.rand(2, 1, 64, 64, generator=g)
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=False, pretrained=True, biasinit=0.75, sentinelbuildings=True).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, {"input": x}, padding=False, occupancymodel=False)
+        out = m({"input": x.cuda()}, padding=False)
+    assert out["scale"] is None and ref["scale"] is None
+    assert rel_err(out["popdensemap"].cpu(), ref["popdensemap"]) < 1e-4
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.75, sentinelbuildings=False).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.popcorn_forward(sd, {"input": x, "building_counts": bc.clone()}, padding=False, sentinelbuildings=False)
+        out = m({"input": x.cuda(), "building_counts": bc.cuda()}, padding=False)
+    assert rel_err(out["popdensemap"].cpu(), ref["popdensemap"]) < 1e-4
+
+
+def test_input_not_modified_and_errors(pair):
+    m, sd = pair
+    x = torch.randn(1, 6, 40, 40).cuda()
+    keep = x.clone()
+    inp = {"input": x}
+    with torch.no_grad():
+        m(inp, padding=True)
+    assert torch.equal(x, keep) and "building_counts" in inp and inp["building_counts"].shape == (1, 1, 40, 40)
+    with pytest.raises(ValueError):
+        m({"input": torch.randn(6, 40, 40).cuda()})
+    with pytest.raises(ValueError):
+        m({"input": torch.randn(1, 6, 10, 10).cuda()}, padding=True)       # reflect pad 14 >= size, like F.pad

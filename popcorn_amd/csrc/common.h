@@ -5,6 +5,7 @@
 #include "popcorn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (global memory only)
 
 #define PC_CHECK_LAUNCH()                         \
     do {                                          \
@@ -71,4 +72,24 @@ __device__ __forceinline__ float pc_fetch(const pc_src& s, int b, int c, int y, 
         const int ys = pc_reflect(y - s.oy, s.H), xs = pc_reflect(x - s.ox, s.W);
         return s.ptr[b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + xs];
     }
+}
+
+// One 16-byte segment [xg, xg+4) of conv-domain row y of a REFLECT source (reflect padding + channel gather fused into
+// the first conv, popcorn.py:231-258,130-134): interior segments are one (possibly unaligned) 16-byte load, segments that
+// touch a reflected border fall back to four element loads; everything outside the conv domain is the conv's zero padding.
+__device__ __forceinline__ f32x4 pc_fetch_reflect_seg(const pc_src& s, int b, int c, int y, int xg, int H, int W) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y >= (unsigned)H || xg + 3 < 0 || xg >= W) return v;
+    const int ys = pc_reflect(y - s.oy, s.H);
+    const float* row = s.ptr + b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride;
+    const int xs = xg - s.ox;
+    if (xg >= 0 && xg + 3 < W && xs >= 0 && xs + 3 < s.W) {
+        const f32x4u t = *reinterpret_cast<const f32x4u*>(row + xs);
+        v = f32x4{t[0], t[1], t[2], t[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((unsigned)(xg + e) < (unsigned)W) v[e] = row[pc_reflect(xs + e, s.W)];
+    }
+    return v;
 }

@@ -38,7 +38,7 @@ constexpr int COL0 = 4;                  // LDS column of tile x0 (left halo at 
 constexpr int MAXG = PC_MAX_GROUP;       // problems per launch
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-enum { LD_GENERIC = 0, LD_DIRECT = 1, LD_POOL = 2 };
+enum { LD_GENERIC = 0, LD_DIRECT = 1, LD_POOL = 2, LD_REFLECT = 3 };
 
 struct ConvProb {
     pc_src a, b;          // input sources (channels a.C then b.C)
@@ -123,6 +123,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         if (MODE == MODE_FWD || q.act != nullptr) pc_bn_fold(q.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
         else { e_scale[nb] = 1.f; e_shift[nb] = 0.f; }
     }
+    // Consume the BN constants HERE.  They come from global loads issued before the strip loop and are first used in
+    // the epilogue inside it; hipcc's waitcnt pass then keeps them "pending" at the loop header on every iteration and,
+    // unable to count how many prefetch loads were issued since, emits `s_waitcnt vmcnt(0)` in front of the epilogue --
+    // draining the just-issued prefetch loads of the next strip on EVERY strip (load, store and MFMA phases add up
+    // instead of overlapping: tools/ablate_conv.py).  An empty asm use forces the one wait to happen before the loop.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" : : "v"(e_scale[nb]), "v"(e_shift[nb]));
     const float* const act = q.act;
     float* const outp = q.out.ptr;
     const int64_t o_bs = q.out.bstride, o_cs = q.out.cstride, a_bs = q.act_bstride, a_cs = q.act_cstride;
@@ -148,7 +155,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
         rvalid = ok;
-        if (LD == LD_DIRECT) {
+        if (LD == LD_REFLECT) {
+            // first layer: reflect padding + channel gather; handles its own bounds (segments may straddle x = 0 / W)
+            rvalid = l_act;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                R[it] = l_act ? pc_fetch_reflect_seg(q.a, b, ch * CHUNK + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (LD == LD_DIRECT) {
             const int64_t off = ok ? b * my_bs + (int64_t)y * my_rs + xg : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -397,7 +410,7 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     p.dbg = g_conv_dbg;
     // loader choice: all problems of the group must qualify for a staged loader
-    bool direct = CHUNK >= 8, pool = CHUNK >= 8;
+    bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
     bool vec = (p.W % 4) == 0;
     for (int i = 0; i < nprob; ++i) {
         ConvProb& q = p.pr[i];
@@ -410,6 +423,7 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
               ((reinterpret_cast<uintptr_t>(q.out.ptr) & 15) == 0);
         if (q.act) vec = vec && (q.act_rstride % 4 == 0) && (q.act_cstride % 4 == 0) && (q.act_bstride % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(q.act) & 15) == 0);
+        reflect = reflect && q.a.mode == PC_SRC_REFLECT && q.b.C == 0;
     }
     p.vec_ok = vec ? 1 : 0;
     if constexpr (CHUNK >= 8) {
@@ -417,6 +431,9 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
         if constexpr (CIN <= 16) {
             if (pool) return launch_conv_ld<CIN, COUT, MODE, LD_POOL>(p, nprob, stream);
         }
+    }
+    if constexpr (CIN <= 4) {
+        if (reflect) return launch_conv_ld<CIN, COUT, MODE, LD_REFLECT>(p, nprob, stream);
     }
     return launch_conv_ld<CIN, COUT, MODE, LD_GENERIC>(p, nprob, stream);
 }

@@ -201,7 +201,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradArgs
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
         rvalid = ok;
-        if (LD == 1) {
+        if (LD == 3) {
+            rvalid = l_act;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                R[it] = l_act ? pc_fetch_reflect_seg(p.a, b, cbase + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (LD == 1) {
             const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -432,31 +437,27 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     const bool direct = p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g;
     const bool pool = p.fast_a == 2 && p.b.C == 0 && p.fast_g;
     bool launched = false;
-    if constexpr (CINC >= 8) {
-        if (direct || pool) {
-            size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
-            const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
-            if (lw < lred) lw = lred;
-            static bool attr_w[2] = {false, false};
-            if (direct) {
-                if (!attr_w[0]) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-                    if (e != hipSuccess) return (int)e;
-                    attr_w[0] = true;
-                }
-                hipLaunchKernelGGL((conv3x3_wgrad_wave_kernel<CINC, COUT, 1>), dim3(nwg, nchunk), dim3(256), lw, stream, p);
-            } else {
-                if (!attr_w[1]) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-                    if (e != hipSuccess) return (int)e;
-                    attr_w[1] = true;
-                }
-                hipLaunchKernelGGL((conv3x3_wgrad_wave_kernel<CINC, COUT, 2>), dim3(nwg, nchunk), dim3(256), lw, stream, p);
+    const bool reflect = p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && p.fast_g && CINC <= 4;
+    if (direct || pool || reflect) {
+        size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
+        const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
+        if (lw < lred) lw = lred;
+        static bool attr_w[3] = {false, false, false};
+        auto go = [&](auto kern, int slot) -> int {
+            if (!attr_w[slot]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+                if (e != hipSuccess) return (int)e;
+                attr_w[slot] = true;
             }
-            launched = true;
-        }
+            hipLaunchKernelGGL(kern, dim3(nwg, nchunk), dim3(256), lw, stream, p);
+            return 0;
+        };
+        int rc = 0;
+        if (reflect) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 3>, 2);
+        else if (direct) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>, 0);
+        else rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>, 1);
+        if (rc) return rc;
+        launched = true;
     }
     if (!launched) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
     PC_CHECK_LAUNCH();

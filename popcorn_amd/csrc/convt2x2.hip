@@ -67,11 +67,24 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtArgs p) {
         for (int nb = 0; nb < NBK; ++nb) {
             const int ng = nb * 16 + li;
             const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
-            float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + bb;
+            // lane pair (bb = 0, 1) holds the even / odd output x of the same 8 consecutive floats: swap halves so that
+            // each lane owns 4 consecutive x and issues ONE 16-byte store instead of four strided 4-byte stores
+            const f32x4 mine = acc[nb];
+            f32x4 other;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + 4 * lk + r;
-                if (j < p.W) op[2 * j] = acc[nb][r];
+            for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(mine[r], 1);
+            // bb = 0 writes x = 2*jb + {0,1,2,3} (pixels r = 0,1); bb = 1 writes x = 2*jb + {4,5,6,7} (pixels r = 2,3)
+            const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
+            const int jb = j0 + 4 * lk;
+            float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + 2 * jb + 4 * bb;
+            if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+                *reinterpret_cast<f32x4*>(op) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xo = 2 * jb + 4 * bb + e;            // output x
+                    if ((xo >> 1) < p.W) op[e] = v[e];
+                }
             }
         }
     }

@@ -145,6 +145,13 @@ int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bias, const pc
 /* data gradient, fused with the ReLU+BN backward of the layer that produced x (act = x's post-ReLU values) */
 int pc_convt2x2_dgrad(const pc_src* g, const float* w, const pc_src* act, const pc_bn* act_bn,
                       const pc_dst* out, int B, int H, int W, int C, void* stream);
+/* grouped forms (problems of identical geometry in one launch, blockIdx.y = problem) */
+typedef struct pc_convt_fwd_desc { const pc_src* x; const float* w; const float* bias; const pc_dst* out; } pc_convt_fwd_desc;
+typedef struct pc_convt_dgrad_desc {
+    const pc_src* g; const float* w; const pc_src* act; const pc_bn* act_bn; const pc_dst* out;
+} pc_convt_dgrad_desc;
+int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, int H, int W, int C, void* stream);
+int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int B, int H, int W, int C, void* stream);
 int64_t pc_convt2x2_wgrad_ws_bytes(int C);
 int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, float* db, int accumulate, void* ws,
                       int B, int H, int W, int C, void* stream);

@@ -42,6 +42,15 @@ class PcConvDgradDesc(C.Structure):
                 ("out", C.POINTER(PcDst))]
 
 
+class PcConvtFwdDesc(C.Structure):
+    _fields_ = [("x", C.POINTER(PcSrc)), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.POINTER(PcDst))]
+
+
+class PcConvtDgradDesc(C.Structure):
+    _fields_ = [("g", C.POINTER(PcSrc)), ("w", C.c_void_p), ("act", C.POINTER(PcSrc)), ("act_bn", C.POINTER(PcBn)),
+                ("out", C.POINTER(PcDst))]
+
+
 class PcWgradReduceDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
                 ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]

@@ -11,6 +11,9 @@
 
 namespace {
 
+struct CtArgs;
+struct CtGroup;            // up to PC_MAX_GROUP CtArgs of identical geometry: blockIdx.y selects the problem
+
 struct CtArgs {
     pc_src x;              // fwd: input;  dgrad: g (2H x 2W);  wgrad: input
     pc_src g;              // wgrad: g (2H x 2W)
@@ -27,8 +30,13 @@ struct CtArgs {
     pc_fastdiv div_gx, div_gimg;   // by groups_x, by groups per image
 };
 
+struct CtGroup {
+    CtArgs pr[PC_MAX_GROUP];
+};
+
 template <int C>
-__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtArgs p) {
+__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int KS = C / 4, NBK = C / 4;
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtArgs p) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtArgs p) {
+__global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -266,14 +275,49 @@ int fill_groups(CtArgs& p) {
 
 }  // namespace
 
+extern "C" int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, int H, int W, int C, void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || !d) return PC_EINVAL;
+    CtGroup g{};
+    int nwg = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].x || !d[i].w || !d[i].out) return PC_EINVAL;
+        CtArgs& p = g.pr[i];
+        p.x = *d[i].x; p.w = d[i].w; p.bias = d[i].bias; p.out = *d[i].out; p.B = B; p.H = H; p.W = W;
+        nwg = fill_groups(p);
+    }
+    nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;     // keep the total grid size roughly constant
+    if (C == 16) hipLaunchKernelGGL(convt2x2_fwd_kernel<16>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL(convt2x2_fwd_kernel<8>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bias, const pc_dst* out, int B, int H, int W,
                                int C, void* stream) {
-    if (!x || !w || !out) return PC_EINVAL;
-    CtArgs p{};
-    p.x = *x; p.w = w; p.bias = bias; p.out = *out; p.B = B; p.H = H; p.W = W;
-    const int nwg = fill_groups(p);
-    if (C == 16) hipLaunchKernelGGL(convt2x2_fwd_kernel<16>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
-    else if (C == 8) hipLaunchKernelGGL(convt2x2_fwd_kernel<8>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
+    pc_convt_fwd_desc d{x, w, bias, out};
+    return pc_convt2x2_fwd_group(1, &d, B, H, W, C, stream);
+}
+
+extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int B, int H, int W, int C, void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || !d) return PC_EINVAL;
+    CtGroup g{};
+    int nwg = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].g || !d[i].w || !d[i].out) return PC_EINVAL;
+        CtArgs& p = g.pr[i];
+        p.x = *d[i].g; p.w = d[i].w; p.out = *d[i].out; p.B = B; p.H = H; p.W = W;
+        if (d[i].act) {
+            if (!d[i].act_bn) return PC_EINVAL;
+            p.act = d[i].act->ptr; p.act_bstride = d[i].act->bstride; p.act_cstride = d[i].act->cstride;
+            p.act_rstride = d[i].act->rstride;
+            p.bn = *d[i].act_bn;
+        }
+        nwg = fill_groups(p);
+    }
+    nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;
+    if (C == 16) hipLaunchKernelGGL(convt2x2_dgrad_kernel<16>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL(convt2x2_dgrad_kernel<8>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
@@ -281,20 +325,8 @@ extern "C" int pc_convt2x2_fwd(const pc_src* x, const float* w, const float* bia
 
 extern "C" int pc_convt2x2_dgrad(const pc_src* g, const float* w, const pc_src* act, const pc_bn* act_bn,
                                  const pc_dst* out, int B, int H, int W, int C, void* stream) {
-    if (!g || !w || !out) return PC_EINVAL;
-    CtArgs p{};
-    p.x = *g; p.w = w; p.out = *out; p.B = B; p.H = H; p.W = W;
-    if (act) {
-        if (!act_bn) return PC_EINVAL;
-        p.act = act->ptr; p.act_bstride = act->bstride; p.act_cstride = act->cstride; p.act_rstride = act->rstride;
-        p.bn = *act_bn;
-    }
-    const int nwg = fill_groups(p);
-    if (C == 16) hipLaunchKernelGGL(convt2x2_dgrad_kernel<16>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
-    else if (C == 8) hipLaunchKernelGGL(convt2x2_dgrad_kernel<8>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, p);
-    else return PC_EINVAL;
-    PC_CHECK_LAUNCH();
-    return 0;
+    pc_convt_dgrad_desc d{g, w, act, act_bn, out};
+    return pc_convt2x2_dgrad_group(1, &d, B, H, W, C, stream);
 }
 
 extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {

@@ -213,12 +213,14 @@ class UNetEngine:
         if not encoder_no_grad:
             G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
         g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
-        G_e2 = {}
+        G_e2, probs = {}, []
         for s in S:
             oy, ox = A[s]["o1"]
             g_u1v = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
             wgt(s, "up1t", A[s]["e2"], g_u1v)
-            G_e2[s] = ops.convt2x2_dgrad(g_u1v, ly(s, "up1t").w, E(8, H1, W1), act=A[s]["e2"], act_bn=ly(s, "up2b").bn_nobias)
+            G_e2[s] = E(8, H1, W1)
+            probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
+        ops.convt2x2_dgrad_group(probs)
         for s in S:
             wg(s, "up2b", A[s]["e1"], G_e2[s])
         G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
@@ -227,14 +229,16 @@ class UNetEngine:
         if not encoder_no_grad:
             G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
         g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
-        G_c2 = {}
+        G_c2, probs = {}, []
         for s in S:
             oy, ox = A[s]["o2"]
             g_u2v = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
             wgt(s, "up2t", A[s]["c2"], g_u2v)
             if not encoder_no_grad:
-                G_c2[s] = ops.convt2x2_dgrad(g_u2v, ly(s, "up2t").w, E(16, H2, W2), act=A[s]["c2"],
-                                             act_bn=ly(s, "d2b").bn_nobias)
+                G_c2[s] = E(16, H2, W2)
+                probs.append({"g": g_u2v, "w": ly(s, "up2t").w, "out": G_c2[s], "act": A[s]["c2"], "act_bn": ly(s, "d2b").bn_nobias})
+        if probs:
+            ops.convt2x2_dgrad_group(probs)
         if encoder_no_grad:
             finish()
             return
@@ -311,11 +315,16 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
     b2 = conv("d1b", b1, 16, H1, W1)
     c1 = conv("d2a", b2, 16, H2, W2, a_mode=L.PC_SRC_POOL2)
     c2 = conv("d2b", c1, 16, H2, W2)
-    u2 = {k: ops.convt2x2(c2[k], ly(k, "up2t").w, ly(k, "up2t").b) for k in keys}
+    def convt(tag, ins, c, h, w):
+        outs = {k: E(c, h, w) for k in keys}
+        ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in keys])
+        return outs
+
+    u2 = convt("up2t", c2, 16, 2 * H2, 2 * W2)
     o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
     e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
     e2 = conv("up2b", e1, 8, H1, W1)
-    u1 = {k: ops.convt2x2(e2[k], ly(k, "up1t").w, ly(k, "up1t").b) for k in keys}
+    u1 = convt("up1t", e2, 8, 2 * H1, 2 * W1)
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
     f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
     f0s = {s: f0 for s, _, _, f0 in streams}

@@ -161,6 +161,34 @@ def convt2x2(x, w, bias, out=None):
     return out
 
 
+def convt2x2_group(problems):
+    """Grouped ConvTranspose2d: problems = list of {x, w, bias, out}; one launch."""
+    n = len(problems)
+    x0 = problems[0]["x"]
+    B, Cc, H, W = x0.shape
+    keep, descs = [], (L.PcConvtFwdDesc * n)()
+    for i, pr in enumerate(problems):
+        sx, d = L.src(pr["x"]), L.dst(pr["out"])
+        keep += [sx, d]
+        descs[i].x, descs[i].w, descs[i].bias, descs[i].out = C.pointer(sx), pr["w"].data_ptr(), pr["bias"].data_ptr(), C.pointer(d)
+    L.check(L.lib().pc_convt2x2_fwd_group(n, descs, B, H, W, Cc, L.stream_ptr()), "pc_convt2x2_fwd_group")
+
+
+def convt2x2_dgrad_group(problems):
+    """Grouped convT data gradient: problems = list of {g, w, out, act, act_bn}."""
+    n = len(problems)
+    B, Cc, H, W = problems[0]["out"].shape
+    keep, descs = [], (L.PcConvtDgradDesc * n)()
+    for i, pr in enumerate(problems):
+        sg, d = L.src(pr["g"]), L.dst(pr["out"])
+        sa = L.src(pr["act"]) if pr.get("act") is not None else None
+        keep += [sg, d, sa]
+        descs[i].g, descs[i].w, descs[i].out = C.pointer(sg), pr["w"].data_ptr(), C.pointer(d)
+        descs[i].act = C.pointer(sa) if sa is not None else None
+        descs[i].act_bn = C.pointer(pr["act_bn"]) if pr.get("act_bn") is not None else None
+    L.check(L.lib().pc_convt2x2_dgrad_group(n, descs, B, H, W, Cc, L.stream_ptr()), "pc_convt2x2_dgrad_group")
+
+
 def convt2x2_dgrad(g, w, out, act=None, act_bn=None):
     L.require_device(g, w, out)
     B, Cc, H, W = out.shape

@@ -25,7 +25,7 @@ constexpr int IN_CS = 18 * IN_RS + 20;       // 740 == 4 mod 32: the (at most) t
 constexpr int IN_COL0 = 4;                   // LDS column of tile x0 (16-byte aligned interior for ds_write_b128)
 constexpr int G_RS = 34;                     // == 2 mod 32
 constexpr int G_CS = 16 * G_RS + 4;          // 548 == 4 mod 32
-constexpr int MAX_WG = 512;
+constexpr int MAX_WG = 256;
 
 struct WgradArgs {
     pc_src a, b, g;

@@ -127,6 +127,11 @@ int pc_conv3x3_wgrad(const pc_src* a, const pc_src* b, const pc_src* g, float* d
  * many layers is then done by ONE pc_wgrad_reduce_batch launch.  Each deferred call needs its own ws slice. */
 int pc_conv3x3_wgrad_partial(const pc_src* a, const pc_src* b, const pc_src* g, void* ws, int B, int H, int W,
                              int Cin, int Cout, int* nwg_out, void* stream);
+/* grouped first stage (e.g. the SAR and optical streams of a layer): one launch, each problem with its own ws slice;
+ * *nwg_out = partials per problem (identical for all) */
+typedef struct pc_conv_wgrad_desc { const pc_src* a; const pc_src* b; const pc_src* g; void* ws; } pc_conv_wgrad_desc;
+int pc_conv3x3_wgrad_partial_group(int n, const pc_conv_wgrad_desc* d, int B, int H, int W, int Cin, int Cout,
+                                   int* nwg_out, void* stream);
 int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B, int H, int W, int C, int* nwg_out,
                               void* stream);
 typedef struct pc_wgrad_reduce_desc {

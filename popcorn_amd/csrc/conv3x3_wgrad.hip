@@ -161,8 +161,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
 constexpr int WIN_RS = 44;                   // == 12 mod 32: rows v = 0..3 land on banks {0,12,24,4} (+dx, +16 for k)
 constexpr int WIN_CSW = 6 * WIN_RS;          // 264
 
+struct WgradGroup {
+    WgradArgs pr[PC_MAX_GROUP];      // problems of identical geometry and loader kind: blockIdx.z selects
+};
+
 template <int CINC, int COUT, int LD>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGroup grp_) {
+    const WgradArgs& p = grp_.pr[blockIdx.z];
     using Cfg = WgradCfg<CINC, COUT>;
     constexpr int NBLK = Cfg::NBLK, MB = Cfg::MB;
     constexpr int NIT = CINC;
@@ -408,59 +413,77 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const Wreduce
     }
 }
 
+// geometry + loader classification of one problem; returns the loader kind (0 generic, 1 direct, 2 pool, 3 reflect)
 template <int CINC, int COUT>
-int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, void* ws, hipStream_t stream,
-                 int* nwg_out = nullptr) {
-    using Cfg = WgradCfg<CINC, COUT>;
+int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
-    const int nchunk = Cin / CINC;
-    int nwg = p.ntiles < MAX_WG / nchunk ? p.ntiles : MAX_WG / nchunk;
+    nchunk = Cin / CINC;
+    nwg = p.ntiles < MAX_WG / nchunk ? p.ntiles : MAX_WG / nchunk;
     if (nwg < 1) nwg = 1;
     p.partial = reinterpret_cast<float*>(ws);
     p.ci0 = 0;
     p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);
     p.fast_b = pc_src_fast_mode(p.b, p.H, p.W);
     p.fast_g = pc_src_fast_mode(p.g, p.H, p.W) == 1;
-    const size_t ldsb = (size_t)Cfg::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<CINC, COUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     const bool lay = p.b.C == 0 || (p.a.bstride == p.b.bstride && p.a.rstride == p.b.rstride);
-    const bool direct = p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g;
-    const bool pool = p.fast_a == 2 && p.b.C == 0 && p.fast_g;
-    bool launched = false;
-    const bool reflect = p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && p.fast_g && CINC <= 4;
-    if (direct || pool || reflect) {
-        size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
-        const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
-        if (lw < lred) lw = lred;
-        static bool attr_w[3] = {false, false, false};
-        auto go = [&](auto kern, int slot) -> int {
-            if (!attr_w[slot]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-                if (e != hipSuccess) return (int)e;
-                attr_w[slot] = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(nwg, nchunk), dim3(256), lw, stream, p);
-            return 0;
-        };
-        int rc = 0;
-        if (reflect) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 3>, 2);
-        else if (direct) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>, 0);
-        else rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>, 1);
-        if (rc) return rc;
-        launched = true;
-    }
-    if (!launched) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
+    if (p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && p.fast_g && CINC <= 4) return 3;
+    if (p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g) return 1;
+    if (p.fast_a == 2 && p.b.C == 0 && p.fast_g) return 2;
+    return 0;
+}
+
+template <int CINC, int COUT>
+int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int nwg, int nchunk, hipStream_t stream) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
+    const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
+    if (lw < lred) lw = lred;
+    static bool attr_w[3] = {false, false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_w[slot]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+            if (e != hipSuccess) return (int)e;
+            attr_w[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(nwg, nchunk, n), dim3(256), lw, stream, g);
+        return 0;
+    };
+    int rc = 0;
+    if (kind == 3) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 3>, 2);
+    else if (kind == 1) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>, 0);
+    else rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>, 1);
+    if (rc) return rc;
     PC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int CINC, int COUT>
+int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, void* ws, hipStream_t stream,
+                 int* nwg_out = nullptr) {
+    using Cfg = WgradCfg<CINC, COUT>;
+    int nwg, nchunk;
+    const int kind = prepare_wgrad<CINC, COUT>(p, Cin, ws, nwg, nchunk);
+    if (kind != 0) {
+        WgradGroup g{};
+        g.pr[0] = p;
+        const int rc = launch_wgrad_wave<CINC, COUT>(g, 1, kind, nwg, nchunk, stream);
+        if (rc) return rc;
+    } else {
+        const size_t ldsb = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<CINC, COUT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
+        PC_CHECK_LAUNCH();
+    }
     if (nwg_out) {            // deferred: the caller batches the reductions of many layers into one launch
         *nwg_out = nwg;
         return 0;
@@ -470,6 +493,30 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     const int n_out = COUT * Cin * 9 + COUT;
     hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CINC, COUT>), dim3((n_out + 15) / 16), dim3(256), 0, stream, r);
     PC_CHECK_LAUNCH();
+    return 0;
+}
+
+// grouped first stage: one launch for all problems when they share the loader kind, else one launch each
+template <int CINC, int COUT>
+int launch_wgrad_group(WgradArgs* ps, void* const* wss, int n, int Cin, hipStream_t stream, int* nwg_out) {
+    WgradGroup g{};
+    int nwg = 0, nchunk = 0, kind0 = -1;
+    bool same = true;
+    for (int i = 0; i < n; ++i) {
+        int w, c;
+        const int k = prepare_wgrad<CINC, COUT>(ps[i], Cin, wss[i], w, c);
+        if (i == 0) { kind0 = k; nwg = w; nchunk = c; }
+        same = same && k == kind0 && w == nwg;
+        g.pr[i] = ps[i];
+    }
+    if (same && kind0 != 0) {
+        *nwg_out = nwg;
+        return launch_wgrad_wave<CINC, COUT>(g, n, kind0, nwg, nchunk, stream);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = launch_wgrad<CINC, COUT>(ps[i], Cin, nullptr, nullptr, 0, wss[i], stream, nwg_out);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -595,6 +642,29 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
         PC_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int pc_conv3x3_wgrad_partial_group(int n, const pc_conv_wgrad_desc* d, int B, int H, int W, int Cin, int Cout,
+                                              int* nwg_out, void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || !d || !nwg_out) return PC_EINVAL;
+    WgradArgs ps[PC_MAX_GROUP];
+    void* wss[PC_MAX_GROUP];
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].a || !d[i].g || !d[i].ws) return PC_EINVAL;
+        ps[i] = WgradArgs{};
+        ps[i].a = *d[i].a;
+        if (d[i].b) ps[i].b = *d[i].b;
+        ps[i].g = *d[i].g;
+        if (ps[i].a.C + ps[i].b.C != Cin || d[i].g->C != Cout) return PC_EINVAL;
+        ps[i].B = B; ps[i].H = H; ps[i].W = W;
+        wss[i] = d[i].ws;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define PC_CASE(ci, co) \
+    if (Cin == ci && Cout == co) return launch_wgrad_group<cinc_of(ci), co>(ps, wss, n, Cin, st, nwg_out);
+    PC_CASE(2, 8) PC_CASE(4, 8) PC_CASE(8, 8) PC_CASE(16, 8) PC_CASE(32, 8) PC_CASE(8, 16) PC_CASE(16, 16)
+#undef PC_CASE
+    return PC_EINVAL;
 }
 
 extern "C" int pc_conv3x3_wgrad_partial(const pc_src* a, const pc_src* b, const pc_src* g, void* ws, int B, int H, int W,

@@ -183,6 +183,17 @@ class UNetEngine:
             lay = ly(s, tag)
             on_side(lambda: wb.conv3x3(a, g, lay.w.shape[0], grads[prefix + lay.wname], grads[prefix + lay.bname], **kw))
 
+        def wgs(tag, a_key, gs, b_key=None, off_key=None, **kw):
+            """weight gradients of layer `tag` for all streams in ONE launch (same shapes)"""
+            probs = []
+            for s in S:
+                lay = ly(s, tag)
+                pr = {"a": A[s][a_key], "g": gs[s], "dw": grads[prefix + lay.wname], "db": grads[prefix + lay.bname]}
+                if b_key is not None:
+                    pr["b"], pr["b_offset"] = A[s][b_key], A[s][off_key]
+                probs.append(pr)
+            on_side(lambda: wb.conv3x3_group(probs, ly(S[0], tag).w.shape[0], **kw))
+
         def wgt(s, tag, x, g):
             lay = ly(s, tag)
             on_side(lambda: wb.convt2x2(x, g, grads[prefix + lay.wname], grads[prefix + lay.bname]))
@@ -205,11 +216,9 @@ class UNetEngine:
             return outs
 
         G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
-        for s in S:
-            wg(s, "up1b", A[s]["f1"], G_f2[s])
+        wgs("up1b", "f1", G_f2)
         G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
-        for s in S:
-            wg(s, "up1a", A[s]["a2"], G_f1[s], b=A[s]["u1"], b_offset=A[s]["o1"])
+        wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
         if not encoder_no_grad:
             G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
         g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
@@ -221,11 +230,9 @@ class UNetEngine:
             G_e2[s] = E(8, H1, W1)
             probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
         ops.convt2x2_dgrad_group(probs)
-        for s in S:
-            wg(s, "up2b", A[s]["e1"], G_e2[s])
+        wgs("up2b", "e1", G_e2)
         G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
-        for s in S:
-            wg(s, "up2a", A[s]["b2"], G_e1[s], b=A[s]["u2"], b_offset=A[s]["o2"])
+        wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
         if not encoder_no_grad:
             G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
         g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
@@ -243,20 +250,15 @@ class UNetEngine:
             finish()
             return
         # encoder
-        for s in S:
-            wg(s, "d2b", A[s]["c1"], G_c2[s])
+        wgs("d2b", "c1", G_c2)
         G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
-        for s in S:
-            wg(s, "d2a", A[s]["b2"], G_c1[s], a_mode=L.PC_SRC_POOL2)
+        wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
         dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
-        for s in S:
-            wg(s, "d1b", A[s]["b1"], G_b2[s])
+        wgs("d1b", "b1", G_b2)
         G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
-        for s in S:
-            wg(s, "d1a", A[s]["a2"], G_b1[s], a_mode=L.PC_SRC_POOL2)
+        wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
         dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
-        for s in S:
-            wg(s, "inc2", A[s]["a1"], G_a2[s])
+        wgs("inc2", "a1", G_a2)
         G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
         for s, chmap, cin, f0 in self.streams:
             wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)

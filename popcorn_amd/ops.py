@@ -370,6 +370,30 @@ class WgradBatch:
                 "pc_conv3x3_wgrad_partial")
         self.entries.append((ws, dw, db, nwg.value, Ca + Cb, cout, 0))
 
+    def conv3x3_group(self, problems, cout, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), a_channels=None):
+        """problems: list of dicts {a, g, dw, db, b (opt), b_offset (opt), chmap (opt)} of identical geometry -> one launch"""
+        n = len(problems)
+        g0, a0 = problems[0]["g"], problems[0]["a"]
+        B, Cg, H, W = g0.shape
+        Ca = a0.shape[1] if a_channels is None else a_channels
+        Cb = 0 if problems[0].get("b") is None else problems[0]["b"].shape[1]
+        keep, descs, slots = [], (L.PcConvWgradDesc * n)(), []
+        for i, pr in enumerate(problems):
+            sa = L.src(pr["a"], C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=pr.get("chmap", (0, 1, 2, 3)))
+            bo = pr.get("b_offset", (0, 0))
+            sb = L.src(pr["b"], oy=bo[0], ox=bo[1]) if pr.get("b") is not None else None
+            sg = L.src(pr["g"])
+            ws = self._slice()
+            keep += [sa, sb, sg]
+            slots.append(ws)
+            descs[i].a, descs[i].g, descs[i].ws = C.pointer(sa), C.pointer(sg), ws
+            descs[i].b = C.pointer(sb) if sb is not None else None
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_conv3x3_wgrad_partial_group(n, descs, B, H, W, Ca + Cb, cout, C.byref(nwg), L.stream_ptr()),
+                "pc_conv3x3_wgrad_partial_group")
+        for ws, pr in zip(slots, problems):
+            self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
+
     def convt2x2(self, x, g, dw, db):
         B, Cc, H, W = x.shape
         sx, sg = L.src(x), L.src(g)

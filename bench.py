@@ -37,7 +37,7 @@ def parse():
 
 
 def dominant_kernel_roofline(torch, trainer, sample, reps=10):
-    """The kernel with the largest share of the step (profiles/r1_*_kernel_stats.csv) is `head_bwd_kernel`: the
+    """The kernel with the largest share of the step (profiles/r1_*_kernel_stats.csv) is `head_bwd_pc_kernel`: the
     backward of the sparse 16-64-64-64-1 head (forward recompute + data gradients + weight gradients on fp32 MFMA).
     Timed live: `reps` back-to-back launches between two events on the launch stream, on the step's real tensors.
     Algorithmic flops per launch = 56,064 flop per selected pixel x selected pixels."""
@@ -77,7 +77,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
             traffic = json.load(fh)["traffic_bytes"] if (B, H, W) == (64, 100, 100) else None
     except OSError:
         pass
-    return {"bound": "mfma", "kernel": "head_bwd_kernel (sparse head backward, fp32 MFMA 16x16x4; + memset + reduce)",
+    return {"bound": "mfma", "kernel": "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4; + memset + reduce of the same call)",
             "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "alg_flop_per_launch": flops, "units_per_launch": nsel,

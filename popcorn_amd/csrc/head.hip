@@ -15,6 +15,7 @@
 // workgroup in LDS as ready-made A fragments (lane-linear, conflict-free); the 64->1 last layer is 16 VALU FMAs + 2
 // cross-lane adds.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -250,6 +251,7 @@ struct HeadBwdArgs {
     pc_dst g_feat;
     pc_bn fbn[2];                // BN of the layers that produced feat channels 0-7 / 8-15 (fuse_feat_bn)
     int fuse_feat_bn;            // 1: g_feat *= (feat > 0) * bn_scale  (ReLU + frozen-BN backward of those layers)
+    int dbg;                     // ablation (tools/ablate_head.py): 1 consumer idle, 2 no hand-off, 4 no per-group global loads
     float* partial;              // [nwg][PE_TOTAL]
     int total_groups;
 };
@@ -536,6 +538,364 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         for (int e = tid; e < 1281; e += 256) {
             const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
             part[PE_W0 + e] = t;     // PE_W0.. contiguous: W0(1024) W6(64) B0 B2 B4 (64 each) B6(1)
+        }
+    }
+}
+
+// ---- head backward, producer / consumer form ----------------------------------------------------------------------
+// The single-role kernel above needs 209 accumulator registers per wave for the three weight-gradient GEMMs, which
+// pins it at ONE wave per SIMD: every global-load, LDS round trip and VALU stretch of that wave idles the matrix pipe
+// (measured 0.50 of the fp32 MFMA peak).  Here a 512-thread workgroup runs two roles with <= 256 registers each, i.e.
+// two waves per SIMD:
+//   producers (waves 0-3): per 16-pixel group, forward recompute + the data-gradient chain (288 MFMAs, ~130 registers);
+//       after each layer they hand the (G = pre-activation gradient, H = layer input) pair to their consumer through
+//       a 2-slot LDS ring as (hidden x pixel) matrices;
+//   consumers (waves 4-7): the weight-gradient GEMMs dW += G . H^T (144 MFMAs per group) and the bias gradients (row
+//       sums of G), accumulated in registers for the whole kernel.
+// Hand-off: per pair two LDS counters (produced / consumed) + a done flag, polled with s_sleep; LDS operations of a wave
+// are performed in order, so "data writes, then counter write" needs no fence beyond a compiler barrier.  Slots carry
+// no tag: every processed group emits exactly three slots (layer 3, 2, 1), so slot k is of kind k % 3.
+constexpr int PC_SLOT = 2 * 64 * SCR_LD;                 // G[64][20] + H[64][20]
+constexpr int PC_NSLOT = 2;
+constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is shared with the single-role kernel
+constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
+constexpr int LP_END = LP_FLAGS + 16;
+
+__global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const HeadArgs& p = a.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int pair = wave & 3;
+    const bool producer = wave < 4;
+    head_stage_weights(lds, p);
+    __syncthreads();                // its bias block (L_B0..) overlaps LB_T3: let it land before T3 is filled
+    for (int e = tid; e < 64 * 64; e += blockDim.x) {
+        const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
+        const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
+        const int col = 16 * mi + (l & 15);                           // i
+        lds[LB_T3 + e] = p.w4[row * HID + col];
+        lds[LB_T2 + e] = p.w2[row * HID + col];
+    }
+    for (int e = tid; e < 16 * 64; e += blockDim.x) {
+        const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
+        const int row = 16 * mb + 4 * (l >> 4) + r;
+        lds[LB_T1 + e] = p.w0[row * 16 + (l & 15)];
+    }
+    for (int e = tid; e < 64; e += blockDim.x) {
+        lds[LB_B0 + e] = p.b0[e];
+        lds[LB_B2 + e] = p.b2[e];
+        lds[LB_B4 + e] = p.b4[e];
+        lds[LB_W6 + e] = p.w6[e];
+    }
+    if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
+    int* flags = reinterpret_cast<int*>(lds + LP_FLAGS);
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();
+
+    float* ring = lds + LP_RING + pair * PC_NSLOT * PC_SLOT;
+    volatile int* prod_p = flags + pair * 4 + 0;
+    volatile int* cons_p = flags + pair * 4 + 1;
+    volatile int* done_p = flags + pair * 4 + 2;
+    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
+
+    // Role-private accumulators: declared here (they feed the common reduction below) but initialised ONLY inside the
+    // role that owns them, so that their live ranges do not extend through the other role's code (a shared
+    // zero-initialisation made the allocator keep all 160 accumulator registers live in the producer: 157 spills).
+    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4];
+    float dbs[3][4];          // consumer: bias-gradient partial sums (row 16q + li, pixels = lk mod 4)
+    float db6;
+
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(2);   // producers are the critical path: they win the
+                                                                                    // MFMA arbitration, the consumer fills their bubbles
+    if (producer) {
+        db6 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int HW = p.H * p.W;
+        const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
+        float fscale[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fscale[r] = 1.f;
+            if (a.fuse_feat_bn) {
+                const int c = 4 * lk + r;
+                float sh;
+                pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
+            }
+        }
+        int nprod = 0;
+        auto acquire = [&]() -> float* {
+            while (true) {
+                const int c = __builtin_amdgcn_readfirstlane(*cons_p);
+                if (nprod - c < PC_NSLOT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+            return ring + (nprod % PC_NSLOT) * PC_SLOT;
+        };
+        auto release = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++nprod;
+            if (lane == 0) *prod_p = nprod;
+        };
+        const int cperm = (li & 3) * 4 + (li >> 2);
+        // per-group inputs are fetched one group ahead (raw loads only; everything derived is recomputed)
+        float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
+        unsigned n_msk = 1;
+        auto fetch = [&](int gg) {
+            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+            const int q = g * 16 + li;
+            const bool valid = q < HW;
+            const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
+            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
+            const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                n_xv[j] = (a.dbg & 4) ? 0.01f * (float)(lane + j) : fp[(4 * j + lk) * p.feat.cstride];
+                n_fv[j] = ((a.dbg & 4) || !a.fuse_feat_bn) ? 1.f : fp[(4 * lk + j) * p.feat.cstride];
+            }
+            if (!(a.dbg & 4)) {
+                n_msk = p.mask ? p.mask[pix] : 1;
+                n_bld = p.building[pix];
+                if (p.admin) n_adm = p.admin[pix];
+                if (a.g_popdense) n_gpd = a.g_popdense[pix];
+                if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
+            }
+        };
+        const int gstep = gridDim.x * 4;
+        int gg = blockIdx.x * 4 + wave;
+        if (gg < a.total_groups) fetch(gg);
+        for (; gg < a.total_groups; gg += gstep) {
+            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+            const int q = g * 16 + li;
+            const bool valid = q < HW;
+            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
+            const bool sel = valid && n_msk != 0;
+            float xv[4], fvv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = valid ? n_fv[j] : 1.f; }
+            float gup = 0.f;
+            if (a.dbg & 4) gup = 1.f;
+            else if (sel) {
+                const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
+                gup = gsc;
+                if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
+                if (a.g_popdense) gup += n_gpd * n_bld;
+                if (a.g_scale_map) gup += n_gsm;
+            }
+            if (gg + gstep < a.total_groups) fetch(gg + gstep);       // in flight during this group's MFMA chain
+            if (!__any(sel)) continue;
+            f32x4 h1[4], h2[4], h3[4];
+            head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
+            relu4(h1);
+            head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
+            relu4(h2);
+            head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
+            relu4(h3);
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float outv = s + lds[LB_W6 + 64];
+            const float gout = (sel && outv > 0.f) ? gup : 0.f;
+            if (!__any(gout != 0.f)) continue;
+
+            f32x4 g3[4], g2[4], g1[4];
+            if (lk == 0) db6 += gout;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                }
+            }
+            if (!(a.dbg & 2)) {   // slot kind 0: (G3, H2) -> dW4, db4
+                float* sl = acquire();
+                head_store_mat(sl, li, lk, g3);
+                head_store_mat(sl + 64 * SCR_LD, li, lk, h2);
+                release();
+            }
+            head_dgrad64(lds, LB_T3, lane, g3, g2);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+            if (!(a.dbg & 2)) {   // slot kind 1: (G2, H1) -> dW2, db2
+                float* sl = acquire();
+                head_store_mat(sl, li, lk, g2);
+                head_store_mat(sl + 64 * SCR_LD, li, lk, h1);
+                release();
+            }
+            head_dgrad64(lds, LB_T2, lane, g2, g1);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+            if (!(a.dbg & 2)) {   // slot kind 2: (G1, X) -> dW0, db0
+                float* sl = acquire();
+                head_store_mat(sl, li, lk, g1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sl[64 * SCR_LD + (4 * j + lk) * SCR_LD + cperm] = xv[j];
+                release();
+            }
+            f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA dependent latency
+#pragma unroll                                                                       // (40 cyc) exceeds the issue interval (32)
+            for (int mb = 0; mb < 4; mb += 2) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(&lds[LB_T1 + (mb * 64 + lane) * 4]);
+                const f32x4 u4 = *reinterpret_cast<const f32x4*>(&lds[LB_T1 + ((mb + 1) * 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
+                    gx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[r], g1[mb + 1][r], gx2, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
+            if (valid) {
+                float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float o = gx[r];
+                    if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
+                    op[(4 * lk + r) * a.g_feat.cstride] = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *done_p = 1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dW0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        int ncons = 0;
+        // wait until slot `ncons` has been produced; returns false when the producer has finished without producing it
+        auto wait_slot = [&]() -> bool {
+            while (true) {
+                if (__builtin_amdgcn_readfirstlane(*prod_p) > ncons) return true;
+                if (__builtin_amdgcn_readfirstlane(*done_p)) return __builtin_amdgcn_readfirstlane(*prod_p) > ncons;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        // fetch the (G, H) fragments of the current slot and hand the slot back
+        auto take = [&](f32x4 (&af)[4], f32x4 (&bf)[4], bool x_only) {
+            asm volatile("" ::: "memory");
+            const float* gm = ring + (ncons % PC_NSLOT) * PC_SLOT;
+            const float* hm = gm + 64 * SCR_LD;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[q] = *reinterpret_cast<const f32x4*>(&gm[(16 * q + li) * SCR_LD + 4 * lk]);
+                bf[q] = *reinterpret_cast<const f32x4*>(&hm[(16 * (x_only ? 0 : q) + li) * SCR_LD + 4 * lk]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++ncons;
+            if (lane == 0) *cons_p = ncons;          // slot is free again: everything needed is in registers
+        };
+        // every processed group emits exactly three slots, in this order: no tags, no dynamic dispatch
+        while (wait_slot()) {
+            f32x4 af[4], bf[4];
+            take(af, bf, false);                                             // (G3, H2) -> dW4, db4
+            if (a.dbg & 1) { wait_slot(); take(af, bf, false); wait_slot(); take(af, bf, true); continue; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[2][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        dW4[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW4[mb][nb], 0, 0, 0);
+            wait_slot();
+            take(af, bf, false);                                             // (G2, H1) -> dW2, db2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[1][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        dW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW2[mb][nb], 0, 0, 0);
+            wait_slot();
+            take(af, bf, true);                                              // (G1, X) -> dW0, db0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[0][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[0][ks], dW0[mb], 0, 0, 0);
+        }
+    }
+
+    // ---- reductions: producers own dw6 / db6, consumers own dW4, dW2, dW0 and the bias sums
+    if (producer) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
+        db6 = lane_sum16(db6);
+    } else {
+#pragma unroll
+        for (int l3 = 0; l3 < 3; ++l3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = dbs[l3][q];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                dbs[l3][q] = v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int stage = 0; stage < 2; ++stage) {
+        if (!producer) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    *reinterpret_cast<f32x4*>(&lds[pair * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
+        }
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 512)
+            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
+        __syncthreads();
+    }
+    {
+        float* w = lds + pair * 1344;       // [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1]
+        if (!producer) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
+            if (lk == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w[1088 + 16 * q + li] = dbs[0][q];
+                    w[1152 + 16 * q + li] = dbs[1][q];
+                    w[1216 + 16 * q + li] = dbs[2][q];
+                }
+            }
+        } else if (li == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[1024 + 16 * mb + 4 * lk + r] = dw6[mb][r];
+            if (lk == 0) w[1280] = db6;
+        }
+        __syncthreads();
+        for (int e = tid; e < 1281; e += 512) {
+            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
+            part[PE_W0 + e] = t;
         }
     }
 }
@@ -831,14 +1191,27 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     int nwg = (a.total_groups + 3) / 4;
     if (nwg > 256) nwg = 256;
     if (nwg < 1) nwg = 1;
+    {
+        const char* dv = getenv("POPCORN_HEAD_DBG");
+        a.dbg = dv ? atoi(dv) : 0;
+    }
+    static int use_pc = -1;
+    if (use_pc < 0) {
+        const char* ev = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");
+        use_pc = (ev && ev[0] == '1') ? 0 : 1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
+        if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
+    if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
     HeadReduceArgs r{};
     r.partial = a.partial; r.nwg = nwg; r.accumulate = accumulate;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "popcorn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,6 +14,24 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
         hipError_t e__ = hipGetLastError();       \
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
+
+// Workgroups of 256 threads (one wave per SIMD) that are resident on the whole chip at once for a kernel using `regs`
+// unified VGPR+AGPR registers per lane (512 per SIMD lane, allocated in blocks of 8) and `lds` bytes of LDS (160 KB / CU).
+static inline int pc_resident_workgroups(int regs, size_t lds) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int r = regs < 8 ? 8 : (regs + 7) & ~7;
+    int per_cu = 512 / r;
+    if (lds > 0 && (int)((160u * 1024u) / lds) < per_cu) per_cu = (int)((160u * 1024u) / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu * cus;
+}
 
 // Division by a launch-invariant divisor without the ~40-instruction VALU sequence the compiler emits for a runtime
 // integer divide (there is no hardware integer divide; in the persistent tile loops those sequences were ~1000

@@ -92,49 +92,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     const int s_row = li >> 3, col = li & 7;
     if (p.dbg & 8) return;
 
-    // ---- B fragments: bw[ci][dx][nb] = w[co = nb*8+col][ci][dy = lk - s_row][dx]
-    // The (strided, possibly transposed) weight slice is first copied into LDS by the whole workgroup with coalesced,
-    // independent loads -- one memory round trip -- and the per-lane fragments are then gathered from LDS.
-    float bw[CIN][3][NB];
-    {
-        for (int e = tid; e < COUT * CIN * 9; e += 256) {
-            const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-            lds[e] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
-        }
-        __syncthreads();
-        const int dy = lk - s_row;
-        const bool valid = dy >= 0 && dy <= 2;
-        const int dyc = valid ? dy : 0;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float v = lds[((nb * 8 + col) * CIN + ci) * 9 + dyc * 3 + dx];
-                    bw[ci][dx][nb] = valid ? v : 0.f;
-                }
-        __syncthreads();   // the weight image is dead: waves may now overwrite their LDS regions
-    }
-    // ---- per-lane epilogue constants for co = nb*8 + col
-    float e_scale[NB], e_shift[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        if (MODE == MODE_FWD || q.act != nullptr) pc_bn_fold(q.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
-        else { e_scale[nb] = 1.f; e_shift[nb] = 0.f; }
-    }
-    // Consume the BN constants HERE.  They come from global loads issued before the strip loop and are first used in
-    // the epilogue inside it; hipcc's waitcnt pass then keeps them "pending" at the loop header on every iteration and,
-    // unable to count how many prefetch loads were issued since, emits `s_waitcnt vmcnt(0)` in front of the epilogue --
-    // draining the just-issued prefetch loads of the next strip on EVERY strip (load, store and MFMA phases add up
-    // instead of overlapping: tools/ablate_conv.py).  An empty asm use forces the one wait to happen before the loop.
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) asm volatile("" : : "v"(e_scale[nb]), "v"(e_shift[nb]));
-    const float* const act = q.act;
-    float* const outp = q.out.ptr;
-    const int64_t o_bs = q.out.bstride, o_cs = q.out.cstride, a_bs = q.act_bstride, a_cs = q.act_cstride;
-    const int o_rs = q.out.rstride, a_rs = q.act_rstride;
-
     float* const wl = lds + wave * (CHUNK * CSW);        // this wave's LDS region
 
     // ---- staged loader: lane = (row r of the 6-row strip, 16-byte segment seg of the 40-float row)
@@ -217,6 +174,56 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         x0 = (rem - ty * p.tiles_x) * TW;
         y0 = ty * TH + 4 * wave;
     };
+
+    // The loads of the first strip are in flight while the weights are staged.
+    int b = 0, y0 = 0, x0 = 0;
+    if (nstages > 0) {
+        strip_coords(0, b, y0, x0);
+        if (STAGED && !(p.dbg & 1)) issue(0, b, y0, x0);
+    }
+
+    // ---- B fragments: bw[ci][dx][nb] = w[co = nb*8+col][ci][dy = lk - s_row][dx]
+    // The (strided, possibly transposed) weight slice is first copied into LDS by the whole workgroup with coalesced,
+    // independent loads -- one memory round trip -- and the per-lane fragments are then gathered from LDS.
+    float bw[CIN][3][NB];
+    {
+        for (int e = tid; e < COUT * CIN * 9; e += 256) {
+            const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+            lds[e] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+        }
+        __syncthreads();
+        const int dy = lk - s_row;
+        const bool valid = dy >= 0 && dy <= 2;
+        const int dyc = valid ? dy : 0;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = lds[((nb * 8 + col) * CIN + ci) * 9 + dyc * 3 + dx];
+                    bw[ci][dx][nb] = valid ? v : 0.f;
+                }
+        __syncthreads();   // the weight image is dead: waves may now overwrite their LDS regions
+    }
+    // ---- per-lane epilogue constants for co = nb*8 + col
+    float e_scale[NB], e_shift[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (MODE == MODE_FWD || q.act != nullptr) pc_bn_fold(q.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
+        else { e_scale[nb] = 1.f; e_shift[nb] = 0.f; }
+    }
+    // Consume the BN constants HERE.  They come from global loads issued before the strip loop and are first used in
+    // the epilogue inside it; hipcc's waitcnt pass then keeps them "pending" at the loop header on every iteration and,
+    // unable to count how many prefetch loads were issued since, emits `s_waitcnt vmcnt(0)` in front of the epilogue --
+    // draining the just-issued prefetch loads of the next strip on EVERY strip (load, store and MFMA phases add up
+    // instead of overlapping: tools/ablate_conv.py).  An empty asm use forces the one wait to happen before the loop.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" : : "v"(e_scale[nb]), "v"(e_shift[nb]));
+    const float* const act = q.act;
+    float* const outp = q.out.ptr;
+    const int64_t o_bs = q.out.bstride, o_cs = q.out.cstride, a_bs = q.act_bstride, a_cs = q.act_cstride;
+    const int o_rs = q.out.rstride, a_rs = q.act_rstride;
 
     // deferred epilogue: the results of strip t are stored while strip t+1 is in its MFMA phase
     f32x4 pacc[4][NB];
@@ -314,11 +321,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         }
     };
 
-    int b = 0, y0 = 0, x0 = 0;
-    if (nstages > 0) {
-        strip_coords(0, b, y0, x0);
-        if (STAGED && !(p.dbg & 1)) issue(0, b, y0, x0);
-    }
     f32x4 acc[4][NB];
     for (int stage = 0; stage < nstages; ++stage) {
         const int ch = stage % NCHUNK;
@@ -381,17 +383,31 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     size_t lds = (size_t)4 * CHUNK * CSW * sizeof(float);
     if (lds < (size_t)COUT * CIN * 9 * sizeof(float)) lds = (size_t)COUT * CIN * 9 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
+    if (!resident) {
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, lds);
+        if (getenv("POPCORN_CONV_DBG"))
+            fprintf(stderr, "conv3x3<%d,%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD,
+                    fa.numRegs, lds, resident);
     }
-    // persistent workgroups: about 3 per CU in total, split over the grouped problems
-    int max_grid = g_conv_max_grid > 0 ? g_conv_max_grid : 768 / nprob;
-    if (max_grid < 128) max_grid = 128;
-    const int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
+    // Persistent workgroups, all resident at once (one wave of a 256-thread workgroup per SIMD; the register count
+    // decides how many workgroups a CU holds), split over the grouped problems; the grid is then shrunk to the smallest
+    // one with the same number of rounds so that the last round is as full as the others.
+    int max_grid = g_conv_max_grid > 0 ? g_conv_max_grid : resident / nprob;
+    if (max_grid < 1) max_grid = 1;
+    int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
+    const int rounds = (p.ntiles + grid - 1) / grid;
+    grid = (p.ntiles + rounds - 1) / rounds;
+    if (p.dbg & 16) {                      // ablation: the round-1 sizing (3 workgroups per CU whatever the kernel)
+        grid = 768 / nprob < 128 ? 128 : 768 / nprob;
+        if (grid > p.ntiles) grid = p.ntiles;
+    }
     hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,53 @@
+"""Ablation of the grouped conv3x3 forward launch as the train step issues it: 4 problems (2 networks x 2 streams),
+B=64, distinct buffers, rotated over NSETS buffer sets so that the 256 MiB Infinity Cache is cold.  GPU only.
+
+    python3 tools/ablate_conv_group.py [cin cout hw]
+"""
+import os
+import sys
+sys.path.insert(0, os.getcwd())
+import torch
+from popcorn_amd import ops, _lib as L
+
+lib = L.lib()
+B, NSETS, REPS = 64, 4, 15
+cfgs = [(8, 8, 128), (16, 8, 128), (16, 16, 64), (32, 8, 64)]
+if len(sys.argv) == 4:
+    cfgs = [tuple(int(v) for v in sys.argv[1:4])]
+variants = [(0, 0, "full"), (1, 0, "no loader"), (2, 0, "no mfma"), (4, 0, "no store"), (5, 0, "mfma only"),
+            (6, 0, "loader only"), (3, 0, "store only"), (7, 0, "nothing"), (0, 128, "full 2 WG/CU"),
+            (0, 256, "full 4 WG/CU"), (0, 384, "full 6 WG/CU")]
+if os.environ.get("ABL_ONLY_FULL"):
+    variants = [(0, 0, "full"), (16, 0, "old grid"), (0, 0, "full"), (16, 0, "old grid")]
+for (cin, cout, hw) in cfgs:
+    sets = []
+    for s in range(NSETS):
+        probs = []
+        for i in range(4):
+            ca = cin if cin <= 8 else cin // 2
+            a = torch.randn(B, ca, hw, hw, device="cuda")
+            b = torch.randn(B, cin - ca, hw, hw, device="cuda") if cin > ca else None
+            w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.1
+            bias = torch.zeros(cout, device="cuda")
+            probs.append({"a": a, "b": b, "w": w, "bn": L.bn(bias), "out": torch.empty(B, cout, hw, hw, device="cuda"),
+                          "_keep": bias})
+        sets.append(probs)
+    flop = 4 * B * hw * hw * 2 * 9 * cin * cout
+    byts = 4 * B * hw * hw * 4 * (cin + cout)
+    for dbg, grid, tag in variants:
+        lib.pc_debug_conv(dbg, grid)
+        for s in sets:
+            ops.conv3x3_fwd_group(s)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            for s in sets:
+                ops.conv3x3_fwd_group(s)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (REPS * NSETS)
+        print(f"{cin:2d}->{cout:2d}@{hw:3d} x4  {tag:14s} {us:7.1f} us   {flop / us / 1e6:6.1f} TFLOP/s  {byts / us / 1e6:5.2f} TB/s",
+              flush=True)
+    lib.pc_debug_conv(0, 0)
+    del sets

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int NB = COUT / 8;
     constexpr bool STAGED = LD != LD_GENERIC;
     constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
+    constexpr int W_RL = CIN * 3 + 4;                    // weight image: floats per (dy, co) row (== 4 mod 8: spreads banks)
+    constexpr int W_DYS = COUT * W_RL + 16;              // ... and per dy plane
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const ConvProb& q = p.pr[blockIdx.y];
@@ -182,30 +184,42 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         if (STAGED && !(p.dbg & 1)) issue(0, b, y0, x0);
     }
 
-    // ---- B fragments: bw[ci][dx][nb] = w[co = nb*8+col][ci][dy = lk - s_row][dx]
-    // The (strided, possibly transposed) weight slice is first copied into LDS by the whole workgroup with coalesced,
-    // independent loads -- one memory round trip -- and the per-lane fragments are then gathered from LDS.
-    float bw[CIN][3][NB];
+    // ---- B fragments: bw[ci][dx][nb] = w[co = nb*8+col][ch*CHUNK + ci][dy = lk - s_row][dx]  (0 when dy is not a tap)
+    // The (strided, possibly transposed) weight tensor is copied ONCE per workgroup into an LDS image behind the wave
+    // regions, laid out [dy 0..3][co][ci*3+dx] with an all-zero dy = 3 plane for the lanes whose (row, output row) pair
+    // is not a tap; a lane's fragments for one 8-channel chunk are then 24 consecutive floats = 6 ds_read_b128.  Only
+    // the current chunk's fragments live in registers (24 per 8 output channels whatever CIN is): holding all of them
+    // cost 96 registers at CIN = 32 and left 16->8 / 32->8 / 16->16 with two or ONE wave per SIMD.
+    float* const w2 = lds + 4 * CHUNK * CSW;
     {
+        for (int e = tid; e < 4 * W_DYS; e += 256) w2[e] = 0.f;
+        __syncthreads();
         for (int e = tid; e < COUT * CIN * 9; e += 256) {
             const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-            lds[e] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+            w2[(tap / 3) * W_DYS + co * W_RL + ci * 3 + (tap % 3)] =
+                q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
         }
         __syncthreads();
-        const int dy = lk - s_row;
-        const bool valid = dy >= 0 && dy <= 2;
-        const int dyc = valid ? dy : 0;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float v = lds[((nb * 8 + col) * CIN + ci) * 9 + dyc * 3 + dx];
-                    bw[ci][dx][nb] = valid ? v : 0.f;
-                }
-        __syncthreads();   // the weight image is dead: waves may now overwrite their LDS regions
     }
+    const float* const wlane = w2 + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * W_DYS + col * W_RL;
+    float bw[CHUNK][3][NB];
+    auto load_bw = [&](int ch) {
+        if constexpr (CHUNK == 8) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(wlane + nb * 8 * W_RL + ch * 24 + 4 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bw[(4 * j + e) / 3][(4 * j + e) % 3][nb] = t[e];
+                }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int k = 0; k < CHUNK * 3; ++k) bw[k / 3][k % 3][nb] = wlane[nb * 8 * W_RL + k];
+        }
+    };
     // ---- per-lane epilogue constants for co = nb*8 + col
     float e_scale[NB], e_shift[NB];
 #pragma unroll
@@ -344,24 +358,20 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (!(p.dbg & 2)) {
+            load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
+            const float* lrow = wl + lk * RS + (COL0 - 1) + li;
 #pragma unroll
-            for (int chc = 0; chc < NCHUNK; ++chc) {
-                if (chc != ch) continue;
-                const float* lrow = wl + lk * RS + (COL0 - 1) + li;
+            for (int ci = 0; ci < CHUNK; ++ci) {
 #pragma unroll
-                for (int ci = 0; ci < CHUNK; ++ci) {
+                for (int dx = 0; dx < 3; ++dx) {
+                    float av[4];
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        float av[4];
+                    for (int u = 0; u < 4; ++u) av[u] = lrow[ci * CSW + (u >> 1) * 2 * RS + (u & 1) * 16 + dx];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) av[u] = lrow[ci * CSW + (u >> 1) * 2 * RS + (u & 1) * 16 + dx];
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[chc * CHUNK + ci][dx][nb],
-                                                                                  acc[u][nb], 0, 0, 0);
-                    }
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[ci][dx][nb], acc[u][nb], 0, 0, 0);
                 }
             }
         }
@@ -381,8 +391,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 template <int CIN, int COUT, int MODE, int LD>
 int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
-    size_t lds = (size_t)4 * CHUNK * CSW * sizeof(float);
-    if (lds < (size_t)COUT * CIN * 9 * sizeof(float)) lds = (size_t)COUT * CIN * 9 * sizeof(float);
+    const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD>);

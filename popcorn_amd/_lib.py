@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpopcorn_hip.so")
+LIB_PATH = os.environ.get("POPCORN_HIP_LIB") or os.path.join(_HERE, "libpopcorn_hip.so")   # override: A/B builds
 
 PC_SRC_DIRECT, PC_SRC_POOL2, PC_SRC_REFLECT = 0, 1, 2
 

@@ -28,7 +28,9 @@
 #include "tile_loader.h"
 
 static int g_conv_dbg = 0, g_conv_max_grid = 0;
+static long long* g_conv_ts = nullptr;     // debug: per-workgroup (start, end, hw id) timestamps (tools/conv_timeline.py)
 extern "C" void pc_debug_conv(int dbg, int max_grid) { g_conv_dbg = dbg; g_conv_max_grid = max_grid; }
+extern "C" void pc_debug_conv_ts(void* buf) { g_conv_ts = (long long*)buf; }
 
 namespace {
 
@@ -64,6 +66,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, ntiles;
     pc_fastdiv div_tx, div_tpi;   // by tiles_x, by tiles per image
     int dbg;              // ablation switches (tools/ablate_conv.py): 1 skip loader, 2 skip MFMA, 4 skip stores
+    long long* ts;        // debug timeline buffer (8 slots per workgroup) or NULL
 };
 
 // Wave-private strips.  Each wave owns a 32 x 4 output strip (4 MFMA units), stages its own (CHUNK x 6 x 40) halo
@@ -93,6 +96,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     const int li = lane & 15, lk = lane >> 4;      // A: (i, k);  B: (k, n = li);  D: (n = li, rows 4*lk + r)
     const int s_row = li >> 3, col = li & 7;
     if (p.dbg & 8) return;
+    if (p.ts && tid == 0) {
+        long long* t = p.ts + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        t[0] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+    }
 
     float* const wl = lds + wave * (CHUNK * CSW);        // this wave's LDS region
 
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         b = nb_; y0 = ny0; x0 = nx0;
     }
     if (have_prev && !(p.dbg & 4)) epilogue();
+    if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
 template <int CIN, int COUT, int MODE, int LD>
@@ -434,6 +443,7 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     p.dbg = g_conv_dbg;
+    p.ts = g_conv_ts;
     // loader choice: all problems of the group must qualify for a staged loader
     bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
     bool vec = (p.W % 4) == 0;

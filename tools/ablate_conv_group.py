@@ -10,14 +10,16 @@ import torch
 from popcorn_amd import ops, _lib as L
 
 lib = L.lib()
-B, NSETS, REPS = 64, 4, 15
+B, NSETS, REPS = 64, 4, 10
 cfgs = [(8, 8, 128), (16, 8, 128), (16, 16, 64), (32, 8, 64)]
 if len(sys.argv) == 4:
     cfgs = [tuple(int(v) for v in sys.argv[1:4])]
 variants = [(0, 0, "full"), (1, 0, "no loader"), (2, 0, "no mfma"), (4, 0, "no store"), (5, 0, "mfma only"),
             (6, 0, "loader only"), (3, 0, "store only"), (7, 0, "nothing"), (0, 128, "full 2 WG/CU"),
             (0, 256, "full 4 WG/CU"), (0, 384, "full 6 WG/CU")]
-if os.environ.get("ABL_ONLY_FULL"):
+if os.environ.get("ABL_ONE"):
+    variants = [(int(os.environ["ABL_ONE"], 0), 0, "dbg=" + os.environ["ABL_ONE"])]
+elif os.environ.get("ABL_ONLY_FULL"):
     variants = [(0, 0, "full"), (16, 0, "old grid"), (0, 0, "full"), (16, 0, "old grid")]
 for (cin, cout, hw) in cfgs:
     sets = []
@@ -39,15 +41,24 @@ for (cin, cout, hw) in cfgs:
         for s in sets:
             ops.conv3x3_fwd_group(s)
         torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()          # graph replay: no CPU launch floor between the kernels
+        cap = torch.cuda.Stream()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap):
+                for _ in range(REPS):
+                    for s in sets:
+                        ops.conv3x3_fwd_group(s)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(REPS):
-            for s in sets:
-                ops.conv3x3_fwd_group(s)
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (REPS * NSETS)
         print(f"{cin:2d}->{cout:2d}@{hw:3d} x4  {tag:14s} {us:7.1f} us   {flop / us / 1e6:6.1f} TFLOP/s  {byts / us / 1e6:5.2f} TB/s",
               flush=True)
+        del g
     lib.pc_debug_conv(0, 0)
     del sets

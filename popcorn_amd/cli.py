@@ -19,10 +19,11 @@ import torch
 
 from . import ops
 from .data import stats
-from .data.collate import Population_Dataset_collate_fn, augment_geometric
+from .data.collate import Population_Dataset_collate_fn
 from .data.dataset import SyntheticTestRaster, SyntheticWeaksupDataset
 from .distributed import FlatReducer, init_from_env
 from .model import get_model_kwargs, model_dict
+from .utils.transform import default_train_transform
 
 
 def train_parser():
@@ -120,12 +121,20 @@ def new_log(folder, args=None):
     return exp
 
 
-def normalize_sample(sample, device):
-    """to_cuda_inplace + apply_normalize + concat [S2, S1] (utils/utils.py:22-43,105-127,171) on the device."""
-    s2, s1 = sample["S2"].to(device, non_blocking=True), sample["S1"].to(device, non_blocking=True)
-    raw = torch.cat([s2, s1], 1).contiguous().float()
+def normalize_sample(sample, device, transform=None):
+    """to_cuda_inplace + apply_transformations_and_normalize (utils/utils.py:22-43,130-214) on the device: S2 augmentations
+    on the raw digital numbers, per-band normalisation + concat [S2, S1] (one HIP kernel), then the joint geometric
+    transform of input and admin_mask."""
+    s2, s1 = sample["S2"].to(device, non_blocking=True).float(), sample["S1"].to(device, non_blocking=True).float()
+    if transform is not None and "S2" in transform:
+        s2 = transform["S2"](s2)
+    raw = torch.cat([s2, s1], 1).contiguous()
     x = ops.select_normalize(raw, (0, 1, 2, 3, 4, 5), stats.MEAN6, stats.STD6)
-    out = {"input": x, "admin_mask": sample["admin_mask"].to(device).float().contiguous(),
+    admin = sample["admin_mask"].to(device).float()
+    if transform is not None and "general" in transform:
+        x, m = transform["general"]((x, admin.unsqueeze(1)))
+        admin = m[:, 0]
+    out = {"input": x.contiguous(), "admin_mask": admin.contiguous(),
            "census_idx": sample["census_idx"].to(device).contiguous(), "y": sample["y"].to(device).float().contiguous()}
     return out
 
@@ -150,6 +159,7 @@ class Trainer:
                                                   collate_fn=Population_Dataset_collate_fn, drop_last=True)
         self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)
         seed_all(args.seed + 2)
+        self.data_transform = default_train_transform()                    # run_train.py:386-402
         self.reducer = FlatReducer()
         self.info = {"epoch": 0, "iter": 0, "sampleitr": 0}
         if args.torch_optimizer:
@@ -201,8 +211,7 @@ class Trainer:
     # ---- loop ------------------------------------------------------------------------------------------------------
     def train_step(self, sample):
         a = self.args
-        s = normalize_sample(sample, self.device)
-        s["input"], s["admin_mask"] = augment_geometric(s["input"], s["admin_mask"])
+        s = normalize_sample(sample, self.device, self.data_transform)
         num_pix = s["input"].shape[0] * s["input"].shape[2] * s["input"].shape[3]
         enc_ng = unet_ng = False                                           # run_train.py:191-198
         if num_pix > a.limit1:

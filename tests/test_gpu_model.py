@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import pytest
+import random
+
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -189,6 +191,7 @@ def test_torch_optimizer_path_equals_fused_path(tmp_path):
     sample = next(iter(ta.loader))
     for t in (ta, tb):
         torch.manual_seed(11)
+        random.seed(11)                      # the augmentations draw from both generators (utils/transform.py)
         t.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()})
     for (k1, v1), (k2, v2) in zip(ta.model.state_dict().items(), tb.model.state_dict().items()):
         torch.testing.assert_close(v1, v2, rtol=0, atol=2e-6, msg=lambda m, k=k1: f"{k}: {m}")

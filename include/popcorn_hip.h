@@ -234,6 +234,13 @@ int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n
                       float weight_decay, float beta1, float beta2, float eps, float max_norm,
                       const float* norm_dev, int32_t* step_dev, void* stream);
 
+/* The same in ONE launch: every workgroup computes the total norm of g itself (written to norm_out_dev if non-NULL), then
+ * clips and updates; max_norm <= 0: no clipping.  g must be 16-byte aligned.  Must not run concurrently with itself on
+ * two streams of one process (a device-side ticket decides which workgroup advances the step counter). */
+int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
+                            float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                            float* norm_out_dev, int32_t* step_dev, void* stream);
+
 /* Band selection + per-band (x - mean) / std: data/PopulationDataset.py:566-568 + utils/utils.py:105-127.
  * raw: B x Craw x H x W; out: B x 6 x H x W; band6/mean6/std6: host arrays of 6. */
 int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,

@@ -909,9 +909,11 @@ struct HeadReduceArgs {
 
 // outputs: w0 (1024) b0 (64) w2 (4096) b2 (64) w4 (4096) b4 (64) w6 (128) b6 (2)  = 9538
 __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceArgs p) {
+    // 32 outputs x 8 slices of the partial list per workgroup (299 workgroups): the sums are short dependent-latency
+    // chains, so the launch is sized for memory-level parallelism, not for arithmetic
     __shared__ float red[256];
-    const int tid = threadIdx.x, slice = tid >> 6;
-    const int o = blockIdx.x * 64 + (tid & 63);
+    const int tid = threadIdx.x, slice = tid >> 5;
+    const int o = blockIdx.x * 32 + (tid & 31);
     int t = -1, idx = 0, e = -1;      // tensor id, index within tensor, partial element (-1 = structural zero)
     if (o < 1024) { t = 0; idx = o; const int r = o >> 4, c = o & 15; e = PE_W0 + (((r >> 4) * 64) + ((r & 15) >> 2) * 16 + c) * 4 + (r & 3); }
     else if (o < 1088) { t = 1; idx = o - 1024; e = PE_B0 + idx; }
@@ -924,12 +926,15 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceAr
     else if (o < 9536) { t = 6; idx = o - 9408; e = idx < 64 ? PE_W6 + idx : -1; }
     else if (o < 9538) { t = 7; idx = o - 9536; e = idx == 0 ? PE_B6 : -1; }
     float s = 0.f;
-    if (t >= 0 && e >= 0)
-        for (int w = slice; w < p.nwg; w += 4) s += p.partial[(int64_t)w * PE_TOTAL + e];
+    if (t >= 0 && e >= 0) {
+#pragma unroll 8
+        for (int w = slice; w < p.nwg; w += 8) s += p.partial[(int64_t)w * PE_TOTAL + e];
+    }
     red[tid] = s;
     __syncthreads();
-    if (tid < 64 && t >= 0 && p.dhw[t]) {
-        const float tot = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    if (tid < 32 && t >= 0 && p.dhw[t]) {
+        const float tot = (((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) +
+                           ((red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid])));
         float* d = p.dhw[t] + idx;
         *d = p.accumulate ? *d + tot : tot;
     }
@@ -1216,7 +1221,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     HeadReduceArgs r{};
     r.partial = a.partial; r.nwg = nwg; r.accumulate = accumulate;
     for (int i = 0; i < 8; ++i) r.dhw[i] = dhw[i];
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((9538 + 63) / 64), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((9538 + 31) / 32), dim3(256), 0, st, r);
     PC_CHECK_LAUNCH();
     return 0;
 }

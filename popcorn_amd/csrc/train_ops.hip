@@ -109,6 +109,65 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(const AdamArgs a) {
 
 __global__ void adam_step_inc_kernel(int32_t* step) { *step += 1; }
 
+// One-launch variant: every workgroup first computes the total gradient norm itself (the flat buffer is ~157 KB and sits
+// in L2; all workgroups add in the same order, so they all get the same bits), then updates its 256 elements; the
+// workgroup that finishes last advances the step counter (every workgroup has read it by then).  Replaces the
+// single-workgroup norm kernel + the update + the one-thread counter kernel (3 dependent launches at the end of a step).
+__global__ __launch_bounds__(256) void adam_clip_fused_kernel(const AdamArgs a, float* norm_out, unsigned* ticket) {
+    __shared__ double red[256];
+    __shared__ float sh[3];
+    const int tid = threadIdx.x;
+    float coef = 1.f;
+    if (a.max_norm > 0.f) {
+        double acc = 0.0;
+        const int n4 = a.n >> 2;
+        for (int i = tid; i < n4; i += 256) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+            acc += (double)g[0] * g[0] + (double)g[1] * g[1] + (double)g[2] * g[2] + (double)g[3] * g[3];
+        }
+        for (int i = 4 * n4 + tid; i < a.n; i += 256) acc += (double)a.g[i] * a.g[i];
+        red[tid] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        const float norm = (float)sqrt(red[0]);
+        if (blockIdx.x == 0 && tid == 0 && norm_out) *norm_out = norm;
+        coef = a.max_norm / (norm + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+    }
+    if (tid == 0) {
+        const int t = *a.step + 1;
+        const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
+        const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+        sh[0] = (float)((double)a.hyper[0] / bc1);          // step size
+        sh[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2s = sh[1];
+    const int i = blockIdx.x * 256 + tid;
+    if (i < a.n) {
+        float g = a.g[i] * coef;
+        const float p = a.p[i];
+        if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p, g);
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / bc2s + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *a.step += 1;
+            *ticket = 0u;
+        }
+    }
+}
+
 // ---- band select + normalise -------------------------------------------------------------------------------------------
 // raw tile (B, Craw, H, W) -> model input (B, 6, H, W) = [(raw[band[c]] - mean[c]) / std[c]]
 struct SelNormArgs { const float* raw; float* out; int band[6]; float mean[6], stdv[6]; int Craw; int64_t hw, n; };
@@ -171,6 +230,26 @@ extern "C" int pc_adam_clip_step(float* p, const float* g, float* m, float* v, i
     hipLaunchKernelGGL(adam_clip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n, int n_decay,
+                                       const float* hyper_dev, float weight_decay, float beta1, float beta2, float eps,
+                                       float max_norm, float* norm_out_dev, int32_t* step_dev, void* stream) {
+    if (!p || !g || !m || !v || !hyper_dev || !step_dev) return PC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) != 0) return PC_EINVAL;
+    static unsigned* ticket = nullptr;      // zero-initialised once; the kernel leaves it at zero
+    if (!ticket) {
+        hipError_t e = hipMalloc(&ticket, sizeof(unsigned));
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset(ticket, 0, sizeof(unsigned));
+        if (e != hipSuccess) return (int)e;
+    }
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_decay = n_decay; a.hyper = hyper_dev; a.wd = weight_decay;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.norm = nullptr; a.step = step_dev;
+    hipLaunchKernelGGL(adam_clip_fused_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, norm_out_dev, ticket);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -331,6 +331,15 @@ def adam_clip_step(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, 
             "pc_adam_clip_step")
 
 
+def adam_clip_step_fused(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm_out, step):
+    """grad-norm + clip + Adam in one launch (norm_out receives the total norm)."""
+    L.require_device(p, g, m, v, hyper, step)
+    L.check(L.lib().pc_adam_clip_step_fused(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), n_decay, L.ptr(hyper),
+                                            C.c_float(weight_decay), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                                            C.c_float(max_norm), L.ptr(norm_out), L.ptr(step), L.stream_ptr()),
+            "pc_adam_clip_step_fused")
+
+
 class WgradBatch:
     """Collects the first-stage (per-workgroup partial) weight-gradient launches of a backward pass and finishes them
     with ONE batched reduction launch.  Each layer gets its own slice of a persistent workspace."""

@@ -133,10 +133,8 @@ class FusedTrainStep:
         self._ctx = None
 
     def _update(self):
-        if self.clip and self.clip > 0:
-            ops.grad_norm(self.flat_g, self.norm)
-        ops.adam_clip_step(self.flat_p, self.flat_g, self.m, self.v, self.n_decay, self.hyper, self.wd, self.betas[0],
-                           self.betas[1], self.eps, self.clip or 0.0, self.norm, self.step_count)
+        ops.adam_clip_step_fused(self.flat_p, self.flat_g, self.m, self.v, self.n_decay, self.hyper, self.wd, self.betas[0],
+                                 self.betas[1], self.eps, self.clip or 0.0, self.norm, self.step_count)
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod

@@ -437,18 +437,29 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
 }
 
 template <int CINC, int COUT>
-int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int nwg, int nchunk, hipStream_t stream) {
+int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk, hipStream_t stream) {
     using Cfg = WgradCfg<CINC, COUT>;
     size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
     const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
     if (lw < lred) lw = lred;
-    static bool attr_w[3] = {false, false, false};
+    static int resident[3] = {0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
     auto go = [&](auto kern, int slot) -> int {
-        if (!attr_w[slot]) {
+        if (!resident[slot]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
             if (e != hipSuccess) return (int)e;
-            attr_w[slot] = true;
+            hipFuncAttributes fa;
+            e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+            if (e != hipSuccess) return (int)e;
+            resident[slot] = pc_resident_workgroups(fa.numRegs, lw);
+            if (getenv("POPCORN_CONV_DBG"))
+                fprintf(stderr, "wgrad<%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CINC, COUT, slot, fa.numRegs, lw,
+                        resident[slot]);
         }
+        // all workgroups of the launch resident at once (the 16-channel instantiations hold ONE workgroup per CU: a
+        // fixed 2-per-CU grid ran them in two rounds), never more partial sums than the workspace holds
+        int cap = resident[slot] / (nchunk * n);
+        if (cap < 1) cap = 1;
+        if (nwg > cap) nwg = cap;
         hipLaunchKernelGGL(kern, dim3(nwg, nchunk, n), dim3(256), lw, stream, g);
         return 0;
     };
@@ -510,8 +521,9 @@ int launch_wgrad_group(WgradArgs* ps, void* const* wss, int n, int Cin, hipStrea
         g.pr[i] = ps[i];
     }
     if (same && kind0 != 0) {
+        const int rc = launch_wgrad_wave<CINC, COUT>(g, n, kind0, nwg, nchunk, stream);
         *nwg_out = nwg;
-        return launch_wgrad_wave<CINC, COUT>(g, n, kind0, nwg, nchunk, stream);
+        return rc;
     }
     for (int i = 0; i < n; ++i) {
         const int rc = launch_wgrad<CINC, COUT>(ps[i], Cin, nullptr, nullptr, 0, wss[i], stream, nwg_out);

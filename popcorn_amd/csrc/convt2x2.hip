@@ -149,7 +149,11 @@ struct CtWgradCfg {
     static constexpr int E = NBK * 256 + NBK * 64;
 };
 
-template <int C>
+// VEC: aligned tensors with W % 16 == 0.  The K dimension of the GEMM is "pixels", and any pixel order works as long as
+// both operands use it: lane (., lk) takes pixels 4*lk .. 4*lk+3 of the 16-pixel group, so k-step ks holds pixel 4*lk + ks
+// and a lane's four A values are ONE 16-byte load of x, its four B values the even or odd floats of TWO 16-byte loads of
+// the g row (4 + 4*C/4 scalar gathers before: 12 / 20 four-byte loads per group and lane).
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtArgs p) {
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
@@ -174,16 +178,33 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtArgs p) {
         const int j0 = gx * 16;
         const float* xp = p.x.ptr + b * p.x.bstride + li * p.x.cstride + (int64_t)i * p.x.rstride;
         float av[4], bv[4][NBK];
+        if (VEC) {
+            const f32x4 xv = li < C ? *reinterpret_cast<const f32x4*>(xp + j0 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int j = j0 + 4 * ks + lk;
-            av[ks] = (li < C && j < p.W) ? xp[j] : 0.f;
+            for (int ks = 0; ks < 4; ++ks) av[ks] = xv[ks];
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) {
                 const int ng = nb * 16 + li;
                 const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
-                bv[ks][nb] = j < p.W ? p.g.ptr[b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j + bb]
-                                     : 0.f;
+                const float* gp = p.g.ptr + b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j0 + 8 * lk;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                bv[0][nb] = bb ? g0[1] : g0[0];
+                bv[1][nb] = bb ? g0[3] : g0[2];
+                bv[2][nb] = bb ? g1[1] : g1[0];
+                bv[3][nb] = bb ? g1[3] : g1[2];
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int j = j0 + 4 * ks + lk;
+                av[ks] = (li < C && j < p.W) ? xp[j] : 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) {
+                    const int ng = nb * 16 + li;
+                    const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
+                    bv[ks][nb] = j < p.W ? p.g.ptr[b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j + bb]
+                                         : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -334,6 +355,27 @@ extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {
     return (int64_t)CT_MAX_WG * (4 * 256 + 4 * 64) * sizeof(float);
 }
 
+namespace {
+bool ct_wgrad_vec_ok(const CtArgs& p) {
+    auto al = [](const pc_src& s) {
+        return ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && s.rstride % 4 == 0 && s.cstride % 4 == 0 && s.bstride % 4 == 0;
+    };
+    return p.W % 16 == 0 && al(p.x) && al(p.g);
+}
+int launch_ct_wgrad(const CtArgs& p, int C, int nwg, hipStream_t st) {
+    const bool vec = ct_wgrad_vec_ok(p);
+    if (C == 16) {
+        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, true>), dim3(nwg), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, false>), dim3(nwg), dim3(256), 0, st, p);
+    } else if (C == 8) {
+        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, true>), dim3(nwg), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, false>), dim3(nwg), dim3(256), 0, st, p);
+    } else return PC_EINVAL;
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
 extern "C" int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B, int H, int W, int C, int* nwg_out,
                                          void* stream) {
     if (!x || !g || !ws || !nwg_out) return PC_EINVAL;
@@ -342,11 +384,8 @@ extern "C" int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void*
     p.partial = reinterpret_cast<float*>(ws);
     int nwg = fill_groups(p);
     if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;
-    hipStream_t st = (hipStream_t)stream;
-    if (C == 16) hipLaunchKernelGGL(convt2x2_wgrad_kernel<16>, dim3(nwg), dim3(256), 0, st, p);
-    else if (C == 8) hipLaunchKernelGGL(convt2x2_wgrad_kernel<8>, dim3(nwg), dim3(256), 0, st, p);
-    else return PC_EINVAL;
-    PC_CHECK_LAUNCH();
+    const int rc = launch_ct_wgrad(p, C, nwg, (hipStream_t)stream);
+    if (rc) return rc;
     *nwg_out = nwg;
     return 0;
 }
@@ -362,15 +401,10 @@ extern "C" int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, fl
     CtReduceArgs r{};
     r.partial = p.partial; r.nwg = nwg; r.dw = dw; r.db = db; r.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 16) {
-        hipLaunchKernelGGL(convt2x2_wgrad_kernel<16>, dim3(nwg), dim3(256), 0, st, p);
-        PC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<16>, dim3((16 * 16 * 4 + 16 + 15) / 16), dim3(256), 0, st, r);
-    } else if (C == 8) {
-        hipLaunchKernelGGL(convt2x2_wgrad_kernel<8>, dim3(nwg), dim3(256), 0, st, p);
-        PC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<8>, dim3((8 * 8 * 4 + 8 + 15) / 16), dim3(256), 0, st, r);
-    } else return PC_EINVAL;
+    const int rc = launch_ct_wgrad(p, C, nwg, st);
+    if (rc) return rc;
+    if (C == 16) hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<16>, dim3((16 * 16 * 4 + 16 + 15) / 16), dim3(256), 0, st, r);
+    else hipLaunchKernelGGL(convt2x2_wgrad_reduce_kernel<8>, dim3((8 * 8 * 4 + 8 + 15) / 16), dim3(256), 0, st, r);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -119,13 +119,25 @@ __global__ __launch_bounds__(256) void adam_clip_fused_kernel(const AdamArgs a, 
     const int tid = threadIdx.x;
     float coef = 1.f;
     if (a.max_norm > 0.f) {
+        // 8 independent 16-byte loads in flight per thread (a plain loop is one dependent L2 round trip per iteration:
+        // 39 of them, 20 us)
         double acc = 0.0;
         const int n4 = a.n >> 2;
-        for (int i = tid; i < n4; i += 256) {
-            const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
-            acc += (double)g[0] * g[0] + (double)g[1] * g[1] + (double)g[2] * g[2] + (double)g[3] * g[3];
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(a.g);
+        int i = tid;
+        for (; i + 7 * 256 < n4; i += 8 * 256) {
+            f32x4 g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = g4[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc += ((double)g[u][0] * g[u][0] + (double)g[u][1] * g[u][1]) + ((double)g[u][2] * g[u][2] + (double)g[u][3] * g[u][3]);
         }
-        for (int i = 4 * n4 + tid; i < a.n; i += 256) acc += (double)a.g[i] * a.g[i];
+        for (; i < n4; i += 256) {
+            const f32x4 g = g4[i];
+            acc += ((double)g[0] * g[0] + (double)g[1] * g[1]) + ((double)g[2] * g[2] + (double)g[3] * g[3]);
+        }
+        for (int j = 4 * n4 + tid; j < a.n; j += 256) acc += (double)a.g[j] * a.g[j];
         red[tid] = acc;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {

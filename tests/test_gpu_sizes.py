@@ -144,3 +144,38 @@ def test_input_not_modified_and_errors(pair):
         m({"input": torch.randn(6, 40, 40).cuda()})
     with pytest.raises(ValueError):
         m({"input": torch.randn(1, 6, 10, 10).cuda()}, padding=True)       # reflect pad 14 >= size, like F.pad
+
+
+def _fresh_trainer(use_graph):
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    return FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,),
+                          scale_regularization=0.01, lam_weak=100.0, use_graph=use_graph)
+
+
+def test_config3_batch64_train_step_is_deterministic_and_graph_equals_eager():
+    """BASELINE config[2] size (B=64 tiles of 100x100, rwa recipe): size-independent properties of the fused step --
+    (1) bit-identical parameters from two independent runs (fixed-order reductions, no atomics on fp data),
+    (2) HIP-graph replay == eager launches bit for bit, (3) the step moves the parameters and lowers the loss it
+    optimises on a repeated batch."""
+    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    batch = make_raw_batch(64, 100, 100, seed=1601)
+    sample = {"input": select_normalize_reference(batch["raw"]).cuda(), "admin_mask": batch["admin_mask"].cuda(),
+              "census_idx": batch["census_idx"].cuda(), "y": batch["y"].cuda()}
+    results = []
+    for use_graph in (False, False, True):
+        tr = _fresh_trainer(use_graph)
+        p0 = tr.flat_p.clone()
+        losses = []
+        for _ in range(3):
+            torch.manual_seed(5)                       # the mask's row/column selection draws from the CPU generator
+            losses.append(tr.step(dict(sample))[0].item())
+        torch.cuda.synchronize()
+        results.append((tr.flat_p.clone(), losses))
+        assert not torch.equal(p0, tr.flat_p)
+    (pa, la), (pb, lb), (pg, lg) = results
+    assert torch.equal(pa, pb) and la == lb            # (1)
+    assert torch.equal(pa, pg) and la == lg            # (2)
+    assert all(np.isfinite(la)) and la[2] < la[0]      # (3)

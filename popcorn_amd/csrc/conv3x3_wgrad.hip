@@ -42,7 +42,8 @@ struct WgradCfg {
     static constexpr int NCOL = CINC * 12;
     static constexpr int NBLK = (NCOL + 15) / 16;
     static constexpr int MB = COUT / 8;
-    static constexpr int E = MB * NBLK * 256 + MB * 64;   // accumulators + bias partial sums
+    static constexpr int E = MB * NBLK * 256 + MB * 64;   // accumulators + bias partial sums (MFMA fragment layout, in LDS)
+    static constexpr int EC = COUT * CINC * 9 + COUT;     // one partial in global memory: dW[co][cil][tap] + db[co], compacted
     static constexpr int LDS_FLOATS = CINC * IN_CS + COUT * G_CS;
 };
 
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
     }
 
     // ---- cross-wave reduction through LDS (fixed order), one partial per workgroup
-    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::E;
+    // The partial leaves the workgroup COMPACTED to dW[co][cil][tap] + db[co]: the fragment layout carries every weight
+    // twice (output-row slot s = 0 / 1 of the pair mapping) plus dead (row, tap) slots, 2.7x the bytes, and the batched
+    // second stage is bound by reading the partials.
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         __syncthreads();
@@ -138,18 +143,33 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
         for (int nb = 0; nb < NBLK; ++nb)
             *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
         __syncthreads();
-        for (int e = tid; e < NBLK * 256; e += 256) {
-            const float s = ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e];
-            part[mb * NBLK * 256 + e] = s;
+        for (int idx = tid; idx < 8 * CINC * 9; idx += 256) {
+            const int c8 = idx / (CINC * 9), rem = idx - c8 * (CINC * 9);
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
+            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = ng0 + 3;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (((ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+            const int e1 = (((ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * (CINC * 9) + rem] = wsum(e0) + wsum(e1);
         }
     }
     __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
     __syncthreads();
-    for (int e = tid; e < MB * 64; e += 256) {
-        const float s = ((lds[e] + lds[MB * 64 + e]) + lds[2 * MB * 64 + e]) + lds[3 * MB * 64 + e];
-        part[MB * NBLK * 256 + e] = s;
+    if (tid < COUT) {
+        // bias: the 8 lanes (s in 0..1, lk in 0..3) that carry channel co
+        const int mb = tid >> 3, c8 = tid & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int lk = 0; lk < 4; ++lk) {
+            const int ea = mb * 64 + lk * 16 + c8, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[MB * 64 + ea]) + lds[2 * MB * 64 + ea]) + lds[3 * MB * 64 + ea];
+            const float sb = ((lds[eb] + lds[MB * 64 + eb]) + lds[2 * MB * 64 + eb]) + lds[3 * MB * 64 + eb];
+            t += sa + sb;
+        }
+        part[COUT * CINC * 9 + tid] = t;
     }
 }
 
@@ -321,7 +341,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
     }
 
     // ---- cross-wave reduction through LDS (fixed order), one partial per workgroup
-    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::E;
+    // The partial leaves the workgroup COMPACTED to dW[co][cil][tap] + db[co]: the fragment layout carries every weight
+    // twice (output-row slot s = 0 / 1 of the pair mapping) plus dead (row, tap) slots, 2.7x the bytes, and the batched
+    // second stage is bound by reading the partials.
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         __syncthreads();
@@ -329,18 +353,33 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
         for (int nb = 0; nb < NBLK; ++nb)
             *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
         __syncthreads();
-        for (int e = tid; e < NBLK * 256; e += 256) {
-            const float s = ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e];
-            part[mb * NBLK * 256 + e] = s;
+        for (int idx = tid; idx < 8 * CINC * 9; idx += 256) {
+            const int c8 = idx / (CINC * 9), rem = idx - c8 * (CINC * 9);
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
+            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = ng0 + 3;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (((ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+            const int e1 = (((ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * (CINC * 9) + rem] = wsum(e0) + wsum(e1);
         }
     }
     __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
     __syncthreads();
-    for (int e = tid; e < MB * 64; e += 256) {
-        const float s = ((lds[e] + lds[MB * 64 + e]) + lds[2 * MB * 64 + e]) + lds[3 * MB * 64 + e];
-        part[MB * NBLK * 256 + e] = s;
+    if (tid < COUT) {
+        // bias: the 8 lanes (s in 0..1, lk in 0..3) that carry channel co
+        const int mb = tid >> 3, c8 = tid & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int lk = 0; lk < 4; ++lk) {
+            const int ea = mb * 64 + lk * 16 + c8, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[MB * 64 + ea]) + lds[2 * MB * 64 + ea]) + lds[3 * MB * 64 + ea];
+            const float sb = ((lds[eb] + lds[MB * 64 + eb]) + lds[2 * MB * 64 + eb]) + lds[3 * MB * 64 + eb];
+            t += sa + sb;
+        }
+        part[COUT * CINC * 9 + tid] = t;
     }
 }
 
@@ -360,7 +399,6 @@ struct WreduceArgs {
 template <int CINC, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WreduceArgs p) {
     using Cfg = WgradCfg<CINC, COUT>;
-    constexpr int NBLK = Cfg::NBLK;
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int slice = tid >> 4, o = blockIdx.x * 16 + (tid & 15);
@@ -371,35 +409,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const Wreduce
         const int tap = o % 9, ci = (o / 9) % p.Cin, co = o / (9 * p.Cin);
         const int dy = tap / 3, dx = tap % 3;
         const int chunk = ci / CINC, cil = ci % CINC;
-        const int mb = co >> 3, c8 = co & 7;
-        // D[m = s*8 + c8][ng]; lane = (m>>2)*16 + (ng&15), reg = m&3
-        const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
-        const int m0 = c8, m1 = 8 + c8;
-        const int e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
-        const int e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
-        const float* base = p.partial + (int64_t)chunk * p.nwg * Cfg::E;
+        (void)dy; (void)dx;
+        const int oc = co * (CINC * 9) + cil * 9 + tap;       // compacted partial: dW[co][cil][tap]
+        const float* base = p.partial + (int64_t)chunk * p.nwg * Cfg::EC;
         int w = slice;
         for (; w + 48 < p.nwg; w += 64) {
-            const float* q0 = base + (int64_t)w * Cfg::E;
-            const float* q1 = q0 + (int64_t)16 * Cfg::E;
-            const float* q2 = q0 + (int64_t)32 * Cfg::E;
-            const float* q3 = q0 + (int64_t)48 * Cfg::E;
-            s0 += q0[e0] + q0[e1];
-            s1 += q1[e0] + q1[e1];
-            s2 += q2[e0] + q2[e1];
-            s3 += q3[e0] + q3[e1];
+            const float* q0 = base + (int64_t)w * Cfg::EC;
+            s0 += q0[oc];
+            s1 += q0[(int64_t)16 * Cfg::EC + oc];
+            s2 += q0[(int64_t)32 * Cfg::EC + oc];
+            s3 += q0[(int64_t)48 * Cfg::EC + oc];
         }
-        for (; w < p.nwg; w += 16) s0 += base[(int64_t)w * Cfg::E + e0] + base[(int64_t)w * Cfg::E + e1];
+        for (; w < p.nwg; w += 16) s0 += base[(int64_t)w * Cfg::EC + oc];
     } else if (o < n_out) {
-        // bias: sum over the 8 lanes (s in 0..1, lk in 0..3) that carry channel co; chunk 0 only
-        const int co = o - n_w, mb = co >> 3, c8 = co & 7;
-        for (int w = slice; w < p.nwg; w += 16) {
-            const float* q = p.partial + (int64_t)w * Cfg::E + Cfg::MB * NBLK * 256 + mb * 64;
-            float t = 0.f;
-#pragma unroll
-            for (int lk = 0; lk < 4; ++lk) t += q[lk * 16 + c8] + q[lk * 16 + 8 + c8];
-            s0 += t;
-        }
+        // bias: chunk 0 only
+        const int co = o - n_w;
+        for (int w = slice; w < p.nwg; w += 16) s0 += p.partial[(int64_t)w * Cfg::EC + COUT * CINC * 9 + co];
     }
     red[tid] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -552,41 +577,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
     int n_w, n_out;
     if (q.kind == 0) {
         const int CINC = q.Cin < 16 ? q.Cin : 16;
-        const int NBLK = (CINC * 12 + 15) / 16, MB = q.Cout / 8;
-        const int E = MB * NBLK * 256 + MB * 64;
+        const int EC = q.Cout * CINC * 9 + q.Cout;           // compacted partial (WgradCfg::EC)
         n_w = q.Cout * q.Cin * 9;
         n_out = n_w + q.Cout;
         if (o < n_w) {
             const int tap = o % 9, ci = (o / 9) % q.Cin, co = o / (9 * q.Cin);
-            const int dy = tap / 3, dx = tap % 3;
             const int chunk = ci / CINC, cil = ci % CINC;
-            const int mb = co >> 3, c8 = co & 7;
-            const int ng0 = cil * 12 + dy * 3 + dx, ng1 = cil * 12 + (dy + 1) * 3 + dx;
-            const int m0 = c8, m1 = 8 + c8;
-            const int e0 = ((mb * NBLK + (ng0 >> 4)) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
-            const int e1 = ((mb * NBLK + (ng1 >> 4)) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
-            const float* base = q.partial + (int64_t)chunk * q.nwg * E;
+            const int oc = co * (CINC * 9) + cil * 9 + tap;
+            const float* base = q.partial + (int64_t)chunk * q.nwg * EC;
             int w = slice;
             for (; w + 48 < q.nwg; w += 64) {
-                const float* q0 = base + (int64_t)w * E;
-                const float* q1 = q0 + (int64_t)16 * E;
-                const float* q2 = q0 + (int64_t)32 * E;
-                const float* q3 = q0 + (int64_t)48 * E;
-                s0 += q0[e0] + q0[e1];
-                s1 += q1[e0] + q1[e1];
-                s2 += q2[e0] + q2[e1];
-                s3 += q3[e0] + q3[e1];
+                const float* q0 = base + (int64_t)w * EC;
+                s0 += q0[oc];
+                s1 += q0[(int64_t)16 * EC + oc];
+                s2 += q0[(int64_t)32 * EC + oc];
+                s3 += q0[(int64_t)48 * EC + oc];
             }
-            for (; w < q.nwg; w += 16) s0 += base[(int64_t)w * E + e0] + base[(int64_t)w * E + e1];
+            for (; w < q.nwg; w += 16) s0 += base[(int64_t)w * EC + oc];
         } else if (o < n_out) {
-            const int co = o - n_w, mb = co >> 3, c8 = co & 7;
-            for (int w = slice; w < q.nwg; w += 16) {
-                const float* pq = q.partial + (int64_t)w * E + MB * NBLK * 256 + mb * 64;
-                float t = 0.f;
-#pragma unroll
-                for (int lk = 0; lk < 4; ++lk) t += pq[lk * 16 + c8] + pq[lk * 16 + 8 + c8];
-                s0 += t;
-            }
+            const int co = o - n_w;
+            for (int w = slice; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * EC + q.Cout * CINC * 9 + co];
         }
     } else {
         const int C = q.Cin, NBK = C / 4, E = NBK * 256 + NBK * 64;

@@ -90,7 +90,13 @@ int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, con
 #define PC_MAX_GROUP 4
 typedef struct pc_conv_fwd_desc {
     const pc_src* a; const pc_src* b; const float* w; const pc_bn* bn; const pc_dst* out;
+    /* optional second output: MaxPool2d(2) of `out` (B x Cout x H/2 x W/2), written by the same epilogue, so that the
+     * `Down` block that follows (networks.py:284-295) reads a quarter of the bytes instead of pooling the full-resolution
+     * map on the fly.  Only when pc_conv3x3_pool_out_ok(out, H, W) (W % 32 == 0, H % 4 == 0, 16-byte aligned `out`);
+     * otherwise the call returns PC_EINVAL. */
+    const pc_dst* pool_out;
 } pc_conv_fwd_desc;
+int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);
 int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,
                                  void* stream);
 

@@ -24,6 +24,7 @@ extern "C" int pc_sizeof(int which) {
         case 0: return (int)sizeof(pc_src);
         case 1: return (int)sizeof(pc_dst);
         case 2: return (int)sizeof(pc_bn);
+        case 3: return (int)sizeof(pc_conv_fwd_desc);
         default: return -1;
     }
 }

@@ -51,6 +51,7 @@ struct ConvProb {
     int act_rstride;
     int fast_a, fast_b;   // pc_src_fast_mode of the two sources (generic loader)
     pc_dst out;
+    pc_dst pool_out;      // FWD: 2x2-max-pooled copy of the output (ptr NULL = not wanted)
 };
 
 struct ConvArgs {
@@ -79,7 +80,9 @@ struct ConvArgs {
 constexpr int SROWS = 6;                 // input rows of a 4-row strip
 constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS region
 
-template <int CIN, int COUT, int MODE, int LD>
+// POOLOUT: the forward epilogue also writes the 2x2-max-pooled output (ConvProb::pool_out); a separate instantiation so
+// that the other shapes keep their register count.
+template <int CIN, int COUT, int MODE, int LD, bool POOLOUT>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
@@ -284,6 +287,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         }
                     }
                     *reinterpret_cast<f32x4*>(op) = v;
+                    if (POOLOUT && MODE == MODE_FWD && q.pool_out.ptr) {
+                        // MaxPool2d(2): the x pairs are in the lane, the row pair (s_row 0 / 1) sits 8 lanes apart
+                        float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
+                        m0 = fmaxf(m0, __shfl_xor(m0, 8));
+                        m1 = fmaxf(m1, __shfl_xor(m1, 8));
+                        if (s_row == 0) {
+                            float* pp = q.pool_out.ptr + eb * q.pool_out.bstride + (nb * 8 + col) * q.pool_out.cstride +
+                                        (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride + (ex0 >> 1) + (u & 1) * 8 + 2 * lk;
+                            *reinterpret_cast<float2*>(pp) = make_float2(m0, m1);
+                        }
+                    }
                 }
             return;
         }
@@ -397,13 +411,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-template <int CIN, int COUT, int MODE, int LD>
-int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
+template <int CIN, int COUT, int MODE, int LD, bool POOLOUT>
+int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, POOLOUT>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -426,9 +440,19 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
         grid = 768 / nprob < 128 ? 128 : 768 / nprob;
         if (grid > p.ntiles) grid = p.ntiles;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, POOLOUT>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
+}
+
+template <int CIN, int COUT, int MODE, int LD>
+int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
+    if constexpr (MODE == MODE_FWD && CIN >= 8) {       // the layers in front of a Down block: inc.conv.3 (8->8), down1 conv.3 (16->16)
+        bool po = false;
+        for (int i = 0; i < nprob; ++i) po = po || p.pr[i].pool_out.ptr != nullptr;
+        if (po) return launch_conv_po<CIN, COUT, MODE, LD, true>(p, nprob, stream);
+    }
+    return launch_conv_po<CIN, COUT, MODE, LD, false>(p, nprob, stream);
 }
 
 bool same_layout(const pc_src& a, const pc_src& b) { return b.C == 0 || (a.bstride == b.bstride && a.rstride == b.rstride); }
@@ -513,7 +537,15 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
     return 0;
 }
 
+// the pooled second output needs every strip on the vector epilogue: full 32 x 4 strips, 16-byte aligned output
+bool pool_out_geometry_ok(const pc_dst& out, int H, int W) {
+    return W % 32 == 0 && H % 4 == 0 && out.rstride % 4 == 0 && out.cstride % 4 == 0 && out.bstride % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(out.ptr) & 15) == 0;
+}
+
 }  // namespace
+
+extern "C" int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W) { return out && pool_out_geometry_ok(*out, H, W) ? 1 : 0; }
 
 extern "C" int pc_conv3x3_bn_relu_fwd(const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, int relu,
                                       const pc_dst* out, int B, int H, int W, int Cin, int Cout, void* stream) {
@@ -534,6 +566,13 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
     for (int i = 0; i < n; ++i) {
         const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
         if (rc) return rc;
+        if (d[i].pool_out) {
+            const pc_dst& po = *d[i].pool_out;
+            if (Cin < 8 || !pool_out_geometry_ok(*d[i].out, H, W) || !po.ptr || po.rstride % 2 != 0 || po.cstride % 2 != 0 ||
+                po.bstride % 2 != 0 || (reinterpret_cast<uintptr_t>(po.ptr) & 7) != 0)
+                return PC_EINVAL;
+            p.pr[i].pool_out = po;
+        }
     }
     p.w_co_stride = Cin * 9;
     p.w_ci_stride = 9;

@@ -252,11 +252,17 @@ class UNetEngine:
         # encoder
         wgs("d2b", "c1", G_c2)
         G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
-        wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
+        if all(A[s].get("pb2") is not None for s in S):
+            wgs("d2a", "pb2", G_c1)                   # the pooled map was saved by the forward pass
+        else:
+            wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
         dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
         wgs("d1b", "b1", G_b2)
         G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
-        wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
+        if all(A[s].get("pa2") is not None for s in S):
+            wgs("d1a", "pa2", G_b1)
+        else:
+            wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
         dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
         wgs("inc2", "a1", G_a2)
         G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
@@ -292,16 +298,29 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
     keys = [(e, s) for e in range(nE) for s, _, _, _ in streams]
     ly = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
 
-    def conv(tag, ins, c, h, w, outs=None, bs=None, **kw):
+    def conv(tag, ins, c, h, w, outs=None, bs=None, pooled=None, **kw):
+        """pooled: dict to receive the MaxPool2d(2) copy of every output (written by the same epilogue) -- left empty when
+        the geometry does not qualify, in which case the Down block pools on the fly (PC_SRC_POOL2 loader)."""
         outs = outs or {k: E(c, h, w) for k in keys}
         probs = []
         for k in keys:
             pr = {"a": ins[k], "w": ly(k, tag).w, "bn": ly(k, tag).bn, "out": outs[k]}
             if bs is not None:
                 pr["b"] = bs[k]
+            if pooled is not None:
+                po = ops.pool_out_like(outs[k])
+                if po is not None:
+                    pooled[k] = pr["pool_out"] = po
             probs.append(pr)
         ops.conv3x3_fwd_group(probs, **kw)
+        if pooled is not None and len(pooled) != len(keys):
+            pooled.clear()
         return outs
+
+    def down(tag, full, pooled, c, h, w):
+        if pooled:
+            return conv(tag, pooled, c, h, w)
+        return conv(tag, full, c, h, w, a_mode=L.PC_SRC_POOL2)
 
     # first layer: reflect padding + channel gather fused; Cin differs per stream -> one launch per stream kind
     a1 = {}
@@ -312,10 +331,11 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
             a1[k] = E(8, Hp, Wp)
             probs.append({"a": X, "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k], "chmap": chmap})
         ops.conv3x3_fwd_group(probs, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), out_hw=(Hp, Wp), a_channels=cin)
-    a2 = conv("inc2", a1, 8, Hp, Wp)
-    b1 = conv("d1a", a2, 16, H1, W1, a_mode=L.PC_SRC_POOL2)
-    b2 = conv("d1b", b1, 16, H1, W1)
-    c1 = conv("d2a", b2, 16, H2, W2, a_mode=L.PC_SRC_POOL2)
+    pa2, pb2 = {}, {}
+    a2 = conv("inc2", a1, 8, Hp, Wp, pooled=pa2)
+    b1 = down("d1a", a2, pa2, 16, H1, W1)
+    b2 = conv("d1b", b1, 16, H1, W1, pooled=pb2)
+    c1 = down("d2a", b2, pb2, 16, H2, W2)
     c2 = conv("d2b", c1, 16, H2, W2)
     def convt(tag, ins, c, h, w):
         outs = {k: E(c, h, w) for k in keys}
@@ -340,7 +360,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
         for s, _, _, _ in streams:
             k = (e, s)
             sv[s] = dict(a1=a1[k], a2=a2[k], b1=b1[k], b2=b2[k], c1=c1[k], c2=c2[k], u2=u2[k], e1=e1[k], e2=e2[k],
-                         u1=u1[k], f1=f1[k], o1=o1, o2=o2)
+                         u1=u1[k], f1=f1[k], o1=o1, o2=o2, pa2=pa2.get(k), pb2=pb2.get(k))
         sv["X"] = X
         sv["geom"] = (pad_top, pad_left, Hp, Wp)
         sv["feats"] = feats[e]

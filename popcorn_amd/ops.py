@@ -42,7 +42,8 @@ def conv3x3_raw(a, w, bnd, relu=True, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 
 
 def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), out_hw=None, a_channels=None,
                       b_offset=(0, 0)):
-    """Grouped form of conv3x3_raw: ``problems`` = list (<= 4) of dicts {a, w, bn, out, b (optional), chmap (optional)}
+    """Grouped form of conv3x3_raw: ``problems`` = list (<= 4) of dicts {a, w, bn, out, b (optional), chmap (optional),
+    pool_out (optional: MaxPool2d(2) of out, see pool_out_like)}
     with identical geometry; one launch (blockIdx.y = problem)."""
     n = len(problems)
     assert 1 <= n <= L.PC_MAX_GROUP
@@ -70,8 +71,22 @@ def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0),
         descs[i].w = pr["w"].data_ptr()
         descs[i].bn = C.pointer(pr["bn"])
         descs[i].out = C.pointer(d)
+        if pr.get("pool_out") is not None:
+            dp = L.dst(pr["pool_out"])
+            keep.append(dp)
+            descs[i].pool_out = C.pointer(dp)
     L.check(L.lib().pc_conv3x3_bn_relu_fwd_group(n, descs, int(relu), B, H, W, Ca + Cb, Cout, L.stream_ptr()),
             "pc_conv3x3_bn_relu_fwd_group")
+
+
+def pool_out_like(out):
+    """Buffer for the 2x2-max-pooled second output of conv3x3_fwd_group (problem key "pool_out"), or None when the
+    geometry of ``out`` (B, C, H, W) does not qualify (pc_conv3x3_pool_out_ok)."""
+    B, Cc, H, W = out.shape
+    d = L.dst(out)
+    if not L.lib().pc_conv3x3_pool_out_ok(C.byref(d), H, W):
+        return None
+    return torch.empty(B, Cc, H // 2, W // 2, device=out.device, dtype=torch.float32)
 
 
 def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):

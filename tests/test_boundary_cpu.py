@@ -136,3 +136,4 @@ def test_c_abi_exports_every_declared_symbol():
     # struct layouts agree with the header (sizes of the C structs, from the compiler)
     assert ctypes.sizeof(L.PcSrc) == lib.pc_sizeof(0) and ctypes.sizeof(L.PcDst) == lib.pc_sizeof(1)
     assert ctypes.sizeof(L.PcBn) == lib.pc_sizeof(2)
+    assert ctypes.sizeof(L.PcConvFwdDesc) == lib.pc_sizeof(3)

@@ -95,6 +95,11 @@ typedef struct pc_conv_fwd_desc {
      * map on the fly.  Only when pc_conv3x3_pool_out_ok(out, H, W) (W % 32 == 0, H % 4 == 0, 16-byte aligned `out`);
      * otherwise the call returns PC_EINVAL. */
     const pc_dst* pool_out;
+    /* optional, Cout == 8 only: instead of `out` (may then be NULL) write the single-channel map
+     * dot_out[b][0][y][x] = sum_co dot_w[co] * relu(bn(conv))[co] -- the contribution of this layer's 8 feature channels to a
+     * following 1x1 convolution (the frozen building extractor's fusion_out_conv, popcorn.py:301: its feature map has no
+     * other consumer, so it is never written).  Same geometry condition as pool_out. */
+    const float* dot_w; const pc_dst* dot_out;
 } pc_conv_fwd_desc;
 int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);
 int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,

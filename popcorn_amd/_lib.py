@@ -34,7 +34,7 @@ class PcBn(C.Structure):
 
 class PcConvFwdDesc(C.Structure):
     _fields_ = [("a", C.POINTER(PcSrc)), ("b", C.POINTER(PcSrc)), ("w", C.c_void_p), ("bn", C.POINTER(PcBn)),
-                ("out", C.POINTER(PcDst)), ("pool_out", C.POINTER(PcDst))]
+                ("out", C.POINTER(PcDst)), ("pool_out", C.POINTER(PcDst)), ("dot_w", C.c_void_p), ("dot_out", C.POINTER(PcDst))]
 
 
 class PcConvDgradDesc(C.Structure):

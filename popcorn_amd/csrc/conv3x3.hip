@@ -52,6 +52,8 @@ struct ConvProb {
     int fast_a, fast_b;   // pc_src_fast_mode of the two sources (generic loader)
     pc_dst out;
     pc_dst pool_out;      // FWD: 2x2-max-pooled copy of the output (ptr NULL = not wanted)
+    const float* dot_w;   // FWD (EPI_DOT): weights of a following 1x1 conv over this layer's 8 channels ...
+    pc_dst dot_out;       // ... whose partial sum replaces the output (ptr NULL = ordinary output)
 };
 
 struct ConvArgs {
@@ -80,9 +82,11 @@ struct ConvArgs {
 constexpr int SROWS = 6;                 // input rows of a 4-row strip
 constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS region
 
-// POOLOUT: the forward epilogue also writes the 2x2-max-pooled output (ConvProb::pool_out); a separate instantiation so
-// that the other shapes keep their register count.
-template <int CIN, int COUT, int MODE, int LD, bool POOLOUT>
+// EPI: extra work of the forward vector epilogue, as separate instantiations so that the other shapes keep their register
+// count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
+// write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
+enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2 };
+template <int CIN, int COUT, int MODE, int LD, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
@@ -286,8 +290,25 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                             for (int r = 0; r < 4; ++r) v[r] += o4[r];
                         }
                     }
+                    if (EPI == EPI_DOT && MODE == MODE_FWD && q.dot_w) {
+                        // sum over the 8 channels = the 8 lanes `col` of a 16-lane group half; lane col == 0 stores
+                        const float wl = q.dot_w[nb * 8 + col];
+                        f32x4 t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = v[r] * wl;
+                            x += __shfl_xor(x, 1);
+                            x += __shfl_xor(x, 2);
+                            x += __shfl_xor(x, 4);
+                            t[r] = x;
+                        }
+                        if (col == 0)
+                            *reinterpret_cast<f32x4*>(q.dot_out.ptr + eb * q.dot_out.bstride +
+                                                      (int64_t)(ey0 + s_row + (u >> 1) * 2) * q.dot_out.rstride + ex0 + (u & 1) * 16 + 4 * lk) = t;
+                        continue;
+                    }
                     *reinterpret_cast<f32x4*>(op) = v;
-                    if (POOLOUT && MODE == MODE_FWD && q.pool_out.ptr) {
+                    if (EPI == EPI_POOL && MODE == MODE_FWD && q.pool_out.ptr) {
                         // MaxPool2d(2): the x pairs are in the lane, the row pair (s_row 0 / 1) sits 8 lanes apart
                         float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
                         m0 = fmaxf(m0, __shfl_xor(m0, 8));
@@ -411,13 +432,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-template <int CIN, int COUT, int MODE, int LD, bool POOLOUT>
+template <int CIN, int COUT, int MODE, int LD, int EPI>
 int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, POOLOUT>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -440,7 +461,7 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
         grid = 768 / nprob < 128 ? 128 : 768 / nprob;
         if (grid > p.ntiles) grid = p.ntiles;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, POOLOUT>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -450,9 +471,14 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     if constexpr (MODE == MODE_FWD && CIN >= 8) {       // the layers in front of a Down block: inc.conv.3 (8->8), down1 conv.3 (16->16)
         bool po = false;
         for (int i = 0; i < nprob; ++i) po = po || p.pr[i].pool_out.ptr != nullptr;
-        if (po) return launch_conv_po<CIN, COUT, MODE, LD, true>(p, nprob, stream);
+        if (po) return launch_conv_po<CIN, COUT, MODE, LD, EPI_POOL>(p, nprob, stream);
     }
-    return launch_conv_po<CIN, COUT, MODE, LD, false>(p, nprob, stream);
+    if constexpr (MODE == MODE_FWD && CIN == 8 && COUT == 8) {      // up1.conv.3, the layer in front of the 1x1 out-conv
+        bool dot = false;
+        for (int i = 0; i < nprob; ++i) dot = dot || p.pr[i].dot_w != nullptr;
+        if (dot) return launch_conv_po<CIN, COUT, MODE, LD, EPI_DOT>(p, nprob, stream);
+    }
+    return launch_conv_po<CIN, COUT, MODE, LD, EPI_NONE>(p, nprob, stream);
 }
 
 bool same_layout(const pc_src& a, const pc_src& b) { return b.C == 0 || (a.bstride == b.bstride && a.rstride == b.rstride); }
@@ -507,13 +533,13 @@ int dispatch_conv(ConvArgs& p, int nprob, int Cin, int Cout, hipStream_t stream)
 }
 
 int fill_fwd(ConvProb& q, const pc_src* a, const pc_src* b, const float* w, const pc_bn* bn, const pc_dst* out, int Cin) {
-    if (!a || !w || !bn || !out) return PC_EINVAL;
+    if (!a || !w || !bn) return PC_EINVAL;
     q.a = *a;
     if (b) q.b = *b;
     if (q.a.C + q.b.C != Cin) return PC_EINVAL;
     q.w = w;
     q.bn = *bn;
-    q.out = *out;
+    if (out) q.out = *out;
     return 0;
 }
 
@@ -566,6 +592,17 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
     for (int i = 0; i < n; ++i) {
         const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
         if (rc) return rc;
+        if (d[i].dot_w) {
+            // the partial 1x1 sum replaces the feature map: all strips must take the vector epilogue
+            if (!d[i].dot_out || !d[i].dot_out->ptr || Cin != 8 || Cout != 8 || !relu || d[i].pool_out ||
+                !pool_out_geometry_ok(*d[i].dot_out, H, W))
+                return PC_EINVAL;
+            p.pr[i].dot_w = d[i].dot_w;
+            p.pr[i].dot_out = *d[i].dot_out;
+            if (!d[i].out) p.pr[i].out = *d[i].dot_out;     // keeps the alignment checks of the launcher meaningful
+        } else if (!d[i].out) {
+            return PC_EINVAL;
+        }
         if (d[i].pool_out) {
             const pc_dst& po = *d[i].pool_out;
             if (Cin < 8 || !pool_out_geometry_ok(*d[i].out, H, W) || !po.ptr || po.rstride % 2 != 0 || po.cstride % 2 != 0 ||

@@ -1115,7 +1115,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
 
 extern "C" int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const float* bias, const pc_dst* out,
                                        int B, int H, int W, int py, int px, void* stream) {
-    if (!feat || !w || !bias || !out || (feat->C != 16 && feat->C != 8)) return PC_EINVAL;
+    if (!feat || !w || !bias || !out || feat->C < 1 || feat->C > 16) return PC_EINVAL;
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;

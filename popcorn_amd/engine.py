@@ -18,6 +18,7 @@ All launches go to the current torch stream, so a whole step can be captured int
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -130,11 +131,23 @@ class UNetEngine:
     def building_score(self, X, pad=14):
         """create_building_score (popcorn.py:279-322): reflect-pad 14, frozen U-Net, fusion_out_conv, sigmoid, crop."""
         B, _, H, W = X.shape
+        if self.single_out is None:
+            f, _ = forward_multi([self], X, pad, pad, H + 2 * pad, W + 2 * pad, [False], logit_only=[True])
+            return self.score_from_features(f[0], H, W, pad, pad)
         feats, _ = self.forward(X, pad, pad, H + 2 * pad, W + 2 * pad, save=False)
         if self.single_out is not None:
             f0 = self.streams[0][3]
             return ops.outconv_sigmoid_crop(feats[:, f0:f0 + 8], self.single_out[0], self.single_out[1], H, W, pad, pad)
         return ops.outconv_sigmoid_crop(feats, self.fusion_w, self.fusion_b, H, W, pad, pad)
+
+    def score_from_features(self, f, H, W, py, px):
+        """fusion_out_conv + sigmoid + crop from either the 16-channel feature map or the (B,2,.,.) partial logits that
+        ``forward_multi(logit_only=...)`` returns."""
+        if f.shape[1] == 2:
+            if getattr(self, "_ones2", None) is None or self._ones2.device != f.device:
+                self._ones2 = torch.ones(2, device=f.device, dtype=torch.float32)
+            return ops.outconv_sigmoid_crop(f, self._ones2, self.fusion_b, H, W, py, px)
+        return ops.outconv_sigmoid_crop(f, self.fusion_w, self.fusion_b, H, W, py, px)
 
     def feat_bn(self):
         """BN descriptors of the two layers that produce the feature map (for the head-backward epilogue)."""
@@ -271,11 +284,17 @@ class UNetEngine:
         finish()
 
 
-def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None):
+def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None, logit_only=None):
     """Forward of several DualStreamUNets (e.g. the frozen building extractor and the trainable U-Net) on the same
     input and geometry, layer by layer, with ONE launch per layer for all (network, stream) pairs: 4x fewer
     launches than per-stream execution and 4x more workgroups per launch on the 32x32 layers.
-    Returns ([features], [saved-or-None])."""
+    Returns ([features], [saved-or-None]).
+
+    logit_only[e] = True (dual-stream engines that are not saved, i.e. the frozen building extractor): the network's
+    feature map is only ever consumed by its 1x1 ``fusion_out_conv`` (popcorn.py:301), so the last conv of each stream
+    writes that layer's partial sum over its own 8 channels instead of the features; ``features[e]`` is then the
+    (B, 2, Hp, Wp) tensor of the two partial logits (add them and the bias: ``partial_logit_weights``), or the ordinary
+    16-channel map when the geometry does not qualify."""
     L.require_device(X)
     B = X.shape[0]
     if pad_top >= X.shape[2] or pad_left >= X.shape[3] or Hp - X.shape[2] - pad_top >= X.shape[2] \
@@ -291,7 +310,14 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
         feats_list = [None] * nE
     # single-stream engines leave the other 8 feature channels at zero
     mk = torch.empty if len(engines[0].streams) == 2 else torch.zeros
-    feats = [f if f is not None else mk(B, 16, Hp, Wp, device=dev, dtype=torch.float32) for f in feats_list]
+    if logit_only is None:
+        logit_only = [False] * nE
+    dot_ok = len(engines[0].streams) == 2 and Wp % 32 == 0 and Hp % 4 == 0
+    logit_only = [bool(lo) and dot_ok and not saves[e] and feats_list[e] is None and engines[e].fusion_w is not None
+                  for e, lo in enumerate(logit_only)]
+    feats = [f if f is not None else
+             (torch.empty(B, 2, Hp, Wp, device=dev, dtype=torch.float32) if logit_only[e] else
+              mk(B, 16, Hp, Wp, device=dev, dtype=torch.float32)) for e, f in enumerate(feats_list)]
     E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=torch.float32)  # noqa: E731
     streams = engines[0].streams
     assert all([st[0] for st in e.streams] == [st[0] for st in streams] for e in engines)
@@ -350,7 +376,18 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None)
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
     f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
     f0s = {s: f0 for s, _, _, f0 in streams}
-    conv("up1b", f1, 8, Hp, Wp, outs={k: feats[k[0]][:, f0s[k[1]]:f0s[k[1]] + 8] for k in keys})
+    probs = []
+    for k in keys:
+        pr = {"a": f1[k], "w": ly(k, "up1b").w, "bn": ly(k, "up1b").bn}
+        f0 = f0s[k[1]]
+        if logit_only[k[0]]:
+            si = f0 // 8                                   # stream index = channel of the partial-logit tensor
+            pr["dot_w"] = engines[k[0]].fusion_w.reshape(-1)[f0:f0 + 8].contiguous()
+            pr["dot_out"] = feats[k[0]][:, si:si + 1]
+        else:
+            pr["out"] = feats[k[0]][:, f0:f0 + 8]
+        probs.append(pr)
+    ops.conv3x3_fwd_group(probs)
     saved = []
     for e in range(nE):
         if not saves[e]:

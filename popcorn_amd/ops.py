@@ -43,7 +43,8 @@ def conv3x3_raw(a, w, bnd, relu=True, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 
 def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), out_hw=None, a_channels=None,
                       b_offset=(0, 0)):
     """Grouped form of conv3x3_raw: ``problems`` = list (<= 4) of dicts {a, w, bn, out, b (optional), chmap (optional),
-    pool_out (optional: MaxPool2d(2) of out, see pool_out_like)}
+    pool_out (optional: MaxPool2d(2) of out, see pool_out_like), dot_w + dot_out (optional, 8 -> 8 layers: write
+    sum_co dot_w[co] * out[co] as a one-channel map instead of out)}
     with identical geometry; one launch (blockIdx.y = problem)."""
     n = len(problems)
     assert 1 <= n <= L.PC_MAX_GROUP
@@ -64,13 +65,18 @@ def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0),
     for i, pr in enumerate(problems):
         sa = L.src(pr["a"], C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=pr.get("chmap", (0, 1, 2, 3)))
         sb = L.src(pr["b"], oy=b_offset[0], ox=b_offset[1]) if pr.get("b") is not None else None
-        d = L.dst(pr["out"])
+        d = L.dst(pr["out"]) if pr.get("out") is not None else None
         keep += [sa, sb, d]
         descs[i].a = C.pointer(sa)
         descs[i].b = C.pointer(sb) if sb is not None else None
         descs[i].w = pr["w"].data_ptr()
         descs[i].bn = C.pointer(pr["bn"])
-        descs[i].out = C.pointer(d)
+        descs[i].out = C.pointer(d) if d is not None else None
+        if pr.get("dot_w") is not None:          # 1x1-conv partial sum over the 8 output channels instead of the map
+            dd = L.dst(pr["dot_out"])
+            keep += [dd, pr["dot_w"]]
+            descs[i].dot_w = pr["dot_w"].data_ptr()
+            descs[i].dot_out = C.pointer(dd)
         if pr.get("pool_out") is not None:
             dp = L.dst(pr["pool_out"])
             keep.append(dp)

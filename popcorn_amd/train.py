@@ -93,8 +93,8 @@ class FusedTrainStep:
         fused = (pt, pb, pl, pr) == (m.p, m.p, m.p, m.p)      # e.g. 100x100 tiles: both networks see the same 128x128 domain
         if fused:
             (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
-                                                       [False, not unet_no_grad])
-            building = ops.outconv_sigmoid_crop(f_b, eng_b.fusion_w, eng_b.fusion_b, H, W, pt, pl)
+                                                       [False, not unet_no_grad], logit_only=[True, False])
+            building = eng_b.score_from_features(f_b, H, W, pt, pl)
         else:
             building = eng_b.building_score(X, m.p)
         s["building_counts"] = building

@@ -185,3 +185,61 @@ def test_conv_wgrad_fused_loaders():
     y.backward(g)
     dw, _ = ops.conv3x3_wgrad(skip.cuda(), g.cuda(), 8, b=upt.cuda(), b_offset=(0, 0))
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (2, 64, 64)), (16, 16, (3, 32, 64)), (8, 8, (1, 128, 32))])
+def test_conv_fwd_pooled_second_output(cin, cout, shape):
+    """pool_out of the grouped forward == MaxPool2d(2) of the ordinary output (networks.py:289), bit for bit, next to a
+    problem of the same launch that does not ask for it."""
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, H, W = shape
+    probs, refs = [], []
+    for i in range(2):
+        x = _mk(B, cin, H, W, seed=10 + i).cuda()
+        w = (_mk(cout, cin, 3, 3, seed=20 + i, scale=0.2)).cuda()
+        b = _mk(cout, seed=30 + i, scale=0.1).cuda()
+        out = torch.empty(B, cout, H, W, device="cuda")
+        pr = {"a": x, "w": w, "bn": L.bn(b), "out": out, "_k": b}
+        if i == 0:
+            pr["pool_out"] = ops.pool_out_like(out)
+            assert pr["pool_out"] is not None and pr["pool_out"].shape == (B, cout, H // 2, W // 2)
+        probs.append(pr)
+        refs.append(F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)))
+    ops.conv3x3_fwd_group(probs)
+    for pr, ref in zip(probs, refs):
+        torch.testing.assert_close(pr["out"].cpu(), ref, rtol=1e-5, atol=2e-5)
+    assert torch.equal(probs[0]["pool_out"], F.max_pool2d(probs[0]["out"], 2))
+
+
+def test_conv_fwd_pooled_output_needs_full_strips():
+    from popcorn_amd import ops
+    assert ops.pool_out_like(torch.empty(1, 8, 36, 52, device="cuda")) is None      # W % 32 != 0
+    assert ops.pool_out_like(torch.empty(1, 8, 30, 64, device="cuda")) is None      # H % 4 != 0
+
+
+def test_conv_fwd_partial_logit_output():
+    """dot_w / dot_out: sum_co dot_w[co] * relu(bn(conv))[co] as a one-channel map, for one problem of a group; the
+    other problem writes its feature map as usual."""
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, H, W = 2, 32, 64
+    gamma, beta, mean, var = _bn_params(8, 41)
+    xs = [_mk(B, 8, H, W, seed=50 + i) for i in range(2)]
+    ws = [_mk(8, 8, 3, 3, seed=60 + i, scale=0.2) for i in range(2)]
+    bs = [_mk(8, seed=70 + i, scale=0.1) for i in range(2)]
+    dw = _mk(8, seed=80)
+    logits = torch.full((B, 2, H, W), float("nan"), device="cuda")
+    out1 = torch.empty(B, 8, H, W, device="cuda")
+    keep = [t.cuda() for t in (gamma, beta, mean, var)]
+    bsd = [b.cuda() for b in bs]                       # L.bn() stores raw pointers: the tensors must stay alive
+    bns = [L.bn(b, *keep) for b in bsd]
+    dwd = dw.cuda()
+    probs = [{"a": xs[0].cuda(), "w": ws[0].cuda(), "bn": bns[0], "dot_w": dwd, "dot_out": logits[:, 1:2]},
+             {"a": xs[1].cuda(), "w": ws[1].cuda(), "bn": bns[1], "out": out1}]
+    ops.conv3x3_fwd_group(probs)
+    ref0 = _ref_cbr(xs[0], ws[0], bs[0], gamma, beta, mean, var)
+    ref1 = _ref_cbr(xs[1], ws[1], bs[1], gamma, beta, mean, var)
+    torch.testing.assert_close(logits[:, 1].cpu(), (ref0 * dw.view(1, 8, 1, 1)).sum(1), rtol=1e-5, atol=5e-5)
+    assert torch.isnan(logits[:, 0]).all()                      # the other channel is untouched
+    torch.testing.assert_close(out1.cpu(), ref1, rtol=1e-5, atol=2e-5)

@@ -187,6 +187,14 @@ int pc_sparsity_mask(const float* building, const float* admin_mask, const int64
                      const uint8_t* rowsel, const uint8_t* colsel, int occupancymodel,
                      uint8_t* mask, int32_t* counts, int B, int H, int W, void* stream);
 
+/* pc_outconv_sigmoid_crop + pc_sparsity_mask in ONE launch (the building score feeds the mask directly; the empty-selection
+ * fallback and the count fix-up are done by the last block to finish).  Same arguments and results as the two calls.
+ * Must not run concurrently with itself on two streams of one process (library-owned accumulator + ticket). */
+int pc_building_score_mask(const pc_src* feat, const float* w, const float* bias, const pc_dst* building_out,
+                           const float* admin_mask, const int64_t* census_idx, const uint8_t* rowsel,
+                           const uint8_t* colsel, int occupancymodel, uint8_t* mask, int32_t* counts,
+                           int B, int H, int W, int py, int px, void* stream);
+
 /* ---- the sparse head, popcorn.py:80-85,161-190,195-228:
  * per selected pixel 16 -> 64 -> 64 -> 64 -> (channel 0 of 2) 1x1-conv MLP with ReLUs, scale = relu(out),
  * popdensemap = scale * building, popcount[b] = sum over region pixels.  mask == NULL: dense head.

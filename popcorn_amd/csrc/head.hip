@@ -1005,6 +1005,89 @@ __global__ void sparsity_mask_fix_count_kernel(int32_t* counts) {
     if (counts[0] == 0) counts[0] = counts[1];
 }
 
+// ---- building score + sparsity mask in ONE launch -----------------------------------------------------------------
+// outconv_sigmoid_crop_kernel + sparsity_mask_kernel + the empty-selection fallback + the count fix-up (a memset and four
+// dependent launches, ~38 us between the U-Net forward and the head) as one kernel: every block accumulates {nsel, nregion}
+// into a scratch pair and takes a ticket; the block that draws the last ticket publishes the counts, applies the
+// fallback of popcorn.py:374-375 if the whole batch selected nothing (rare; done by that one block).  The accumulators live
+// in a library-owned scratch that a one-wave kernel zeroes in front of every launch.
+// Zero fills inside the train step are kernels, not hipMemsetAsync: memset nodes captured into the step's HIP graph were
+// not reliably re-executed / ordered on replay once the node sequence of the graph changed (a 16- or 32-byte one never
+// replayed; with it gone the 67 MB one of the head backward went wrong too: garbage gradients from the second replay on,
+// eager launches always correct).
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* p, int64_t n4, int64_t rem) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = z;
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) p[4 * n4 + threadIdx.x] = 0.f;
+}
+
+__global__ void zero_words_kernel(uint32_t* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+
+struct ScoreMaskArgs {
+    pc_src feat; const float* w; const float* bias; pc_dst out;      // 1x1 conv + sigmoid + crop (as outconv_sigmoid_crop)
+    const float* admin; const int64_t* census; const uint8_t* rowsel; const uint8_t* colsel;
+    int occ; uint8_t* mask; int32_t* counts; unsigned* scratch;      // scratch: {acc nsel, acc nregion, ticket, -}, zeroed before the launch
+    int B, H, W, py, px;
+};
+
+__global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) {
+    const int64_t n = (int64_t)a.B * a.H * a.W;
+    float wv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) wv[c] = c < a.feat.C ? a.w[c] : 0.f;
+    const float bv = a.bias[0];
+    int nsel = 0, nreg = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
+        const unsigned row = i / (unsigned)a.W;
+        const int x = (int)(i - row * (unsigned)a.W), y = (int)(row % (unsigned)a.H), b = (int)(row / (unsigned)a.H);
+        const float* fp = a.feat.ptr + b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + a.px + x;
+        float s = bv;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.feat.C) s = fmaf(fp[c * a.feat.cstride], wv[c], s);
+        const float building = 1.f / (1.f + expf(-s));
+        a.out.ptr[b * a.out.bstride + (int64_t)y * a.out.rstride + x] = building;
+        const bool region = a.admin[i] == (float)a.census[b];
+        const bool base = a.occ ? (building > 0.f) : true;
+        const bool m = region && (base || (a.rowsel[y] && a.colsel[x]));
+        a.mask[i] = m ? 1 : 0;
+        nsel += m;
+        nreg += region;
+    }
+    __shared__ int red[2][4];
+    __shared__ unsigned last;
+    for (int off = 32; off > 0; off >>= 1) { nsel += __shfl_down(nsel, off); nreg += __shfl_down(nreg, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nsel; red[1][threadIdx.x >> 6] = nreg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        // integer counts: order-independent, exact.  ONE 64-bit atomic per block {nsel | nregion << 32}: device-scope
+        // atomics on one address retire at ~13 ns each (2048 blocks x 3 atomics took 80 us)
+        if (s0 | s1) atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), (unsigned long long)(unsigned)s0 | ((unsigned long long)(unsigned)s1 << 32));
+        __threadfence();
+        last = atomicAdd(&a.scratch[2], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), 0ull);
+    const unsigned tot_sel = (unsigned)tot, tot_reg = (unsigned)(tot >> 32);
+    __syncthreads();                       // every thread of this block has read the totals before counts[0] is fixed up
+    if (tot_sel == 0) {
+        // an empty selection falls back to the region mask (popcorn.py:374-375)
+        for (unsigned i = threadIdx.x; i < (unsigned)n; i += blockDim.x) {
+            const int b = (int)(i / (unsigned)(a.W * a.H));
+            a.mask[i] = a.admin[i] == (float)a.census[b] ? 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.counts[0] = (int32_t)(tot_sel ? tot_sel : tot_reg);
+        a.counts[1] = (int32_t)tot_reg;
+    }
+}
+
 // ---- ordered compaction: out[rank(i)] = src[i] for mask[i] != 0 (row-major order) --------------------------------
 constexpr int CBLK = 1024;   // elements per block
 
@@ -1126,13 +1209,40 @@ extern "C" int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const
     return 0;
 }
 
+extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const float* bias, const pc_dst* building_out,
+                                      const float* admin_mask, const int64_t* census_idx, const uint8_t* rowsel,
+                                      const uint8_t* colsel, int occupancymodel, uint8_t* mask, int32_t* counts,
+                                      int B, int H, int W, int py, int px, void* stream) {
+    if (!feat || !w || !bias || !building_out || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !counts ||
+        feat->C < 1 || feat->C > 16)
+        return PC_EINVAL;
+    static unsigned* scratch = nullptr;     // {acc nsel, acc nregion, ticket, -}: device-scope atomics only, never reused
+    if (!scratch) {
+        hipError_t e = hipMalloc(&scratch, 4 * sizeof(unsigned));
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(scratch), 4);
+    PC_CHECK_LAUNCH();
+    ScoreMaskArgs a{};
+    a.feat = *feat; a.w = w; a.bias = bias; a.out = *building_out; a.admin = admin_mask; a.census = census_idx;
+    a.rowsel = rowsel; a.colsel = colsel; a.occ = occupancymodel; a.mask = mask; a.counts = counts; a.scratch = scratch;
+    a.B = B; a.H = H; a.W = W; a.py = py; a.px = px;
+    const int64_t n = (int64_t)B * H * W;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 256) grid = 256;            // one block per CU: the per-block atomics are the serial part
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(score_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pc_sparsity_mask(const float* building, const float* admin_mask, const int64_t* census_idx,
                                 const uint8_t* rowsel, const uint8_t* colsel, int occupancymodel,
                                 uint8_t* mask, int32_t* counts, int B, int H, int W, void* stream) {
     if (!building || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !counts) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t*>(counts), 2);
+    PC_CHECK_LAUNCH();
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
     if (grid > 512) grid = 512;
@@ -1175,8 +1285,13 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     if (admin_mask && !census_idx) return PC_EINVAL;
     if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(g_feat->ptr, 0, (size_t)B * 16 * Hp * Wp * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    {
+        // zero fill by a kernel, not a memset node (see zero_fill_kernel)
+        const int64_t n4 = (int64_t)B * 16 * Hp * Wp / 4, rem = (int64_t)B * 16 * Hp * Wp - 4 * n4;
+        if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(2048), dim3(256), 0, st, g_feat->ptr, n4, rem);
+        PC_CHECK_LAUNCH();
+    }
     HeadBwdArgs a{};
     HeadArgs& p = a.f;
     p.feat = *feat; p.py = py; p.px = px;

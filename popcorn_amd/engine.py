@@ -149,6 +149,17 @@ class UNetEngine:
             return ops.outconv_sigmoid_crop(f, self._ones2, self.fusion_b, H, W, py, px)
         return ops.outconv_sigmoid_crop(f, self.fusion_w, self.fusion_b, H, W, py, px)
 
+    def score_and_mask(self, f, H, W, py, px, admin_mask, census_idx, rowsel, colsel, occupancymodel=True):
+        """score_from_features + get_sparsity_mask (popcorn.py:361-377) in one launch: (building, mask, counts)."""
+        if f.shape[1] == 2:
+            if getattr(self, "_ones2", None) is None or self._ones2.device != f.device:
+                self._ones2 = torch.ones(2, device=f.device, dtype=torch.float32)
+            w = self._ones2
+        else:
+            w = self.fusion_w
+        return ops.building_score_mask(f, w, self.fusion_b, H, W, py, px, admin_mask, census_idx, rowsel, colsel,
+                                       occupancymodel)
+
     def feat_bn(self):
         """BN descriptors of the two layers that produce the feature map (for the head-backward epilogue)."""
         plain = L.bn()       # missing stream: its feature channels are identically zero, any scale will do

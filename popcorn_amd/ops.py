@@ -259,6 +259,22 @@ def sparsity_mask(building, admin_mask, census_idx, rowsel, colsel, occupancymod
     return mask, counts
 
 
+def building_score_mask(feat, w, bias, H, W, py, px, admin_mask, census_idx, rowsel, colsel, occupancymodel=True):
+    """outconv_sigmoid_crop + sparsity_mask in one launch.  Returns (building (B,1,H,W), mask uint8 (B,H,W), counts)."""
+    L.require_device(feat, w, bias, admin_mask, census_idx, rowsel, colsel)
+    B = feat.shape[0]
+    dev = feat.device
+    building = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+    mask = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    sf, d = L.src(feat), L.dst(building)
+    L.check(L.lib().pc_building_score_mask(C.byref(sf), L.ptr(w), L.ptr(bias), C.byref(d), L.ptr(admin_mask),
+                                           L.ptr(census_idx), L.ptr(rowsel), L.ptr(colsel), int(occupancymodel),
+                                           L.ptr(mask), L.ptr(counts), B, H, W, py, px, L.stream_ptr()),
+            "pc_building_score_mask")
+    return building, mask, counts
+
+
 def _hw_array(head_tensors):
     arr = (C.c_void_p * 8)(*[t.data_ptr() for t in head_tensors])
     return arr

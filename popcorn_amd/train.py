@@ -94,14 +94,14 @@ class FusedTrainStep:
         if fused:
             (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
                                                        [False, not unet_no_grad], logit_only=[True, False])
-            building = eng_b.score_from_features(f_b, H, W, pt, pl)
+            building, mask, counts = eng_b.score_and_mask(f_b, H, W, pt, pl, s["admin_mask"], s["census_idx"], sel[:H],
+                                                          sel[H:], m.occupancymodel)
         else:
             building = eng_b.building_score(X, m.p)
+            mask, counts = ops.sparsity_mask(building, s["admin_mask"], s["census_idx"], sel[:H], sel[H:], m.occupancymodel)
         s["building_counts"] = building
         if not m.occupancymodel:
             building = torch.ones_like(building)
-        mask, counts = ops.sparsity_mask(s["building_counts"], s["admin_mask"], s["census_idx"], sel[:H], sel[H:],
-                                         m.occupancymodel)
         if not fused:
             feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,

@@ -179,3 +179,29 @@ def test_config3_batch64_train_step_is_deterministic_and_graph_equals_eager():
     assert torch.equal(pa, pb) and la == lb            # (1)
     assert torch.equal(pa, pg) and la == lg            # (2)
     assert all(np.isfinite(la)) and la[2] < la[0]      # (3)
+
+
+def test_graph_replay_equals_eager_over_many_steps_with_static_buffers():
+    """Ten steps through the loader-facing static buffers: HIP-graph replay and eager launches give bit-identical losses.
+    Regression guard for stale state across replays (a memset node that was captured but not re-executed on replay
+    produced correct first replays and garbage gradients afterwards; zero fills are kernels now)."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    batch = make_raw_batch(64, 100, 100, seed=1602, device="cuda")
+    runs = []
+    for use_graph in (False, True):
+        tr = _fresh_trainer(use_graph)
+        buf = tr.static_buffers(64, 100, 100)
+        buf["admin_mask"].copy_(batch["admin_mask"])
+        buf["census_idx"].copy_(batch["census_idx"])
+        buf["y"].copy_(batch["y"])
+        torch.manual_seed(7)
+        losses = []
+        for _ in range(10):
+            ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6, out=buf["input"])
+            losses.append(tr.step(buf).tolist())
+        torch.cuda.synchronize()
+        runs.append((losses, tr.flat_p.clone(), int(tr.step_count.item())))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2] == 10

@@ -131,12 +131,25 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
             const int j = j0 + 4 * lk;
             float* op = p.out.ptr + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j;
             const float* ap = p.act ? p.act + b * p.act_bstride + li * p.act_cstride + (int64_t)i * p.act_rstride + j : nullptr;
+            const bool vec = j + 3 < p.W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0) &&
+                             (!ap || (reinterpret_cast<uintptr_t>(ap) & 15) == 0);
+            if (vec) {
+                // the lane's 4 consecutive x of one channel row: one 16-byte load of the mask, one 16-byte store
+                f32x4 o = acc;
+                if (ap) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (j + r < p.W) {
-                    float o = acc[r];
-                    if (ap) o = ap[r] > 0.f ? o * e_scale : 0.f;
-                    op[r] = o;
+                    for (int r = 0; r < 4; ++r) o[r] = a4[r] > 0.f ? o[r] * e_scale : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(op) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (j + r < p.W) {
+                        float o = acc[r];
+                        if (ap) o = ap[r] > 0.f ? o * e_scale : 0.f;
+                        op[r] = o;
+                    }
                 }
             }
         }

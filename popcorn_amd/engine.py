@@ -63,7 +63,8 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
     return names
 
 
-OVERLAP_WGRAD = False     # measured on MI355X: 22.5 k -> 21.6 k patches/s with the side stream (both branches are bandwidth-bound)
+OVERLAP_WGRAD = False     # measured on MI355X, twice: 22.5 k -> 21.6 k patches/s (v4), 2.19 -> 2.33 ms (v9, also with both
+                          # chains at half the resident grid): the two branches compete for the same memory pipe
 _SIDE = {}
 
 

@@ -84,6 +84,48 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
             "unit_def": "selected pixel, 56,064 flop"}
 
 
+def conv_kernel_roofline(torch, B, reps=5, nsets=4):
+    """Second roofline object: the most frequent heavy launch of the step, the grouped 3x3 conv 8->8 @128x128 (4 problems =
+    2 networks x 2 streams, B tiles each), timed live with events over rotating buffer sets (cold Infinity Cache).  It sits
+    at the ridge of this chip (18 flop / compulsory byte), so both views are given: algorithmic bytes against the HBM peak
+    and algorithmic flops against the fp32-matrix peak."""
+    from popcorn_amd import ops, _lib as L
+    sets = []
+    for _ in range(nsets):
+        probs = []
+        for _ in range(4):
+            bias = torch.zeros(8, device="cuda")
+            probs.append({"a": torch.randn(B, 8, 128, 128, device="cuda"), "w": torch.randn(8, 8, 3, 3, device="cuda") * 0.1,
+                          "bn": L.bn(bias), "out": torch.empty(B, 8, 128, 128, device="cuda"), "_keep": bias})
+        sets.append(probs)
+    for s in sets:
+        ops.conv3x3_fwd_group(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            for _ in range(reps):
+                for s in sets:
+                    ops.conv3x3_fwd_group(s)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
+    nbytes = 4 * B * 128 * 128 * 4 * (8 + 8)                 # compulsory: read 8 channels, write 8 channels, fp32
+    flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
+    return {"bound": "hbm", "kernel": "conv3x3_mfma_kernel<8,8,fwd> grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
+            "achieved": round(nbytes / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / dur / 8e12, 4),
+            "traffic": None, "launch_us": round(dur * 1e6, 2), "alg_bytes_per_launch": nbytes,
+            "mfma_view": {"achieved_tflops": round(flops / dur / 1e12, 2), "peak": FP32_MATRIX_PEAK / 1e12,
+                          "frac": round(flops / dur / FP32_MATRIX_PEAK, 4)}}
+
+
 def cpu_baseline(torch, sd, cpu_batch, iters):
     """The oracle (CPU restatement of the reference path, oracle/popcorn_oracle.py) timed on the host cores on a
     bounded sample of the same workload: `iters` train steps (fwd + loss + bwd + clip + Adam) at B=cpu_batch."""
@@ -199,6 +241,7 @@ def main():
             "step_frac_of_fp32_mfma_peak": round(value * FLOP_TRAIN_PER_TILE / (FP32_MATRIX_PEAK * world), 4),
         }
         res["roofline"] = dominant_kernel_roofline(torch, trainer, sample)
+        res["roofline_conv"] = conv_kernel_roofline(torch, B)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_batch, args.cpu_iters)
         else:

@@ -205,14 +205,40 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // is not a tap; a lane's fragments for one 8-channel chunk are then 24 consecutive floats = 6 ds_read_b128.  Only
     // the current chunk's fragments live in registers (24 per 8 output channels whatever CIN is): holding all of them
     // cost 96 registers at CIN = 32 and left 16->8 / 32->8 / 16->16 with two or ONE wave per SIMD.
+    // Prologue latency: the weight elements and the raw BN parameters are loaded into registers FIRST (one memory round
+    // trip, in flight together with the first strip), the LDS image is zeroed meanwhile, and only then are they consumed
+    // -- the prologue used to be three dependent round trips (zero fill + barrier, weights, BN), ~4.6 us of every launch.
     float* const w2 = lds + 4 * CHUNK * CSW;
+    constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
+    float wreg[NWR];
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+        const int e = tid + k * 256;
+        const int ec = e < COUT * CIN * 9 ? e : 0;
+        const int tap = ec % 9, ci = (ec / 9) % CIN, co = ec / (9 * CIN);
+        wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+    }
+    const bool has_bn = MODE == MODE_FWD || q.act != nullptr;
+    float bn_raw[NB][5];            // {conv bias, gamma, var, mean, beta} of channel nb*8 + col
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int c = nb * 8 + col;
+        bn_raw[nb][0] = has_bn && q.bn.conv_bias ? q.bn.conv_bias[c] : 0.f;
+        bn_raw[nb][1] = has_bn && q.bn.gamma ? q.bn.gamma[c] : 1.f;
+        bn_raw[nb][2] = has_bn && q.bn.gamma ? q.bn.var[c] : 1.f;
+        bn_raw[nb][3] = has_bn && q.bn.gamma ? q.bn.mean[c] : 0.f;
+        bn_raw[nb][4] = has_bn && q.bn.gamma ? q.bn.beta[c] : 0.f;
+    }
     {
         for (int e = tid; e < 4 * W_DYS; e += 256) w2[e] = 0.f;
         __syncthreads();
-        for (int e = tid; e < COUT * CIN * 9; e += 256) {
-            const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-            w2[(tap / 3) * W_DYS + co * W_RL + ci * 3 + (tap % 3)] =
-                q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) {
+            const int e = tid + k * 256;
+            if (e < COUT * CIN * 9) {
+                const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+                w2[(tap / 3) * W_DYS + co * W_RL + ci * 3 + (tap % 3)] = wreg[k];
+            }
         }
         __syncthreads();
     }
@@ -239,8 +265,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     float e_scale[NB], e_shift[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        if (MODE == MODE_FWD || q.act != nullptr) pc_bn_fold(q.bn, nb * 8 + col, e_scale[nb], e_shift[nb]);
-        else { e_scale[nb] = 1.f; e_shift[nb] = 0.f; }
+        // folded BN (pc_bn_fold): scale = gamma / sqrt(var + eps); shift = (bias - mean) * scale + beta
+        if (has_bn && q.bn.gamma) {
+            e_scale[nb] = bn_raw[nb][1] * (1.0f / sqrtf(bn_raw[nb][2] + q.bn.eps));
+            e_shift[nb] = (bn_raw[nb][0] - bn_raw[nb][3]) * e_scale[nb] + bn_raw[nb][4];
+        } else {
+            e_scale[nb] = 1.f;
+            e_shift[nb] = has_bn ? bn_raw[nb][0] : 0.f;
+        }
     }
     // Consume the BN constants HERE.  They come from global loads issued before the strip loop and are first used in
     // the epilogue inside it; hipcc's waitcnt pass then keeps them "pending" at the loop header on every iteration and,

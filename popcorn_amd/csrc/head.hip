@@ -1185,7 +1185,23 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     p.groups = (H * W + 15) / 16;
     p.div_w = pc_make_fastdiv(W);
     p.div_groups = pc_make_fastdiv(p.groups);
-    p.groups_per_wave = 8;
+    // One round of workgroups: every workgroup stages the 36 KB of weights, so the launch holds exactly the workgroups
+    // that are resident at once (B images x chunks-per-image <= resident) and each wave walks enough 16-pixel groups to
+    // cover its image chunk -- with a fixed 8 groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on
+    // 1024 slots, i.e. a second, quarter-full round.
+    static int resident = 0;
+    if (!resident) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
+    }
+    int chunks = resident / (B > 0 ? B : 1);                      // chunks per image that fit in one round
+    const int max_chunks = (p.groups + 31) / 32;                  // never fewer than 8 groups per wave (workspace bound)
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    p.groups_per_wave = (p.groups + 4 * chunks - 1) / (4 * chunks);
+    if (p.groups_per_wave < 8) p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);

@@ -9,6 +9,7 @@ Order of operations of the training loop is the reference's (run_train.py:146-26
 from __future__ import annotations
 
 import argparse
+import collections
 import json
 import os
 import random
@@ -221,7 +222,8 @@ class Trainer:
                 if num_pix > a.limit3:
                     return None
         if self.fused is not None:
-            return self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0]
+            # loss_out is one device buffer overwritten by every step: keep a copy for the running log mean
+            return self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0].clone()
         from torch.nn.utils import clip_grad_norm_
         from .utils.losses import get_loss
         out = self.model(s, train=True, padding=False, sparse=True, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
@@ -241,6 +243,8 @@ class Trainer:
         log = open(os.path.join(self.exp, "train_log.jsonl"), "a") if self.rank == 0 else None
         lr = a.learning_rate * (a.lr_gamma ** (self.info["epoch"] // a.lr_step))
         t0 = time.time()
+        recent = collections.deque(maxlen=a.logstep_train)                  # running window for the log line, across epochs
+        losses = []
         for epoch in range(self.info["epoch"], a.num_epochs):
             self.model.train()
             losses = []
@@ -248,10 +252,11 @@ class Trainer:
                 loss = self.train_step(sample)
                 if loss is not None:
                     losses.append(loss)
+                    recent.append(loss)
                 self.info["iter"] += 1
                 self.info["sampleitr"] += a.weak_batch_size
-                if (i + 1) % a.logstep_train == 0 and log:
-                    mean = torch.stack(losses[-a.logstep_train:]).mean().item()
+                if self.info["iter"] % a.logstep_train == 0 and log and recent:      # by global iteration (run_train.py:240)
+                    mean = torch.stack(list(recent)).mean().item()
                     log.write(json.dumps({"iter": self.info["iter"], "epoch": epoch, "loss": mean, "lr": lr}) + "\n")
                     log.flush()
                 if a.max_steps and self.info["iter"] >= a.max_steps:

@@ -24,11 +24,18 @@ class SyntheticWeaksupDataset(Dataset):
             hw = torch.randint(min_hw, max_hw + 1, (n_regions, 2), generator=g)
             self.hw = [tuple(int(v) for v in r) for r in hw]
         self.seed = seed
+        self._cache = {}
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
+        # deterministic per index: generated once, then served from memory (the reference reads tiles from disk)
+        if i not in self._cache:
+            self._cache[i] = self._make(i)
+        return dict(self._cache[i])
+
+    def _make(self, i):
         h, w = self.hw[i]
         g = torch.Generator().manual_seed(self.seed * 7919 + i)
         s2 = torch.randint(0, 10000, (4, h, w), generator=g).float()

@@ -149,6 +149,9 @@ class Trainer:
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
         self.exp = new_log(os.path.join(args.save_dir, "So2Sat"), args) if self.rank == 0 else None
+        # host-side glue (collate, augmentation draws) is many tiny CPU ops: an OpenMP pool as wide as a 256-core host
+        # costs more per op than the op itself
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
         seed_all(args.seed)
         ds = SyntheticWeaksupDataset(args.synthetic_regions, seed=args.seed, fixed_hw=args.fixed_hw)
         sampler = None

@@ -145,6 +145,11 @@ int pc_conv3x3_wgrad_partial_group(int n, const pc_conv_wgrad_desc* d, int B, in
                                    int* nwg_out, void* stream);
 int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B, int H, int W, int C, int* nwg_out,
                               void* stream);
+/* grouped form: n <= PC_MAX_GROUP problems of identical geometry (the two streams of an Up block) in one launch; every
+ * problem gets *nwg_out partials in its own ws */
+typedef struct pc_convt_wgrad_desc { const pc_src* x; const pc_src* g; void* ws; } pc_convt_wgrad_desc;
+int pc_convt2x2_wgrad_partial_group(int n, const pc_convt_wgrad_desc* d, int B, int H, int W, int C, int* nwg_out,
+                                    void* stream);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */

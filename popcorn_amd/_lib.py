@@ -55,6 +55,10 @@ class PcConvWgradDesc(C.Structure):
     _fields_ = [("a", C.POINTER(PcSrc)), ("b", C.POINTER(PcSrc)), ("g", C.POINTER(PcSrc)), ("ws", C.c_void_p)]
 
 
+class PcConvtWgradDesc(C.Structure):
+    _fields_ = [("x", C.POINTER(PcSrc)), ("g", C.POINTER(PcSrc)), ("ws", C.c_void_p)]
+
+
 class PcWgradReduceDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
                 ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]

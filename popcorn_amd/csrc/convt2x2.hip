@@ -167,7 +167,8 @@ struct CtWgradCfg {
 // and a lane's four A values are ONE 16-byte load of x, its four B values the even or odd floats of TWO 16-byte loads of
 // the g row (4 + 4*C/4 scalar gathers before: 12 / 20 four-byte loads per group and lane).
 template <int C, bool VEC>
-__global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtArgs p) {
+__global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
     __shared__ __attribute__((aligned(16))) float lds[4 * NBK * 256];
@@ -375,17 +376,23 @@ bool ct_wgrad_vec_ok(const CtArgs& p) {
     };
     return p.W % 16 == 0 && al(p.x) && al(p.g);
 }
-int launch_ct_wgrad(const CtArgs& p, int C, int nwg, hipStream_t st) {
-    const bool vec = ct_wgrad_vec_ok(p);
+int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t st) {
+    bool vec = true;
+    for (int i = 0; i < n; ++i) vec = vec && ct_wgrad_vec_ok(g.pr[i]);
     if (C == 16) {
-        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, true>), dim3(nwg), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, false>), dim3(nwg), dim3(256), 0, st, p);
+        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, true>), dim3(nwg, n), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, false>), dim3(nwg, n), dim3(256), 0, st, g);
     } else if (C == 8) {
-        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, true>), dim3(nwg), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, false>), dim3(nwg), dim3(256), 0, st, p);
+        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, true>), dim3(nwg, n), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, false>), dim3(nwg, n), dim3(256), 0, st, g);
     } else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
+}
+int launch_ct_wgrad(const CtArgs& p, int C, int nwg, hipStream_t st) {
+    CtGroup g{};
+    g.pr[0] = p;
+    return launch_ct_wgrad_group(g, 1, C, nwg, st);
 }
 }  // namespace
 
@@ -398,6 +405,26 @@ extern "C" int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void*
     int nwg = fill_groups(p);
     if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;
     const int rc = launch_ct_wgrad(p, C, nwg, (hipStream_t)stream);
+    if (rc) return rc;
+    *nwg_out = nwg;
+    return 0;
+}
+
+extern "C" int pc_convt2x2_wgrad_partial_group(int n, const pc_convt_wgrad_desc* d, int B, int H, int W, int C, int* nwg_out,
+                                               void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || !d || !nwg_out) return PC_EINVAL;
+    CtGroup g{};
+    int nwg = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].x || !d[i].g || !d[i].ws) return PC_EINVAL;
+        CtArgs& p = g.pr[i];
+        p.x = *d[i].x; p.g = *d[i].g; p.B = B; p.H = H; p.W = W;
+        p.partial = reinterpret_cast<float*>(d[i].ws);
+        nwg = fill_groups(p);
+    }
+    if (nwg > CT_MAX_WG / n) nwg = CT_MAX_WG / n;      // the same total number of workgroups as a single-problem launch
+    if (nwg < 1) nwg = 1;
+    const int rc = launch_ct_wgrad_group(g, n, C, nwg, (hipStream_t)stream);
     if (rc) return rc;
     *nwg_out = nwg;
     return 0;

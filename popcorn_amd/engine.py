@@ -219,9 +219,11 @@ class UNetEngine:
                 probs.append(pr)
             on_side(lambda: wb.conv3x3_group(probs, ly(S[0], tag).w.shape[0], **kw))
 
-        def wgt(s, tag, x, g):
-            lay = ly(s, tag)
-            on_side(lambda: wb.convt2x2(x, g, grads[prefix + lay.wname], grads[prefix + lay.bname]))
+        def wgts(tag, xs, gs):
+            """transposed-conv weight gradients of layer `tag` for all streams in ONE launch"""
+            probs = [{"x": xs[s], "g": gs[s], "dw": grads[prefix + ly(s, tag).wname], "db": grads[prefix + ly(s, tag).bname]}
+                     for s in S]
+            on_side(lambda: wb.convt2x2_group(probs))
 
         def finish():
             on_side(wb.finish)
@@ -248,12 +250,13 @@ class UNetEngine:
             G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
         g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
         G_e2, probs = {}, []
+        g_u1vs = {}
         for s in S:
             oy, ox = A[s]["o1"]
-            g_u1v = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
-            wgt(s, "up1t", A[s]["e2"], g_u1v)
+            g_u1v = g_u1vs[s] = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
             G_e2[s] = E(8, H1, W1)
             probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
+        wgts("up1t", {s: A[s]["e2"] for s in S}, g_u1vs)
         ops.convt2x2_dgrad_group(probs)
         wgs("up2b", "e1", G_e2)
         G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
@@ -262,13 +265,14 @@ class UNetEngine:
             G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
         g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
         G_c2, probs = {}, []
+        g_u2vs = {}
         for s in S:
             oy, ox = A[s]["o2"]
-            g_u2v = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
-            wgt(s, "up2t", A[s]["c2"], g_u2v)
+            g_u2v = g_u2vs[s] = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
             if not encoder_no_grad:
                 G_c2[s] = E(16, H2, W2)
                 probs.append({"g": g_u2v, "w": ly(s, "up2t").w, "out": G_c2[s], "act": A[s]["c2"], "act_bn": ly(s, "d2b").bn_nobias})
+        wgts("up2t", {s: A[s]["c2"] for s in S}, g_u2vs)
         if probs:
             ops.convt2x2_dgrad_group(probs)
         if encoder_no_grad:

@@ -449,6 +449,25 @@ class WgradBatch:
                                                   L.stream_ptr()), "pc_convt2x2_wgrad_partial")
         self.entries.append((ws, dw, db, nwg.value, Cc, Cc, 1))
 
+    def convt2x2_group(self, problems):
+        """problems: list (<= 4) of dicts {x, g, dw, db} with identical geometry: one launch."""
+        n = len(problems)
+        x0 = problems[0]["x"]
+        B, Cc, H, W = x0.shape
+        descs = (L.PcConvtWgradDesc * n)()
+        keep, slices = [], []
+        for i, pr in enumerate(problems):
+            sx, sg = L.src(pr["x"]), L.src(pr["g"])
+            ws = self._slice()
+            keep += [sx, sg]
+            slices.append(ws)
+            descs[i].x, descs[i].g, descs[i].ws = C.pointer(sx), C.pointer(sg), ws
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_convt2x2_wgrad_partial_group(n, descs, B, H, W, Cc, C.byref(nwg), L.stream_ptr()),
+                "pc_convt2x2_wgrad_partial_group")
+        for ws, pr in zip(slices, problems):
+            self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Cc, Cc, 1))
+
     def finish(self):
         n = len(self.entries)
         if n == 0:

@@ -68,7 +68,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
         run()
     e1.record()
     torch.cuda.synchronize()
-    dur = e0.elapsed_time(e1) * 1e-3 / reps       # includes the 42 MB memset + the 10 us reduce kernel of the call
+    dur = e0.elapsed_time(e1) * 1e-3 / reps       # includes the 67 MB zero-fill kernel + the 8 us reduce kernel of the call
     flops = 56064.0 * nsel
     achieved = flops / dur / 1e12
     traffic = None                              # HBM bytes per launch from the committed PMC pass (cannot be read live)
@@ -77,7 +77,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
             traffic = json.load(fh)["traffic_bytes"] if (B, H, W) == (64, 100, 100) else None
     except OSError:
         pass
-    return {"bound": "mfma", "kernel": "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4; + memset + reduce of the same call)",
+    return {"bound": "mfma", "kernel": "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4; + zero fill + reduce kernels of the same call)",
             "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "alg_flop_per_launch": flops, "units_per_launch": nsel,

@@ -293,6 +293,50 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     auto epilogue = [&]() {
         // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + (u&1)*16 + 4*lk + r), r = 0..3
         if (ey0 >= p.H) return;
+        if (MODE == MODE_DGRAD && p.pool && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W)) {
+            // MaxPool2d(2) backward on an interior strip of aligned tensors: the lane's four pooled pixels cover 8 x 2
+            // full-resolution pixels = two 16-byte pieces per row of `act` and of the accumulated output (the scalar path
+            // below issues 12 four-byte accesses per pooled pixel; these two launches were 127 us of the step)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int y = ey0 + 2 * (u >> 1) + s_row, x = ex0 + (u & 1) * 16 + 4 * lk;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = nb * 8 + col;
+                    const f32x4 v = pacc[u][nb];
+                    const float* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs + 2 * x;
+                    float* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs + 2 * x;
+                    f32x4 A[2][2], O[2][2];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            A[rr][h] = *reinterpret_cast<const f32x4*>(a0 + rr * a_rs + 4 * h);
+                            O[rr][h] = *reinterpret_cast<const f32x4*>(o0 + rr * o_rs + 4 * h);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int h = r >> 1, e = (r & 1) * 2;
+                        const float w00 = A[0][h][e], w01 = A[0][h][e + 1], w10 = A[1][h][e], w11 = A[1][h][e + 1];
+                        int am = 0;
+                        float m = w00;
+                        if (w01 > m) { m = w01; am = 1; }
+                        if (w10 > m) { m = w10; am = 2; }
+                        if (w11 > m) { m = w11; am = 3; }
+                        const float g = m > 0.f ? v[r] * e_scale[nb] : 0.f;
+                        O[0][h][e] += am == 0 ? g : 0.f;
+                        O[0][h][e + 1] += am == 1 ? g : 0.f;
+                        O[1][h][e] += am == 2 ? g : 0.f;
+                        O[1][h][e + 1] += am == 3 ? g : 0.f;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(o0 + rr * o_rs + 4 * h) = O[rr][h];
+                }
+            }
+            return;
+        }
         const bool full = p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W) && !p.pool;
         if (full) {
             // interior strip, aligned tensors: no bounds checks, 16-byte accesses only

@@ -125,11 +125,13 @@ def test_conv_dgrad_plain_and_masked(cin_total, c0, cn, cg):
     torch.testing.assert_close(out2.cpu(), ref2, rtol=1e-5, atol=2e-5)
 
 
-def test_conv_dgrad_pool_scatter_matches_autograd():
-    """d1a-style: y = conv(maxpool(relu_bn_out)); gradient w.r.t. the pre-pool activation's conv output."""
+@pytest.mark.parametrize("shape", [(2, 38, 53), (2, 64, 128), (3, 16, 64)])
+def test_conv_dgrad_pool_scatter_matches_autograd(shape):
+    """d1a-style: y = conv(maxpool(relu_bn_out)); gradient w.r.t. the pre-pool activation's conv output.  The aligned
+    shapes take the 16-byte epilogue, the ragged one the scalar path."""
     from popcorn_amd import ops
     from popcorn_amd import _lib as L
-    B, Hs, Ws = 2, 38, 53
+    B, Hs, Ws = shape
     pre = _mk(B, 8, Hs, Ws, seed=30).requires_grad_(True)         # conv output of the producing layer (pre-BN)
     gamma, beta, mean, var = _bn_params(8, 31)
     act = F.relu(F.batch_norm(pre, mean, var, gamma, beta, training=False, eps=1e-5))

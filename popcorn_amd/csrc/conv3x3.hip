@@ -85,7 +85,7 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 // EPI: extra work of the forward vector epilogue, as separate instantiations so that the other shapes keep their register
 // count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
 // write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
-enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2 };
+enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3 };   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
 template <int CIN, int COUT, int MODE, int LD, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     auto epilogue = [&]() {
         // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + (u&1)*16 + 4*lk + r), r = 0..3
         if (ey0 >= p.H) return;
-        if (MODE == MODE_DGRAD && p.pool && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W)) {
+        constexpr bool POOLB = MODE == MODE_DGRAD && EPI == EPI_POOLBWD;   // p.pool, as a compile-time property
+        if (POOLB && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W)) {
             // MaxPool2d(2) backward on an interior strip of aligned tensors: the lane's four pooled pixels cover 8 x 2
             // full-resolution pixels = two 16-byte pieces per row of `act` and of the accumulated output (the scalar path
             // below issues 12 four-byte accesses per pooled pixel; these two launches were 127 us of the step)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             }
             return;
         }
-        const bool full = p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W) && !p.pool;
+        const bool full = !POOLB && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W);
         if (full) {
             // interior strip, aligned tensors: no bounds checks, 16-byte accesses only
             float* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0 + 4 * lk;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         const float o = v[r] * e_scale[nb] + e_shift[nb];
                         if (x + r < p.W) op[r] = p.relu ? fmaxf(o, 0.f) : o;
                     }
-                } else if (!p.pool) {
+                } else if (!POOLB) {
                     float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
                     const float* ap = act ? act + eb * a_bs + co * a_cs + (int64_t)y * a_rs + x : nullptr;
 #pragma unroll
@@ -553,6 +554,10 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
         bool dot = false;
         for (int i = 0; i < nprob; ++i) dot = dot || p.pr[i].dot_w != nullptr;
         if (dot) return launch_conv_po<CIN, COUT, MODE, LD, EPI_DOT>(p, nprob, stream);
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+        // the pool-backward epilogues live in their own instantiation: in the plain one they cost a wave per SIMD
+        if (p.pool) return launch_conv_po<CIN, COUT, MODE, LD, EPI_POOLBWD>(p, nprob, stream);
     }
     return launch_conv_po<CIN, COUT, MODE, LD, EPI_NONE>(p, nprob, stream);
 }

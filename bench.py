@@ -175,6 +175,7 @@ def main():
     rank, local_rank, world = init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    local_rank %= max(1, torch.cuda.device_count())     # (functional runs with more ranks than GPUs share a device)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch

@@ -187,3 +187,33 @@ def test_head_bwd_vs_oracle_autograd(sparse, shape):
                                    g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
                                    g_scale_const=torch.tensor([g_const], device="cuda"))
     assert all(torch.equal(a, b) for a, b in zip(grads, grads2)) and torch.equal(g_feat, g_feat2)
+
+
+@pytest.mark.parametrize("case", ["regions", "empty_selection", "no_occupancy"])
+@pytest.mark.parametrize("C_", [16, 2])
+def test_building_score_mask_equals_the_two_separate_ops(case, C_):
+    """pc_building_score_mask (one launch) == pc_outconv_sigmoid_crop + pc_sparsity_mask, bit for bit: building score, mask
+    and {nsel, nregion}; incl. the batch-wide empty selection (popcorn.py:374-375 fallback) and repeated calls (the
+    library-owned accumulator is re-zeroed per call)."""
+    from popcorn_amd import ops
+    B, H, W, pad = 3, 37, 52, 14
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(B, C_, H + 2 * pad, W + 2 * pad, generator=g).cuda()
+    w = torch.randn(C_, generator=g).cuda()
+    bias = torch.randn(1, generator=g).cuda()
+    admin = torch.randint(1, 4, (B, H, W), generator=g).float().cuda()
+    census = torch.tensor([1, 2, 3], dtype=torch.int64).cuda()
+    if case == "empty_selection":
+        census = torch.tensor([7, 8, 9], dtype=torch.int64).cuda()          # no pixel belongs to the regions asked for
+    rowsel = (torch.rand(H, generator=g) < 0.5).to(torch.uint8).cuda()
+    colsel = (torch.rand(W, generator=g) < 0.5).to(torch.uint8).cuda()
+    occ = case != "no_occupancy"
+    rb = ops.outconv_sigmoid_crop(feat, w, bias, H, W, pad, pad)
+    rm, rc = ops.sparsity_mask(rb, admin, census, rowsel, colsel, occ)
+    for _ in range(3):
+        b2, m2, c2 = ops.building_score_mask(feat, w, bias, H, W, pad, pad, admin, census, rowsel, colsel, occ)
+        assert torch.equal(b2, rb) and torch.equal(m2, rm) and c2.tolist() == rc.tolist()
+    if case == "empty_selection":
+        assert rc.tolist() == [0, 0] and int(rm.sum()) == 0
+    else:
+        assert rc[0].item() == int(rm.sum()) > 0

@@ -26,6 +26,7 @@ constexpr int IN_COL0 = 4;                   // LDS column of tile x0 (16-byte a
 constexpr int G_RS = 34;                     // == 2 mod 32
 constexpr int G_CS = 16 * G_RS + 4;          // 548 == 4 mod 32
 constexpr int MAX_WG = 256;
+constexpr int PC_WGRAD_SINGLE_WG = 512;      // workgroups of a single-problem launch (256 / 512 / 1024 / 2048 measured: 2.098 / 2.083 / 2.085 / 2.099 ms per step)
 
 struct WgradArgs {
     pc_src a, b, g;
@@ -504,6 +505,14 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     int nwg, nchunk;
     const int kind = prepare_wgrad<CINC, COUT>(p, Cin, ws, nwg, nchunk);
     if (kind != 0) {
+        // A single-problem launch (the first layers: their Cin differs per stream, so they cannot be grouped) gets the
+        // workgroups a grouped launch would spread over its problems -- as many partials as the workspace slice holds
+        // (it is sized for the largest layer), at most PC_WGRAD_SINGLE_WG; launch_wgrad_wave caps it to one resident round.
+        const int64_t room = (int64_t)MAX_WG * (2 * 12 * 256 + 128) / ((int64_t)Cfg::EC * nchunk);
+        int want = PC_WGRAD_SINGLE_WG;
+        if (want > room) want = (int)room;
+        if (want > p.ntiles) want = p.ntiles;
+        if (want > nwg) nwg = want;
         WgradGroup g{};
         g.pr[0] = p;
         const int rc = launch_wgrad_wave<CINC, COUT>(g, 1, kind, nwg, nchunk, stream);

@@ -126,18 +126,35 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     const int g_begin = (blockIdx.x * 4 + wave) * p.groups_per_wave;
     int g_end = g_begin + p.groups_per_wave;
     if (g_end > p.groups) g_end = p.groups;
+    // The inputs of group g + 1 (mask byte, 4 feature values per lane) are loaded while group g runs its MFMA chain: the
+    // gather is unconditional (clamped pixel) so that it does not sit behind the selection branch.
+    auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
+        const int q = g * 16 + li;
+        const bool valid = q < HW && g < g_end;
+        const int qc = valid ? q : 0;
+        sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
+        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = fp[(4 * j + lk) * p.feat.cstride];
+            xv[j] = valid ? v : 0.f;
+        }
+    };
+    bool sel_n = false;
+    float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g_begin < g_end) fetch(g_begin, sel_n, xv_n);
     for (int g = g_begin; g < g_end; ++g) {
         const int q = g * 16 + li;
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
-        const bool sel = valid && (p.mask ? p.mask[pix] != 0 : true);
+        const bool sel = sel_n;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xv_n[j];
+        fetch(g + 1, sel_n, xv_n);
         float outv = 0.f;
         if (__any(sel)) {
-            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-            const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
-            float xv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = valid ? fp[(4 * j + lk) * p.feat.cstride] : 0.f;
             f32x4 h[4], acc[4];
             head_layer1(lds, L_A1, L_B0, lane, lk, xv, h);
             relu4(h);

@@ -25,14 +25,13 @@ def calculate_input_channels(args) -> int:
     return 2 * bool(args.Sentinel1) + 1 * bool(args.NIR) + 3 * bool(args.Sentinel2)
 
 
+_CTOR_FLAGS = ("feature_extractor", "occupancymodel", "pretrained", "biasinit", "sentinelbuildings")
+
+
 def get_model_kwargs(args, model_name: str) -> Dict[str, Any]:
+    """Constructor kwargs of ``model_dict[model_name]`` from the parsed flags (get_model.py:35-61); unknown names raise."""
     if model_name not in model_dict:
         raise ValueError(f"Model {model_name} not found in model dictionary")
-    return {
-        "input_channels": calculate_input_channels(args),
-        "feature_extractor": args.feature_extractor,
-        "occupancymodel": args.occupancymodel,
-        "pretrained": args.pretrained,
-        "biasinit": args.biasinit,
-        "sentinelbuildings": args.sentinelbuildings,
-    }
+    kwargs = {"input_channels": calculate_input_channels(args)}
+    kwargs.update((name, getattr(args, name)) for name in _CTOR_FLAGS)
+    return kwargs

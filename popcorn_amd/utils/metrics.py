@@ -1,18 +1,22 @@
-"""utils/metrics.py:12-24 surface: ``get_test_metrics(pred, y, tag)`` on census-level vectors."""
+"""Census-level evaluation metrics with the key names the reference logs (utils/metrics.py:12-24):
+``get_test_metrics(pred, y, tag)`` -> {"Population_<tag>/<metric>": tensor}."""
 import torch
-import torch.nn.functional as F
 
 from .losses import mape_func, r2
 
+# metric name -> function of (pred, y, log1p(pred), log1p(y)); insertion order = the reference's key order
+_METRICS = (
+    ("l1_loss", lambda p, y, lp, ly: (p - y).abs().mean()),
+    ("r2", lambda p, y, lp, ly: r2(p, y)),
+    ("mape", lambda p, y, lp, ly: mape_func(p, y)),
+    ("log_l1_loss", lambda p, y, lp, ly: (lp - ly).abs().mean()),
+    ("mse_loss", lambda p, y, lp, ly: (p - y).square().mean()),
+    ("log_mse_loss", lambda p, y, lp, ly: (lp - ly).square().mean()),
+    ("Correlation", lambda p, y, lp, ly: torch.corrcoef(torch.stack((p, y)))[0, 1]),
+)
+
 
 def get_test_metrics(pred, y, tag=""):
-    log_dict = {
-        "l1_loss": F.l1_loss(pred, y),
-        "r2": r2(pred, y),
-        "mape": mape_func(pred, y),
-        "log_l1_loss": F.l1_loss(torch.log(pred + 1), torch.log(y + 1)),
-        "mse_loss": F.mse_loss(pred, y),
-        "log_mse_loss": F.mse_loss(torch.log(pred + 1), torch.log(y + 1)),
-        "Correlation": torch.corrcoef(torch.stack([pred, y]))[0, 1],
-    }
-    return {"Population_" + tag + "/" + key: value for key, value in log_dict.items()}
+    lp, ly = torch.log(pred + 1), torch.log(y + 1)
+    prefix = f"Population_{tag}/"
+    return {prefix + name: fn(pred, y, lp, ly) for name, fn in _METRICS}

@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         bn_raw[nb][4] = has_bn && q.bn.gamma ? q.bn.beta[c] : 0.f;
     }
     {
-        for (int e = tid; e < 4 * W_DYS; e += 256) w2[e] = 0.f;
-        __syncthreads();
+        // only the dy = 3 plane has to be zero (the pad floats of the other planes are never read): disjoint from the weight
+        // writes below, so one barrier covers both
+        for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
 #pragma unroll
         for (int k = 0; k < NWR; ++k) {
             const int e = tid + k * 256;

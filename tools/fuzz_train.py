@@ -1,0 +1,49 @@
+"""Random tile geometries through the fused train step vs the CPU oracle's loss and 56 gradients (ad-hoc fuzz)."""
+import os, sys, random
+sys.path.insert(0, os.getcwd())
+import torch
+from oracle import popcorn_oracle as O
+from popcorn_amd import ops
+from popcorn_amd.data import stats
+from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+from popcorn_amd.model import POPCORN
+from popcorn_amd.train import FusedTrainStep
+rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+special = [(2, 100, 100), (1, 36, 68), (2, 64, 64), (1, 98, 98), (2, 50, 82)]
+worst = 0.0
+bad = 0
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
+    B, H, W = special[it] if it < len(special) else (rnd.randint(1, 3), rnd.randint(40, 120), rnd.randint(40, 120))
+    torch.manual_seed(1600)
+    model = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = make_raw_batch(B, H, W, seed=100 + it, region="disc" if it % 2 else "full")
+    x_ref = select_normalize_reference(batch["raw"])
+    x = ops.select_normalize(batch["raw"].cuda(), stats.BAND6, stats.MEAN6, stats.STD6)
+    sample = {"input": x, "admin_mask": batch["admin_mask"].cuda(), "census_idx": batch["census_idx"].cuda(), "y": batch["y"].cuda()}
+    tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+    torch.manual_seed(3)
+    loss = tr.step(sample)
+    torch.cuda.synchronize()
+    torch.manual_seed(3)
+    ref_loss, ref_out, ref_grads, _ = O.train_step_grads(sd, {"input": x_ref, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]})
+    w = max((tr.grads[n].cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-3) for n, r in ref_grads.items())
+    le = abs(loss[0].item() - ref_loss.item()) / max(1.0, abs(ref_loss.item()))
+    worst = max(worst, w, le)
+    print(f"B={B} H={H} W={W} region={'disc' if it % 2 else 'full'}: loss rel err {le:.2e}, worst grad rel err {w:.2e}", flush=True)
+    if not (w < 2e-4 and le < 1e-4):
+        # the backward pass has discrete decisions (max-pool arg-max, ReLU masks): a value within rounding of a tie flips
+        # them in ONE of two fp32 evaluations.  Ask the oracle again in fp64 and see which fp32 result it sides with.
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        torch.manual_seed(3)
+        _, _, g64, _ = O.train_step_grads(sd64, {"input": x_ref.double(), "admin_mask": batch["admin_mask"].double(),
+                                                 "census_idx": batch["census_idx"], "y": batch["y"].double()})
+        rel = lambda a, r: ((a.double() - r).abs().max() / max(r.abs().max().item(), 1e-3)).item()  # noqa: E731
+        w_hip = max(rel(tr.grads[n].cpu(), g64[n]) for n in g64)
+        w_o32 = max(rel(ref_grads[n], g64[n]) for n in g64)
+        print(f"    vs the fp64 oracle: HIP {w_hip:.2e}, fp32 oracle {w_o32:.2e}")
+        if w_hip < 2e-4:
+            print("    -> the fp32 oracle took the other side of a tie; the HIP gradients match exact arithmetic")
+        else:
+            bad += 1
+print("worst", worst, "cases out of tolerance:", bad)

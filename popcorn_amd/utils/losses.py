@@ -4,10 +4,7 @@ These are O(batch) scalar reductions on B-element vectors (plus one mean over th
 they are host-side glue in torch ops, device-agnostic.  The fused training path (popcorn_amd/train.py) computes the
 same optimisation loss and its gradient in one HIP kernel instead (pc_loss_fwd_bwd) and never calls ``.item()``.
 """
-from collections import defaultdict
-
 import torch
-import torch.nn.functional as F
 
 
 def mape_func(pred, gt, eps=1e-8):
@@ -24,37 +21,44 @@ def r2(pred, gt, eps=1e-8):
     return 1 - ss_res / (ss_tot + eps)
 
 
-def get_loss(output, gt, scale=None, loss=["l1_loss"], lam=[1.0], tag="", scale_regularization=0.0):
-    """utils/losses.py:12-88: weighted sum of population losses + scale regularisation; auxdict of floats
-    (``.item()`` -> device sync, exactly like the reference)."""
-    auxdict = defaultdict(float)
-    for k in ("popcount", "popdensemap", "scale"):
-        if output.get(k) is not None and output[k].dtype != torch.float32:
-            output[k] = output[k].float()
-    y_pred, y_gt = output["popcount"], gt["y"]
-    metricdict = {
-        "l1_loss": F.l1_loss(y_pred, y_gt),
-        "log_l1_loss": F.l1_loss(torch.log(y_pred + 1), torch.log(y_gt + 1)),
-        "mse_loss": F.mse_loss(y_pred, y_gt),
-        "log_mse_loss": F.mse_loss(torch.log(y_pred + 1), torch.log(y_gt + 1)),
-        "mr2": r2(y_pred, y_gt) if len(y_pred) > 1 else torch.tensor(0.0),
-        "mape": mape_func(y_pred, y_gt),
-        "mCorrelation": torch.corrcoef(torch.stack([y_pred, y_gt]))[0, 1] if len(y_pred) > 1 else torch.tensor(0.0),
+def _population_terms(pred, y):
+    """The per-batch population metrics of get_loss (utils/losses.py:49-60), keyed as the reference logs them."""
+    lp, ly = torch.log(pred + 1), torch.log(y + 1)
+    several = len(pred) > 1                      # R2 / Pearson need at least two samples (losses.py:57,59)
+    zero = torch.tensor(0.0)
+    return {
+        "l1_loss": (pred - y).abs().mean(),
+        "log_l1_loss": (lp - ly).abs().mean(),
+        "mse_loss": (pred - y).square().mean(),
+        "log_mse_loss": (lp - ly).square().mean(),
+        "mr2": r2(pred, y) if several else zero,
+        "mape": mape_func(pred, y),
+        "mCorrelation": torch.corrcoef(torch.stack((pred, y)))[0, 1] if several else zero,
     }
-    optimization_loss = torch.tensor(0, device=y_pred.device, dtype=y_pred.dtype)
-    for lo, la in zip(loss, lam):
-        if lo in metricdict:
-            optimization_loss = optimization_loss + metricdict[lo] * la
+
+
+def get_loss(output, gt, scale=None, loss=["l1_loss"], lam=[1.0], tag="", scale_regularization=0.0):
+    """utils/losses.py:12-88: weighted sum of the selected population losses + ``scale_regularization * mean|scale|``;
+    returns (optimisation loss tensor, {"Population[_tag]/<metric>": float, "optimization_loss": float}).  The float
+    conversion synchronises the device, exactly like the reference (the fused step avoids it)."""
+    for key in ("popcount", "popdensemap", "scale"):
+        t = output.get(key)
+        if t is not None and t.dtype != torch.float32:
+            output[key] = t.float()
+    pred = output["popcount"]
+    terms = _population_terms(pred, gt["y"])
+    total = torch.zeros((), device=pred.device, dtype=pred.dtype)
+    for name, weight in zip(loss, lam):
+        if name in terms:
+            total = total + weight * terms[name]
     if scale is not None:
-        if torch.isnan(scale).any():
-            raise ValueError("nan values detected in scale.")
-        if torch.isinf(scale).any():
-            raise ValueError("inf values detected in scale.")
-        metricdict["scale"] = scale.float().abs().mean()
+        for bad, what in ((torch.isnan, "nan"), (torch.isinf, "inf")):
+            if bad(scale).any():
+                raise ValueError(f"{what} values detected in scale.")
+        terms["scale"] = scale.float().abs().mean()
         if scale_regularization > 0.0:
-            optimization_loss = optimization_loss + scale_regularization * metricdict["scale"]
-    pre = "Population/" if tag == "" else "Population_" + tag + "/"
-    auxdict = {**auxdict, **{pre + key: value for key, value in metricdict.items()}}
-    auxdict["optimization_loss"] = optimization_loss
-    auxdict = {key: value.detach().item() for key, value in auxdict.items()}
-    return optimization_loss, auxdict
+            total = total + scale_regularization * terms["scale"]
+    prefix = "Population/" if tag == "" else f"Population_{tag}/"
+    log = {prefix + name: value.detach().item() for name, value in terms.items()}
+    log["optimization_loss"] = total.detach().item()
+    return total, log

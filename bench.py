@@ -130,7 +130,7 @@ def cpu_baseline(torch, sd, cpu_batch, iters):
     """The oracle (CPU restatement of the reference path, oracle/popcorn_oracle.py) timed on the host cores on a
     bounded sample of the same workload: `iters` train steps (fwd + loss + bwd + clip + Adam) at B=cpu_batch."""
     from oracle import popcorn_oracle as O
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -138,7 +138,7 @@ def cpu_baseline(torch, sd, cpu_batch, iters):
     cores = max(1, min(avail, 32))          # oneDNN stops scaling (and oversubscription thrashes) beyond a few dozen threads
     torch.set_num_threads(cores)
     batch = make_raw_batch(cpu_batch, 100, 100, seed=1600)
-    sample = {"input": select_normalize_reference(batch["raw"]), "admin_mask": batch["admin_mask"],
+    sample = {"input": O.select_normalize(batch["raw"]), "admin_mask": batch["admin_mask"],
               "census_idx": batch["census_idx"], "y": batch["y"]}
     params, state = dict(sd), {}
 

@@ -33,11 +33,3 @@ def make_raw_batch(B, H=100, W=100, seed=1600, device="cpu", region="full"):
     out = {"raw": raw, "admin_mask": admin, "census_idx": ids, "y": y}
     return {k: v.to(device) for k, v in out.items()}
 
-
-def select_normalize_reference(raw):
-    """Plain torch statement of the loader's band selection + apply_normalize (utils/utils.py:105-127) -- device
-    agnostic glue used for tests / CPU baselines; the HIP path is ops.select_normalize."""
-    x = raw[:, list(stats.BAND6)]
-    mean = torch.tensor(stats.MEAN6, device=raw.device).view(1, 6, 1, 1)
-    std = torch.tensor(stats.STD6, device=raw.device).view(1, 6, 1, 1)
-    return (x - mean) / std

@@ -119,7 +119,8 @@ class RandomGamma:
             if x.shape[cdim] == 3:
                 x = adjust_brightness(x, gamma)
             elif x.dim() == 4:
-                x = adjust_gamma(x, gamma)                   # the per-channel loop of the reference, all channels at once
+                for i in range(x.shape[1]):                  # channel by channel like the reference (transform.py:220-221):
+                    x[:, i:i + 1] = adjust_gamma(x[:, i:i + 1], gamma)      # bit-equal to it on CPU (fixture g10)
             else:
                 # 3-D input with C != 3: the reference loops over range(x.shape[1]) but slices dim 0 (transform.py:207-208)
                 x = x.clone()

@@ -341,9 +341,201 @@ def g8_single_modality(popcorn, losses):
     np.savez_compressed(os.path.join(OUT, "g8_single_modality.npz"), **out)
 
 
+def _stub_rasterio():
+    for name in ("rasterio", "rasterio.warp", "rasterio.windows", "rasterio.features", "rasterio.transform", "rasterio.crs",
+                 "rasterio.enums"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["rasterio.warp"].transform_geom = None
+    sys.modules["rasterio.windows"].Window = object
+    sys.modules["rasterio"].windows = sys.modules["rasterio.windows"]
+
+
+def g9_census():
+    """The REAL ``Population_Dataset.convert_popmap_to_census(gpu_mode=False)`` and ``adjust_map_to_census``
+    (data/PopulationDataset.py:675-852) on a seeded raster.  Both only need ``rasterio.open(path).read(1)`` and a census
+    CSV: a fake ``rasterio.open`` (context manager whose ``read(1)`` returns the seeded boundary raster) and a temporary
+    CSV stand in for the GeoTIFF / file I/O; the arithmetic is the reference's own."""
+    import tempfile
+    import pandas as pd
+    _stub_rasterio()
+    import data.PopulationDataset as PD
+    out = {}
+    for name, seed, h, w, nreg in [("a", 91, 96, 120, 13), ("b", 92, 257, 190, 40)]:
+        g = torch.Generator().manual_seed(seed)
+        # blocky region map: ids 1..nreg on a coarse grid, 0 = no-data, one id that never occurs, one region of all zeros
+        gy, gx = max(1, h // 12), max(1, w // 10)
+        coarse = torch.randint(0, nreg + 1, ((h + gy - 1) // gy, (w + gx - 1) // gx), generator=g)
+        boundary = coarse.repeat_interleave(gy, 0).repeat_interleave(gx, 1)[:h, :w].contiguous().to(torch.int32)
+        pred = torch.rand(h, w, generator=g) * 3.0
+        pred[torch.rand(h, w, generator=g) < 0.4] = 0.0
+        zero_id = int(boundary[h // 2, w // 2])
+        pred[boundary == zero_id] = 0.0              # a region whose prediction sums to exactly 0 (adjust skips it)
+        ids, bbox, pop, count = [], [], [], []
+        for cid in list(range(1, nreg + 1)) + [nreg + 5]:      # nreg + 5: a census row whose id is absent from the raster
+            m = boundary == cid
+            if m.any():
+                xs, ys = torch.where(m)
+                bb = (int(xs.min()), int(xs.max()) + 1, int(ys.min()), int(ys.max()) + 1)
+            else:
+                bb = (0, 1, 0, 1)
+            ids.append(cid)
+            bbox.append(str(bb))
+            pop.append(float(torch.rand(1, generator=g).item() * 900.0))
+            count.append(int(m.sum()))
+        tmp = tempfile.mkdtemp()
+        csv = os.path.join(tmp, "census.csv")
+        pd.DataFrame({"idx": ids, "bbox": bbox, "POP20": pop, "count": count}).to_csv(csv, index=False)
+
+        class FakeSrc:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+            def read(self, band):
+                assert band == 1
+                return boundary.numpy().copy()
+
+        PD.rasterio.open = lambda path, mode="r": FakeSrc()
+
+        class Dummy:
+            pass
+
+        d = Dummy()
+        d.file_paths = {"fine": {"boundary": "boundary.tif", "census": csv}}
+        d.train_level = "fine"
+        cp, cg = PD.Population_Dataset.convert_popmap_to_census(d, pred.clone(), gpu_mode=False, level="fine")
+        adj = PD.Population_Dataset.adjust_map_to_census(d, pred.clone())
+        cp2, _ = PD.Population_Dataset.convert_popmap_to_census(d, adj.clone(), gpu_mode=False, level="fine")
+        out[f"{name}/pred"], out[f"{name}/boundary"] = np_(pred), np_(boundary)
+        out[f"{name}/census_idx"] = np.array(ids, dtype=np.int64)
+        out[f"{name}/census_bbox"] = np.array([list(map(int, b.strip("()").split(","))) for b in bbox], dtype=np.int64)
+        out[f"{name}/census_pop"] = np.array(pop, dtype=np.float64)
+        out[f"{name}/census_pred"], out[f"{name}/census_gt"] = np_(cp), np_(cg)
+        out[f"{name}/adjusted"] = np_(adj)
+        out[f"{name}/census_pred_adjusted"] = np_(cp2)
+    np.savez_compressed(os.path.join(OUT, "g9_census.npz"), **out)
+
+
+def _stub_torchvision():
+    """torchvision is absent from this image.  The five functionals utils/transform.py calls are restated here from
+    torchvision's published float-tensor definitions (torchvision/transforms/_functional_tensor.py; requirements.txt of
+    the reference does not pin a version, the definitions have been stable since 0.8):
+      vflip = flip(-2), hflip = flip(-1);
+      adjust_brightness(img, f) = _blend(img, zeros, f) = clamp(f * img, 0, 1);
+      adjust_gamma(img, g, gain=1) = clamp(gain * img ** g, 0, 1);
+      rotate(img, angle, expand=True[, fill]) for angle in {90, 180, 270} = the exact counter-clockwise quarter turns
+        (nearest-neighbour affine grid through pixel centres; `fill` never shows for right angles with expand=True).
+    Everything ELSE -- which functional is called when, on what, with which random draws -- is the reference's code."""
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tf = types.ModuleType("torchvision.transforms.functional")
+    tf.vflip = lambda img: img.flip(-2)
+    tf.hflip = lambda img: img.flip(-1)
+    tf.adjust_brightness = lambda img, f: (img * f).clamp(0.0, 1.0)
+    tf.adjust_gamma = lambda img, gamma, gain=1: (gain * img.pow(gamma)).clamp(0.0, 1.0)
+
+    def rotate(img, angle, interpolation=None, expand=False, center=None, fill=None):
+        assert angle % 90 == 0 and (expand or img.shape[-1] == img.shape[-2])
+        return torch.rot90(img, (angle // 90) % 4, dims=(-2, -1))
+
+    tf.rotate = rotate
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    tvt.Compose = Compose
+    tvt.functional = tf
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.functional"] = tf
+    return tvt
+
+
+def g10_transform():
+    """The reference's augmentation classes (utils/transform.py:54-276) and ``apply_transformations_and_normalize``
+    (utils/utils.py:105-214) with the trainer's transform set (run_train.py:386-402), on seeded inputs.  torchvision's
+    functionals are restated (see _stub_torchvision); ``Tensor.cuda`` is the identity (utils.py:115-121 hard-code it)."""
+    import json
+    import random
+    tvt = _stub_torchvision()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import utils.transform as T
+    import utils.utils as U
+    out = {}
+    g = torch.Generator().manual_seed(101)
+    s2 = torch.randint(0, 10000, (3, 4, 9, 7), generator=g).float()
+    s2[0, 0, 0, :3] = -5.0                                      # negative digital numbers: clipped by RandomGamma only
+    out["s2"] = np_(s2)
+    x6 = torch.randn(3, 6, 9, 7, generator=g)
+    mk = torch.randint(-1, 4, (3, 2, 9, 7), generator=g).float()
+    out["x6"], out["mask"] = np_(x6), np_(mk)
+
+    def seeded(seed):
+        torch.manual_seed(seed)
+        random.seed(seed)
+
+    for seed in range(6):
+        seeded(seed)
+        out[f"brightness/{seed}"] = np_(T.RandomBrightness(p=0.9, beta_limit=(0.666, 1.5))(s2.clone()))
+        seeded(seed)
+        out[f"gamma/{seed}"] = np_(T.RandomGamma(p=0.9, gamma_limit=(0.6666, 1.5))(s2.clone()))
+        seeded(seed)
+        out[f"gamma3/{seed}"] = np_(T.RandomGamma(p=0.9, gamma_limit=(0.6666, 1.5))(s2[:, :3].clone()))   # RGB quirk
+        seeded(seed)
+        out[f"s2compose/{seed}"] = np_(T.OwnCompose([T.RandomBrightness(p=0.9, beta_limit=(0.666, 1.5)),
+                                                     T.RandomGamma(p=0.9, gamma_limit=(0.6666, 1.5))])(s2.clone()))
+        for cname, cls in (("vflip", T.RandomVerticalFlip), ("hflip", T.RandomHorizontalFlip)):
+            for allsame in (True, False):
+                seeded(seed)
+                a, b = cls(p=0.5, allsame=allsame)((x6.clone(), mk.clone()))
+                out[f"{cname}/same{int(allsame)}/{seed}/x"], out[f"{cname}/same{int(allsame)}/{seed}/mask"] = np_(a), np_(b)
+        seeded(seed)
+        a, b = T.RandomRotationTransform(angles=[90, 180, 270], p=0.75)((x6.clone(), mk.clone()))
+        out[f"rot/{seed}/x"], out[f"rot/{seed}/mask"] = np_(a), np_(b)
+    # whole pipeline as the trainer runs it (run_train.py:186-188)
+    with open(os.path.join(REF, "data/config/dataset_stats.json")) as fh:
+        stats = json.load(fh)
+    for mkey in stats:
+        if isinstance(stats[mkey], dict):
+            for key, val in stats[mkey].items():
+                stats[mkey][key] = torch.tensor(val)
+    transform = {"general": tvt.Compose([T.RandomVerticalFlip(p=0.5, allsame=True), T.RandomHorizontalFlip(p=0.5, allsame=True),
+                                         T.RandomRotationTransform(angles=[90, 180, 270], p=0.75)]),
+                 "S2": T.OwnCompose([T.RandomBrightness(p=0.9, beta_limit=(0.666, 1.5)),
+                                     T.RandomGamma(p=0.9, gamma_limit=(0.6666, 1.5))]),
+                 "S1": tvt.Compose([])}
+    s1 = torch.randn(3, 2, 9, 7, generator=g) * 5.0 - 12.0
+    admin = torch.randint(-1, 5, (3, 9, 7), generator=g).float()
+    out["pipe/S2"], out["pipe/S1"], out["pipe/admin_mask"] = np_(s2), np_(s1), np_(admin)
+    for seed in range(6):
+        seeded(seed + 40)
+        smp = {"S2": s2.clone(), "S1": s1.clone(), "admin_mask": admin.clone()}
+        r = U.apply_transformations_and_normalize(smp, transform, stats)
+        out[f"pipe/{seed}/input"], out[f"pipe/{seed}/admin_mask"] = np_(r["input"].contiguous()), np_(r["admin_mask"].contiguous())
+    smp = {"S2": s2.clone(), "S1": s1.clone(), "admin_mask": admin.clone()}
+    r = U.apply_transformations_and_normalize(smp, None, stats)            # validation / test path: normalise only
+    out["pipe/none/input"] = np_(r["input"].contiguous())
+    np.savez_compressed(os.path.join(OUT, "g10_transform.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     popcorn, networks, get_model, losses, metrics = import_reference()
+    only = set(sys.argv[1:])                    # e.g. `make_golden.py g9 g10`: regenerate just those fixture files
+    if only:
+        for tag, fn in (("g9", g9_census), ("g10", g10_transform)):
+            if tag in only:
+                fn()
+        return
     m = g1_weights(popcorn)
     g2_forward(popcorn, m)
     g3_layers(popcorn, m)
@@ -352,6 +544,8 @@ def main():
     g6_loss_metrics(losses, metrics)
     g7_dataset_helpers()
     g8_single_modality(popcorn, losses)
+    g9_census()
+    g10_transform()
     args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
                           pretrained=True, biasinit=0.9407, sentinelbuildings=True)
     kw = get_model.get_model_kwargs(args, "POPCORN")

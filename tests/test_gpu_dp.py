@@ -20,9 +20,9 @@ def _free_port():
 
 
 def _make(B, seed=3):
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     b = make_raw_batch(B, 64, 48, seed=seed, region="disc")
-    return {"input": select_normalize_reference(b["raw"]), "admin_mask": b["admin_mask"], "census_idx": b["census_idx"],
+    return {"input": O.select_normalize(b["raw"]), "admin_mask": b["admin_mask"], "census_idx": b["census_idx"],
             "y": b["y"]}
 
 

@@ -51,6 +51,42 @@ def test_census_sum_and_adjust_vs_reference_loop(shape, nreg):
     torch.testing.assert_close(adj.cpu(), ref_adj, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_census_kernels_vs_reference_fixture_g9(name):
+    """csrc/census.hip against outputs of the reference's own convert_popmap_to_census / adjust_map_to_census
+    (fixture g9: the real functions behind a fake rasterio.open; data/PopulationDataset.py:675-852).  The reference sums
+    each region in fp32 inside its bbox, the kernel accumulates fp64 over the whole raster in one pass: region sums
+    agree to fp32 round-off of the reference's own reduction (3e-6), the index path (which pixels belong to a region,
+    which regions are skipped) exactly."""
+    from popcorn_amd import eval as E
+    g = np.load(os.path.join(G, "g9_census.npz"))
+    pred = torch.from_numpy(g[f"{name}/pred"]).cuda()
+    boundary = torch.from_numpy(g[f"{name}/boundary"]).cuda()
+    idx = g[f"{name}/census_idx"].tolist()
+    pop = g[f"{name}/census_pop"]
+    cp, cg = E.convert_popmap_to_census(pred, boundary, idx, pop)
+    ref = g[f"{name}/census_pred"]
+    np.testing.assert_allclose(cp.cpu().numpy(), ref, rtol=3e-6, atol=1e-5)
+    assert np.array_equal(cp.cpu().numpy() == 0, ref == 0)            # absent ids / all-zero regions: exactly 0, as in the reference
+    assert np.array_equal(cg.cpu().numpy(), g[f"{name}/census_gt"])
+    adj = E.adjust_map_to_census(pred.clone(), boundary, idx, pop)
+    radj = g[f"{name}/adjusted"]
+    np.testing.assert_allclose(adj.cpu().numpy(), radj, rtol=4e-6, atol=1e-6)
+    assert np.array_equal(adj.cpu().numpy() == g[f"{name}/pred"], radj == g[f"{name}/pred"])   # same pixels left untouched
+    cp2, _ = E.convert_popmap_to_census(adj, boundary, idx, pop)
+    np.testing.assert_allclose(cp2.cpu().numpy(), g[f"{name}/census_pred_adjusted"], rtol=1e-5, atol=1e-4)
+
+
+def test_select_normalize_vs_reference_fixture_g10():
+    """pc_select_normalize against the reference's apply_transformations_and_normalize(transform=None) output."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    g = np.load(os.path.join(G, "g10_transform.npz"))
+    raw = torch.cat([torch.from_numpy(g["pipe/S2"]), torch.from_numpy(g["pipe/S1"])], 1).contiguous().cuda()
+    x = ops.select_normalize(raw, (0, 1, 2, 3, 4, 5), stats.MEAN6, stats.STD6)
+    np.testing.assert_allclose(x.cpu().numpy(), g["pipe/none/input"], rtol=1e-6, atol=1e-6)
+
+
 def test_census_properties_large_raster():
     """BASELINE-scale raster (2048 x 4096, 20k regions): checksum of checksums + idempotence."""
     from popcorn_amd import eval as E

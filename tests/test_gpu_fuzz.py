@@ -41,14 +41,14 @@ def test_forward_random_geometry(pair, B, H, W, padding):
 def test_train_step_random_geometry(B, H, W, disc):
     from popcorn_amd import ops
     from popcorn_amd.data import stats
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     from popcorn_amd.model import POPCORN
     from popcorn_amd.train import FusedTrainStep
     torch.manual_seed(1600)
     model = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     batch = make_raw_batch(B, H, W, seed=H * 1000 + W, region="disc" if disc else "full")
-    x_ref = select_normalize_reference(batch["raw"])
+    x_ref = O.select_normalize(batch["raw"])
     x = ops.select_normalize(batch["raw"].cuda(), stats.BAND6, stats.MEAN6, stats.STD6)
     tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
     torch.manual_seed(3)

@@ -28,10 +28,10 @@ def pair():
 
 def test_config2_batch64_forward_parity(pair):
     """BASELINE config[1]: batch=64 synthetic S1+S2 100x100 tiles, full DDA_model + sparse-head forward, vs CPU."""
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     m, sd = pair
     b = make_raw_batch(64, 100, 100, seed=1600, region="disc")
-    x = select_normalize_reference(b["raw"])
+    x = O.select_normalize(b["raw"])
     cpu = {"input": x, "admin_mask": b["admin_mask"], "census_idx": b["census_idx"]}
     torch.manual_seed(7)
     with torch.no_grad():
@@ -47,9 +47,9 @@ def test_config2_batch64_forward_parity(pair):
 
 def test_config1_single_tile_eval_call(pair):
     """BASELINE config[0]: one 100x100 tile, eval-style call (run_eval.py:109)."""
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     m, sd = pair
-    x = select_normalize_reference(make_raw_batch(1, 100, 100, seed=5)["raw"])
+    x = O.select_normalize(make_raw_batch(1, 100, 100, seed=5)["raw"])
     with torch.no_grad():
         ref = O.popcorn_forward(sd, {"input": x}, padding=False)
         out = m({"input": x.cuda()}, padding=False)
@@ -160,9 +160,9 @@ def test_config3_batch64_train_step_is_deterministic_and_graph_equals_eager():
     (1) bit-identical parameters from two independent runs (fixed-order reductions, no atomics on fp data),
     (2) HIP-graph replay == eager launches bit for bit, (3) the step moves the parameters and lowers the loss it
     optimises on a repeated batch."""
-    from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+    from popcorn_amd.data.synthetic import make_raw_batch
     batch = make_raw_batch(64, 100, 100, seed=1601)
-    sample = {"input": select_normalize_reference(batch["raw"]).cuda(), "admin_mask": batch["admin_mask"].cuda(),
+    sample = {"input": O.select_normalize(batch["raw"]).cuda(), "admin_mask": batch["admin_mask"].cuda(),
               "census_idx": batch["census_idx"].cuda(), "y": batch["y"].cuda()}
     results = []
     for use_graph in (False, False, True):

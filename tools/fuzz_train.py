@@ -5,7 +5,7 @@ import torch
 from oracle import popcorn_oracle as O
 from popcorn_amd import ops
 from popcorn_amd.data import stats
-from popcorn_amd.data.synthetic import make_raw_batch, select_normalize_reference
+from popcorn_amd.data.synthetic import make_raw_batch
 from popcorn_amd.model import POPCORN
 from popcorn_amd.train import FusedTrainStep
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
@@ -18,7 +18,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     model = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     batch = make_raw_batch(B, H, W, seed=100 + it, region="disc" if it % 2 else "full")
-    x_ref = select_normalize_reference(batch["raw"])
+    x_ref = O.select_normalize(batch["raw"])
     x = ops.select_normalize(batch["raw"].cuda(), stats.BAND6, stats.MEAN6, stats.STD6)
     sample = {"input": x, "admin_mask": batch["admin_mask"].cuda(), "census_idx": batch["census_idx"].cuda(), "y": batch["y"].cuda()}
     tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 1
+#define PC_ABI_VERSION 2
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -75,7 +75,8 @@ int pc_abi_version(void);
 /* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
 int pc_device_count(void);
 const char* pc_error_string(int code);
-/* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn (lets a binding verify its struct layout) */
+/* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn, 3 = pc_conv_fwd_desc, 4 = pc_adam_groups
+   (lets a binding verify its struct layout) */
 int pc_sizeof(int which);
 
 /* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
@@ -251,19 +252,35 @@ int pc_loss_fwd_bwd(const float* popcount, const float* y, const double* stats, 
 /* L2 norm of a flat gradient buffer (torch.nn.utils.clip_grad_norm_'s total_norm, run_train.py:233-234); deterministic. */
 int pc_grad_norm(const float* g, int n, float* norm_out, void* stream);
 
+/* Parameter groups of the flat buffer for the Adam step.  The reference gives the encoder (limit1) or the whole U-Net
+ * (limit2) no gradient on large samples (run_train.py:191-198; networks.py:124-132), and torch.optim.Adam skips a
+ * parameter whose .grad is None entirely: no weight decay, no moment update, no per-parameter step increment.  The flat
+ * buffer is cut into nseg consecutive segments [seg_end[i-1], seg_end[i]) (seg_end[nseg-1] == n), each belonging to one
+ * of PC_ADAM_GROUPS groups; groups whose bit is clear in active_mask are left untouched (p, m, v and the group's step
+ * counter), and step_dev is then int32[PC_ADAM_GROUPS] -- one counter per group, torch's per-parameter `step`. */
+#define PC_ADAM_MAX_SEG 8
+#define PC_ADAM_GROUPS 4
+typedef struct pc_adam_groups {
+    int32_t nseg;
+    int32_t seg_end[PC_ADAM_MAX_SEG];
+    int32_t seg_group[PC_ADAM_MAX_SEG];
+    int32_t active_mask;
+} pc_adam_groups;
+
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step over flat buffers (run_train.py:82-90,233-238).  Weight decay
  * (L2, added to the gradient) applies to elements [0, n_decay) only.  hyper_dev: device float[1] {lr};
- * step_dev: device int32 step counter, incremented by the call.  max_norm <= 0 or norm_dev == NULL: no clipping. */
+ * step_dev: device int32 step counter(s), incremented by the call (groups == NULL: one counter, everything updated).
+ * max_norm <= 0 or norm_dev == NULL: no clipping. */
 int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
                       float weight_decay, float beta1, float beta2, float eps, float max_norm,
-                      const float* norm_dev, int32_t* step_dev, void* stream);
+                      const float* norm_dev, int32_t* step_dev, const pc_adam_groups* groups, void* stream);
 
 /* The same in ONE launch: every workgroup computes the total norm of g itself (written to norm_out_dev if non-NULL), then
  * clips and updates; max_norm <= 0: no clipping.  g must be 16-byte aligned.  Must not run concurrently with itself on
  * two streams of one process (a device-side ticket decides which workgroup advances the step counter). */
 int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
                             float weight_decay, float beta1, float beta2, float eps, float max_norm,
-                            float* norm_out_dev, int32_t* step_dev, void* stream);
+                            float* norm_out_dev, int32_t* step_dev, const pc_adam_groups* groups, void* stream);
 
 /* Band selection + per-band (x - mean) / std: data/PopulationDataset.py:566-568 + utils/utils.py:105-127.
  * raw: B x Craw x H x W; out: B x 6 x H x W; band6/mean6/std6: host arrays of 6. */

@@ -65,6 +65,12 @@ class PcWgradReduceDesc(C.Structure):
 
 
 PC_MAX_GROUP = 4
+PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
+
+
+class PcAdamGroups(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("seg_end", C.c_int32 * PC_ADAM_MAX_SEG), ("seg_group", C.c_int32 * PC_ADAM_MAX_SEG),
+                ("active_mask", C.c_int32)]
 
 
 class PopcornHipError(RuntimeError):

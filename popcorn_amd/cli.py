@@ -62,6 +62,9 @@ def train_parser():
     p.add_argument("-w", "--num_workers", type=int, default=0)
     p.add_argument("-lt", "--logstep_train", type=int, default=25)
     p.add_argument("-val", "--val_every_n_epochs", type=int, default=2)
+    p.add_argument("-wv", "--weak_validation", action="store_true")
+    p.add_argument("-testi", "--test_every_i_steps", type=int, default=500000)
+    p.add_argument("-vi", "--val_every_i_steps", type=int, default=500000)
     p.add_argument("--seed", type=int, default=1600)
     p.add_argument("--save-model", default="both", choices=["last", "best", "no", "both"])
     p.add_argument("-mws", "--max_weak_samples", type=int, default=None)
@@ -71,6 +74,10 @@ def train_parser():
     p.add_argument("--torch_optimizer", action="store_true",
                    help="reference recipe through torch autograd + torch.optim.Adam instead of the fused HIP step")
     p.add_argument("--max_steps", type=int, default=None)
+    p.add_argument("--synthetic_val_regions", type=int, default=16, help="size of the synthetic weak-validation set")
+    p.add_argument("--test_raster_hw", type=int, nargs=2, default=[384, 448], help="synthetic target-test raster (test_target)")
+    p.add_argument("--test_patchsize", type=int, default=256)
+    p.add_argument("--test_overlap", type=int, default=32)
     return p
 
 
@@ -152,20 +159,31 @@ class Trainer:
         # host-side glue (collate, augmentation draws) is many tiny CPU ops: an OpenMP pool as wide as a 256-core host
         # costs more per op than the op itself
         torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+        if self.world > 1 and args.torch_optimizer:
+            raise SystemExit("--torch_optimizer is the single-process reference recipe: it has no gradient all-reduce; "
+                             "data-parallel runs use the fused step (drop the flag)")
         seed_all(args.seed)
         ds = SyntheticWeaksupDataset(args.synthetic_regions, seed=args.seed, fixed_hw=args.fixed_hw)
-        sampler = None
+        self.sampler = None
         if self.world > 1:
-            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
-                                                                      shuffle=True, seed=args.seed, drop_last=True)
+            self.sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
+                                                                           shuffle=True, seed=args.seed, drop_last=True)
         self.loader = torch.utils.data.DataLoader(ds, batch_size=args.weak_batch_size, num_workers=args.num_workers,
-                                                  shuffle=sampler is None, sampler=sampler,
+                                                  shuffle=self.sampler is None, sampler=self.sampler,
                                                   collate_fn=Population_Dataset_collate_fn, drop_last=True)
-        self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)
-        seed_all(args.seed + 2)
+        # weak validation set (run_train.py:410-414: a second Population_Dataset in weaksup mode, batch size -wvb)
+        self.val_loader = torch.utils.data.DataLoader(
+            SyntheticWeaksupDataset(args.synthetic_val_regions, seed=args.seed + 77, fixed_hw=args.fixed_hw),
+            batch_size=args.weak_val_batch_size, shuffle=False, collate_fn=Population_Dataset_collate_fn, drop_last=False)
+        self._test_raster = None
+        self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)   # same seed: same init on every rank
+        # from here on the CPU generators feed per-rank randomness (augmentation coins, the 60x60 sparsity grid of
+        # get_sparsity_mask): every rank gets its own stream, rank 0 keeps the single-process one
+        seed_all(args.seed + 2 + 1000 * self.rank)
         self.data_transform = default_train_transform()                    # run_train.py:386-402
         self.reducer = FlatReducer()
         self.info = {"epoch": 0, "iter": 0, "sampleitr": 0}
+        self._r2buf = collections.deque()
         if args.torch_optimizer:
             head_name = ["head.6.weight", "head.6.bias"]                     # run_train.py:82-90
             named = list(self.model.named_parameters())
@@ -191,32 +209,63 @@ class Trainer:
             return None
         path = os.path.join(self.exp, f"{prefix}_model.pth")
         if self.fused is not None:
-            opt = {"fused_adam": {"m": self.fused.m.cpu(), "v": self.fused.v.cpu(), "step": self.fused.step_count.cpu(),
-                                  "lr": self.fused.lr}}
-            sched = {"lr": self.fused.lr}
+            # torch.optim.Adam / StepLR state-dict layout (what the reference's resume() loads, run_train.py:458-472),
+            # plus the flat buffers themselves under an extra key
+            a = self.args
+            opt = self.fused.torch_adam_state_dict([n for n, _ in self.model.named_parameters()])
+            opt["fused_adam"] = self.fused.optimizer_state()
+            ep = self.info["epoch"] - 1                       # StepLR.last_epoch at the time the reference saves
+            sched = {"step_size": a.lr_step, "gamma": a.lr_gamma, "base_lrs": [a.learning_rate] * 3, "last_epoch": max(ep, 0),
+                     "_step_count": max(ep, 0) + 1, "_get_lr_called_within_step": False, "_last_lr": [self.fused.lr] * 3,
+                     "lr": self.fused.lr}
         else:
             opt, sched = self.optimizer.state_dict(), self.scheduler.state_dict()
         torch.save({"model": self.model.state_dict(), "epoch": self.info["epoch"], "iter": self.info["iter"],
                     "optimizer": opt, "scheduler": sched}, path)
         return path
 
+    def _lr_at(self, epoch):
+        """StepLR(step_size=lr_step, gamma=lr_gamma) stepped once per finished epoch (run_train.py:93,139-141)."""
+        a = self.args
+        return a.learning_rate * (a.lr_gamma ** (epoch // a.lr_step)) if a.lr_gamma != 1.0 else a.learning_rate
+
     def resume(self, path):
         ck = torch.load(path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["model"])
+        if self.fused is not None:
+            self.fused.sync_from_model()
         self.info["epoch"], self.info["iter"] = ck["epoch"], ck["iter"]
-        if self.fused is not None and "fused_adam" in ck["optimizer"]:
-            fa = ck["optimizer"]["fused_adam"]
-            self.fused.m.copy_(fa["m"]); self.fused.v.copy_(fa["v"]); self.fused.step_count.copy_(fa["step"])
-            self.fused.set_lr(fa["lr"])
-        elif self.fused is None:
-            self.optimizer.load_state_dict(ck["optimizer"])
-            self.scheduler.load_state_dict(ck["scheduler"])
+        opt = ck.get("optimizer") or {}
+        if self.fused is not None:
+            if "fused_adam" in opt:
+                self.fused.load_optimizer_state(opt["fused_adam"])
+            elif "state" in opt and "param_groups" in opt:
+                # a torch.optim.Adam state dict (reference checkpoints, --torch_optimizer runs): per-parameter
+                # exp_avg / exp_avg_sq / step -> the flat buffers, matched through the parameter order of run_train.py:82-90
+                self.fused.load_torch_adam_state(opt, [n for n, _ in self.model.named_parameters()])
+            else:
+                print("warning: checkpoint holds no usable optimizer state; Adam moments start from zero")
+            self.fused.set_lr(self._lr_at(self.info["epoch"]))       # the checkpoint is written BEFORE the epoch's lr update
+        else:
+            if "fused_adam" in opt:
+                print("warning: fused-step optimizer state in the checkpoint is not loaded into torch.optim.Adam "
+                      "(moments start from zero)")
+            else:
+                self.optimizer.load_state_dict(opt)
+                self.scheduler.load_state_dict(ck["scheduler"])
 
     # ---- loop ------------------------------------------------------------------------------------------------------
     def train_step(self, sample):
         a = self.args
         s = normalize_sample(sample, self.device, self.data_transform)
         num_pix = s["input"].shape[0] * s["input"].shape[2] * s["input"].shape[3]
+        if self.world > 1 and a.fixed_hw is None:
+            # variable tile sizes: ranks must take the same regime (and skip together), or their collective counts
+            # diverge and the job hangs.  The largest rank decides.
+            import torch.distributed as dist
+            t = torch.tensor([num_pix], device=self.device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            num_pix = int(t.item())
         enc_ng = unet_ng = False                                           # run_train.py:191-198
         if num_pix > a.limit1:
             enc_ng = True
@@ -226,7 +275,9 @@ class Trainer:
                     return None
         if self.fused is not None:
             # loss_out is one device buffer overwritten by every step: keep a copy for the running log mean
-            return self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0].clone()
+            loss = self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0].clone()
+            self._buffer_r2(self.fused.last["popcount"], s["y"])
+            return loss
         from torch.nn.utils import clip_grad_norm_
         from .utils.losses import get_loss
         out = self.model(s, train=True, padding=False, sparse=True, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
@@ -239,17 +290,73 @@ class Trainer:
         if a.gradient_clip > 0.0:
             clip_grad_norm_(self.model.parameters(), a.gradient_clip)
         self.optimizer.step()
+        self._buffer_r2(out["popcount"].detach(), s["y"])
         return loss.detach()
+
+    def _buffer_r2(self, pred, y):
+        """The 300-sample prediction / target buffers behind the logged training R2 (run_train.py:107-108,220-221,272);
+        kept on the device, read at log steps only."""
+        self._r2buf.append((pred.detach().clone(), y.detach().clone()))
+        while sum(p.numel() for p, _ in self._r2buf) > 300 and len(self._r2buf) > 1:
+            self._r2buf.popleft()
+
+    # ---- validation / in-training target test (run_train.py:289-370) ---------------------------------------------------
+    def validate_weak(self):
+        """Weak validation: census-level metrics of model(sample, padding=False) over the validation regions."""
+        from .utils.metrics import get_test_metrics
+        self.model.eval()
+        pred, gt = [], []
+        with torch.no_grad():
+            for sample in self.val_loader:
+                s = normalize_sample(sample, self.device, None)
+                out = self.model(s, padding=False)
+                pred.append(out["popcount"])
+                gt.append(s["y"])
+        stats = get_test_metrics(torch.cat(pred), torch.cat(gt).float(), tag="MainCensus_synthetic_fine")
+        self.valweak_stats = {k + "/val": float(v) for k, v in stats.items()}
+        self._log(self.valweak_stats)
+        return self.valweak_stats
+
+    def test_target(self, save=False):
+        """In-training target test: sliding windows over the test raster -> stitched map -> census aggregation -> metrics
+        (run_train.py:314-370).  The reference accumulates in fp16 host maps; here the accumulators are fp32 and stay on
+        the device (popcorn_amd.eval.Stitcher)."""
+        from . import eval as E
+        from .utils.metrics import get_test_metrics
+        a = self.args
+        if self._test_raster is None:
+            self._test_raster = SyntheticTestRaster(a.test_raster_hw[0], a.test_raster_hw[1], seasons=1, n_regions=64,
+                                                    seed=a.seed + 10, device=self.device)
+        data = self._test_raster
+        self.model.eval()
+        out, _, scale, _ = E.evaluate_raster([self.model], data.raster, a.test_patchsize, a.test_overlap, False,
+                                             FlatReducer(), 0) if self.world == 1 else \
+            E.evaluate_raster([self.model], data.raster, a.test_patchsize, a.test_overlap, False, self.reducer, self.rank)
+        cp, cg = E.convert_popmap_to_census(out, data.boundary, data.census_idx, data.census_pop)
+        stats = get_test_metrics(cp, cg, tag="MainCensus_synthetic_fine")
+        self.target_test_stats = {k + "/targettest": float(v) for k, v in stats.items()}
+        if save and self.rank == 0:
+            torch.save({"popdensemap": out.cpu(), "scale": None if scale is None else scale.cpu()},
+                       os.path.join(self.exp, "synthetic_predictions.pt"))
+        self._log(self.target_test_stats)
+        return self.target_test_stats
+
+    def _log(self, record):
+        if self.rank == 0:
+            with open(os.path.join(self.exp, "train_log.jsonl"), "a") as fh:
+                fh.write(json.dumps({**record, **self.info}) + "\n")
 
     def train(self):
         a = self.args
         log = open(os.path.join(self.exp, "train_log.jsonl"), "a") if self.rank == 0 else None
-        lr = a.learning_rate * (a.lr_gamma ** (self.info["epoch"] // a.lr_step))
+        lr = self._lr_at(self.info["epoch"])
         t0 = time.time()
         recent = collections.deque(maxlen=a.logstep_train)                  # running window for the log line, across epochs
         losses = []
         for epoch in range(self.info["epoch"], a.num_epochs):
             self.model.train()
+            if self.sampler is not None:
+                self.sampler.set_epoch(epoch)                              # a fresh shuffle per epoch on every rank
             losses = []
             for i, sample in enumerate(self.loader):
                 loss = self.train_step(sample)
@@ -258,17 +365,41 @@ class Trainer:
                     recent.append(loss)
                 self.info["iter"] += 1
                 self.info["sampleitr"] += a.weak_batch_size
-                if self.info["iter"] % a.logstep_train == 0 and log and recent:      # by global iteration (run_train.py:240)
-                    mean = torch.stack(list(recent)).mean().item()
-                    log.write(json.dumps({"iter": self.info["iter"], "epoch": epoch, "loss": mean, "lr": lr}) + "\n")
-                    log.flush()
+                if (i + 1) % a.val_every_i_steps == 0 and a.weak_validation:          # run_train.py:255-259
+                    self.validate_weak()
+                    self.model.train()
+                if (i + 1) % a.test_every_i_steps == 0:                              # run_train.py:262-265
+                    self.test_target(save=True)
+                    self.model.train()
+                if self.info["iter"] % a.logstep_train == 0 and recent:              # by global iteration (run_train.py:240)
+                    window = torch.stack(list(recent))
+                    # the fused step never reads the loss back; its NaN/Inf guard (run_train.py:224-227) is this one
+                    # device->host read per log step, covering every step of the window
+                    if not bool(torch.isfinite(window).all()):
+                        raise Exception("detected NaN/Inf loss..")
+                    if log:
+                        from .utils.losses import r2
+                        pr = torch.cat([p_ for p_, _ in self._r2buf])[-300:]
+                        yy = torch.cat([y_ for _, y_ in self._r2buf])[-300:]
+                        rec = {"iter": self.info["iter"], "epoch": epoch, "loss": window.mean().item(), "lr": lr,
+                               "Population_weak/r2": float(r2(pr, yy)) if pr.numel() > 1 else 0.0}
+                        log.write(json.dumps(rec) + "\n")
+                        log.flush()
                 if a.max_steps and self.info["iter"] >= a.max_steps:
                     break
+            if losses and not bool(torch.isfinite(torch.stack(losses)).all()):
+                raise Exception("detected NaN/Inf loss..")
             self.info["epoch"] = epoch + 1
             if a.save_model in ("last", "both"):
                 self.save_model("last")
+            if (epoch + 1) % a.val_every_n_epochs == 0:                              # run_train.py:126-137
+                if a.weak_validation:
+                    self.validate_weak()
+                self.test_target(save=True)
+                if a.save_model in ("last", "both"):
+                    self.save_model("last")
             if a.lr_gamma != 1.0:                                          # StepLR(step_size=lr_step, gamma), run_train.py:93,141
-                lr = a.learning_rate * (a.lr_gamma ** ((epoch + 1) // a.lr_step))
+                lr = self._lr_at(epoch + 1)
                 if self.fused is not None:
                     self.fused.set_lr(lr)
                 else:

@@ -18,13 +18,15 @@ extern "C" const char* pc_error_string(int code) {
     }
 }
 
-// sizeof() of the ABI structs as the compiler laid them out: 0 = pc_src, 1 = pc_dst, 2 = pc_bn (binding self-check)
+// sizeof() of the ABI structs as the compiler laid them out: 0 = pc_src, 1 = pc_dst, 2 = pc_bn,
+// 3 = pc_conv_fwd_desc, 4 = pc_adam_groups (binding self-check)
 extern "C" int pc_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(pc_src);
         case 1: return (int)sizeof(pc_dst);
         case 2: return (int)sizeof(pc_bn);
         case 3: return (int)sizeof(pc_conv_fwd_desc);
+        case 4: return (int)sizeof(pc_adam_groups);
         default: return -1;
     }
 }

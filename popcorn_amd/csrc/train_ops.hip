@@ -69,45 +69,68 @@ __global__ __launch_bounds__(1024) void grad_norm_kernel(const float* g, int n, 
 // clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)) folded in.  Elements [0, n_decay) get weight decay, the
 // tail (head.6.*) does not (run_train.py:82-90).  hyper (device): {lr}.  step (device int32) is incremented here so a
 // captured graph advances the bias correction on every replay.
+// Parameter groups (pc_adam_groups): the reference leaves `.grad = None` on the encoder (limit1) or the whole U-Net
+// (limit2) for large samples (run_train.py:191-198, networks.py:124-132), and torch.optim.Adam then SKIPS those
+// parameters: no weight decay, no moment update, no per-parameter step increment.  Elements of an inactive group are left
+// untouched here, and every group keeps its own step counter (torch's per-parameter `step`), so bias correction of a group
+// only advances on the steps that updated it.
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     int n, n_decay;
     const float* hyper; float wd, beta1, beta2, eps, max_norm;
     const float* norm; int32_t* step;
+    pc_adam_groups grp;        // nseg == 0: one group, always active, counter step[0]
 };
 
-__global__ __launch_bounds__(256) void adam_clip_kernel(const AdamArgs a) {
-    __shared__ float sh[3];
-    if (threadIdx.x == 0) {
-        const int t = *a.step + 1;
+__device__ __forceinline__ int adam_group_of(const AdamArgs& a, int i) {
+    int g = 0;
+#pragma unroll
+    for (int s = PC_ADAM_MAX_SEG - 1; s >= 0; --s)
+        if (s < a.grp.nseg && i < a.grp.seg_end[s]) g = a.grp.seg_group[s];
+    return g;
+}
+
+// per-group {step size, sqrt(bias correction 2)} into shared memory; thread t < PC_ADAM_GROUPS handles group t
+__device__ __forceinline__ void adam_group_constants(const AdamArgs& a, float (*sh)[2], int tid) {
+    if (tid < (a.grp.nseg ? PC_ADAM_GROUPS : 1)) {
+        const int t = a.step[tid] + 1;
         const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
         const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
-        sh[0] = (float)((double)a.hyper[0] / bc1);          // step size
-        sh[1] = (float)sqrt(bc2);
-        float coef = 1.f;
-        if (a.max_norm > 0.f && a.norm) {
-            coef = a.max_norm / (*a.norm + 1e-6f);
-            coef = coef > 1.f ? 1.f : coef;
-        }
-        sh[2] = coef;
-    }
-    __syncthreads();
-    const float step_size = sh[0], bc2s = sh[1], coef = sh[2];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n) {
-        float g = a.g[i] * coef;
-        const float p = a.p[i];
-        if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p, g);
-        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        const float denom = sqrtf(v) / bc2s + a.eps;
-        a.p[i] = p - step_size * (m / denom);
+        sh[tid][0] = (float)((double)a.hyper[0] / bc1);          // step size
+        sh[tid][1] = (float)sqrt(bc2);
     }
 }
 
-__global__ void adam_step_inc_kernel(int32_t* step) { *step += 1; }
+__device__ __forceinline__ void adam_update_one(const AdamArgs& a, int i, float coef, const float (*sh)[2]) {
+    const int grp = a.grp.nseg ? adam_group_of(a, i) : 0;
+    if (a.grp.nseg && !((a.grp.active_mask >> grp) & 1)) return;      // grad is None: parameter and state untouched
+    float g = a.g[i] * coef;
+    const float p = a.p[i];
+    if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p, g);
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    const float denom = sqrtf(v) / sh[grp][1] + a.eps;
+    a.p[i] = p - sh[grp][0] * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(const AdamArgs a) {
+    __shared__ float sh[PC_ADAM_GROUPS][2];
+    adam_group_constants(a, sh, threadIdx.x);
+    __syncthreads();
+    float coef = 1.f;
+    if (a.max_norm > 0.f && a.norm) {
+        coef = a.max_norm / (*a.norm + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) adam_update_one(a, i, coef, sh);
+}
+
+__global__ void adam_step_inc_kernel(int32_t* step, int ngroups, int active_mask) {
+    if ((int)threadIdx.x < ngroups && ((active_mask >> threadIdx.x) & 1)) step[threadIdx.x] += 1;
+}
 
 // One-launch variant: every workgroup first computes the total gradient norm itself (the flat buffer is ~157 KB and sits
 // in L2; all workgroups add in the same order, so they all get the same bits), then updates its 256 elements; the
@@ -115,7 +138,7 @@ __global__ void adam_step_inc_kernel(int32_t* step) { *step += 1; }
 // single-workgroup norm kernel + the update + the one-thread counter kernel (3 dependent launches at the end of a step).
 __global__ __launch_bounds__(256) void adam_clip_fused_kernel(const AdamArgs a, float* norm_out, unsigned* ticket) {
     __shared__ double red[256];
-    __shared__ float sh[3];
+    __shared__ float sh[PC_ADAM_GROUPS][2];
     const int tid = threadIdx.x;
     float coef = 1.f;
     if (a.max_norm > 0.f) {
@@ -149,32 +172,17 @@ __global__ __launch_bounds__(256) void adam_clip_fused_kernel(const AdamArgs a, 
         coef = a.max_norm / (norm + 1e-6f);
         coef = coef > 1.f ? 1.f : coef;
     }
-    if (tid == 0) {
-        const int t = *a.step + 1;
-        const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
-        const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
-        sh[0] = (float)((double)a.hyper[0] / bc1);          // step size
-        sh[1] = (float)sqrt(bc2);
-    }
+    adam_group_constants(a, sh, tid);
     __syncthreads();
-    const float step_size = sh[0], bc2s = sh[1];
     const int i = blockIdx.x * 256 + tid;
-    if (i < a.n) {
-        float g = a.g[i] * coef;
-        const float p = a.p[i];
-        if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p, g);
-        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        const float denom = sqrtf(v) / bc2s + a.eps;
-        a.p[i] = p - step_size * (m / denom);
-    }
+    if (i < a.n) adam_update_one(a, i, coef, sh);
     __syncthreads();
     if (tid == 0) {
         __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            *a.step += 1;
+            const int ng = a.grp.nseg ? PC_ADAM_GROUPS : 1;
+            for (int g = 0; g < ng; ++g)
+                if (!a.grp.nseg || ((a.grp.active_mask >> g) & 1)) a.step[g] += 1;
             *ticket = 0u;
         }
     }
@@ -231,34 +239,52 @@ extern "C" int pc_grad_norm(const float* g, int n, float* norm_out, void* stream
     return 0;
 }
 
+static int fill_groups(AdamArgs& a, const pc_adam_groups* groups, int n) {
+    if (!groups) return 0;
+    if (groups->nseg < 1 || groups->nseg > PC_ADAM_MAX_SEG || groups->seg_end[groups->nseg - 1] != n) return PC_EINVAL;
+    for (int s = 0; s < groups->nseg; ++s) {
+        if (groups->seg_group[s] < 0 || groups->seg_group[s] >= PC_ADAM_GROUPS) return PC_EINVAL;
+        if (s && groups->seg_end[s] < groups->seg_end[s - 1]) return PC_EINVAL;
+    }
+    a.grp = *groups;
+    return 0;
+}
+
 extern "C" int pc_adam_clip_step(float* p, const float* g, float* m, float* v, int n, int n_decay, const float* hyper_dev,
                                  float weight_decay, float beta1, float beta2, float eps, float max_norm,
-                                 const float* norm_dev, int32_t* step_dev, void* stream) {
+                                 const float* norm_dev, int32_t* step_dev, const pc_adam_groups* groups, void* stream) {
     if (!p || !g || !m || !v || !hyper_dev || !step_dev) return PC_EINVAL;
     AdamArgs a{};
+    if (int rc = fill_groups(a, groups, n)) return rc;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_decay = n_decay; a.hyper = hyper_dev; a.wd = weight_decay;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.norm = norm_dev; a.step = step_dev;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_clip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
     PC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(64), 0, st, step_dev, groups ? PC_ADAM_GROUPS : 1,
+                       groups ? groups->active_mask : 1);
     PC_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n, int n_decay,
                                        const float* hyper_dev, float weight_decay, float beta1, float beta2, float eps,
-                                       float max_norm, float* norm_out_dev, int32_t* step_dev, void* stream) {
+                                       float max_norm, float* norm_out_dev, int32_t* step_dev,
+                                       const pc_adam_groups* groups, void* stream) {
     if (!p || !g || !m || !v || !hyper_dev || !step_dev) return PC_EINVAL;
     if ((reinterpret_cast<uintptr_t>(g) & 15) != 0) return PC_EINVAL;
     static unsigned* ticket = nullptr;      // zero-initialised once; the kernel leaves it at zero
     if (!ticket) {
         hipError_t e = hipMalloc(&ticket, sizeof(unsigned));
         if (e != hipSuccess) return (int)e;
+        // synchronous memset + device-wide sync: the first kernel may run on a non-blocking stream, which a null-stream
+        // memset alone does not order against
         e = hipMemset(ticket, 0, sizeof(unsigned));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) return (int)e;
     }
     AdamArgs a{};
+    if (int rc = fill_groups(a, groups, n)) return rc;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_decay = n_decay; a.hyper = hyper_dev; a.wd = weight_decay;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.norm = nullptr; a.step = step_dev;
     hipLaunchKernelGGL(adam_clip_fused_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, norm_out_dev, ticket);

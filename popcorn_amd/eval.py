@@ -52,10 +52,11 @@ class Stitcher:
         if torch.device(device).type != "cuda":
             raise L.PopcornHipError("Stitcher accumulates on a HIP device only")
         self.h, self.w = h, w
-        z = lambda dt: torch.zeros(h, w, dtype=dt, device=device)  # noqa: E731
-        self.out, self.out_sq = z(torch.float32), z(torch.float32)
-        self.scale, self.scale_sq = (z(torch.float32), z(torch.float32)) if with_scale else (None, None)
-        self.count = z(torch.int16)
+        # the fp32 accumulators are planes of ONE allocation: a multi-GPU run sums them with a single collective
+        self.acc = torch.zeros(4 if with_scale else 2, h, w, dtype=torch.float32, device=device)
+        self.out, self.out_sq = self.acc[0], self.acc[1]
+        self.scale, self.scale_sq = (self.acc[2], self.acc[3]) if with_scale else (None, None)
+        self.count = torch.zeros(h, w, dtype=torch.int16, device=device)
 
     def add_window(self, xl, yl, popdense, scale=None, overlap=OVERLAP):
         """popdense / scale: (M, ps, ps) member outputs of the window whose origin is row xl, column yl (the reference's
@@ -73,12 +74,10 @@ class Stitcher:
         the bottom/right catch-up windows overlap them -- the count map handles both)."""
         if reducer.world > 1:
             import torch.distributed as dist
-            for t in (self.out, self.out_sq, self.scale, self.scale_sq):
-                if t is not None:
-                    dist.all_reduce(t, group=reducer.group)
-            c = self.count.to(torch.int32)
+            dist.all_reduce(self.acc, group=reducer.group)            # all fp32 planes in one ring pass
+            c = self.count.to(torch.int32)                            # RCCL has no 16-bit integer sum
             dist.all_reduce(c, group=reducer.group)
-            self.count.copy_(c.to(torch.int16))
+            self.count.copy_(c)
 
     def finalize(self):
         n = self.h * self.w

@@ -137,12 +137,15 @@ def conv3x3_dgrad(g, w, c0, cn, out, act=None, act_bn=None, pool=False, accumula
 
 
 _ws_cache = {}
+_ws_retired = []       # outgrown workspaces stay allocated: a captured HIP graph may hold their device pointers
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     key = (str(device), "ws")
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
+        if t is not None:
+            _ws_retired.append(t)
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
     return t
@@ -360,20 +363,42 @@ def grad_norm(flat, norm_out):
     L.check(L.lib().pc_grad_norm(L.ptr(flat), flat.numel(), L.ptr(norm_out), L.stream_ptr()), "pc_grad_norm")
 
 
-def adam_clip_step(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm, step):
+def adam_groups(segments, active):
+    """pc_adam_groups from [(end_offset, group id), ...] (consecutive segments of the flat buffer) and the set of group
+    ids that are updated in this call; the others are skipped like parameters whose .grad is None in torch.optim.Adam."""
+    g = L.PcAdamGroups()
+    assert 1 <= len(segments) <= L.PC_ADAM_MAX_SEG
+    g.nseg = len(segments)
+    for i, (end, grp) in enumerate(segments):
+        assert 0 <= grp < L.PC_ADAM_GROUPS
+        g.seg_end[i], g.seg_group[i] = int(end), int(grp)
+    g.active_mask = sum(1 << int(a) for a in set(active))
+    return g
+
+
+def _check_steps(step, groups):
+    need = L.PC_ADAM_GROUPS if groups is not None else 1
+    assert step.dtype == torch.int32 and step.numel() >= need, "step: one int32 counter per Adam group"
+
+
+def adam_clip_step(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm, step, groups=None):
     L.require_device(p, g, m, v)
+    _check_steps(step, groups)
     L.check(L.lib().pc_adam_clip_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), n_decay, L.ptr(hyper),
                                       C.c_float(weight_decay), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
-                                      C.c_float(max_norm), L.ptr(norm), L.ptr(step), L.stream_ptr()),
+                                      C.c_float(max_norm), L.ptr(norm), L.ptr(step),
+                                      C.byref(groups) if groups is not None else None, L.stream_ptr()),
             "pc_adam_clip_step")
 
 
-def adam_clip_step_fused(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm_out, step):
-    """grad-norm + clip + Adam in one launch (norm_out receives the total norm)."""
+def adam_clip_step_fused(p, g, m, v, n_decay, hyper, weight_decay, beta1, beta2, eps, max_norm, norm_out, step, groups=None):
+    """grad-norm + clip + Adam in one launch (norm_out receives the total norm).  groups: ops.adam_groups(...) or None."""
     L.require_device(p, g, m, v, hyper, step)
+    _check_steps(step, groups)
     L.check(L.lib().pc_adam_clip_step_fused(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), n_decay, L.ptr(hyper),
                                             C.c_float(weight_decay), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
-                                            C.c_float(max_norm), L.ptr(norm_out), L.ptr(step), L.stream_ptr()),
+                                            C.c_float(max_norm), L.ptr(norm_out), L.ptr(step),
+                                            C.byref(groups) if groups is not None else None, L.stream_ptr()),
             "pc_adam_clip_step_fused")
 
 
@@ -395,6 +420,8 @@ class WgradBatch:
         need = (self.slot + 1) * self.slot_bytes
         buf = WgradBatch._ws.get(key)
         if buf is None or buf.numel() < need:
+            if buf is not None:
+                _ws_retired.append(buf)       # earlier entries of this batch / captured graphs still point into it
             nbuf = torch.empty(max(need, 32 * self.slot_bytes), dtype=torch.uint8, device=self.device)
             WgradBatch._ws[key] = buf = nbuf
         ptr_ = buf.data_ptr() + self.slot * self.slot_bytes

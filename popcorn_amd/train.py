@@ -51,7 +51,22 @@ class FusedTrainStep:
         model.invalidate_cache()
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
-        self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        # Adam parameter groups: 0 = U-Net encoder, 1 = U-Net decoder, 2 = head.  limit1 / limit2 samples give the
+        # encoder / the whole U-Net no gradient (run_train.py:191-198) and torch.optim.Adam then skips those parameters
+        # (state and per-parameter step untouched): one step counter per group, inactive groups are not updated.
+        segs, off = [], 0
+        for n_, k in zip(self.names, sizes):
+            if n_.startswith("head."):
+                grp = 2
+            else:
+                grp = 0 if any(("." + E.CONVS[t][0] + ".") in n_ for t in E.ENCODER) else 1
+            off += k
+            if segs and segs[-1][1] == grp:
+                segs[-1] = (off, grp)
+            else:
+                segs.append((off, grp))
+        self.segments = segs
+        self.step_count = torch.zeros(L.PC_ADAM_GROUPS, device=dev, dtype=torch.int32)
         self.hyper = torch.tensor([lr], device=dev, dtype=torch.float32)
         self.lr = lr
         self.wd, self.betas, self.eps, self.clip = weight_decay, betas, eps, gradient_clip
@@ -76,6 +91,95 @@ class FusedTrainStep:
         """StepLR-style schedule hook (run_train.py:93,141): takes effect on the next step, also under graph replay."""
         self.lr = lr
         self.hyper.fill_(lr)
+
+    # ---- optimizer state <-> checkpoints ----------------------------------------------------------------------------
+    def sync_from_model(self):
+        """After ``model.load_state_dict``: the parameters must still be views of the flat buffer (load_state_dict copies
+        in place, so they are); re-home any that were replaced."""
+        table = dict(self.model.named_parameters())
+        off = 0
+        for n_ in self.names:
+            p = table[n_]
+            k = p.numel()
+            view = self.flat_p[off:off + k].view_as(p)
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data)
+                p.data = view
+            off += k
+        self.model.invalidate_cache()
+
+    def optimizer_state(self):
+        return {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.step_count.cpu(), "lr": self.lr,
+                "names": list(self.names), "segments": list(self.segments)}
+
+    def load_optimizer_state(self, fa):
+        self.m.copy_(fa["m"])
+        self.v.copy_(fa["v"])
+        st = fa["step"].to(torch.int32).reshape(-1)
+        if st.numel() == 1:                    # checkpoints written before the per-group counters: one shared step
+            st = st.expand(3)
+        self.step_count.zero_()
+        self.step_count[: min(st.numel(), self.step_count.numel())].copy_(st[: self.step_count.numel()])
+
+    def _torch_adam_index(self, param_names):
+        """name -> index in torch.optim.Adam's state dict for the reference's three parameter groups
+        (run_train.py:82-90): [not head.6 and not unetmodel], [unetmodel], [head.6]."""
+        groups = [[n for n in param_names if n not in HEAD_NO_DECAY and "unetmodel" not in n],
+                  [n for n in param_names if n not in HEAD_NO_DECAY and "unetmodel" in n],
+                  [n for n in param_names if n in HEAD_NO_DECAY and "unetmodel" not in n]]
+        index, i = {}, 0
+        for g in groups:
+            for n in g:
+                index[n] = i
+                i += 1
+        return index, [len(g) for g in groups]
+
+    def load_torch_adam_state(self, opt_sd, param_names):
+        """Moments / steps of a ``torch.optim.Adam.state_dict()`` (the reference's checkpoint format) -> flat buffers."""
+        index, _ = self._torch_adam_index(param_names)
+        state = opt_sd["state"]
+        steps = {0: 0, 1: 0, 2: 0}
+        off = 0
+        table = dict(self.model.named_parameters())
+        seg_of = list(self.segments)
+        for n_ in self.names:
+            k = table[n_].numel()
+            st = state.get(index[n_])
+            if st is not None:
+                self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                grp = next(g for e, g in seg_of if off < e)
+                steps[grp] = max(steps[grp], int(st["step"]))
+            off += k
+        self.step_count.zero_()
+        for g, t in steps.items():
+            self.step_count[g] = t
+
+    def torch_adam_state_dict(self, param_names):
+        """The flat optimizer state in ``torch.optim.Adam.state_dict()`` form for the reference's parameter groups, so a
+        checkpoint written by the fused step loads into the reference trainer's optimizer (run_train.py:458-472)."""
+        index, sizes = self._torch_adam_index(param_names)
+        table = dict(self.model.named_parameters())
+        steps = self.step_count.cpu().tolist()
+        state, off = {}, 0
+        seg_of = list(self.segments)
+        m, v = self.m.cpu(), self.v.cpu()
+        for n_ in self.names:
+            p = table[n_]
+            k = p.numel()
+            grp = next(g for e, g in seg_of if off < e)
+            if steps[grp] > 0:
+                state[index[n_]] = {"step": torch.tensor(float(steps[grp])), "exp_avg": m[off:off + k].view_as(p).clone(),
+                                    "exp_avg_sq": v[off:off + k].view_as(p).clone()}
+            off += k
+        groups, start = [], 0
+        for gi, cnt in enumerate(sizes):
+            groups.append({"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                           "weight_decay": 0.0 if gi == 2 else self.wd, "amsgrad": False, "maximize": False, "foreach": None,
+                           "capturable": False, "differentiable": False, "fused": None,
+                           "params": list(range(start, start + cnt))})
+            start += cnt
+        return {"state": state, "param_groups": groups}
 
     def attach_grads(self):
         """Expose the flat gradient views as ``param.grad`` (for logging / wandb.watch-style consumers)."""
@@ -132,9 +236,11 @@ class FusedTrainStep:
             eng_u.backward(saved, G, self.grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
         self._ctx = None
 
-    def _update(self):
+    def _update(self, encoder_no_grad=False, unet_no_grad=False):
+        active = {2} if unet_no_grad else ({1, 2} if encoder_no_grad else {0, 1, 2})
         ops.adam_clip_step_fused(self.flat_p, self.flat_g, self.m, self.v, self.n_decay, self.hyper, self.wd, self.betas[0],
-                                 self.betas[1], self.eps, self.clip or 0.0, self.norm, self.step_count)
+                                 self.betas[1], self.eps, self.clip or 0.0, self.norm, self.step_count,
+                                 groups=ops.adam_groups(self.segments, active))
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -161,7 +267,7 @@ class FusedTrainStep:
             self.reducer.reduce_stats(self.stats)
             self._backward(s, encoder_no_grad, unet_no_grad)
             self.reducer.reduce_grads(self.flat_g)
-            self._update()
+            self._update(encoder_no_grad, unet_no_grad)
             return self.loss_out
         return self._graph_step(sample, sel_host, encoder_no_grad, unet_no_grad)
 
@@ -210,7 +316,7 @@ class FusedTrainStep:
             for _ in range(2):
                 self._forward(st, sel, enc_ng, unet_ng)
                 self._backward(st, enc_ng, unet_ng)
-                self._update()
+                self._update(enc_ng, unet_ng)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.flat_p.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
@@ -220,7 +326,7 @@ class FusedTrainStep:
             with torch.cuda.graph(g):
                 self._forward(st, sel, enc_ng, unet_ng)
                 self._backward(st, enc_ng, unet_ng)
-                self._update()
+                self._update(enc_ng, unet_ng)
             graphs = [g]
         else:
             g0, g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -230,6 +336,6 @@ class FusedTrainStep:
             with torch.cuda.graph(g1, pool=pool):
                 self._backward(st, enc_ng, unet_ng)
             with torch.cuda.graph(g2, pool=pool):
-                self._update()
+                self._update(enc_ng, unet_ng)
             graphs = [g0, g1, g2]
         self._graphs = (key, st, sel, graphs)

@@ -236,3 +236,120 @@ def test_single_modality_vs_reference_golden(ic):
     for n in got:
         r = g[f"ic{ic}/grad/{n}"]
         assert np.abs(tr.grads[n].cpu().numpy() - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3), n
+
+
+def test_fused_step_skips_frozen_groups_like_torch_adam():
+    """limit1 / limit2 steps (run_train.py:191-198) leave the encoder / the whole U-Net without a gradient, and
+    torch.optim.Adam skips such parameters entirely (no weight decay, no moment decay, no per-parameter step).  The fused
+    step must do the same: frozen parameters bit-identical across the step, and after a mixed sequence of regimes every
+    parameter equals the drop-in module + torch autograd + torch.optim.Adam run (per-group bias-correction steps)."""
+    from torch.nn.utils import clip_grad_norm_
+    from popcorn_amd import engine as E
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    from popcorn_amd.utils.losses import get_loss
+    g = np.load(os.path.join(G, "g5_train.npz"))
+    sample0 = {k: torch.from_numpy(g[k]).cuda() for k in ("input", "admin_mask", "census_idx", "y")}
+    kw = dict(input_channels=6, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407,
+              sentinelbuildings=True)
+    torch.manual_seed(1600)
+    ma = POPCORN(**kw).cuda()
+    torch.manual_seed(1600)
+    mb = POPCORN(**kw).cuda()
+    wd = 1e-3                                    # large, so that a wrongly decayed frozen weight shows at once
+    fused = FusedTrainStep(ma, lr=1e-3, weight_decay=wd, gradient_clip=0.01)
+    head_name = ["head.6.weight", "head.6.bias"]
+    named = list(mb.named_parameters())
+    opt = torch.optim.Adam([
+        {"params": [p for n, p in named if n not in head_name], "weight_decay": wd},
+        {"params": [p for n, p in named if n in head_name], "weight_decay": 0.0}], lr=1e-3)
+    is_enc = lambda n: n.startswith("unetmodel.") and any(("." + E.CONVS[t][0] + ".") in n for t in E.ENCODER)  # noqa: E731
+    regimes = [dict(), dict(encoder_no_grad=True), dict(encoder_no_grad=True, unet_no_grad=True), dict(),
+               dict(encoder_no_grad=True)]
+    for it, flags in enumerate(regimes):
+        before = {n: p.detach().clone() for n, p in ma.named_parameters()}
+        m_before, v_before = fused.m.clone(), fused.v.clone()
+        torch.manual_seed(40 + it)
+        fused.step(dict(sample0), **flags)
+        torch.manual_seed(40 + it)
+        mb.train()
+        s = dict(sample0)
+        o = mb(s, train=True, padding=False, sparse=True, **flags)
+        loss, _ = get_loss(o, s, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01, tag="weak")
+        opt.zero_grad()                            # set_to_none: parameters outside the graph keep grad None -> skipped
+        (loss * 100.0).backward()
+        clip_grad_norm_(mb.parameters(), 0.01)
+        opt.step()
+        # frozen groups: bit-identical parameters and moments
+        off = 0
+        for n, p in zip(fused.names, [dict(ma.named_parameters())[n] for n in fused.names]):
+            k = p.numel()
+            frozen = (flags.get("unet_no_grad") and n.startswith("unetmodel.")) or (flags.get("encoder_no_grad") and is_enc(n))
+            if frozen:
+                assert torch.equal(p.detach(), before[n]), (it, n)
+                assert torch.equal(fused.m[off:off + k], m_before[off:off + k]) and torch.equal(fused.v[off:off + k], v_before[off:off + k])
+            else:
+                assert not torch.equal(p.detach(), before[n]), (it, n)
+            off += k
+    assert fused.step_count.tolist()[:3] == [2, 3, 5]          # encoder, decoder, head updates in the sequence above
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for n in fused.names:
+        torch.testing.assert_close(pa[n].detach(), pb[n].detach(), rtol=0, atol=5e-6, msg=lambda m_, n=n: f"{n}: {m_}")
+
+
+def test_trainer_validation_test_loops_guards_and_checkpoint_interop(tmp_path):
+    """Trainer behaviour around the step (run_train.py:111-141,224-227,289-370,445-476): weak validation and the
+    in-training target test run every --val_every_n_epochs and log their metrics; a non-finite loss raises on the fused
+    path; a fused-step checkpoint carries a torch.optim.Adam state dict that the torch-optimizer trainer (= the reference
+    recipe) loads, and vice versa; resuming recomputes the learning rate from the epoch."""
+    import json as _json
+    from popcorn_amd.cli import Trainer, train_parser
+    base = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-3 --synthetic_regions 8 -wb 4 "
+            f"--save_dir {tmp_path} -lt 1 -wv -val 1 -lrs 1 -lrg 0.5 --fixed_hw 64 64").split()
+    t = Trainer(train_parser().parse_args(base + ["-e", "2"]))
+    t.train()
+    recs = [_json.loads(l) for l in open(os.path.join(t.exp, "train_log.jsonl"))]
+    val = [r for r in recs if any(k.endswith("/val") for k in r)]
+    tst = [r for r in recs if any(k.endswith("/targettest") for k in r)]
+    assert len(val) == 2 and len(tst) == 2
+    assert {"Population_MainCensus_synthetic_fine/r2/val", "Population_MainCensus_synthetic_fine/mape/val"} <= set(val[0])
+    assert all(np.isfinite(v) for r in tst for k, v in r.items() if k.endswith("/targettest"))
+    assert any("Population_weak/r2" in r for r in recs)
+    assert os.path.exists(os.path.join(t.exp, "synthetic_predictions.pt"))
+    assert abs(t.fused.lr - 1e-3 * 0.25) < 1e-12                     # two epochs of StepLR(1, 0.5)
+    ck = os.path.join(t.exp, "last_model.pth")
+    d = torch.load(ck, weights_only=False)
+    assert set(d) == {"model", "epoch", "iter", "optimizer", "scheduler"}
+    assert {"state", "param_groups"} <= set(d["optimizer"]) and [len(g["params"]) for g in d["optimizer"]["param_groups"]] == [86, 108, 2]
+    # fused checkpoint -> fused trainer: moments, per-group steps, lr recomputed from the epoch
+    t2 = Trainer(train_parser().parse_args(base + ["-e", "3", "-r", ck]))
+    assert torch.equal(t2.fused.m.cpu(), t.fused.m.cpu()) and torch.equal(t2.fused.step_count.cpu(), t.fused.step_count.cpu())
+    assert abs(t2.fused.lr - 1e-3 * 0.25) < 1e-12 and t2.info["epoch"] == 2
+    # fused checkpoint -> torch.optim.Adam (the reference's resume path), and both continue identically for one step
+    t3 = Trainer(train_parser().parse_args(base + ["-e", "3", "-r", ck, "--torch_optimizer"]))
+    st = t3.optimizer.state_dict()["state"]
+    assert len(st) == 56 and all(int(v["step"]) == 4 for v in st.values())
+    # (the torch path resumes with the checkpoint's scheduler state, which -- as in the reference, run_train.py:123-141 --
+    # was saved before the epoch's scheduler.step(); the fused path recomputes lr from the epoch instead)
+    sample = next(iter(t3.loader))
+    torch.manual_seed(11)
+    random.seed(11)
+    t3.model.train()
+    t3.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sample.items()})
+    # torch-Adam checkpoint -> fused trainer
+    ck3 = t3.save_model("torch")
+    t4 = Trainer(train_parser().parse_args(base + ["-e", "3", "-r", ck3]))
+    assert t4.fused.step_count.cpu().tolist()[:3] == [5, 5, 5]
+    off = 0
+    idx, _ = t4.fused._torch_adam_index([n for n, _ in t4.model.named_parameters()])
+    st3 = t3.optimizer.state_dict()["state"]
+    for n_, p in zip(t4.fused.names, [dict(t4.model.named_parameters())[n] for n in t4.fused.names]):
+        k = p.numel()
+        assert torch.equal(t4.fused.m[off:off + k].cpu(), st3[idx[n_]]["exp_avg"].reshape(-1).cpu()), n_
+        off += k
+    # non-finite loss: raised at the next log step of the fused path
+    t5 = Trainer(train_parser().parse_args(base + ["-e", "1"]))
+    with torch.no_grad():
+        t5.model.head[6].bias.fill_(float("nan"))
+    with pytest.raises(Exception, match="NaN/Inf"):
+        t5.train()

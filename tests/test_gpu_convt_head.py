@@ -217,3 +217,37 @@ def test_building_score_mask_equals_the_two_separate_ops(case, C_):
         assert rc.tolist() == [0, 0] and int(rm.sum()) == 0
     else:
         assert rc[0].item() == int(rm.sum()) > 0
+
+
+@pytest.mark.parametrize("losses,lams", [(("l1_loss",), (1.0,)), (("log_l1_loss",), (1.0,)), (("mse_loss",), (1.0,)),
+                                         (("log_mse_loss",), (1.0,)), (("l1_loss", "log_mse_loss", "mse_loss"), (0.5, 2.0, 0.01))])
+def test_loss_fwd_bwd_kernel_all_losses_vs_oracle(losses, lams):
+    """pc_loss_fwd_bwd for every loss the reference offers (utils/losses.py:49-56) and a weighted mix, against the oracle's
+    get_loss + autograd: loss value, regulariser, d(lam_weak * loss)/d popcount and the constant regulariser gradient
+    (utils/losses.py:74-76), incl. a rank-style global batch (inv_B of twice the local batch)."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd import ops
+    from popcorn_amd.train import LOSS_INDEX
+    g = np.load(os.path.join(G, "g6_loss_metrics.npz"))
+    pred, y, scale = (torch.from_numpy(g[k]) for k in ("pred", "y", "scale"))
+    lam_weak, sreg = 100.0, 0.01
+    p = pred.clone().requires_grad_(True)
+    sc = scale.clone().requires_grad_(True)
+    ref, _ = O.get_loss({"popcount": p}, {"y": y}, scale=sc, loss=list(losses), lam=list(lams), scale_regularization=sreg, tag="weak")
+    (ref * lam_weak).backward()
+    lam4 = [0.0] * 4
+    for lo, la in zip(losses, lams):
+        lam4[LOSS_INDEX[lo]] += la
+    B = pred.numel()
+    for world in (1, 2):
+        stats = torch.tensor([float(scale.numel()), float(scale.double().sum())], dtype=torch.float64, device="cuda")
+        loss_out = torch.zeros(2, device="cuda")
+        g_pc = torch.zeros(B, device="cuda")
+        g_sc = torch.zeros(1, device="cuda")
+        ops.loss_fwd_bwd(pred.cuda(), y.cuda(), stats, lam4, sreg, lam_weak, 1.0 / (world * B), loss_out, g_pc, g_sc)
+        torch.cuda.synchronize()
+        reg = sreg * scale.abs().mean().item()
+        assert abs(loss_out[1].item() - reg) <= 1e-6 * max(1.0, reg)
+        assert abs((loss_out[0].item() - reg) * world + reg - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+        torch.testing.assert_close(g_pc.cpu() * world, p.grad, rtol=2e-6, atol=1e-7)
+        assert abs(g_sc.item() - sc.grad[0].item()) <= 1e-6 * abs(sc.grad[0].item())

@@ -22,4 +22,4 @@ for use_graph in (False, True):
         l = tr.step(sample)
         torch.cuda.synchronize()
         out.append(round(l[0].item(), 6))
-    print("graph" if use_graph else "eager", out, "step_count", tr.step_count.item())
+    print("graph" if use_graph else "eager", out, "step_count", tr.step_count.tolist())

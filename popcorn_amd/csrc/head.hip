@@ -271,6 +271,8 @@ struct HeadBwdArgs {
     int dbg;                     // ablation (tools/ablate_head.py): 1 consumer idle, 2 no hand-off, 4 no per-group global loads
     float* partial;              // [nwg][PE_TOTAL]
     int total_groups;
+    int Hp, Wp;                  // extent of the padded feature / gradient maps
+    int zero_in_kernel;          // producer / consumer kernel: g_feat is zeroed by the kernel itself (border + skipped groups)
 };
 
 __device__ __forceinline__ float lane_sum16(float v) {
@@ -702,7 +704,16 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 if (a.g_scale_map) gup += n_gsm;
             }
             if (gg + gstep < a.total_groups) fetch(gg + gstep);       // in flight during this group's MFMA chain
-            if (!__any(sel)) continue;
+            // g_feat is written exactly once per element by this kernel (no zero-fill pass in front of it): crop pixels
+            // by the producer that owns their group -- zeros when the group is skipped --, the border by the consumers
+            auto store_zero = [&]() {
+                if (a.zero_in_kernel && valid) {
+                    float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0.f;
+                }
+            };
+            if (!__any(sel)) { store_zero(); continue; }
             f32x4 h1[4], h2[4], h3[4];
             head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
             relu4(h1);
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             s += __shfl_xor(s, 32);
             const float outv = s + lds[LB_W6 + 64];
             const float gout = (sel && outv > 0.f) ? gup : 0.f;
-            if (!__any(gout != 0.f)) continue;
+            if (!__any(gout != 0.f)) { store_zero(); continue; }
 
             f32x4 g3[4], g2[4], g1[4];
             if (lk == 0) db6 += gout;
@@ -795,6 +806,29 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.zero_in_kernel) {
+            // The consumers have nothing to do until the first slot arrives: they write the zero border of g_feat (the
+            // padding frame around the H x W crop: 39 % of a 128 x 128 map for 100 x 100 tiles) -- the only part of the
+            // gradient map the producers never touch.  One (b, c, row) job per half-wave: rows above / below the crop in
+            // full (16-byte stores when the row allows), crop rows only left and right of it.
+            const int Hp = a.Hp, Wp = a.Wp;
+            const int l32 = tid & 31;
+            const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + ((tid - 256) >> 5);
+            const int njobs = p.B * 16 * Hp;
+            const bool v4 = (Wp & 3) == 0;
+            const int right0 = p.px + p.W;
+            for (int j = hw; j < njobs; j += nhw) {
+                const int row = j % Hp;
+                float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
+                if (row < p.py || row >= p.py + p.H) {
+                    if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                } else {
+                    for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
+                    for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                }
+            }
         }
         int ncons = 0;
         // wait until slot `ncons` has been produced; returns false when the producer has finished without producing it
@@ -1356,14 +1390,22 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     if (admin_mask && !census_idx) return PC_EINVAL;
     if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    {
+    if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
+    static int use_pc = -1;
+    if (use_pc < 0) {
+        const char* ev = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");
+        use_pc = (ev && ev[0] == '1') ? 0 : 1;
+    }
+    const char* zv = getenv("POPCORN_HEAD_ZERO_FILL");            // A/B switch: 1 = the round-1 separate zero-fill launch
+    const bool zero_launch = !use_pc || (zv && zv[0] == '1');
+    if (zero_launch) {
         // zero fill by a kernel, not a memset node (see zero_fill_kernel)
         const int64_t n4 = (int64_t)B * 16 * Hp * Wp / 4, rem = (int64_t)B * 16 * Hp * Wp - 4 * n4;
-        if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
         hipLaunchKernelGGL(zero_fill_kernel, dim3(2048), dim3(256), 0, st, g_feat->ptr, n4, rem);
         PC_CHECK_LAUNCH();
     }
     HeadBwdArgs a{};
+    a.Hp = Hp; a.Wp = Wp; a.zero_in_kernel = zero_launch ? 0 : 1;
     HeadArgs& p = a.f;
     p.feat = *feat; p.py = py; p.px = px;
     p.w0 = hw[0]; p.b0 = hw[1]; p.w2 = hw[2]; p.b2 = hw[3]; p.w4 = hw[4]; p.b4 = hw[5]; p.w6 = hw[6]; p.b6 = hw[7];
@@ -1385,11 +1427,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     {
         const char* dv = getenv("POPCORN_HEAD_DBG");
         a.dbg = dv ? atoi(dv) : 0;
-    }
-    static int use_pc = -1;
-    if (use_pc < 0) {
-        const char* ev = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");
-        use_pc = (ev && ev[0] == '1') ? 0 : 1;
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -141,7 +141,8 @@ def _launch(world):
     procs = [ctx.Process(target=_eval_rank, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=600)
+    from tests.test_gpu_dp import _get
+    out = _get(q, procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -20,6 +20,7 @@ def _free_port():
 
 
 def _make(B, seed=3):
+    from oracle import popcorn_oracle as O
     from popcorn_amd.data.synthetic import make_raw_batch
     b = make_raw_batch(B, 64, 48, seed=seed, region="disc")
     return {"input": O.select_normalize(b["raw"]), "admin_mask": b["admin_mask"], "census_idx": b["census_idx"],
@@ -54,6 +55,21 @@ def _run(rank, world, port, use_graph, q):
         dist.destroy_process_group()
 
 
+def _get(q, procs, timeout=600):
+    """q.get that gives up as soon as a child has died without reporting (instead of sitting out the whole timeout)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise RuntimeError("a rank died: " + str([p.exitcode for p in procs]))
+            if time.time() - t0 > timeout:
+                raise
+
+
 def _launch(world, use_graph):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -61,7 +77,7 @@ def _launch(world, use_graph):
     procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=600)
+    out = _get(q, procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

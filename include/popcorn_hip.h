@@ -79,6 +79,23 @@ const char* pc_error_string(int code);
    (lets a binding verify its struct layout) */
 int pc_sizeof(int which);
 
+/* ---- arithmetic mode -----------------------------------------------------------------------------------
+ * PC_PREC_FP32 (default): fp32 operands on the fp32 MFMA (v_mfma_f32_16x16x4_f32), the reference's arithmetic.
+ * PC_PREC_BF16: bf16 mixed precision (BASELINE config 4; the reference has no such mode -- its only hook is the unused
+ *   `half` flag of to_cuda_inplace, utils/utils.py:22-27).  Rounding points, restated by oracle/popcorn_oracle_bf16.py:
+ *     - every operand of a matrix product (conv / transposed conv / 1x1 head layer: activations, gradients, weights) is a
+ *       bf16 value (round-to-nearest-even); products accumulate in fp32;
+ *     - every activation / activation-gradient tensor a kernel writes (conv + BN + ReLU outputs, pooled copies, transposed-
+ *       conv outputs, the feature map, all data gradients) is rounded to bf16 by the producing epilogue, after the fp32
+ *       bias / BN / ReLU-mask / accumulate arithmetic; the head's hidden layers are rounded after their ReLU;
+ *     - everything else stays fp32: BN folding, partial logits and the building score, masks, occupancy product, census
+ *       sums, loss, all WEIGHT gradients, the gradient all-reduce, clip, Adam and the master weights.
+ *   Tensors keep their fp32 containers (values are bf16-representable); the mode is read when a call is enqueued.
+ * Process-global; returns the previous mode (pc_set_precision) / the current one. */
+enum pc_precision { PC_PREC_FP32 = 0, PC_PREC_BF16 = 1 };
+int pc_set_precision(int mode);
+int pc_get_precision(void);
+
 /* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
  * Input channels = a.C + b.C (torch.cat([skip, up]) fused, networks.py:318); conv domain H x W, batch B.
  * w: [Cout][Cin][3][3].  Supported (Cin,Cout): (2,8) (4,8) (8,8) (16,8) (32,8) (8,16) (16,16). */

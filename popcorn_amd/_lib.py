@@ -97,6 +97,28 @@ def lib():
     return _lib
 
 
+PC_PREC_FP32, PC_PREC_BF16 = 0, 1
+PRECISIONS = {"fp32": PC_PREC_FP32, "bf16": PC_PREC_BF16}
+
+
+class precision:
+    """``with precision("bf16"):`` -- the arithmetic mode of every call enqueued inside the block (pc_set_precision; the
+    mode is read at enqueue time, so a HIP graph captured inside the block keeps it).  Restores the previous mode."""
+
+    def __init__(self, mode):
+        self.mode = PRECISIONS[mode] if isinstance(mode, str) else int(mode)
+
+    def __enter__(self):
+        self.prev = lib().pc_set_precision(self.mode)
+        if self.prev < 0:
+            raise PopcornHipError(f"pc_set_precision({self.mode}) failed")
+        return self
+
+    def __exit__(self, *a):
+        lib().pc_set_precision(self.prev)
+        return False
+
+
 def check(code: int, what: str = ""):
     if code != 0:
         msg = lib().pc_error_string(int(code)).decode()

@@ -247,12 +247,11 @@ class Trainer:
                 print("warning: checkpoint holds no usable optimizer state; Adam moments start from zero")
             self.fused.set_lr(self._lr_at(self.info["epoch"]))       # the checkpoint is written BEFORE the epoch's lr update
         else:
-            if "fused_adam" in opt:
-                print("warning: fused-step optimizer state in the checkpoint is not loaded into torch.optim.Adam "
-                      "(moments start from zero)")
+            if "state" in opt and "param_groups" in opt:
+                self.optimizer.load_state_dict({"state": opt["state"], "param_groups": opt["param_groups"]})
+                self.scheduler.load_state_dict({k: v for k, v in ck["scheduler"].items() if k != "lr"})
             else:
-                self.optimizer.load_state_dict(opt)
-                self.scheduler.load_state_dict(ck["scheduler"])
+                print("warning: checkpoint holds no torch.optim.Adam state; moments start from zero")
 
     # ---- loop ------------------------------------------------------------------------------------------------------
     def train_step(self, sample):
@@ -375,7 +374,12 @@ class Trainer:
                     window = torch.stack(list(recent))
                     # the fused step never reads the loss back; its NaN/Inf guard (run_train.py:224-227) is this one
                     # device->host read per log step, covering every step of the window
-                    if not bool(torch.isfinite(window).all()):
+                    finite = torch.isfinite(window).all()
+                    if self.fused is not None:
+                        # the conv / hidden-layer ReLU epilogues take the IEEE maximum (a NaN activation becomes 0), so a
+                        # diverged run shows up in the gradient norm and the parameters before it shows up in the loss
+                        finite = finite & torch.isfinite(self.fused.norm).all() & torch.isfinite(self.fused.flat_p.sum())
+                    if not bool(finite):
                         raise Exception("detected NaN/Inf loss..")
                     if log:
                         from .utils.losses import r2

@@ -1,7 +1,18 @@
 // api.hip -- library-level entry points of libpopcorn_hip.so.
 #include "common.h"
 
+int g_pc_precision = PC_PREC_FP32;
+
 extern "C" int pc_abi_version(void) { return PC_ABI_VERSION; }
+
+extern "C" int pc_set_precision(int mode) {
+    if (mode != PC_PREC_FP32 && mode != PC_PREC_BF16) return PC_EINVAL;
+    const int prev = g_pc_precision;
+    g_pc_precision = mode;
+    return prev;
+}
+
+extern "C" int pc_get_precision(void) { return g_pc_precision; }
 
 extern "C" int pc_device_count(void) {
     int n = 0;

@@ -9,6 +9,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (global memory only)
 
+// bf16 mixed precision (PC_PREC_BF16, popcorn_hip.h): round-to-nearest-even of an fp32 value to the nearest bf16, kept in an
+// fp32 register (what torch's `.to(torch.bfloat16).to(torch.float32)` gives; NaN payloads aside).
+__device__ __forceinline__ float pc_bf16r(float x) {
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ f32x4 pc_bf16r4(f32x4 v) { return f32x4{pc_bf16r(v[0]), pc_bf16r(v[1]), pc_bf16r(v[2]), pc_bf16r(v[3])}; }
+extern int g_pc_precision;      // api.hip: pc_set_precision()
+
 #define PC_CHECK_LAUNCH()                         \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \

@@ -86,7 +86,10 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 // count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
 // write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
 enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3 };   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
-template <int CIN, int COUT, int MODE, int LD, int EPI>
+// BF: PC_PREC_BF16 rounding points (popcorn_hip.h) as their own instantiations -- the fp32 kernels compile to the same code
+// as before.  Weights and the first layer's input (the only operand no producer has rounded yet) are rounded when staged,
+// results when stored; the MFMA stays v_mfma_f32_16x16x4_f32 on bf16-representable operands (exact products, fp32 sums).
+template <int CIN, int COUT, int MODE, int LD, int EPI, bool BF>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
     constexpr int W_RL = CIN * 3 + 4;                    // weight image: floats per (dy, co) row (== 4 mod 8: spreads banks)
     constexpr int W_DYS = COUT * W_RL + 16;              // ... and per dy plane
+    auto rnd = [](float x) { return BF ? pc_bf16r(x) : x; };
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const ConvProb& q = p.pr[blockIdx.y];
@@ -135,6 +139,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 R[it] = l_act ? pc_fetch_reflect_seg(q.a, b, ch * CHUNK + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BF) {       // the model input is the one operand no producer has rounded
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) R[it] = pc_bf16r4(R[it]);
+            }
         } else if (LD == LD_DIRECT) {
             const int64_t off = ok ? b * my_bs + (int64_t)y * my_rs + xg : 0;
 #pragma unroll
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             const int cg = ch * CHUNK + ci;
             const float v = cg < CA ? pc_fetch(q.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
                                     : pc_fetch(q.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-            wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
+            wl[ci * CSW + r * RS + (COL0 - 1) + c] = rnd(v);
         }
     };
 
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         const int e = tid + k * 256;
         const int ec = e < COUT * CIN * 9 ? e : 0;
         const int tap = ec % 9, ci = (ec / 9) % CIN, co = ec / (9 * CIN);
-        wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+        wreg[k] = rnd(q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)]);
     }
     const bool has_bn = MODE == MODE_FWD || q.act != nullptr;
     float bn_raw[NB][5];            // {conv bias, gamma, var, mean, beta} of channel nb*8 + col
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(o0 + rr * o_rs + 4 * h) = O[rr][h];
+                        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(o0 + rr * o_rs + 4 * h) = BF ? pc_bf16r4(O[rr][h]) : O[rr][h];
                 }
             }
             return;
@@ -368,9 +376,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                             for (int r = 0; r < 4; ++r) v[r] += o4[r];
                         }
                     }
+                    if (BF) v = pc_bf16r4(v);
                     if (EPI == EPI_DOT && MODE == MODE_FWD && q.dot_w) {
                         // sum over the 8 channels = the 8 lanes `col` of a 16-lane group half; lane col == 0 stores
-                        const float wl = q.dot_w[nb * 8 + col];
+                        const float wl = rnd(q.dot_w[nb * 8 + col]);
                         f32x4 t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float o = v[r] * e_scale[nb] + e_shift[nb];
-                        if (x + r < p.W) op[r] = p.relu ? fmaxf(o, 0.f) : o;
+                        if (x + r < p.W) op[r] = rnd(p.relu ? fmaxf(o, 0.f) : o);
                     }
                 } else if (!POOLB) {
                     float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                             float o = v[r];
                             if (ap) o = ap[r] > 0.f ? o * e_scale[nb] : 0.f;
                             if (p.accumulate) o += op[r];
-                            op[r] = o;
+                            op[r] = rnd(o);
                         }
                     }
                 } else {
@@ -445,10 +454,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                             if (w10 > m) { m = w10; am = 2; }
                             if (w11 > m) { m = w11; am = 3; }
                             const float g = m > 0.f ? v[r] * e_scale[nb] : 0.f;
-                            o0[2 * xx] += am == 0 ? g : 0.f;
-                            o0[2 * xx + 1] += am == 1 ? g : 0.f;
-                            o1[2 * xx] += am == 2 ? g : 0.f;
-                            o1[2 * xx + 1] += am == 3 ? g : 0.f;
+                            o0[2 * xx] = rnd(o0[2 * xx] + (am == 0 ? g : 0.f));
+                            o0[2 * xx + 1] = rnd(o0[2 * xx + 1] + (am == 1 ? g : 0.f));
+                            o1[2 * xx] = rnd(o1[2 * xx] + (am == 2 ? g : 0.f));
+                            o1[2 * xx + 1] = rnd(o1[2 * xx + 1] + (am == 3 ? g : 0.f));
                         }
                     }
                 }
@@ -510,13 +519,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-template <int CIN, int COUT, int MODE, int LD, int EPI>
-int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
+template <int CIN, int COUT, int MODE, int LD, int EPI, bool BF>
+int launch_conv_bf(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, BF>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -539,9 +548,15 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
         grid = 768 / nprob < 128 ? 128 : 768 / nprob;
         if (grid > p.ntiles) grid = p.ntiles;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, BF>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
+}
+
+template <int CIN, int COUT, int MODE, int LD, int EPI>
+int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
+    if (g_pc_precision == PC_PREC_BF16) return launch_conv_bf<CIN, COUT, MODE, LD, EPI, true>(p, nprob, stream);
+    return launch_conv_bf<CIN, COUT, MODE, LD, EPI, false>(p, nprob, stream);
 }
 
 template <int CIN, int COUT, int MODE, int LD>

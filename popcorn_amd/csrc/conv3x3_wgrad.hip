@@ -36,6 +36,8 @@ struct WgradArgs {
     int tiles_x, tiles_y, ntiles;
     pc_fastdiv div_tx, div_tpi;
     int fast_a, fast_b, fast_g;
+    int bf;               // PC_PREC_BF16: the input operand is rounded to bf16 when staged by the reflect / generic loaders
+                          // (the model input; every other operand was rounded by its producer).  dW / db stay fp32.
 };
 
 template <int CINC, int COUT>
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
         const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
         const int x0 = (rem - ty * p.tiles_x) * TW, y0 = ty * TH;
         __syncthreads();
-        pc_load_halo_tile<CINC, IN_RS, IN_CS, IN_COL0, true>(lin, p.a, p.b, p.fast_a, p.fast_b, cbase, b, y0, x0, p.H, p.W, tid);
+        pc_load_halo_tile<CINC, IN_RS, IN_CS, IN_COL0, true>(lin, p.a, p.b, p.fast_a, p.fast_b, cbase, b, y0, x0, p.H, p.W, tid,
+                                                              p.bf != 0);
         // gradient tile: COUT x 16 rows x 32 cols, no halo; 8 lanes x float4 per row
         for (int job = tid >> 3; job < COUT * 16; job += 32) {
             const int co = job >> 4, r = job & 15, l8 = tid & 7;
@@ -232,6 +235,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 R[it] = l_act ? pc_fetch_reflect_seg(p.a, b, cbase + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bf) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) R[it] = pc_bf16r4(R[it]);
+            }
         } else if (LD == 1) {
             const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
 #pragma unroll
@@ -455,6 +462,7 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
     p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);
     p.fast_b = pc_src_fast_mode(p.b, p.H, p.W);
     p.fast_g = pc_src_fast_mode(p.g, p.H, p.W) == 1;
+    p.bf = g_pc_precision == PC_PREC_BF16;
     const bool lay = p.b.C == 0 || (p.a.bstride == p.b.bstride && p.a.rstride == p.b.rstride);
     if (p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && p.fast_g && CINC <= 4) return 3;
     if (p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g) return 1;

@@ -28,6 +28,7 @@ struct CtArgs {
     int B, H, W;           // input resolution
     int groups_x, ngroups;
     pc_fastdiv div_gx, div_gimg;   // by groups_x, by groups per image
+    int bf;                // PC_PREC_BF16: weights rounded to bf16 when loaded, results when stored (popcorn_hip.h)
 };
 
 struct CtGroup {
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
         const int ng = nb * 16 + li;
         binit[nb] = p.bias ? p.bias[ng >> 2] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bw[ks][nb] = p.w[(4 * ks + lk) * 4 * C + ng];
+        for (int ks = 0; ks < KS; ++ks) {
+            const float wv = p.w[(4 * ks + lk) * 4 * C + ng];
+            bw[ks][nb] = p.bf ? pc_bf16r(wv) : wv;
+        }
     }
 
     for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(mine[r], 1);
             // bb = 0 writes x = 2*jb + {0,1,2,3} (pixels r = 0,1); bb = 1 writes x = 2*jb + {4,5,6,7} (pixels r = 2,3)
-            const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
+            f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
+            if (p.bf) v = pc_bf16r4(v);
             const int jb = j0 + 4 * lk;
             float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + 2 * jb + 4 * bb;
             if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
@@ -108,7 +113,10 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
 
     float bw[C];
 #pragma unroll
-    for (int co = 0; co < C; ++co) bw[co] = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
+    for (int co = 0; co < C; ++co) {
+        const float wv = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
+        bw[co] = p.bf ? pc_bf16r(wv) : wv;
+    }
     float e_scale = 1.f, e_shift = 0.f;
     if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
 
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = a4[r] > 0.f ? o[r] * e_scale : 0.f;
                 }
+                if (p.bf) o = pc_bf16r4(o);
                 *reinterpret_cast<f32x4*>(op) = o;
             } else {
 #pragma unroll
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
                     if (j + r < p.W) {
                         float o = acc[r];
                         if (ap) o = ap[r] > 0.f ? o * e_scale : 0.f;
-                        op[r] = o;
+                        op[r] = p.bf ? pc_bf16r(o) : o;
                     }
                 }
             }
@@ -317,7 +326,7 @@ extern "C" int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, i
     for (int i = 0; i < n; ++i) {
         if (!d[i].x || !d[i].w || !d[i].out) return PC_EINVAL;
         CtArgs& p = g.pr[i];
-        p.x = *d[i].x; p.w = d[i].w; p.bias = d[i].bias; p.out = *d[i].out; p.B = B; p.H = H; p.W = W;
+        p.x = *d[i].x; p.w = d[i].w; p.bias = d[i].bias; p.out = *d[i].out; p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
         nwg = fill_groups(p);
     }
     nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;     // keep the total grid size roughly constant
@@ -341,7 +350,7 @@ extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int 
     for (int i = 0; i < n; ++i) {
         if (!d[i].g || !d[i].w || !d[i].out) return PC_EINVAL;
         CtArgs& p = g.pr[i];
-        p.x = *d[i].g; p.w = d[i].w; p.out = *d[i].out; p.B = B; p.H = H; p.W = W;
+        p.x = *d[i].g; p.w = d[i].w; p.out = *d[i].out; p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
         if (d[i].act) {
             if (!d[i].act_bn) return PC_EINVAL;
             p.act = d[i].act->ptr; p.act_bstride = d[i].act->bstride; p.act_cstride = d[i].act->cstride;
@@ -400,7 +409,7 @@ extern "C" int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void*
                                          void* stream) {
     if (!x || !g || !ws || !nwg_out) return PC_EINVAL;
     CtArgs p{};
-    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W;
+    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
     p.partial = reinterpret_cast<float*>(ws);
     int nwg = fill_groups(p);
     if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;
@@ -418,7 +427,7 @@ extern "C" int pc_convt2x2_wgrad_partial_group(int n, const pc_convt_wgrad_desc*
     for (int i = 0; i < n; ++i) {
         if (!d[i].x || !d[i].g || !d[i].ws) return PC_EINVAL;
         CtArgs& p = g.pr[i];
-        p.x = *d[i].x; p.g = *d[i].g; p.B = B; p.H = H; p.W = W;
+        p.x = *d[i].x; p.g = *d[i].g; p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
         p.partial = reinterpret_cast<float*>(d[i].ws);
         nwg = fill_groups(p);
     }
@@ -434,7 +443,7 @@ extern "C" int pc_convt2x2_wgrad(const pc_src* x, const pc_src* g, float* dw, fl
                                  int B, int H, int W, int C, void* stream) {
     if (!x || !g || !dw || !ws) return PC_EINVAL;
     CtArgs p{};
-    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W;
+    p.x = *x; p.g = *g; p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
     p.partial = reinterpret_cast<float*>(ws);
     int nwg = fill_groups(p);
     if (nwg > CT_MAX_WG) nwg = CT_MAX_WG;

@@ -45,6 +45,8 @@ struct HeadArgs {
     int B, H, W;
     int groups, nchunk, groups_per_wave;
     pc_fastdiv div_w, div_groups;
+    int bf;                // PC_PREC_BF16 (popcorn_hip.h): weights rounded to bf16 when staged, hidden activations after their
+                           // ReLU, the gradients G3 / G2 / G1 before they are used as operands, g_feat when stored
 };
 
 // Fill the LDS weight image.  A fragments are packed so that one lane's operands for 4 consecutive K-steps are 16
@@ -57,20 +59,22 @@ __device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p
     const int tid = threadIdx.x;
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
-        lds[L_A1 + e] = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)];
+        const float t = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)];
+        lds[L_A1 + e] = p.bf ? pc_bf16r(t) : t;
     }
     for (int e = tid; e < 64 * 64; e += blockDim.x) {
         const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8, mb = f & 3, mb2 = f >> 2;
         const int col = 16 * mb + 4 * (lane >> 4) + r;
         const int row = 16 * mb2 + (lane & 15);
-        lds[L_A2 + e] = p.w2[row * HID + col];
-        lds[L_A3 + e] = p.w4[row * HID + col];
+        const float t2 = p.w2[row * HID + col], t4 = p.w4[row * HID + col];
+        lds[L_A2 + e] = p.bf ? pc_bf16r(t2) : t2;
+        lds[L_A3 + e] = p.bf ? pc_bf16r(t4) : t4;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[L_B0 + e] = p.b0[e];
         lds[L_B2 + e] = p.b2[e];
         lds[L_B4 + e] = p.b4[e];
-        lds[L_W6 + e] = p.w6[e];          // row 0 of the [2][64] last layer: only channel 0 is used (popcorn.py:162,164)
+        lds[L_W6 + e] = p.bf ? pc_bf16r(p.w6[e]) : p.w6[e];   // row 0 of the [2][64] last layer: only channel 0 is used (popcorn.py:162,164)
     }
     if (tid == 0) lds[L_W6 + 64] = p.b6[0];
 }
@@ -105,13 +109,19 @@ __device__ __forceinline__ void head_layer1(const float* lds, int a_off, int b_o
     }
 }
 
-__device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
+__device__ __forceinline__ void relu4(f32x4 (&h)[4], int bf = 0) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
+    if (bf) {       // bf16 mode: the hidden activation is an operand of the next layer
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h[mb] = pc_bf16r4(h[mb]);
+    }
 }
 
+// BF: PC_PREC_BF16 rounding points as a separate instantiation (a run-time flag in this loop cost the fp32 kernel 9 %)
+template <bool BF>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     head_stage_weights(lds, p);
@@ -157,11 +167,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         if (__any(sel)) {
             f32x4 h[4], acc[4];
             head_layer1(lds, L_A1, L_B0, lane, lk, xv, h);
-            relu4(h);
+            relu4(h, BF);
             head_layer64(lds, L_A2, L_B2, lane, lk, h, acc);
-            relu4(acc);
+            relu4(acc, BF);
             head_layer64(lds, L_A3, L_B4, lane, lk, acc, h);
-            relu4(h);
+            relu4(h, BF);
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -174,7 +184,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
             outv = sel ? s + lds[L_W6 + 64] : 0.f;
         }
         if (valid && lk == 0) {
-            const float scale = fmaxf(outv, 0.f);
+            // NaN-propagating ReLU like torch's (v_max_f32 returns the non-NaN operand): a NaN head output must reach the
+            // loss, where the trainer's guard sees it (run_train.py:224-227).  The hidden ReLUs use the plain maximum.
+            const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);
             const float pd = scale * p.building[pix];
             if (p.scale_map) p.scale_map[pix] = scale;
             p.popdense[pix] = pd;
@@ -338,19 +350,21 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
         const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
         const int col = 16 * mi + (l & 15);                           // i
-        lds[LB_T3 + e] = p.w4[row * HID + col];
-        lds[LB_T2 + e] = p.w2[row * HID + col];
+        const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
+        lds[LB_T3 + e] = p.bf ? pc_bf16r(t4) : t4;
+        lds[LB_T2 + e] = p.bf ? pc_bf16r(t2) : t2;
     }
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
         const int row = 16 * mb + 4 * (l >> 4) + r;
-        lds[LB_T1 + e] = p.w0[row * 16 + (l & 15)];
+        const float t0 = p.w0[row * 16 + (l & 15)];
+        lds[LB_T1 + e] = p.bf ? pc_bf16r(t0) : t0;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[LB_B0 + e] = p.b0[e];
         lds[LB_B2 + e] = p.b2[e];
         lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = p.w6[e];
+        lds[LB_W6 + e] = p.bf ? pc_bf16r(p.w6[e]) : p.w6[e];
     }
     if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
     __syncthreads();
@@ -407,11 +421,11 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         // ---- forward recompute
         f32x4 h1[4], h2[4], h3[4];
         head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-        relu4(h1);
+        relu4(h1, p.bf);
         head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
-        relu4(h2);
+        relu4(h2, p.bf);
         head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
-        relu4(h3);
+        relu4(h3, p.bf);
         float s = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                g3[mb][r] = h3[mb][r] > 0.f ? (p.bf ? pc_bf16r(w[r] * gout) : w[r] * gout) : 0.f;
                 db4[mb][r] += g3[mb][r];
             }
         }
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+                g2[mb][r] = h2[mb][r] > 0.f ? (p.bf ? pc_bf16r(g2[mb][r]) : g2[mb][r]) : 0.f;
                 db2[mb][r] += g2[mb][r];
             }
         // ---- layer 2 (W2)
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+                g1[mb][r] = h1[mb][r] > 0.f ? (p.bf ? pc_bf16r(g1[mb][r]) : g1[mb][r]) : 0.f;
                 db0[mb][r] += g1[mb][r];
             }
         // ---- layer 1 (W0: 64 x 16)
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
                     const float fv = fvv[r];
                     o = fv > 0.f ? o * fscale[r] : 0.f;
                 }
-                op[(4 * lk + r) * a.g_feat.cstride] = o;
+                op[(4 * lk + r) * a.g_feat.cstride] = p.bf ? pc_bf16r(o) : o;
             }
         }
     }
@@ -580,6 +594,7 @@ constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is sha
 constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
 constexpr int LP_END = LP_FLAGS + 16;
 
+template <bool BF>
 __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const HeadArgs& p = a.f;
@@ -593,19 +608,21 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
         const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
         const int col = 16 * mi + (l & 15);                           // i
-        lds[LB_T3 + e] = p.w4[row * HID + col];
-        lds[LB_T2 + e] = p.w2[row * HID + col];
+        const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
+        lds[LB_T3 + e] = BF ? pc_bf16r(t4) : t4;
+        lds[LB_T2 + e] = BF ? pc_bf16r(t2) : t2;
     }
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
         const int row = 16 * mb + 4 * (l >> 4) + r;
-        lds[LB_T1 + e] = p.w0[row * 16 + (l & 15)];
+        const float t0 = p.w0[row * 16 + (l & 15)];
+        lds[LB_T1 + e] = BF ? pc_bf16r(t0) : t0;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[LB_B0 + e] = p.b0[e];
         lds[LB_B2 + e] = p.b2[e];
         lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = p.w6[e];
+        lds[LB_W6 + e] = BF ? pc_bf16r(p.w6[e]) : p.w6[e];
     }
     if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
     int* flags = reinterpret_cast<int*>(lds + LP_FLAGS);
@@ -716,11 +733,11 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             if (!__any(sel)) { store_zero(); continue; }
             f32x4 h1[4], h2[4], h3[4];
             head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-            relu4(h1);
+            relu4(h1, BF);
             head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
-            relu4(h2);
+            relu4(h2, BF);
             head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
-            relu4(h3);
+            relu4(h3, BF);
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                    g3[mb][r] = h3[mb][r] > 0.f ? (BF ? pc_bf16r(w[r] * gout) : w[r] * gout) : 0.f;
                 }
             }
             if (!(a.dbg & 2)) {   // slot kind 0: (G3, H2) -> dW4, db4
@@ -755,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? (BF ? pc_bf16r(g2[mb][r]) : g2[mb][r]) : 0.f;
             if (!(a.dbg & 2)) {   // slot kind 1: (G2, H1) -> dW2, db2
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g2);
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? (BF ? pc_bf16r(g1[mb][r]) : g1[mb][r]) : 0.f;
             if (!(a.dbg & 2)) {   // slot kind 2: (G1, X) -> dW0, db0
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g1);
@@ -793,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 for (int r = 0; r < 4; ++r) {
                     float o = gx[r];
                     if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                    op[(4 * lk + r) * a.g_feat.cstride] = o;
+                    op[(4 * lk + r) * a.g_feat.cstride] = BF ? pc_bf16r(o) : o;
                 }
             }
         }
@@ -824,6 +841,10 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 if (row < p.py || row >= p.py + p.H) {
                     if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
                     else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                } else if (p.px <= 16 && Wp - right0 <= 16) {
+                    // both side strips in one store: lanes 0-15 the left one, lanes 16-31 the right one
+                    const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
+                    if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0.f;
                 } else {
                     for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
                     for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
@@ -993,11 +1014,14 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceAr
 
 // ---- fusion_out_conv (1x1, 16->1) + sigmoid + crop ------------------------------------------------------------
 __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, const float* w, const float* bias,
-                                                                   pc_dst out, int B, int H, int W, int py, int px) {
+                                                                   pc_dst out, int B, int H, int W, int py, int px, int bf) {
     const int64_t n = (int64_t)B * H * W;
     float wv[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wv[c] = c < feat.C ? w[c] : 0.f;       // C = 16 (fusion_out_conv) or 8 (sar/optical_out_conv)
+    for (int c = 0; c < 16; ++c) {      // C = 16 (fusion_out_conv) or 8 (sar/optical_out_conv); bf16 mode: operand rounding
+        const float t = c < feat.C ? w[c] : 0.f;
+        wv[c] = bf ? pc_bf16r(t) : t;
+    }
     const float bv = bias[0];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)W;
@@ -1081,13 +1105,17 @@ struct ScoreMaskArgs {
     const float* admin; const int64_t* census; const uint8_t* rowsel; const uint8_t* colsel;
     int occ; uint8_t* mask; int32_t* counts; unsigned* scratch;      // scratch: {acc nsel, acc nregion, ticket, -}, zeroed before the launch
     int B, H, W, py, px;
+    int bf;
 };
 
 __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) {
     const int64_t n = (int64_t)a.B * a.H * a.W;
     float wv[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wv[c] = c < a.feat.C ? a.w[c] : 0.f;
+    for (int c = 0; c < 16; ++c) {
+        const float t = c < a.feat.C ? a.w[c] : 0.f;
+        wv[c] = a.bf ? pc_bf16r(t) : t;
+    }
     const float bv = a.bias[0];
     int nsel = 0, nreg = 0;
     const bool vec4 = (a.W & 3) == 0 && (a.out.rstride & 3) == 0 && (a.out.bstride & 3) == 0 &&
@@ -1270,7 +1298,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     p.mask = mask; p.building = building; p.admin = admin_mask; p.census = census_idx;
     p.scale_map = scale_map; p.popdense = popdensemap;
     p.partial = reinterpret_cast<float*>(ws);
-    p.B = B; p.H = H; p.W = W;
+    p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
     p.groups = (H * W + 15) / 16;
     p.div_w = pc_make_fastdiv(W);
     p.div_groups = pc_make_fastdiv(p.groups);
@@ -1281,7 +1309,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     static int resident = 0;
     if (!resident) {
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel<false>));
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
     }
@@ -1293,7 +1321,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.groups_per_wave < 8) p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
+    if (p.bf) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
+    else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
                        p.nchunk, stats, nsel_counts, (double)B * H * W);
@@ -1309,7 +1338,7 @@ extern "C" int pc_outconv_sigmoid_crop(const pc_src* feat, const float* w, const
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(outconv_sigmoid_crop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *feat, w, bias, *out,
-                       B, H, W, py, px);
+                       B, H, W, py, px, (int)(g_pc_precision == PC_PREC_BF16));
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -1331,7 +1360,7 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     ScoreMaskArgs a{};
     a.feat = *feat; a.w = w; a.bias = bias; a.out = *building_out; a.admin = admin_mask; a.census = census_idx;
     a.rowsel = rowsel; a.colsel = colsel; a.occ = occupancymodel; a.mask = mask; a.counts = counts; a.scratch = scratch;
-    a.B = B; a.H = H; a.W = W; a.py = py; a.px = px;
+    a.B = B; a.H = H; a.W = W; a.py = py; a.px = px; a.bf = g_pc_precision == PC_PREC_BF16;
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
     if (grid > 256) grid = 256;            // one block per CU: the per-block atomics are the serial part
@@ -1410,7 +1439,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     p.feat = *feat; p.py = py; p.px = px;
     p.w0 = hw[0]; p.b0 = hw[1]; p.w2 = hw[2]; p.b2 = hw[3]; p.w4 = hw[4]; p.b4 = hw[5]; p.w6 = hw[6]; p.b6 = hw[7];
     p.mask = mask; p.building = building; p.admin = admin_mask; p.census = census_idx;
-    p.B = B; p.H = H; p.W = W;
+    p.B = B; p.H = H; p.W = W; p.bf = g_pc_precision == PC_PREC_BF16;
     p.groups = (H * W + 15) / 16;
     p.div_w = pc_make_fastdiv(W);
     p.div_groups = pc_make_fastdiv(p.groups);
@@ -1433,12 +1462,16 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel),
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
+        if (e2 != hipSuccess) return (int)e2;
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    if (use_pc && p.bf) hipLaunchKernelGGL(head_bwd_pc_kernel<true>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel<false>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
     HeadReduceArgs r{};

@@ -93,6 +93,16 @@ class POPCORN(nn.Module):
         self.building_extractor = _new_dualstream()                          # popcorn.py:96
         self._engines = None
         self._w0_pad = None
+        self.precision = "fp32"          # "bf16": PC_PREC_BF16 mixed precision (include/popcorn_hip.h; BASELINE config 4)
+
+    def set_precision(self, mode):
+        """Arithmetic mode of every kernel this module enqueues: "fp32" (the reference's arithmetic) or "bf16" (bf16 MFMA
+        operands, fp32 accumulation, fp32 master weights; rounding points in include/popcorn_hip.h).  Build-specific: the
+        reference constructor has no such switch."""
+        if mode not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
+        self.precision = mode
+        return self
 
     # ------------------------------------------------------------------------------------------- engine plumbing
     def _apply(self, fn, *a, **k):
@@ -170,7 +180,7 @@ class POPCORN(nn.Module):
         L.require_device(X)
         self.building_extractor.eval()
         self.unetmodel.freeze_bn_layers()
-        with torch.no_grad():
+        with torch.no_grad(), L.precision(self.precision):
             return self.engines()[1].building_score(X.contiguous(), self.p)
 
     def get_sparsity_mask(self, inputs, sparse_unet=False):
@@ -224,11 +234,12 @@ class POPCORN(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if unet_no_grad:
             self.unetmodel.eval()
-        if need_grad:
-            popcount, popdense, scale = _PopcornFn.apply(self, X, building, mask, admin, census, geom, sparse,
-                                                         encoder_no_grad, unet_no_grad, *params)
-        else:
-            popcount, popdense, scale = _forward_nograd(self, X, building, mask, admin, census, geom, sparse)
+        with L.precision(self.precision):
+            if need_grad:
+                popcount, popdense, scale = _PopcornFn.apply(self, X, building, mask, admin, census, geom, sparse,
+                                                             encoder_no_grad, unet_no_grad, *params)
+            else:
+                popcount, popdense, scale = _forward_nograd(self, X, building, mask, admin, census, geom, sparse)
         aux = {"scale": scale if self.occupancymodel else None}
         return {"popcount": popcount, "popdensemap": popdense, **aux}
 
@@ -284,18 +295,20 @@ class _PopcornFn(torch.autograd.Function):
         grads = {n: torch.empty_like(p) for n, p in zip(names, params)}
         hgrads = [grads[n] for n in names[-8:]]
         khgrads, fix = model.head_grad_targets(hgrads)
-        _, G = ops.head_bwd(ctx.feats, pt, pl, H, W, model.head_tensors(), building, mask=mask, admin_mask=admin,
-                            census_idx=census,
-                            g_popcount=None if g_popcount is None else g_popcount.contiguous().float(),
-                            g_popdense=None if g_popdense is None else g_popdense.contiguous().float(),
-                            g_scale_map=g_scale_map, grads=khgrads,
-                            feat_bn=None if unet_no_grad else eng.feat_bn())
-        fix()
+        with L.precision(model.precision):
+            _, G = ops.head_bwd(ctx.feats, pt, pl, H, W, model.head_tensors(), building, mask=mask, admin_mask=admin,
+                                census_idx=census,
+                                g_popcount=None if g_popcount is None else g_popcount.contiguous().float(),
+                                g_popdense=None if g_popdense is None else g_popdense.contiguous().float(),
+                                g_scale_map=g_scale_map, grads=khgrads,
+                                feat_bn=None if unet_no_grad else eng.feat_bn())
+            fix()
+            if not unet_no_grad:
+                eng.backward(ctx.saved, G, grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
         n_unet = len(names) - 8
         if unet_no_grad:
             out = [None] * n_unet + hgrads
         else:
-            eng.backward(ctx.saved, G, grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
             out = []
             for n in names[:n_unet]:
                 is_enc = any(("." + E.CONVS[t][0] + ".") in n for t in E.ENCODER)

@@ -263,18 +263,20 @@ class FusedTrainStep:
             s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
             s["admin_mask"] = s["admin_mask"].float()
             sel = sel_host.to(self.device, non_blocking=True)
-            self._forward(s, sel, encoder_no_grad, unet_no_grad)
-            self.reducer.reduce_stats(self.stats)
-            self._backward(s, encoder_no_grad, unet_no_grad)
-            self.reducer.reduce_grads(self.flat_g)
-            self._update(encoder_no_grad, unet_no_grad)
+            with L.precision(self.model.precision):
+                self._forward(s, sel, encoder_no_grad, unet_no_grad)
+                self.reducer.reduce_stats(self.stats)
+                self._backward(s, encoder_no_grad, unet_no_grad)
+                self.reducer.reduce_grads(self.flat_g)
+                self._update(encoder_no_grad, unet_no_grad)
             return self.loss_out
         return self._graph_step(sample, sel_host, encoder_no_grad, unet_no_grad)
 
     def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
-        key = (tuple(sample["input"].shape), encoder_no_grad, unet_no_grad)
+        key = (tuple(sample["input"].shape), encoder_no_grad, unet_no_grad, self.model.precision)
         if self._graphs is None or self._graphs[0] != key:
-            self._capture(sample, sel_host, key)
+            with L.precision(self.model.precision):      # the mode is read when a launch is enqueued = captured
+                self._capture(sample, sel_host, key)
         _, st, sel, graphs = self._graphs
         for k in ("input", "admin_mask", "census_idx", "y"):
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
@@ -301,7 +303,7 @@ class FusedTrainStep:
         return self._static
 
     def _capture(self, sample, sel_host, key):
-        _, enc_ng, unet_ng = key
+        _, enc_ng, unet_ng, _ = key
         if self._static is not None and all(sample[k] is self._static[k] for k in self._static):
             st = dict(self._static)
         else:

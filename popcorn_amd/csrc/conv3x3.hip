@@ -34,6 +34,21 @@ extern "C" void pc_debug_conv_ts(void* buf) { g_conv_ts = (long long*)buf; }
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// bf16 mode (BF instantiations): the MFMA is v_mfma_f32_16x16x32_bf16 with K = 32 = (4 input rows v) x (8 input channels):
+// one instruction per (horizontal tap dx, 16-px block) and 8-channel chunk instead of 8 fp32 ones.  The wave's strip lives
+// in LDS as [6 rows][48 slots][8 channels] bf16 (one 16-byte slot per pixel), so an A operand -- lane (x, v): the 8
+// channels of pixel (row v, x + dx) -- is ONE ds_read_b128; weights are an image [dy plane][co][chunk][dx][8 ci] bf16
+// with an all-zero plane for the (row, output row) pairs that are not a tap.  Both operands enumerate K as
+// slot(lane >> 4, j) = (row, channel j), so the products pair up whatever the hardware's internal K order is.
+constexpr int BSLOTS = 48;               // slots per strip row (40 used; == 0 mod 16: the two lane rows of a b128 group do not collide)
+constexpr int BWAVE_F = 6 * BSLOTS * 4;  // floats (4 per 16-byte slot) of one wave's bf16 strip
+__device__ __forceinline__ unsigned pc_pack_bf16(float lo, float hi) {       // two bf16-representable floats -> one dword
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+
 constexpr int TW = 32, TH = 16;          // output tile
 constexpr int RS = 48;                   // LDS row stride  (== 16 mod 32)
 constexpr int COL0 = 4;                  // LDS column of tile x0 (left halo at COL0-1): keeps float4 stores aligned
@@ -113,7 +128,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 
-    float* const wl = lds + wave * (CHUNK * CSW);        // this wave's LDS region
+    constexpr int WAVE_F = BF ? BWAVE_F : CHUNK * CSW;   // floats of one wave's LDS region
+    float* const wl = lds + wave * WAVE_F;               // this wave's LDS region
 
     // ---- staged loader: lane = (row r of the 6-row strip, 16-byte segment seg of the 40-float row)
     const int l_r = lane / 10, l_seg = lane - l_r * 10;
@@ -169,7 +185,23 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         }
     };
     auto commit = [&]() {
-        if (l_act) {
+        if constexpr (BF) {
+            // the lane holds 4 consecutive pixels of every channel of the chunk: one 16-byte slot (8 channels) per pixel
+            if (l_act) {
+                u32x4* d = reinterpret_cast<u32x4*>(wl) + l_r * BSLOTS + 4 * l_seg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 s;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const float lo = (2 * h < NIT && rvalid) ? R[(2 * h) % NIT][e] : 0.f;
+                        const float hi = (2 * h + 1 < NIT && rvalid) ? R[(2 * h + 1) % NIT][e] : 0.f;
+                        s[h] = pc_pack_bf16(lo, hi);
+                    }
+                    d[e] = s;
+                }
+            }
+        } else if (l_act) {
             float* d = wl + l_r * RS + 4 * l_seg;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
@@ -182,7 +214,18 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             const int cg = ch * CHUNK + ci;
             const float v = cg < CA ? pc_fetch(q.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
                                     : pc_fetch(q.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-            wl[ci * CSW + r * RS + (COL0 - 1) + c] = rnd(v);
+            if constexpr (BF) {
+                reinterpret_cast<unsigned short*>(wl)[(r * BSLOTS + (COL0 - 1) + c) * 8 + ci] =
+                    (unsigned short)(__float_as_uint(rnd(v)) >> 16);
+            } else {
+                wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
+            }
+        }
+        if constexpr (BF && CHUNK < 8) {      // channel slots the layer does not have
+            for (int idx = lane; idx < (8 - CHUNK) * SROWS * 34; idx += 64) {
+                const int c = idx % 34, r = (idx / 34) % SROWS, ci = CHUNK + idx / (34 * SROWS);
+                reinterpret_cast<unsigned short*>(wl)[(r * BSLOTS + (COL0 - 1) + c) * 8 + ci] = 0;
+            }
         }
     };
 
@@ -216,7 +259,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // Prologue latency: the weight elements and the raw BN parameters are loaded into registers FIRST (one memory round
     // trip, in flight together with the first strip), the LDS image is zeroed meanwhile, and only then are they consumed
     // -- the prologue used to be three dependent round trips (zero fill + barrier, weights, BN), ~4.6 us of every launch.
-    float* const w2 = lds + 4 * CHUNK * CSW;
+    float* const w2 = lds + 4 * WAVE_F;
+    // bf16 image: [dy plane 0..3][co][chunk][dx][8 ci] halves, plane 3 all zero
+    constexpr int BW_CO = NCHUNK * 24;                   // halves per (dy plane, co)
+    constexpr int BW_DYS = COUT * BW_CO;                 // halves per dy plane
+    unsigned short* const w2h = reinterpret_cast<unsigned short*>(w2);
     constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
     float wreg[NWR];
 #pragma unroll
@@ -237,7 +284,21 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         bn_raw[nb][3] = has_bn && q.bn.gamma ? q.bn.mean[c] : 0.f;
         bn_raw[nb][4] = has_bn && q.bn.gamma ? q.bn.beta[c] : 0.f;
     }
-    {
+    if constexpr (BF) {
+        // whole image zeroed first (plane 3, and the channel slots a CIN < 8 layer does not have), then the taps
+        for (int e = tid; e < 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) {
+            const int e = tid + k * 256;
+            if (e < COUT * CIN * 9) {
+                const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+                w2h[(tap / 3) * BW_DYS + co * BW_CO + (ci / 8) * 24 + (tap % 3) * 8 + (ci % 8)] =
+                    (unsigned short)(__float_as_uint(wreg[k]) >> 16);          // wreg is already rounded to bf16
+            }
+        }
+        __syncthreads();
+    } else {
         // only the dy = 3 plane has to be zero (the pad floats of the other planes are never read): disjoint from the weight
         // writes below, so one barrier covers both
         for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
@@ -252,6 +313,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         __syncthreads();
     }
     const float* const wlane = w2 + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * W_DYS + col * W_RL;
+    const unsigned short* const wlane_h = w2h + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * BW_DYS + col * BW_CO;
+    bf16x8 bwh[3][NB];
+    auto load_bwh = [&](int ch) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                bwh[dx][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane_h + nb * 8 * BW_CO + ch * 24 + dx * 8));
+    };
     float bw[CHUNK][3][NB];
     auto load_bw = [&](int ch) {
         if constexpr (CHUNK == 8) {
@@ -487,7 +557,24 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!(p.dbg & 2)) {
+        if constexpr (BF) {
+            if (!(p.dbg & 2)) {
+                load_bwh(ch);
+                const u32x4* lrow = reinterpret_cast<const u32x4*>(wl) + lk * BSLOTS + (COL0 - 1) + li;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bf16x8 av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        av[u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSLOTS + (u & 1) * 16 + dx]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], bwh[dx][nb], acc[u][nb], 0, 0, 0);
+                }
+            }
+        } else if (!(p.dbg & 2)) {
             load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
             const float* lrow = wl + lk * RS + (COL0 - 1) + li;
 #pragma unroll
@@ -522,7 +609,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 template <int CIN, int COUT, int MODE, int LD, int EPI, bool BF>
 int launch_conv_bf(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
-    const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
+    const size_t lds = BF ? ((size_t)4 * BWAVE_F * sizeof(float) + (size_t)4 * COUT * (CIN / CHUNK) * 24 * sizeof(unsigned short))
+                          : ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, BF>);

@@ -60,7 +60,8 @@ def test_bf16_forward_vs_bf16_oracle(padding, sparse):
         o32 = O.popcorn_forward(sd, {k: v.clone() for k, v in s.items()}, padding=padding, sparse=sparse)
         with O.bf16_mode():
             torch.manual_seed(1600)
-            o16 = O.popcorn_forward(sd, {k: v.clone() for k, v in s.items()}, padding=padding, sparse=sparse)
+            in16 = {k: v.clone() for k, v in s.items()}
+            o16 = O.popcorn_forward(sd, in16, padding=padding, sparse=sparse)
         m.set_precision("bf16")
         torch.manual_seed(1600)
         inp = {k: v.cuda() for k, v in s.items()}
@@ -70,7 +71,7 @@ def test_bf16_forward_vs_bf16_oracle(padding, sparse):
         e, band = rel(h16[key].cpu(), o16[key]), rel(o16[key], o32[key])
         assert e < tol and e < 0.5 * band, (key, e, band)
         assert band > 10 * 1e-4, "bf16 rounding must be visible against the fp32 result, else the mode is not active"
-    assert rel(inp["building_counts"].cpu(), O.create_building_score(sd, s["input"])) < 2e-2
+    assert rel(inp["building_counts"].cpu(), in16["building_counts"]) < TOL_MAP      # frozen extractor, same rounding points
 
 
 def test_bf16_stored_activations_are_bf16_values_and_fp32_mode_is_untouched():
@@ -138,9 +139,9 @@ def test_bf16_training_lowers_the_loss_with_graph_replay():
     for use_graph in (False, True):
         mm, _ = _model()
         mm.set_precision("bf16")
-        tr = FusedTrainStep(mm, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
+        tr = FusedTrainStep(mm, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
         losses = []
-        for it in range(6):
+        for it in range(5):
             torch.manual_seed(50)
             losses.append(tr.step(dict(s))[0].item())
         torch.cuda.synchronize()
@@ -204,3 +205,100 @@ def test_bf16_two_rank_data_parallel_equals_single_process():
             assert p.exitcode == 0
     p1, p2 = outs
     assert (p1 - p2).abs().max().item() <= 2e-5 * p1.abs().max().item()
+
+
+# ---- op level: the bf16-MFMA conv kernels (v_mfma_f32_16x16x32_bf16) --------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _mk(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _bn(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.2,
+            torch.rand(c, generator=g) + 0.3)
+
+
+def _close_bf16(out, ref_fp32):
+    """out must equal round_bf16(ref) up to the ties an fp32 summation order can flip: every element within one bf16 step
+    (2^-7 relative, or a tiny absolute floor around zero), almost all of them exactly equal."""
+    want = _bf(ref_fp32)
+    assert _is_bf16(out.cuda() if not out.is_cuda else out)
+    o = out.cpu()
+    err = (o - want).abs()
+    assert bool((err <= 2.0 ** -7 * want.abs() + 1e-6).all()), err.max().item()
+    assert float((err == 0).float().mean()) > 0.98
+
+
+@pytest.mark.parametrize("cin,cout", [(2, 8), (4, 8), (8, 8), (16, 8), (32, 8), (8, 16), (16, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 37, 53), (3, 16, 32)])
+def test_bf16_conv_fwd_op(cin, cout, shape):
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    B, H, W = shape
+    x = _bf(_mk(B, cin, H, W, seed=1))                     # activations arrive rounded from their producer
+    w = _mk(cout, cin, 3, 3, seed=2, scale=0.2)
+    b = _mk(cout, seed=3, scale=0.1)
+    gamma, beta, mean, var = _bn(cout, 4)
+    y = F.conv2d(x.double(), _bf(w).double(), b.double(), padding=1)
+    ref = F.relu(F.batch_norm(y, mean.double(), var.double(), gamma.double(), beta.double(), training=False, eps=1e-5)).float()
+    with L.precision("bf16"):
+        out = ops.conv3x3_bn_relu(x.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())
+    _close_bf16(out, ref)
+
+
+def test_bf16_conv_asymmetric_taps_and_loaders():
+    """Single non-zero taps (catch any row / column / channel-slot mix-up of the K = (row, channel) packing), the fused
+    pool and concat loaders, the reflect loader with un-rounded input, and the dgrad epilogues, all in bf16 mode."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    x = _bf(_mk(1, 16, 20, 40, seed=5))
+    with L.precision("bf16"):
+        for (co, ci, dy, dx) in [(1, 6, 0, 2), (7, 0, 2, 0), (3, 11, 1, 0), (0, 15, 2, 2), (5, 8, 0, 0)]:
+            w = torch.zeros(8, 16, 3, 3)
+            w[co, ci, dy, dx] = 1.0
+            ref = F.conv2d(x, w, None, padding=1)
+            out = ops.conv3x3_bn_relu(x.cuda(), w.cuda(), None, relu=False)
+            assert torch.equal(out.cpu(), ref), (co, ci, dy, dx)
+        # pool loader
+        xs = _bf(_mk(2, 8, 64, 64, seed=6))
+        w = _mk(16, 8, 3, 3, seed=7, scale=0.2)
+        b = _mk(16, seed=8, scale=0.1)
+        ref = F.relu(F.conv2d(F.max_pool2d(xs, 2).double(), _bf(w).double(), b.double(), padding=1)).float()
+        out = ops.conv3x3_bn_relu(xs.cuda(), w.cuda(), b.cuda(), a_mode=L.PC_SRC_POOL2)
+        _close_bf16(out, ref)
+        # concat loader (aligned: staged path) and with an offset up tensor (generic path)
+        for (hs, ws, hu, wu) in [(32, 64, 32, 64), (23, 35, 22, 34)]:
+            skip, upt = _bf(_mk(2, 16, hs, ws, seed=10)), _bf(_mk(2, 16, hu, wu, seed=11))
+            w = _mk(8, 32, 3, 3, seed=12, scale=0.1)
+            b = _mk(8, seed=13, scale=0.1)
+            dy, dx = hs - hu, ws - wu
+            upp = F.pad(upt, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+            ref = F.relu(F.conv2d(torch.cat([skip, upp], 1).double(), _bf(w).double(), b.double(), padding=1)).float()
+            out = ops.conv3x3_bn_relu(skip.cuda(), w.cuda(), b.cuda(), b=upt.cuda(), b_offset=(dy // 2, dx // 2))
+            _close_bf16(out, ref)
+        # reflect loader: un-rounded 6-channel input, channel gather
+        X = _mk(2, 6, 100, 100, seed=14)
+        w = _mk(8, 4, 3, 3, seed=15, scale=0.3)
+        b = _mk(8, seed=16, scale=0.1)
+        chmap = (2, 1, 0, 3)
+        xp = F.pad(X[:, list(chmap)], (14, 14, 14, 14), mode="reflect")
+        ref = F.relu(F.conv2d(_bf(xp).double(), _bf(w).double(), b.double(), padding=1)).float()
+        out = ops.conv3x3_raw(X.cuda(), w.cuda(), L.bn(b.cuda()), a_mode=L.PC_SRC_REFLECT, a_pad=(14, 14), chmap=chmap,
+                              out_hw=(128, 128), a_channels=4)
+        _close_bf16(out, ref)
+        # data gradient with the ReLU / BN epilogue of the producing layer
+        g = _bf(_mk(2, 8, 32, 64, seed=17))
+        w = _mk(8, 16, 3, 3, seed=18, scale=0.2)
+        act = F.relu(_mk(2, 8, 32, 64, seed=19))
+        gamma, beta, mean, var = _bn(8, 20)
+        scale = gamma / torch.sqrt(var + 1e-5)
+        full = F.conv_transpose2d(g.double(), _bf(w).double(), padding=1)[:, 8:16]
+        ref = (full * (act > 0) * scale.view(1, 8, 1, 1).double()).float()
+        out = torch.empty(2, 8, 32, 64, device="cuda")
+        ops.conv3x3_dgrad(g.cuda(), w.cuda(), 8, 8, out, act=act.cuda(), act_bn=L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()))
+        _close_bf16(out, ref)

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=7.0, help="CPU work per cpu_baseline leg")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: BASELINE config 4's mixed precision (PC_PREC_BF16) as a SECOND line; the headline stays fp32")
     return ap.parse_args()
 
 
@@ -396,6 +398,7 @@ def main():
     torch.manual_seed(1600)
     model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.set_precision(args.precision)
     trainer = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,),
                              scale_regularization=0.01, lam_weak=100.0, reducer=FlatReducer(),
                              use_graph=not args.no_graph)
@@ -450,7 +453,9 @@ def main():
         res = {
             "metric": "training patches/s (15-band 100x100)", "value": round(value, 1), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands + stored activations; fp32 accumulate, master weights, Adam)",
+            "data": "synthetic",
             "config": {"workload": f"config[1]/[2]: batch={B} synthetic S1+S2 100x100 tiles per GPU, full train step "
                                    "(building extractor + DDA dual-stream U-Net + sparse head fwd/bwd, log-L1 loss, "
                                    "clip 0.01, Adam, rwa flags), every pixel of every tile selected",
@@ -463,8 +468,10 @@ def main():
             "step_tflops": round(value * FLOP_TRAIN_PER_TILE / 1e12, 3),
             "step_frac_of_fp32_mfma_peak": round(value * FLOP_TRAIN_PER_TILE / (FP32_MATRIX_PEAK * world), 4),
         }
-        res["roofline"] = dominant_kernel_roofline(torch, trainer, sample)
-        res["roofline_conv"] = conv_kernel_roofline(torch, B)
+        from popcorn_amd import _lib as L
+        with L.precision(args.precision):
+            res["roofline"] = dominant_kernel_roofline(torch, trainer, sample)
+            res["roofline_conv"] = conv_kernel_roofline(torch, B)
         if world == 1 and not args.no_class_sweep:
             res["roofline_conv_class"] = conv_class_sweep(torch, trainer, sample)
         if world == 1 and not args.no_cpu_baseline:

@@ -12,9 +12,13 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
 // bf16 mixed precision (PC_PREC_BF16, popcorn_hip.h): round-to-nearest-even of an fp32 value to the nearest bf16, kept in an
 // fp32 register (what torch's `.to(torch.bfloat16).to(torch.float32)` gives; NaN payloads aside).
 __device__ __forceinline__ float pc_bf16r(float x) {
-    uint32_t u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return __uint_as_float(u & 0xffff0000u);
+    return (float)(__bf16)x;            // v_cvt_pk_bf16_f32 (round-to-nearest-even in hardware) + a shift
+}
+// two floats -> one dword of two bf16 (lo in bits 0-15), rounding to nearest even: ONE v_cvt_pk_bf16_f32
+typedef __bf16 pc_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pc_pack_bf16(float lo, float hi) {
+    const pc_bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
 }
 __device__ __forceinline__ f32x4 pc_bf16r4(f32x4 v) { return f32x4{pc_bf16r(v[0]), pc_bf16r(v[1]), pc_bf16r(v[2]), pc_bf16r(v[3])}; }
 extern int g_pc_precision;      // api.hip: pc_set_precision()

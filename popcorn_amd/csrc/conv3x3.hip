@@ -45,9 +45,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // slot(lane >> 4, j) = (row, channel j), so the products pair up whatever the hardware's internal K order is.
 constexpr int BSLOTS = 48;               // slots per strip row (40 used; == 0 mod 16: the two lane rows of a b128 group do not collide)
 constexpr int BWAVE_F = 6 * BSLOTS * 4;  // floats (4 per 16-byte slot) of one wave's bf16 strip
-__device__ __forceinline__ unsigned pc_pack_bf16(float lo, float hi) {       // two bf16-representable floats -> one dword
-    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
-}
 
 constexpr int TW = 32, TH = 16;          // output tile
 constexpr int RS = 48;                   // LDS row stride  (== 16 mod 32)
@@ -155,10 +152,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 R[it] = l_act ? pc_fetch_reflect_seg(q.a, b, ch * CHUNK + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (BF) {       // the model input is the one operand no producer has rounded
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) R[it] = pc_bf16r4(R[it]);
-            }
+            // (bf16 mode: the model input is the one operand no producer has rounded -- the pack in commit() rounds it)
         } else if (LD == LD_DIRECT) {
             const int64_t off = ok ? b * my_bs + (int64_t)y * my_rs + xg : 0;
 #pragma unroll

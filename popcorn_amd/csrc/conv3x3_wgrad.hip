@@ -19,6 +19,9 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
 constexpr int TW = 32, TH = 16;
 constexpr int IN_RS = 40;                    // == 8 mod 32: the 4 input rows v of a k-step land 8 banks apart
 constexpr int IN_CS = 18 * IN_RS + 20;       // 740 == 4 mod 32: the (at most) two channels of an N-block interleave
@@ -391,6 +394,223 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
     }
 }
 
+// ---- bf16 variant of the wave-private kernel (PC_PREC_BF16; aligned DIRECT / POOL2 sources, CINC = 8 or 16) --------------
+// v_mfma_f32_16x16x32_bf16: the reduction over pixels rides on K = 32 = one whole strip row, so a strip is 2 x 3 x MB x
+// CINC/4 instructions instead of 16 x MB x CINC*12/16 fp32 ones.  The horizontal tap moves to the GRADIENT operand:
+//     D_dx[(s,co)][(ci,v)] += sum_x' g[co][yp+s][x' - dx + 1] * in[ci][yp+v-1][x'],   x' = x0 .. x0+31
+// A (M = (s, co8)): the lane's 8 k-slots are g at x0 + 8*lk + j - dx + 1, cut from ten consecutive floats that sit in
+//    registers (two 16-byte loads + the two neighbours) -- three shifted packings, no LDS;
+// B (N = (ci, v), 4 channels x 4 input rows per block): in at x0 + 8*lk + j, UNshifted, one aligned ds_read_b128 from the
+//    strip kept in LDS as bf16 ([ci][6 rows][16 B pad + 32 px]); no x halo is needed at all.
+// dW[co][ci][dy][dx] = D_dx[(0,co)][(ci,dy)] + D_dx[(1,co)][(ci,dy+1)]; same compacted partial as the fp32 kernels.
+constexpr int BW_ROWB = 80;                  // bytes of one (channel, row) of the bf16 strip: 16 pad + 64
+
+template <int CINC, int COUT, int LD>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const WgradGroup grp_) {
+    const WgradArgs& p = grp_.pr[blockIdx.z];
+    using Cfg = WgradCfg<CINC, COUT>;
+    constexpr int MB = Cfg::MB;
+    constexpr int NBP = CINC / 4;                // N blocks of (4 channels x 4 rows) per tap
+    constexpr int NBLK = 3 * NBP;                // accumulator blocks per mb: [dx][nbp]  (== Cfg::NBLK for CINC = 8, 16)
+    static_assert(NBLK == Cfg::NBLK, "staging buffer of the cross-wave reduction is sized by Cfg::NBLK");
+    constexpr int NIT = CINC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int cbase = p.ci0 + chunk * CINC;
+    unsigned char* const wl = reinterpret_cast<unsigned char*>(lds) + wave * (CINC * 6 * BW_ROWB);
+
+    // B operand address: lane n = (ci4 = li >> 2, v = li & 3), 8 pixels from x0 + 8*lk
+    int boff[NBP];
+#pragma unroll
+    for (int nb = 0; nb < NBP; ++nb) boff[nb] = ((nb * 4 + (li >> 2)) * 6 + (li & 3)) * BW_ROWB + 16 + 16 * lk;
+
+    // ---- input-strip loader (as in the fp32 kernel): lane = (row r of 6, 16-byte segment of the 40-float row)
+    const int l_r = lane / 10, l_seg = lane - l_r * 10;
+    const bool l_act = lane < 60;
+    const int CA = p.a.C;
+    const int64_t in_bs = p.a.bstride;
+    const int in_rs = p.a.rstride;
+    f32x4 R[NIT];
+    bool rvalid = false;
+    // ---- gradient operand: lane (i = (s, co8), k group lk): ten floats g[x0 + 8*lk - 1 .. x0 + 8*lk + 8] of row y0 + 2*rpi + s
+    const int g_s = li >> 3, g_c = li & 7;
+    f32x4 G0[2][MB], G1[2][MB];
+    float GL[2][MB], GR[2][MB];
+    unsigned gvalid = 0;      // bit rpi*4 + {0: first 4, 1: second 4, 2: left neighbour, 3: right neighbour}
+
+    auto issue = [&](int b, int y0, int x0) {
+        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
+        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
+        rvalid = ok;
+        if (LD == 1) {
+            const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cg = cbase + it;
+                const float* cp = cg < CA ? p.a.ptr + cg * p.a.cstride : p.b.ptr + (cg - CA) * p.b.cstride;
+                R[it] = *reinterpret_cast<const f32x4*>(cp + off);
+            }
+        } else {
+            const int64_t off = ok ? b * in_bs + (int64_t)(2 * y) * in_rs + 2 * xg : 0;
+            const int rs1 = ok ? in_rs : 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float* s0 = p.a.ptr + (cbase + it) * p.a.cstride + off;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + rs1), b1 = *reinterpret_cast<const f32x4*>(s0 + rs1 + 4);
+                f32x4 v;
+                v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
+                v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
+                v[2] = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1]));
+                v[3] = fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]));
+                R[it] = v;
+            }
+        }
+        unsigned gm = 0;
+        const int xx = x0 + 8 * lk;
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const int yy = y0 + 2 * rpi + g_s;
+            const bool rowok = yy < p.H;
+            const bool ok0 = rowok && xx < p.W, ok1 = rowok && xx + 4 < p.W;
+            const bool okl = rowok && xx - 1 >= 0 && xx - 1 < p.W, okr = rowok && xx + 8 < p.W;
+            gm |= (ok0 ? 1u : 0u) << (rpi * 4) | (ok1 ? 2u : 0u) << (rpi * 4) | (okl ? 4u : 0u) << (rpi * 4) | (okr ? 8u : 0u) << (rpi * 4);
+            const int64_t rowoff = rowok ? b * p.g.bstride + (int64_t)yy * p.g.rstride : 0;
+            const int64_t o0 = ok0 ? rowoff + xx : 0, o1 = ok1 ? rowoff + xx + 4 : 0;
+            const int64_t ol = okl ? rowoff + xx - 1 : 0, orr = okr ? rowoff + xx + 8 : 0;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const float* gp = p.g.ptr + (mb * 8 + g_c) * p.g.cstride;
+                G0[rpi][mb] = *reinterpret_cast<const f32x4*>(gp + o0);
+                G1[rpi][mb] = *reinterpret_cast<const f32x4*>(gp + o1);
+                GL[rpi][mb] = gp[ol];
+                GR[rpi][mb] = gp[orr];
+            }
+        }
+        gvalid = gm;
+    };
+    auto commit = [&]() {
+        // segments 1..8 = the strip's own 32 pixels; four pixels of a channel row -> four bf16 = one 8-byte store
+        if (l_act && l_seg >= 1 && l_seg <= 8) {
+            unsigned char* d = wl + l_r * BW_ROWB + 16 + 8 * (l_seg - 1);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const f32x4 v = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<uint2*>(d + it * 6 * BW_ROWB) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
+            }
+        }
+    };
+
+    f32x4 acc[MB][NBLK];
+    float bsum[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) {
+        strip_coords(0, b, y0, x0);
+        issue(b, y0, x0);
+    }
+    for (int k = 0; k < my_tiles; ++k) {
+        commit();
+        // A operands of this strip: f[t] = g[x0 + 8*lk - 1 + t], t = 0..9 (masked); tap dx takes f[2 - dx + j], j = 0..7
+        bf16x8 av[2][MB][3];
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned m = gvalid >> (rpi * 4);
+                float f[10];
+                f[0] = (m & 4u) ? GL[rpi][mb] : 0.f;
+                f[9] = (m & 8u) ? GR[rpi][mb] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[1 + e] = (m & 1u) ? G0[rpi][mb][e] : 0.f;
+                    f[5 + e] = (m & 2u) ? G1[rpi][mb][e] : 0.f;
+                }
+                bsum[mb] += ((f[1] + f[2]) + (f[3] + f[4])) + ((f[5] + f[6]) + (f[7] + f[8]));
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    u32x4w q;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) q[h] = pc_pack_bf16(f[2 - dx + 2 * h], f[3 - dx + 2 * h]);
+                    av[rpi][mb][dx] = __builtin_bit_cast(bf16x8, q);
+                }
+            }
+        if (k + 1 < my_tiles) {
+            strip_coords(k + 1, b, y0, x0);
+            issue(b, y0, x0);
+        }
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb) {
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4w*>(wl + boff[nb] + 2 * rpi * BW_ROWB));
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][dx * NBP + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rpi][mb][dx], bv, acc[mb][dx * NBP + nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS (fixed order), one compacted partial per workgroup (layout of the fp32 kernels)
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+            *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
+        __syncthreads();
+        for (int idx = tid; idx < 8 * CINC * 9; idx += 256) {
+            const int c8 = idx / (CINC * 9), rem = idx - c8 * (CINC * 9);
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            // D_dx[m = s*8 + c8][n = (cil & 3)*4 + v] in block dx*NBP + (cil >> 2); lane = (m>>2)*16 + n, reg = m&3
+            const int blk = dx * NBP + (cil >> 2);
+            const int n0 = (cil & 3) * 4 + dy, n1 = n0 + 1;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
+            const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * (CINC * 9) + rem] = wsum(e0) + wsum(e1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
+    __syncthreads();
+    if (tid < COUT) {
+        const int mb = tid >> 3, c8 = tid & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int lk2 = 0; lk2 < 4; ++lk2) {
+            const int ea = mb * 64 + lk2 * 16 + c8, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[MB * 64 + ea]) + lds[2 * MB * 64 + ea]) + lds[3 * MB * 64 + ea];
+            const float sb = ((lds[eb] + lds[MB * 64 + eb]) + lds[2 * MB * 64 + eb]) + lds[3 * MB * 64 + eb];
+            t += sa + sb;
+        }
+        part[COUT * CINC * 9 + tid] = t;
+    }
+}
+
 struct WreduceArgs {
     const float* partial;
     int nwg;              // partials per chunk
@@ -476,7 +696,7 @@ int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk
     size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
     const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
     if (lw < lred) lw = lred;
-    static int resident[3] = {0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
+    static int resident[5] = {0, 0, 0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
     auto go = [&](auto kern, int slot) -> int {
         if (!resident[slot]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
@@ -498,6 +718,17 @@ int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk
         return 0;
     };
     int rc = 0;
+    bool bf = true;
+    for (int i = 0; i < n; ++i) bf = bf && g.pr[i].bf != 0;
+    if constexpr (CINC >= 8) {
+        if (bf && (kind == 1 || kind == 2)) {
+            if (kind == 1) rc = go(&conv3x3_wgrad_wave_bf16_kernel<CINC, COUT, 1>, 3);
+            else rc = go(&conv3x3_wgrad_wave_bf16_kernel<CINC, COUT, 2>, 4);
+            if (rc) return rc;
+            PC_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (kind == 3) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 3>, 2);
     else if (kind == 1) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>, 0);
     else rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 2>, 1);

@@ -302,3 +302,47 @@ def test_bf16_conv_asymmetric_taps_and_loaders():
         out = torch.empty(2, 8, 32, 64, device="cuda")
         ops.conv3x3_dgrad(g.cuda(), w.cuda(), 8, 8, out, act=act.cuda(), act_bn=L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()))
         _close_bf16(out, ref)
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 8), (32, 8), (8, 16), (16, 16), (4, 8)])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 16, 32), (1, 40, 52), (2, 128, 128)])
+def test_bf16_conv_wgrad_op(cin, cout, shape):
+    """Weight / bias gradient in bf16 mode (v_mfma_f32_16x16x32_bf16 with the reduction over a whole strip row on K, the
+    horizontal tap on the gradient operand): bf16 operands, fp32 sums -- so against torch on the same rounded operands it
+    is an fp32-accuracy check (<= 2e-5 of the largest entry), and the result is NOT bf16-rounded."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    B, H, W = shape
+    x = _bf(_mk(B, cin, H, W, seed=40))
+    w = _mk(cout, cin, 3, 3, seed=41, scale=0.2).double().requires_grad_(True)
+    bias = torch.zeros(cout, dtype=torch.double, requires_grad=True)
+    g = _bf(_mk(B, cout, H, W, seed=42))
+    F.conv2d(x.double(), w, bias, padding=1).backward(g.double())
+    with L.precision("bf16"):
+        dw, db = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
+        dw2, db2 = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
+    sw, sb = w.grad.abs().max().item(), bias.grad.abs().max().item()
+    assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * sw
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * max(sb, 1.0)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                            # deterministic
+    assert not _is_bf16(dw)
+
+
+def test_bf16_conv_wgrad_pool_and_concat_loaders():
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    with L.precision("bf16"):
+        xs = _bf(_mk(2, 8, 64, 128, seed=43))
+        w = _mk(16, 8, 3, 3, seed=44, scale=0.2).double().requires_grad_(True)
+        y = F.conv2d(F.max_pool2d(xs, 2).double(), w, None, padding=1)
+        g = _bf(_mk(*y.shape, seed=45))
+        y.backward(g.double())
+        dw, _ = ops.conv3x3_wgrad(xs.cuda(), g.cuda(), 16, a_mode=L.PC_SRC_POOL2)
+        assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * w.grad.abs().max().item()
+        skip, upt = _bf(_mk(2, 16, 32, 64, seed=46)), _bf(_mk(2, 16, 32, 64, seed=47))
+        w = _mk(8, 32, 3, 3, seed=48, scale=0.1).double().requires_grad_(True)
+        y = F.conv2d(torch.cat([skip, upt], 1).double(), w, None, padding=1)
+        g = _bf(_mk(*y.shape, seed=49))
+        y.backward(g.double())
+        dw, _ = ops.conv3x3_wgrad(skip.cuda(), g.cuda(), 8, b=upt.cuda(), b_offset=(0, 0))
+        assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * w.grad.abs().max().item()

@@ -972,6 +972,563 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
     }
 }
 
+// ---- bf16 mode (PC_PREC_BF16): the head on v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 ---------------------------------------
+// The 64-wide contractions take 2 instructions of K = 32 instead of 16 fp32 ones, so the matrix pipe stops being the limit and
+// the structure changes: ONE role, no LDS hand-off.  The trick that removes the hand-off: a layer computed as
+// D = mfma(A = W fragment, B = packed activations) leaves lane = pixel, registers = hidden units (the operand layout of the
+// NEXT layer); the same two operands swapped, D' = mfma(A = packed activations, B = W fragment), give the transpose: lane =
+// hidden unit, registers = 4 consecutive pixels -- exactly the operand layout of the weight-gradient GEMM dW = G . H^T
+// (contraction over pixels, 16x16x16, K-slots (lk, j) = pixel 4*lk + j).  In bf16 the second orientation costs 36 cheap
+// instructions per 16 pixels and saves the 192 LDS writes + 48 reads + two counters of the producer / consumer ring.
+// K-slot conventions (identical for both operands, so the hardware's internal K order is irrelevant):
+//   64-wide contraction, instruction t of 2:  slot (lk, j) -> hidden unit 16*(2t + (j >> 2)) + 4*lk + (j & 3)
+//       (= D-layout registers h[2t][0..3], h[2t+1][0..3] of the lane, packed in order)
+//   16-wide feature contraction (layer 1):    slot (lk, j) -> feature channel 4*j + lk       (the gather order of `fetch`)
+//   16-pixel contraction (weight gradients):  slot (lk, j) -> pixel 4*lk + j
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef short hs16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+// LDS image (bytes): ready-made fragments, lane-linear
+constexpr int HB_A1 = 0;                          // [4 mb][64 lanes][4 bf16]   W0[16mb+i][4j+lk]
+constexpr int HB_A2 = HB_A1 + 4 * 64 * 8;         // [4 mb2][2 t][64][8 bf16]   W2[16mb2+i][unit(t,lk,j)]
+constexpr int HB_A3 = HB_A2 + 8 * 64 * 16;        // same for W4
+constexpr int HB_T3 = HB_A3 + 8 * 64 * 16;        // [4 mi][2 t][64][8]         W4[unit(t,lk,j)][16mi+i]
+constexpr int HB_T2 = HB_T3 + 8 * 64 * 16;        // same for W2
+constexpr int HB_T1 = HB_T2 + 8 * 64 * 16;        // [2 t][64][8]               W0[unit(t,lk,j)][c = i]
+constexpr int HB_F32 = HB_T1 + 2 * 64 * 16;       // floats: b0[64] b2[64] b4[64] w6[64] (rounded) b6
+constexpr int HB_END = HB_F32 + (4 * 64 + 4) * 4;
+constexpr int HB_RED = 16384 * 4;                 // the cross-wave reduction tail reuses the buffer: 4 x 4096 floats
+
+__device__ __forceinline__ int hb_unit(int t, int lk, int j) { return 16 * (2 * t + (j >> 2)) + 4 * lk + (j & 3); }
+
+__device__ __forceinline__ void head_stage_weights_bf16(unsigned char* lds, const HeadArgs& p, bool backward) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    unsigned short* h = reinterpret_cast<unsigned short*>(lds);
+    auto bits = [](float x) { return (unsigned short)(__float_as_uint(pc_bf16r(x)) >> 16); };
+    for (int e = tid; e < 4 * 64 * 4; e += nt) {
+        const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
+        h[HB_A1 / 2 + e] = bits(p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)]);
+    }
+    for (int e = tid; e < 8 * 64 * 8; e += nt) {
+        const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, t = f & 1, mb2 = f >> 1;
+        const int u = hb_unit(t, lane >> 4, j), i = lane & 15;
+        h[HB_A2 / 2 + e] = bits(p.w2[(16 * mb2 + i) * HID + u]);
+        h[HB_A3 / 2 + e] = bits(p.w4[(16 * mb2 + i) * HID + u]);
+        if (backward) {
+            h[HB_T3 / 2 + e] = bits(p.w4[u * HID + 16 * mb2 + i]);
+            h[HB_T2 / 2 + e] = bits(p.w2[u * HID + 16 * mb2 + i]);
+        }
+    }
+    if (backward)
+        for (int e = tid; e < 2 * 64 * 8; e += nt) {
+            const int j = e & 7, lane = (e >> 3) & 63, t = e >> 9;
+            h[HB_T1 / 2 + e] = bits(p.w0[hb_unit(t, lane >> 4, j) * 16 + (lane & 15)]);
+        }
+    float* f = reinterpret_cast<float*>(lds + HB_F32);
+    for (int e = tid; e < 64; e += nt) {
+        f[e] = p.b0[e];
+        f[64 + e] = p.b2[e];
+        f[128 + e] = p.b4[e];
+        f[192 + e] = pc_bf16r(p.w6[e]);
+    }
+    if (tid == 0) f[256] = p.b6[0];
+}
+
+__device__ __forceinline__ hbf16x8 hb_pack8(const f32x4& a, const f32x4& b) {
+    const hu32x4 q = {pc_pack_bf16(a[0], a[1]), pc_pack_bf16(a[2], a[3]), pc_pack_bf16(b[0], b[1]), pc_pack_bf16(b[2], b[3])};
+    return __builtin_bit_cast(hbf16x8, q);
+}
+__device__ __forceinline__ hs16x4 hb_pack4(float a, float b, float c, float d) {
+    const uint2 q = make_uint2(pc_pack_bf16(a, b), pc_pack_bf16(c, d));
+    return __builtin_bit_cast(hs16x4, q);
+}
+// `lane` may carry an opaque zero (see the group loops): the fragment reads must stay INSIDE the loop -- hoisted, the 36 KB
+// of loop-invariant weight fragments would occupy ~150 registers per lane and spill the accumulators
+__device__ __forceinline__ hbf16x8 hb_frag8(const unsigned char* lds, int off, int blk, int t, int lane) {
+    return __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(lds + off + (blk * 2 + t) * 1024 + lane * 16));
+}
+__device__ __forceinline__ hs16x4 hb_frag4(const unsigned char* lds, int off, int blk, int lane) {
+    return __builtin_bit_cast(hs16x4, *reinterpret_cast<const uint2*>(lds + off + blk * 512 + lane * 8));
+}
+
+// one 64 -> 64 layer in both orientations.  hb[t]: packed input (lane = pixel).  o1[mb2]: D = W . h (lane = pixel, regs =
+// hidden 16*mb2 + 4*lk + r), initialised with the bias; o2[mb2] (optional): the transpose (lane = hidden 16*mb2 + li, regs =
+// pixels 4*lk + r), initialised with the per-lane bias bo2[mb2].
+template <bool O2>
+__device__ __forceinline__ void hb_layer64(const unsigned char* lds, int a_off, const float* bias, int lane, int lk,
+                                           const hbf16x8 (&hb)[2], f32x4 (&o1)[4], f32x4 (&o2)[4], const float (&bo2)[4]) {
+#pragma unroll
+    for (int mb2 = 0; mb2 < 4; ++mb2) {
+        o1[mb2] = *reinterpret_cast<const f32x4*>(&bias[16 * mb2 + 4 * lk]);
+        if (O2) o2[mb2] = f32x4{bo2[mb2], bo2[mb2], bo2[mb2], bo2[mb2]};      // accumulators of both orientations start from the bias
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const hbf16x8 w = hb_frag8(lds, a_off, mb2, t, lane);
+            o1[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hb[t], o1[mb2], 0, 0, 0);
+            if (O2) o2[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb[t], w, o2[mb2], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void hb_relu_round(f32x4 (&h)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mb][r] = pc_bf16r(fmaxf(h[mb][r], 0.f));
+}
+
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    head_stage_weights_bf16(ldsb, p, false);
+    __syncthreads();
+    const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const float cid = p.census ? (float)p.census[b] : 0.f;
+    float pc_sum = 0.f, sc_sum = 0.f;
+    const int g_begin = (blockIdx.x * 4 + wave) * p.groups_per_wave;
+    int g_end = g_begin + p.groups_per_wave;
+    if (g_end > p.groups) g_end = p.groups;
+    auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
+        const int q = g * 16 + li;
+        const bool valid = q < HW && g < g_end;
+        const int qc = valid ? q : 0;
+        sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
+        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = fp[(4 * j + lk) * p.feat.cstride];
+            xv[j] = valid ? v : 0.f;
+        }
+    };
+    bool sel_n = false;
+    float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g_begin < g_end) fetch(g_begin, sel_n, xv_n);
+    for (int g = g_begin; g < g_end; ++g) {
+        const int q = g * 16 + li;
+        const bool valid = q < HW;
+        const int64_t pix = (int64_t)b * HW + q;
+        const bool sel = sel_n;
+        const hs16x4 xb = hb_pack4(xv_n[0], xv_n[1], xv_n[2], xv_n[3]);
+        fetch(g + 1, sel_n, xv_n);
+        float outv = 0.f;
+        if (__any(sel)) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));          // opaque: keeps the fragment reads in the loop
+            f32x4 h[4], acc[4], dummy[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                h[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
+                h[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb_frag4(ldsb, HB_A1, mb, lane_o), xb, h[mb], 0, 0, 0);
+            }
+            hb_relu_round(h);
+            hbf16x8 hb[2] = {hb_pack8(h[0], h[1]), hb_pack8(h[2], h[3])};
+            const float nob[4] = {0.f, 0.f, 0.f, 0.f};
+            hb_layer64<false>(ldsb, HB_A2, lf + 64, lane_o, lk, hb, acc, dummy, nob);
+            hb_relu_round(acc);
+            hb[0] = hb_pack8(acc[0], acc[1]); hb[1] = hb_pack8(acc[2], acc[3]);
+            hb_layer64<false>(ldsb, HB_A3, lf + 128, lane_o, lk, hb, h, dummy, nob);
+            hb_relu_round(h);
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(w[r], h[mb][r], s);
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            outv = sel ? s + lf[256] : 0.f;
+        }
+        if (valid && lk == 0) {
+            const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);
+            const float pd = scale * p.building[pix];
+            if (p.scale_map) p.scale_map[pix] = scale;
+            p.popdense[pix] = pd;
+            const bool region = p.admin ? (p.admin[pix] == cid) : true;
+            pc_sum += region ? pd : 0.f;
+            sc_sum += scale;
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (lk == 0) { red[wave * 16 + li] = pc_sum; red[64 + wave * 16 + li] = sc_sum; }
+    __syncthreads();
+    if (tid < 2) {
+        float t = 0.f;
+        for (int i = 0; i < 64; ++i) t += red[tid * 64 + i];
+        p.partial[((int64_t)b * p.nchunk + blockIdx.x) * 2 + tid] = t;
+    }
+}
+
+// backward, one role per wave, both orientations (see the header of this section).  Same outputs and workgroup-partial
+// layout as head_bwd_pc_kernel (head_bwd_reduce_kernel finishes both).
+__global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const HeadArgs& p = a.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    head_stage_weights_bf16(ldsb, p, true);
+    __syncthreads();
+    const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
+    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
+    const int HW = p.H * p.W;
+
+    if (a.zero_in_kernel) {
+        // padding frame of g_feat (the crop is written below, zeros included): one (b, c, row) job per half-wave
+        const int Hp = a.Hp, Wp = a.Wp;
+        const int l32 = tid & 31;
+        const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + (tid >> 5);
+        const int njobs = p.B * 16 * Hp;
+        const bool v4 = (Wp & 3) == 0;
+        const int right0 = p.px + p.W;
+        for (int j = hw; j < njobs; j += nhw) {
+            const int row = j % Hp;
+            float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
+            if (row < p.py || row >= p.py + p.H) {
+                if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+            } else if (p.px <= 16 && Wp - right0 <= 16) {
+                const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
+                if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0.f;
+            } else {
+                for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
+                for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+            }
+        }
+    }
+
+    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4];
+    float dbs[3][4];
+    float db6 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dW0[i] = dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
+    float fscale[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        fscale[r] = 1.f;
+        if (a.fuse_feat_bn) {
+            const int c = 4 * lk + r;
+            float sh;
+            pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
+        }
+    }
+    // biases in the second orientation are per lane (hidden unit 16*mb + li)
+    float b0o2[4], b2o2[4], b4o2[4], w6o2[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        b0o2[mb] = lf[16 * mb + li]; b2o2[mb] = lf[64 + 16 * mb + li]; b4o2[mb] = lf[128 + 16 * mb + li]; w6o2[mb] = lf[192 + 16 * mb + li];
+    }
+    const bool quad_ok = (p.W & 3) == 0;        // pixel quads 4*lk .. 4*lk+3 of a group never straddle a row
+
+    // per-group inputs, fetched one group ahead
+    float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
+    f32x4 n_xq = f32x4{0.f, 0.f, 0.f, 0.f};    // second orientation: feature channel li, pixels 4*lk .. +3
+    unsigned n_msk = 1;
+    auto fetch = [&](int gg) {
+        const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+        const int q = g * 16 + li;
+        const bool valid = q < HW;
+        const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
+        const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
+        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            n_xv[j] = fp[(4 * j + lk) * p.feat.cstride];
+            n_fv[j] = !a.fuse_feat_bn ? 1.f : fp[(4 * lk + j) * p.feat.cstride];
+        }
+        n_msk = p.mask ? p.mask[pix] : 1;
+        n_bld = p.building[pix];
+        if (p.admin) n_adm = p.admin[pix];
+        if (a.g_popdense) n_gpd = a.g_popdense[pix];
+        if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
+        // the same features with pixels in the registers: channel li, pixels q2 .. q2+3
+        const int q2 = g * 16 + 4 * lk;
+        if (quad_ok) {
+            const bool v2 = q2 < HW;
+            const int y2 = v2 ? (int)pc_div((uint32_t)q2, p.div_w) : 0, x2 = v2 ? q2 - y2 * p.W : 0;
+            const f32x4u t = *reinterpret_cast<const f32x4u*>(p.feat.ptr + b * p.feat.bstride + li * p.feat.cstride +
+                                                              (int64_t)(p.py + y2) * p.feat.rstride + p.px + x2);
+            n_xq = v2 ? f32x4{t[0], t[1], t[2], t[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = q2 + e;
+                const bool vv = qq < HW;
+                const int yy = vv ? (int)pc_div((uint32_t)qq, p.div_w) : 0, xx = vv ? qq - yy * p.W : 0;
+                const float t = p.feat.ptr[b * p.feat.bstride + li * p.feat.cstride + (int64_t)(p.py + yy) * p.feat.rstride + p.px + xx];
+                n_xq[e] = vv ? t : 0.f;
+            }
+        }
+    };
+    const int gstep = gridDim.x * 4;
+    int gg = blockIdx.x * 4 + wave;
+    if (gg < a.total_groups) fetch(gg);
+    for (; gg < a.total_groups; gg += gstep) {
+        const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+        const int q = g * 16 + li;
+        const bool valid = q < HW;
+        const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
+        const bool sel = valid && n_msk != 0;
+        float xv[4], fvv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = valid ? n_fv[j] : 1.f; }
+        const f32x4 xq = n_xq;
+        float gup = 0.f;
+        if (sel) {
+            const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
+            gup = gsc;
+            if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
+            if (a.g_popdense) gup += n_gpd * n_bld;
+            if (a.g_scale_map) gup += n_gsm;
+        }
+        if (gg + gstep < a.total_groups) fetch(gg + gstep);
+        auto store_zero = [&]() {
+            if (a.zero_in_kernel && valid) {
+                float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0.f;
+            }
+        };
+        if (!__any(sel)) { store_zero(); continue; }
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));              // opaque: keeps the weight-fragment reads inside the loop
+
+        // ---- forward, both orientations.  h*: lane = pixel; H*: lane = hidden unit, registers = pixels 4*lk + r.
+        // Only what the backward needs stays live, and in its packed form: hb1 / hb2 (operands of the next layer AND the ReLU
+        // masks of this one: a post-ReLU bf16 is positive iff its bits are non-zero), H1p / H2p (operands of the weight-
+        // gradient GEMMs and masks of the second orientation), h3 in fp32 (dw6), a 16-bit mask of H3.
+        const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
+        hbf16x8 hb1[2], hb2[2];
+        hs16x4 H1p[4], H2p[4];
+        f32x4 h3[4];
+        unsigned M3 = 0;
+        {
+            f32x4 h1[4], H1[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const hs16x4 w = hb_frag4(ldsb, HB_A1, mb, lane_o);
+                h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
+                h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, xb, h1[mb], 0, 0, 0);
+                H1[mb] = f32x4{b0o2[mb], b0o2[mb], b0o2[mb], b0o2[mb]};
+                H1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xb, w, H1[mb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h1[mb][r] = fmaxf(h1[mb][r], 0.f); H1[mb][r] = fmaxf(H1[mb][r], 0.f); }
+            hb1[0] = hb_pack8(h1[0], h1[1]); hb1[1] = hb_pack8(h1[2], h1[3]);            // the pack rounds to bf16
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) H1p[mb] = hb_pack4(H1[mb][0], H1[mb][1], H1[mb][2], H1[mb][3]);
+        }
+        {
+            f32x4 h2[4], H2[4];
+            hb_layer64<true>(ldsb, HB_A2, lf + 64, lane_o, lk, hb1, h2, H2, b2o2);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h2[mb][r] = fmaxf(h2[mb][r], 0.f); H2[mb][r] = fmaxf(H2[mb][r], 0.f); }
+            hb2[0] = hb_pack8(h2[0], h2[1]); hb2[1] = hb_pack8(h2[2], h2[3]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) H2p[mb] = hb_pack4(H2[mb][0], H2[mb][1], H2[mb][2], H2[mb][3]);
+        }
+        {
+            f32x4 H3[4];
+            hb_layer64<true>(ldsb, HB_A3, lf + 128, lane_o, lk, hb2, h3, H3, b4o2);
+            hb_relu_round(h3);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M3 |= (pc_bf16r(H3[mb][r]) > 0.f ? 1u : 0u) << (4 * mb + r);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float outv = s + lf[256];
+        const float gout = (sel && outv > 0.f) ? gup : 0.f;
+        if (!__any(gout != 0.f)) { store_zero(); continue; }
+
+        // masks out of the packed operands: element e of an 8-pack (o1: hidden 16*(2t + (e >> 2)) + 4*lk + (e & 3)) / of a 4-pack
+        auto nz8 = [](const hbf16x8& v, int e) { return ((__builtin_bit_cast(hu32x4, v)[e >> 1] >> (16 * (e & 1))) & 0xffffu) != 0u; };
+        auto nz4 = [](const hs16x4& v, int e) { const uint2 q = __builtin_bit_cast(uint2, v); return (((e >> 1) ? q.y : q.x) >> (16 * (e & 1)) & 0xffffu) != 0u; };
+        // upstream gradient of the group's pixels 4*lk + r for the second orientation
+        float go2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) go2[r] = __shfl(gout, 4 * lk + r, 16);
+        if (lk == 0) db6 += gout;
+        // ---- layer 4 -> G3 (both orientations), dw6;  dW4 += G3 . H2^T, db4 += rowsum(G3)
+        hbf16x8 gb3[2];
+        {
+            f32x4 g3[4], G3[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                    G3[mb][r] = ((M3 >> (4 * mb + r)) & 1u) ? pc_bf16r(w6o2[mb] * go2[r]) : 0.f;
+                }
+            }
+            gb3[0] = hb_pack8(g3[0], g3[1]); gb3[1] = hb_pack8(g3[2], g3[3]);
+            hs16x4 ga[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                ga[q4] = hb_pack4(G3[q4][0], G3[q4][1], G3[q4][2], G3[q4][3]);
+                dbs[2][q4] += (G3[q4][0] + G3[q4][1]) + (G3[q4][2] + G3[q4][3]);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    dW4[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[mb], H2p[nb], dW4[mb][nb], 0, 0, 0);
+        }
+        // ---- G2 = relu'(h2) . (W4^T G3), both orientations;  dW2 += G2 . H1^T
+        hbf16x8 gb2[2];
+        {
+            f32x4 g2[4], G2[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                g2[mi] = G2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const hbf16x8 w = hb_frag8(ldsb, HB_T3, mi, t, lane_o);
+                    g2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, gb3[t], g2[mi], 0, 0, 0);
+                    G2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb3[t], w, G2[mi], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    g2[mi][r] = nz8(hb2[mi >> 1], 4 * (mi & 1) + r) ? g2[mi][r] : 0.f;
+                    G2[mi][r] = nz4(H2p[mi], r) ? pc_bf16r(G2[mi][r]) : 0.f;
+                }
+            }
+            gb2[0] = hb_pack8(g2[0], g2[1]); gb2[1] = hb_pack8(g2[2], g2[3]);
+            hs16x4 ga[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                ga[q4] = hb_pack4(G2[q4][0], G2[q4][1], G2[q4][2], G2[q4][3]);
+                dbs[1][q4] += (G2[q4][0] + G2[q4][1]) + (G2[q4][2] + G2[q4][3]);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    dW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[mb], H1p[nb], dW2[mb][nb], 0, 0, 0);
+        }
+        // ---- G1 = relu'(h1) . (W2^T G2), both orientations;  dW0 += G1 . X^T
+        hbf16x8 gb1[2];
+        {
+            f32x4 g1[4], G1[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                g1[mi] = G1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const hbf16x8 w = hb_frag8(ldsb, HB_T2, mi, t, lane_o);
+                    g1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, gb2[t], g1[mi], 0, 0, 0);
+                    G1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb2[t], w, G1[mi], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    g1[mi][r] = nz8(hb1[mi >> 1], 4 * (mi & 1) + r) ? g1[mi][r] : 0.f;
+                    G1[mi][r] = nz4(H1p[mi], r) ? pc_bf16r(G1[mi][r]) : 0.f;
+                }
+            }
+            gb1[0] = hb_pack8(g1[0], g1[1]); gb1[1] = hb_pack8(g1[2], g1[3]);
+            const hs16x4 xo2 = hb_pack4(xq[0], xq[1], xq[2], xq[3]);        // lane = feature channel li, 4 pixels
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const hs16x4 ga = hb_pack4(G1[q4][0], G1[q4][1], G1[q4][2], G1[q4][3]);
+                dbs[0][q4] += (G1[q4][0] + G1[q4][1]) + (G1[q4][2] + G1[q4][3]);
+                dW0[q4] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga, xo2, dW0[q4], 0, 0, 0);
+            }
+        }
+        // ---- g_x = W0^T G1 (lane = pixel, registers = feature channels 4*lk + r)
+        f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T1, 0, t, lane_o), gb1[t], gx, 0, 0, 0);
+        if (valid) {
+            float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = gx[r];
+                if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
+                op[(4 * lk + r) * a.g_feat.cstride] = pc_bf16r(o);
+            }
+        }
+    }
+
+    // ---- reductions (layout of head_bwd_pc_kernel's partial: every wave here owns what a producer AND its consumer own there)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
+    db6 = lane_sum16(db6);
+#pragma unroll
+    for (int l3 = 0; l3 < 3; ++l3)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float v = dbs[l3][q4];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            dbs[l3][q4] = v;
+        }
+    float* lds = reinterpret_cast<float*>(ldsb);
+    __syncthreads();
+#pragma unroll
+    for (int stage = 0; stage < 2; ++stage) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                *reinterpret_cast<f32x4*>(&lds[wave * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 256)
+            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
+        __syncthreads();
+    }
+    {
+        float* w = lds + wave * 1344;       // [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1]
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
+        if (lk == 0) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                w[1088 + 16 * q4 + li] = dbs[0][q4];
+                w[1152 + 16 * q4 + li] = dbs[1][q4];
+                w[1216 + 16 * q4 + li] = dbs[2][q4];
+            }
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[1024 + 16 * mb + 4 * lk + r] = dw6[mb][r];
+            if (lk == 0) w[1280] = db6;
+        }
+        __syncthreads();
+        for (int e = tid; e < 1281; e += 256) {
+            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
+            part[PE_W0 + e] = t;
+        }
+    }
+}
+
 struct HeadReduceArgs {
     const float* partial;
     int nwg;
@@ -1321,7 +1878,13 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.groups_per_wave < 8) p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
-    if (p.bf) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
+    static int bf_mfma = -1;          // POPCORN_HEAD_BF16_MFMA=0: bf16 mode on the fp32-MFMA kernels (A/B switch)
+    if (bf_mfma < 0) {
+        const char* ev = getenv("POPCORN_HEAD_BF16_MFMA");
+        bf_mfma = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    if (p.bf && bf_mfma) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
+    else if (p.bf) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
@@ -1470,7 +2033,16 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    if (use_pc && p.bf) hipLaunchKernelGGL(head_bwd_pc_kernel<true>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    static int bf_mfma = -1;
+    if (bf_mfma < 0) {
+        const char* ev = getenv("POPCORN_HEAD_BF16_MFMA");
+        bf_mfma = (ev && ev[0] == '0') ? 0 : 1;
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, HB_RED);
+        if (e3 != hipSuccess) return (int)e3;
+    }
+    if (use_pc && p.bf && bf_mfma) hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nwg), dim3(256), HB_RED, st, a);
+    else if (use_pc && p.bf) hipLaunchKernelGGL(head_bwd_pc_kernel<true>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel<false>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();

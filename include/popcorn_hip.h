@@ -210,6 +210,14 @@ int pc_sparsity_mask(const float* building, const float* admin_mask, const int64
                      const uint8_t* rowsel, const uint8_t* colsel, int occupancymodel,
                      uint8_t* mask, int32_t* counts, int B, int H, int W, void* stream);
 
+/* The sparse_unet branch of get_sparsity_mask (popcorn.py:336-359; no caller in the reference uses it):
+ * mask = ((building > threshold) | (rowsel[y] & colsel[x])) & region, and per sample the undersampling ratio
+ * ratio[b] = #(region & building <= threshold) / (#(grid & region & building <= threshold) + 1e-5).  threshold = 0.001 and a
+ * 250 x 250 grid in the reference. */
+int pc_sparsity_mask_unet(const float* building, const float* admin_mask, const int64_t* census_idx,
+                          const uint8_t* rowsel, const uint8_t* colsel, float threshold, uint8_t* mask, float* ratio,
+                          int B, int H, int W, void* stream);
+
 /* pc_outconv_sigmoid_crop + pc_sparsity_mask in ONE launch (the building score feeds the mask directly; the empty-selection
  * fallback and the count fix-up are done by the last block to finish).  Same arguments and results as the two calls.
  * Must not run concurrently with itself on two streams of one process (library-owned accumulator + ticket). */
@@ -253,6 +261,15 @@ int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, cons
 int pc_compact_masked(const float* src, const uint8_t* mask, float* out, int32_t* n_out, void* ws, int64_t n,
                       void* stream);
 int64_t pc_compact_ws_bytes(int64_t n);
+/* The inverse (autograd of that gather): out[i] = mask[i] ? src[rank of i among the selected] : 0, i < n.  src holds at least
+ * Nsel floats; ws as for pc_compact_masked. */
+int pc_scatter_masked(const float* src, const uint8_t* mask, float* out, void* ws, int64_t n, void* stream);
+
+/* F.pad(x, (left, right, top, bottom), mode="reflect") on `planes` contiguous H x W planes -> (H+top+bottom) x (W+left+right):
+ * add_padding as a standalone op (popcorn.py:231-258).  The model path never calls it (the padding is fused into the first
+ * convolution's loader); it backs the POPCORN.add_padding API method. */
+int pc_reflect_pad(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
+                   void* stream);
 
 /* ---- training-step scalars ------------------------------------------------------------------------- */
 

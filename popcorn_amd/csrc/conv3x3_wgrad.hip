@@ -693,11 +693,14 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
 template <int CINC, int COUT>
 int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk, hipStream_t stream) {
     using Cfg = WgradCfg<CINC, COUT>;
-    size_t lw = (size_t)4 * CINC * WIN_CSW * sizeof(float);
-    const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);
-    if (lw < lred) lw = lred;
+    const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);     // staging of the cross-wave reduction (same buffer)
+    size_t lw_f32 = (size_t)4 * CINC * WIN_CSW * sizeof(float);          // fp32 strips
+    if (lw_f32 < lred) lw_f32 = lred;
+    size_t lw_bf = (size_t)4 * CINC * 6 * BW_ROWB;                       // bf16 strips
+    if (lw_bf < lred) lw_bf = lred;
     static int resident[5] = {0, 0, 0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
     auto go = [&](auto kern, int slot) -> int {
+        const size_t lw = slot >= 3 ? lw_bf : lw_f32;
         if (!resident[slot]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
             if (e != hipSuccess) return (int)e;

@@ -1834,7 +1834,111 @@ __global__ __launch_bounds__(256) void compact_write_kernel(const float* src, co
     }
 }
 
+// inverse of compact_write_kernel: out[i] = mask[i] ? src[rank(i)] : 0  (autograd of the boolean-index gather, popcorn.py:173)
+__global__ __launch_bounds__(256) void scatter_masked_kernel(const float* src, const uint8_t* mask, const int32_t* block_off,
+                                                             float* out, int64_t n) {
+    __shared__ int wave_tot[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CBLK;
+    bool m[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        m[k] = i < n && mask[i];
+        bal[k] = __ballot(m[k]);
+        if (lane == 0) wave_tot[k][wave] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    int off = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int pre = 0;
+        for (int w = 0; w < wave; ++w) pre += wave_tot[k][w];
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n) out[i] = m[k] ? src[off + pre + __popcll(bal[k] & ((1ull << lane) - 1ull))] : 0.f;
+        off += wave_tot[k][0] + wave_tot[k][1] + wave_tot[k][2] + wave_tot[k][3];
+    }
+}
+
+// get_sparsity_mask(sparse_unet=True), popcorn.py:336-359: one workgroup per sample.
+//   bmask = building > thresh;  mask = (bmask | grid) & region;  ratio = #(region & ~bmask) / (#(grid & region & ~bmask) + 1e-5)
+__global__ __launch_bounds__(256) void sparsity_mask_unet_kernel(const float* building, const float* admin, const int64_t* census,
+                                                                 const uint8_t* rowsel, const uint8_t* colsel, float thresh,
+                                                                 uint8_t* mask, float* ratio, int H, int W) {
+    __shared__ int red[2][256];
+    const int b = blockIdx.x;
+    const float cid = (float)census[b];
+    const int64_t base = (int64_t)b * H * W;
+    int n_empty = 0, n_sub = 0;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const bool region = admin[base + i] == cid;
+        const bool bm = building[base + i] > thresh;
+        const bool grid = rowsel[y] && colsel[x];
+        mask[base + i] = (uint8_t)((bm || grid) && region);
+        n_empty += (region && !bm) ? 1 : 0;
+        n_sub += (grid && region && !bm) ? 1 : 0;
+    }
+    red[0][threadIdx.x] = n_empty;
+    red[1][threadIdx.x] = n_sub;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ratio[b] = (float)red[0][0] / ((float)red[1][0] + 1e-5f);
+}
+
+// F.pad(x, (left, right, top, bottom), mode="reflect") for NCHW planes (add_padding, popcorn.py:231-258)
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* in, float* out, int64_t planes, int H, int W, int Hp, int Wp,
+                                                          int top, int left) {
+    const int64_t n = planes * Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp);
+        const int64_t pl = i / ((int64_t)Wp * Hp);
+        out[i] = in[(pl * H + pc_reflect(y - top, H)) * W + pc_reflect(x - left, W)];
+    }
+}
+
 }  // namespace
+
+extern "C" int pc_sparsity_mask_unet(const float* building, const float* admin_mask, const int64_t* census_idx,
+                                     const uint8_t* rowsel, const uint8_t* colsel, float threshold, uint8_t* mask, float* ratio,
+                                     int B, int H, int W, void* stream) {
+    if (!building || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !ratio || B < 1) return PC_EINVAL;
+    hipLaunchKernelGGL(sparsity_mask_unet_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, building, admin_mask, census_idx,
+                       rowsel, colsel, threshold, mask, ratio, H, W);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_reflect_pad(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
+                              void* stream) {
+    if (!in || !out || top >= H || bottom >= H || left >= W || right >= W || top < 0 || bottom < 0 || left < 0 || right < 0) return PC_EINVAL;
+    const int Hp = H + top + bottom, Wp = W + left + right;
+    int64_t g = (planes * Hp * Wp + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, in, out, planes, H, W, Hp, Wp, top, left);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_scatter_masked(const float* src, const uint8_t* mask, float* out, void* ws, int64_t n, void* stream) {
+    if (!src || !mask || !out || !ws) return PC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = (int)((n + CBLK - 1) / CBLK);
+    if (nblocks == 0) return 0;
+    int32_t* bc = reinterpret_cast<int32_t*>(ws);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(256), 0, st, mask, bc, n);
+    PC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nblocks, bc + nblocks);
+    PC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scatter_masked_kernel, dim3(nblocks), dim3(256), 0, st, src, mask, bc, out, n);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
     const int groups = (H * W + 15) / 16;

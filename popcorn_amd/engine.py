@@ -63,18 +63,6 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
     return names
 
 
-OVERLAP_WGRAD = False     # measured on MI355X, twice: 22.5 k -> 21.6 k patches/s (v4), 2.19 -> 2.33 ms (v9, also with both
-                          # chains at half the resident grid): the two branches compete for the same memory pipe
-_SIDE = {}
-
-
-def _side_stream(dev):
-    k = str(dev)
-    if k not in _SIDE:
-        _SIDE[k] = torch.cuda.Stream(device=dev)
-    return _SIDE[k]
-
-
 class _Layer:
     __slots__ = ("w", "b", "bn", "bn_nobias", "wname", "bname", "_keep")
 
@@ -186,23 +174,13 @@ class UNetEngine:
         A = {s: saved[s] for s in S}
         ly = lambda s, t: self.layers[(s, t)]  # noqa: E731
 
-        wb = ops.WgradBatch(dev, accumulate)      # first stages now, ONE batched reduction at the end
-        # The weight gradients only READ (x, G): they run on a second HIP stream next to the data-gradient chain (the
-        # critical path).  dgrad kernels are HBM-bound, wgrad kernels MFMA-leaning, and the 32x32 / 64x64 layers do not
-        # fill the chip on their own -- two streams overlap all three.  Fork/join by events, so a HIP-graph capture of
-        # the step records the two branches as parallel graph nodes.
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if OVERLAP_WGRAD else main
+        # first stages now, ONE batched reduction at the end.  Everything stays on the caller's stream: running the weight-
+        # gradient branch on a second stream next to the data-gradient chain was measured three times and lost every time
+        # (both branches are bound by the same memory pipe).
+        wb = ops.WgradBatch(dev, accumulate)
 
         def on_side(fn):
-            if side is main:
-                fn()
-                return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                fn()
+            fn()
 
         def wg(s, tag, a, g, **kw):
             lay = ly(s, tag)
@@ -226,9 +204,7 @@ class UNetEngine:
             on_side(lambda: wb.convt2x2_group(probs))
 
         def finish():
-            on_side(wb.finish)
-            if side is not main:
-                main.wait_stream(side)
+            wb.finish()
 
         def dg(tag, gs, outs, c0, cn, acts=None, act_tag=None, pool=False, acc=False):
             """grouped data-gradient of layer `tag` over both streams"""

@@ -171,8 +171,24 @@ class POPCORN(nn.Module):
 
     # ------------------------------------------------------------------------------------------------- pieces
     def add_padding(self, data, force=True):
-        """Kept for API compatibility (popcorn.py:231-258); the engine fuses this into its first conv."""
-        raise RuntimeError("add_padding is fused into the first HIP conv; use pad_geometry()")
+        """popcorn.py:231-258: (padded tensor, (px1, px2, py1, py2)) with None for an unpadded dimension.  The model path
+        never materialises this (the padding is fused into the first conv's loader); the method exists for callers of the
+        reference API."""
+        L.require_device(data)
+        pt, pb, pl, pr = pad_geometry(data.shape[2], data.shape[3], force)
+        out = ops.reflect_pad(data.float(), pt, pb, pl, pr) if (pt or pb or pl or pr) else data
+        if force:
+            return out, (pt, pb, pl, pr)
+        return out, (pt if (pt or pb) else None, pb if (pt or pb) else None, pl if (pl or pr) else None, pr if (pl or pr) else None)
+
+    def revert_padding(self, data, padding):
+        """popcorn.py:261-276 (a view: no copy)."""
+        px1, px2, py1, py2 = padding
+        if px1 is not None or px2 is not None:
+            data = data[:, :, px1:data.shape[2] - px2, :]
+        if py1 is not None or py2 is not None:
+            data = data[:, :, :, py1:data.shape[3] - py2]
+        return data
 
     def create_building_score(self, inputs):
         """popcorn.py:279-322."""
@@ -188,7 +204,18 @@ class POPCORN(nn.Module):
         generator exactly as in the reference (so a seeded run selects the same grid); the mask itself is built on
         the device.  Returns (bool mask (B,H,W), None)."""
         if sparse_unet:
-            raise NotImplementedError("sparse_unet branch (popcorn.py:371-396) is unused by the reference's callers")
+            # popcorn.py:336-359: threshold 0.001, a 250 x 250 grid, per-sample undersampling ratio
+            admin = inputs["admin_mask"]
+            B, H, W = admin.shape
+            xi = torch.ones(H).multinomial(num_samples=min(250, H), replacement=False)
+            yi = torch.ones(W).multinomial(num_samples=min(250, W), replacement=False)
+            sel = torch.zeros(H + W, dtype=torch.uint8)
+            sel[xi] = 1
+            sel[H + yi] = 1
+            sel = sel.to(admin.device, non_blocking=True)
+            mask, ratio = ops.sparsity_mask_unet(inputs["building_counts"].contiguous(), admin.contiguous().float(),
+                                                 inputs["census_idx"].contiguous(), sel[:H], sel[H:], 0.001)
+            return mask.bool(), ratio
         mask, _ = self._sparsity_mask_u8(inputs)
         return mask.bool(), None
 
@@ -288,8 +315,7 @@ class _PopcornFn(torch.autograd.Function):
         g_scale_map = None
         if g_scale is not None:
             if sparse:
-                g_scale_map = torch.zeros(B, H, W, device=X.device, dtype=torch.float32)
-                g_scale_map[mask.bool()] = g_scale.contiguous().float()
+                g_scale_map = ops.scatter_masked(g_scale.contiguous().float(), mask)       # (B, H, W): autograd of scale[mask]
             else:
                 g_scale_map = g_scale.contiguous().float()
         grads = {n: torch.empty_like(p) for n, p in zip(names, params)}

@@ -262,6 +262,18 @@ def sparsity_mask(building, admin_mask, census_idx, rowsel, colsel, occupancymod
     return mask, counts
 
 
+def sparsity_mask_unet(building, admin_mask, census_idx, rowsel, colsel, threshold=0.001):
+    """get_sparsity_mask(sparse_unet=True), popcorn.py:336-359.  Returns (mask uint8 (B,H,W), ratio float32 (B,))."""
+    L.require_device(building, admin_mask, census_idx, rowsel, colsel)
+    B, H, W = admin_mask.shape
+    mask = torch.empty(B, H, W, dtype=torch.uint8, device=building.device)
+    ratio = torch.empty(B, dtype=torch.float32, device=building.device)
+    L.check(L.lib().pc_sparsity_mask_unet(L.ptr(building), L.ptr(admin_mask), L.ptr(census_idx), L.ptr(rowsel), L.ptr(colsel),
+                                          C.c_float(threshold), L.ptr(mask), L.ptr(ratio), B, H, W, L.stream_ptr()),
+            "pc_sparsity_mask_unet")
+    return mask, ratio
+
+
 def building_score_mask(feat, w, bias, H, W, py, px, admin_mask, census_idx, rowsel, colsel, occupancymodel=True):
     """outconv_sigmoid_crop + sparsity_mask in one launch.  Returns (building (B,1,H,W), mask uint8 (B,H,W), counts)."""
     L.require_device(feat, w, bias, admin_mask, census_idx, rowsel, colsel)
@@ -312,6 +324,29 @@ def compact_masked(src, mask):
     L.check(L.lib().pc_compact_masked(L.ptr(src), L.ptr(mask), L.ptr(out), L.ptr(cnt), L.ptr(ws), C.c_int64(n),
                                       L.stream_ptr()), "pc_compact_masked")
     return out, cnt
+
+
+def scatter_masked(src, mask):
+    """out[mask] = src (row-major), zeros elsewhere: the autograd of compact_masked / of the reference's ``scale[mask]``."""
+    L.require_device(src, mask)
+    n = mask.numel()
+    out = torch.empty(mask.shape, device=mask.device, dtype=torch.float32)
+    ws = _workspace(L.lib().pc_compact_ws_bytes(n), mask.device)
+    L.check(L.lib().pc_scatter_masked(L.ptr(src), L.ptr(mask), L.ptr(out), L.ptr(ws), C.c_int64(n), L.stream_ptr()),
+            "pc_scatter_masked")
+    return out
+
+
+def reflect_pad(x, top, bottom, left, right):
+    """F.pad(x, (left, right, top, bottom), mode='reflect') for a contiguous (..., H, W) fp32 tensor."""
+    L.require_device(x)
+    x = x.contiguous()
+    H, W = x.shape[-2:]
+    out = torch.empty(*x.shape[:-2], H + top + bottom, W + left + right, device=x.device, dtype=torch.float32)
+    planes = x.numel() // (H * W)
+    L.check(L.lib().pc_reflect_pad(L.ptr(x), L.ptr(out), C.c_int64(planes), H, W, top, bottom, left, right, L.stream_ptr()),
+            "pc_reflect_pad")
+    return out
 
 
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,

@@ -341,6 +341,21 @@ def g8_single_modality(popcorn, losses):
     np.savez_compressed(os.path.join(OUT, "g8_single_modality.npz"), **out)
 
 
+def g11_sparse_unet_mask(popcorn, m):
+    """get_sparsity_mask(sparse_unet=True) (model/popcorn.py:336-359): threshold 0.001, 250 x 250 grid, per-sample
+    undersampling ratio.  No caller in the reference uses this branch; pinned for API completeness."""
+    out = {}
+    for name, seed, B, H, W in [("b2_300x280", 15, 2, 300, 280), ("b3_100", 16, 3, 100, 100)]:
+        x, admin, census, y = make_inputs(seed, B, H, W)
+        g = torch.Generator().manual_seed(seed + 100)
+        bc = torch.rand(B, 1, H, W, generator=g) * 0.004          # straddles the 0.001 threshold
+        torch.manual_seed(1600)
+        mask, ratio = m.get_sparsity_mask({"building_counts": bc, "admin_mask": admin, "census_idx": census}, sparse_unet=True)
+        out[f"{name}/building_counts"], out[f"{name}/admin_mask"], out[f"{name}/census_idx"] = np_(bc), np_(admin), np_(census)
+        out[f"{name}/mask"], out[f"{name}/ratio"] = np_(mask), np_(ratio)
+    np.savez_compressed(os.path.join(OUT, "g11_sparse_unet_mask.npz"), **out)
+
+
 def _stub_rasterio():
     for name in ("rasterio", "rasterio.warp", "rasterio.windows", "rasterio.features", "rasterio.transform", "rasterio.crs",
                  "rasterio.enums"):
@@ -535,6 +550,8 @@ def main():
         for tag, fn in (("g9", g9_census), ("g10", g10_transform)):
             if tag in only:
                 fn()
+        if "g11" in only:
+            g11_sparse_unet_mask(popcorn, build_model(popcorn))
         return
     m = g1_weights(popcorn)
     g2_forward(popcorn, m)
@@ -546,6 +563,7 @@ def main():
     g8_single_modality(popcorn, losses)
     g9_census()
     g10_transform()
+    g11_sparse_unet_mask(popcorn, m)
     args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
                           pretrained=True, biasinit=0.9407, sentinelbuildings=True)
     kw = get_model.get_model_kwargs(args, "POPCORN")

@@ -228,3 +228,32 @@ def test_graph_replay_equals_eager_over_many_steps_with_static_buffers():
         runs.append((losses, tr.flat_p.clone(), int(tr.step_count[2].item())))
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2] == 10
+
+
+def test_api_extras_add_padding_scatter_and_sparse_unet_mask(pair):
+    """Reference API surface outside the fused hot path: add_padding / revert_padding (popcorn.py:231-276) vs the oracle,
+    the scatter that backs the autograd of ``scale[mask]``, and the sparse_unet branch of get_sparsity_mask
+    (popcorn.py:336-359) bit-exact against the reference fixture g11."""
+    from popcorn_amd import ops
+    m, sd = pair
+    for (H, W) in [(100, 100), (131, 77), (64, 96)]:
+        x = torch.randn(2, 6, H, W, generator=torch.Generator().manual_seed(H))
+        for force in (True, False):
+            ref, rpads = O.add_padding(x, force)
+            out, pads = m.add_padding(x.cuda(), force)
+            assert tuple(pads) == tuple(rpads)
+            assert torch.equal(out.cpu(), ref)
+            assert torch.equal(m.revert_padding(out, pads).cpu(), O.revert_padding(ref, rpads))
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(3, 40, 52, generator=g) < 0.3)
+    src = torch.randn(int(mask.sum()) + 5, generator=g)
+    ref = torch.zeros(3, 40, 52)
+    ref[mask] = src[: int(mask.sum())]
+    assert torch.equal(ops.scatter_masked(src.cuda(), mask.to(torch.uint8).cuda()).cpu(), ref)
+    gold = np.load(os.path.join(G, "g11_sparse_unet_mask.npz"))
+    for name in ("b2_300x280", "b3_100"):
+        inp = {k: torch.from_numpy(gold[f"{name}/{k}"]).cuda() for k in ("building_counts", "admin_mask", "census_idx")}
+        torch.manual_seed(1600)
+        mk, ratio = m.get_sparsity_mask(inp, sparse_unet=True)
+        assert np.array_equal(mk.cpu().numpy(), gold[f"{name}/mask"]), name                 # index path: exact
+        np.testing.assert_allclose(ratio.cpu().numpy(), gold[f"{name}/ratio"], rtol=1e-6)

@@ -27,9 +27,10 @@ for (cin, cout, hw) in cfgs:
         probs = []
         for i in range(4):
             ca = cin if cin <= 8 else cin // 2
-            a = torch.randn(B, ca, hw, hw, device="cuda")
-            b = torch.randn(B, cin - ca, hw, hw, device="cuda") if cin > ca else None
-            w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.1
+            mk = torch.zeros if os.environ.get("ABL_ZERO") else torch.randn       # zero operands: the power-limit test
+            a = mk(B, ca, hw, hw, device="cuda")
+            b = mk(B, cin - ca, hw, hw, device="cuda") if cin > ca else None
+            w = mk(cout, cin, 3, 3, device="cuda") * 0.1
             bias = torch.zeros(cout, device="cuda")
             probs.append({"a": a, "b": b, "w": w, "bn": L.bn(bias), "out": torch.empty(B, cout, hw, hw, device="cuda"),
                           "_keep": bias})

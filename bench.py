@@ -39,6 +39,7 @@ FLOP_TRAIN_PER_TILE = 1_732_423_680          # SURVEY.md section 8d / BASELINE.m
 FLOP_HEAD_FWD_PX = 18_688                    # 2 x 9344 MACs per selected pixel
 FLOP_HEAD_BWD_PX = 37_376                    # "head bwd 4 x 93.44 M" per 10^4-px tile = data + weight gradients
 FP32_MATRIX_PEAK = 157.3e12                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MATRIX_PEAK = 2500.0e12                 # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense (bf16 mode only)
 HBM_PEAK = 8.0e12                            # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s is what a float4 copy achieves)
 
 
@@ -99,7 +100,10 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     g_pc = torch.ones(B, device=X.device)
     gsc = torch.full((1,), 1e-3, device=X.device)
     grads = [torch.empty_like(t) for t in m.head_tensors()]
-    g_feat = torch.empty(B, 16, H + 28, W + 28, device=X.device)
+    g_feat = torch.empty(B, 16, H + 28, W + 28, device=X.device, dtype=feats.dtype)
+    bf = feats.dtype == torch.bfloat16
+    peak = BF16_MATRIX_PEAK if bf else FP32_MATRIX_PEAK
+    esz = feats.element_size()
     nsel = B * H * W                      # bench regions cover the tile: every pixel is selected
 
     def run():
@@ -121,17 +125,21 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     achieved = flops / dur / 1e12
     pmc = _pmc("r2_pmc_head_bwd.json") or _pmc("r1_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    return {"bound": "mfma", "kernel": "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4) "
-                                       "+ the reduce launch of the same call",
-            "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4), "traffic": traffic,
+    kname = ("head_bwd_bf16_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, bf16 feature + gradient maps)" if bf else
+             "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
+    if bf:
+        pmc = _pmc("r2_pmc_head_bwd_bf16.json")
+        traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
+    return {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call",
+            "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "alg_flop_per_launch": flops, "units_per_launch": nsel,
             "unit_def": f"selected pixel, {FLOP_HEAD_BWD_PX} flop (SURVEY.md 8d head backward)",
             "executed_mfma_view": {"flop_per_unit": FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX,
                                    "achieved_tflops": round(issued / dur / 1e12, 3),
-                                   "frac": round(issued / dur / FP32_MATRIX_PEAK, 4),
+                                   "frac": round(issued / dur / peak, 4),
                                    "note": "includes the forward chain recomputed in registers (not algorithmic work)"},
-            "alg_bytes_per_launch": nsel * (16 * 4 + 4 + 4 + 1) + B * 16 * (H + 28) * (W + 28) * 4}
+            "alg_bytes_per_launch": nsel * (16 * esz + 4 + 4 + 1) + B * 16 * (H + 28) * (W + 28) * esz}
 
 
 def conv_kernel_roofline(torch, B, reps=5, nsets=4):
@@ -140,13 +148,16 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     of this chip (18 flop / compulsory byte): algorithmic bytes against the HBM peak and algorithmic flops against the
     fp32-matrix peak."""
     from popcorn_amd import ops, _lib as L
+    adt = L.act_dtype()
+    esz = 2 if adt == torch.bfloat16 else 4
+    peak = BF16_MATRIX_PEAK if esz == 2 else FP32_MATRIX_PEAK
     sets = []
     for _ in range(nsets):
         probs = []
         for _ in range(4):
             bias = torch.zeros(8, device="cuda")
-            probs.append({"a": torch.randn(B, 8, 128, 128, device="cuda"), "w": torch.randn(8, 8, 3, 3, device="cuda") * 0.1,
-                          "bn": L.bn(bias), "out": torch.empty(B, 8, 128, 128, device="cuda"), "_keep": bias})
+            probs.append({"a": torch.randn(B, 8, 128, 128, device="cuda").to(adt), "w": torch.randn(8, 8, 3, 3, device="cuda") * 0.1,
+                          "bn": L.bn(bias), "out": torch.empty(B, 8, 128, 128, device="cuda", dtype=adt), "_keep": bias})
         sets.append(probs)
     for s in sets:
         ops.conv3x3_fwd_group(s)
@@ -167,15 +178,15 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     e1.record()
     torch.cuda.synchronize()
     dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
-    nbytes = 4 * B * 128 * 128 * 4 * (8 + 8)                 # compulsory: read 8 channels, write 8 channels, fp32
+    nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
-    pmc = _pmc("r2_pmc_conv_8to8.json")
-    return {"bound": "hbm", "kernel": "conv3x3_mfma_kernel<8,8,fwd> grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
+    pmc = _pmc("r2_pmc_conv_8to8_bf16.json" if esz == 2 else "r2_pmc_conv_8to8.json")
+    return {"bound": "hbm", "kernel": f"conv3x3_mfma_kernel<8,8,fwd,{'bf16' if esz == 2 else 'fp32'}> grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
             "traffic": pmc["traffic_bytes"] if pmc and B == 64 else None, "launch_us": round(dur * 1e6, 2),
             "alg_bytes_per_launch": nbytes,
-            "mfma_view": {"achieved_tflops": round(flops / dur / 1e12, 2), "peak": FP32_MATRIX_PEAK / 1e12,
-                          "frac": round(flops / dur / FP32_MATRIX_PEAK, 4)}}
+            "mfma_view": {"achieved_tflops": round(flops / dur / 1e12, 2), "peak": peak / 1e12,
+                          "frac": round(flops / dur / peak, 4)}}
 
 
 def conv_class_sweep(torch, trainer, sample, reps=3):
@@ -189,6 +200,9 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
 
     def numel(t):
         return 0 if t is None else t.numel()
+
+    def nb(t):
+        return 0 if t is None else t.numel() * t.element_size()
 
     def wrap(obj, attr, label, cost):
         orig = getattr(obj, attr)
@@ -212,15 +226,15 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         px = Bn * H * W
         by = 0
         for p in problems:
-            by += 4 * (numel(p["a"]) * (cin if k.get("a_channels") else p["a"].shape[1]) // p["a"].shape[1] + numel(p.get("b")))
-            by += 4 * (numel(p.get("out")) + numel(p.get("pool_out")) + (numel(p.get("dot_out")) if p.get("dot_w") is not None else 0))
+            by += nb(p["a"]) * (cin if k.get("a_channels") else p["a"].shape[1]) // p["a"].shape[1] + nb(p.get("b"))
+            by += nb(p.get("out")) + nb(p.get("pool_out")) + (nb(p.get("dot_out")) if p.get("dot_w") is not None else 0)
         return 2.0 * 9 * cin * cout * px * n, by, f"fwd {cin}->{cout} @{H}x{W} x{n}"
 
     def c_dgrad(problems, c0, cn, pool=False, accumulate=False):
         p0 = problems[0]
         Bn, cg, H, W = p0["g"].shape
         n = len(problems)
-        by = sum(4 * (numel(p["g"]) + numel(p["out"]) * (2 if (accumulate or pool) else 1) + numel(p.get("act"))) for p in problems)
+        by = sum(nb(p["g"]) + nb(p["out"]) * (2 if (accumulate or pool) else 1) + nb(p.get("act")) for p in problems)
         return 2.0 * 9 * cg * cn * Bn * H * W * n, by, f"dgrad {cg}->{cn} @{H}x{W} x{n}{' pool' if pool else ''}"
 
     def c_wgrad_g(self, problems, cout, **k):
@@ -228,32 +242,32 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         Bn, cg, H, W = p0["g"].shape
         cin = (k.get("a_channels") or p0["a"].shape[1]) + (p0["b"].shape[1] if p0.get("b") is not None else 0)
         n = len(problems)
-        by = sum(4 * (numel(p["g"]) + numel(p["a"]) + numel(p.get("b"))) for p in problems)
+        by = sum(nb(p["g"]) + nb(p["a"]) + nb(p.get("b")) for p in problems)
         return 2.0 * 9 * cin * cout * Bn * H * W * n, by, f"wgrad {cin}->{cout} @{H}x{W} x{n}"
 
     def c_wgrad_1(self, a, g, cout, dw, db, **k):
         Bn, cg, H, W = g.shape
         cin = k.get("a_channels") or a.shape[1]
-        return 2.0 * 9 * cin * cout * Bn * H * W, 4 * (numel(g) + Bn * cin * H * W), f"wgrad {cin}->{cout} @{H}x{W} x1 (reflect loader)"
+        return 2.0 * 9 * cin * cout * Bn * H * W, nb(g) + Bn * cin * H * W * a.element_size(), f"wgrad {cin}->{cout} @{H}x{W} x1 (reflect loader)"
 
     def c_convt(problems):
         p0 = problems[0]
         Bn, C_, H, W = p0["x"].shape
         n = len(problems)
-        return 2.0 * 4 * C_ * C_ * Bn * H * W * n, sum(4 * (numel(p["x"]) + numel(p["out"])) for p in problems), f"convT fwd {C_} @{H}x{W} x{n}"
+        return 2.0 * 4 * C_ * C_ * Bn * H * W * n, sum(nb(p["x"]) + nb(p["out"]) for p in problems), f"convT fwd {C_} @{H}x{W} x{n}"
 
     def c_convt_d(problems):
         p0 = problems[0]
         Bn, C_, H, W = p0["out"].shape
         n = len(problems)
-        by = sum(4 * (numel(p["g"]) + numel(p["out"]) + numel(p.get("act"))) for p in problems)
+        by = sum(nb(p["g"]) + nb(p["out"]) + nb(p.get("act")) for p in problems)
         return 2.0 * 4 * C_ * C_ * Bn * H * W * n, by, f"convT dgrad {C_} @{H}x{W} x{n}"
 
     def c_convt_w(self, problems):
         p0 = problems[0]
         Bn, C_, H, W = p0["x"].shape
         n = len(problems)
-        return 2.0 * 4 * C_ * C_ * Bn * H * W * n, sum(4 * (numel(p["x"]) + numel(p["g"])) for p in problems), f"convT wgrad {C_} @{H}x{W} x{n}"
+        return 2.0 * 4 * C_ * C_ * Bn * H * W * n, sum(nb(p["x"]) + nb(p["g"]) for p in problems), f"convT wgrad {C_} @{H}x{W} x{n}"
 
     def c_finish(self):
         return 0.0, 0, "wgrad second stage (batched reduce)"
@@ -282,6 +296,7 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
             setattr(obj, attr, orig)
         trainer.use_graph = saved_graph
         trainer.flat_p.copy_(snap[0]); trainer.m.copy_(snap[1]); trainer.v.copy_(snap[2]); trainer.step_count.copy_(snap[3])
+    mpeak = BF16_MATRIX_PEAK if trainer.model.precision == "bf16" else FP32_MATRIX_PEAK
     layers, tot = [], {}
     for i in sorted(per):
         label, desc, us, fl, by = per[i]
@@ -294,8 +309,8 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
     fl = sum(t[1] for t in tot.values())
     by = sum(t[2] for t in tot.values())
     return {"launches": len(layers), "us": round(us, 1), "alg_gflop": round(fl / 1e9, 2), "alg_mbytes": round(by / 1e6, 1),
-            "mfma_view": {"achieved_tflops": round(fl / us / 1e6, 2), "peak": FP32_MATRIX_PEAK / 1e12,
-                          "frac": round(fl / us * 1e6 / FP32_MATRIX_PEAK, 4)},
+            "mfma_view": {"achieved_tflops": round(fl / us / 1e6, 2), "peak": mpeak / 1e12,
+                          "frac": round(fl / us * 1e6 / mpeak, 4)},
             "hbm_view": {"achieved_gbps": round(by / us / 1e3, 1), "peak": HBM_PEAK / 1e9, "frac": round(by / us * 1e6 / HBM_PEAK, 4)},
             "by_kind": {k: {"launches": t[3], "us": round(t[0], 1), "tflops": round(t[1] / t[0] / 1e6, 2), "gbps": round(t[2] / t[0] / 1e3, 1)}
                         for k, t in tot.items()},

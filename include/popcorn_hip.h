@@ -9,7 +9,8 @@
  *   - plain C, device pointers + sizes only, no torch types;
  *   - every function enqueues on the hipStream_t passed as `void* stream` (0 = the null stream),
  *     never synchronises, and returns 0 or a hipError_t / negative PC_E* code;
- *   - tensors are fp32, NCHW, described by pc_src / pc_dst (strides in elements);
+ *   - tensors are NCHW, described by pc_src / pc_dst (strides in ELEMENTS; element type = `dtype`: fp32, or bf16 for the
+ *     activation / activation-gradient tensors of PC_PREC_BF16); parameters, weight gradients and scalars are always fp32;
  *   - pointers are borrowed for the duration of the enqueued work only.
  */
 #ifndef POPCORN_HIP_H
@@ -21,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 2
+#define PC_ABI_VERSION 3
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -39,8 +40,10 @@ enum pc_src_mode {
                             add_padding + channel reorder fused into the first conv (model/popcorn.py:231-258,130-134) */
 };
 
+enum pc_dtype { PC_F32 = 0, PC_BF16 = 1 };
+
 typedef struct pc_src {
-    const float* ptr;    /* element (b=0, c=0, y=0, x=0) */
+    const float* ptr;    /* element (b=0, c=0, y=0, x=0); points at 2-byte elements when dtype == PC_BF16 */
     int32_t C;           /* channels taken from this source (0 = unused) */
     int32_t H, W;        /* spatial extent of the source tensor */
     int64_t bstride;     /* elements between consecutive batch items */
@@ -49,13 +52,15 @@ typedef struct pc_src {
     int32_t mode;        /* enum pc_src_mode */
     int32_t oy, ox;      /* DIRECT: placement of the source origin in the conv domain; REFLECT: top/left pad */
     int32_t chmap[4];    /* REFLECT only: conv channel c reads source channel chmap[c] */
+    int32_t dtype;       /* enum pc_dtype */
+    int32_t _pad;
 } pc_src;
 
 typedef struct pc_dst {
-    float* ptr;
+    float* ptr;          /* 2-byte elements when dtype == PC_BF16 */
     int64_t bstride, cstride;
     int32_t rstride;
-    int32_t _pad;
+    int32_t dtype;       /* enum pc_dtype */
 } pc_dst;
 
 /* folded BatchNorm2d(eval) + conv bias of one layer: y = relu(conv * scale + shift) with
@@ -90,7 +95,10 @@ int pc_sizeof(int which);
  *       bias / BN / ReLU-mask / accumulate arithmetic; the head's hidden layers are rounded after their ReLU;
  *     - everything else stays fp32: BN folding, partial logits and the building score, masks, occupancy product, census
  *       sums, loss, all WEIGHT gradients, the gradient all-reduce, clip, Adam and the master weights.
- *   Tensors keep their fp32 containers (values are bf16-representable); the mode is read when a call is enqueued.
+ *   Activation / activation-gradient tensors (everything a conv, transposed-conv or head kernel hands to another kernel:
+ *   pc_src / pc_dst operands) are bf16 CONTAINERS in this mode (dtype = PC_BF16, half the HBM bytes); the model input, the
+ *   partial logits / building score, masks, popdensemap, scale map, all parameters and all weight gradients stay fp32.  A
+ *   call whose descriptors do not match the mode returns PC_EINVAL.  The mode is read when a call is enqueued.
  * Process-global; returns the previous mode (pc_set_precision) / the current one. */
 enum pc_precision { PC_PREC_FP32 = 0, PC_PREC_BF16 = 1 };
 int pc_set_precision(int mode);

@@ -19,12 +19,12 @@ PC_SRC_DIRECT, PC_SRC_POOL2, PC_SRC_REFLECT = 0, 1, 2
 class PcSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32), ("mode", C.c_int32),
-                ("oy", C.c_int32), ("ox", C.c_int32), ("chmap", C.c_int32 * 4)]
+                ("oy", C.c_int32), ("ox", C.c_int32), ("chmap", C.c_int32 * 4), ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
 
 class PcDst(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("dtype", C.c_int32)]
 
 
 class PcBn(C.Structure):
@@ -98,7 +98,13 @@ def lib():
 
 
 PC_PREC_FP32, PC_PREC_BF16 = 0, 1
+PC_F32_T, PC_BF16_T = 0, 1          # enum pc_dtype
 PRECISIONS = {"fp32": PC_PREC_FP32, "bf16": PC_PREC_BF16}
+
+
+def act_dtype():
+    """Container type of activation / activation-gradient tensors in the current arithmetic mode."""
+    return torch.bfloat16 if lib().pc_get_precision() == PC_PREC_BF16 else torch.float32
 
 
 class precision:
@@ -141,9 +147,10 @@ def ptr(t) -> C.c_void_p:
 
 
 def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2, 3)) -> PcSrc:
-    """Descriptor of a (B, C, H, W) fp32 tensor (any batch/channel/row stride, unit x stride)."""
-    assert t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+    """Descriptor of a (B, C, H, W) fp32 or bf16 tensor (any batch/channel/row stride, unit x stride; strides in elements)."""
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.stride(3) == 1
     s = PcSrc()
+    s.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
     s.ptr = t.data_ptr()
     s.C = t.shape[1] if C_ is None else C_
     s.H, s.W = t.shape[2], t.shape[3]
@@ -154,8 +161,9 @@ def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2
 
 
 def dst(t: torch.Tensor) -> PcDst:
-    assert t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.stride(3) == 1
     d = PcDst()
+    d.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
     d.ptr = t.data_ptr()
     d.bstride, d.cstride, d.rstride = t.stride(0), t.stride(1), t.stride(2)
     return d

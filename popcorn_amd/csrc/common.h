@@ -23,6 +23,31 @@ __device__ __forceinline__ unsigned pc_pack_bf16(float lo, float hi) {
 __device__ __forceinline__ f32x4 pc_bf16r4(f32x4 v) { return f32x4{pc_bf16r(v[0]), pc_bf16r(v[1]), pc_bf16r(v[2]), pc_bf16r(v[3])}; }
 extern int g_pc_precision;      // api.hip: pc_set_precision()
 
+// ---- element access for fp32 / bf16 containers (bf16 = unsigned short bits) -------------------------------------------------
+typedef unsigned short pc_bf16_t;
+__device__ __forceinline__ float pc_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short pc_f2bf(float x) { return (unsigned short)(pc_pack_bf16(x, 0.f) & 0xffffu); }
+__device__ __forceinline__ float pc_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float pc_ld1(const pc_bf16_t* p) { return pc_bf2f(*p); }
+__device__ __forceinline__ void pc_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void pc_st1(pc_bf16_t* p, float v) { *p = pc_f2bf(v); }
+// four consecutive elements; the bf16 forms need 8-byte alignment, the fp32 forms 16-byte
+__device__ __forceinline__ f32x4 pc_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 pc_ld4(const pc_bf16_t* p) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void pc_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void pc_st4(pc_bf16_t* p, f32x4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
+}
+__device__ __forceinline__ void pc_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void pc_st2(pc_bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pc_pack_bf16(a, b); }
+// element i of a source described by a pc_src (run-time dtype: generic / fallback paths only)
+__device__ __forceinline__ float pc_src_at(const pc_src& s, int64_t i) {
+    return s.dtype == PC_BF16 ? pc_bf2f(reinterpret_cast<const pc_bf16_t*>(s.ptr)[i]) : s.ptr[i];
+}
+
 #define PC_CHECK_LAUNCH()                         \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \
@@ -97,14 +122,14 @@ __device__ __forceinline__ float pc_fetch(const pc_src& s, int b, int c, int y, 
     if (s.mode == PC_SRC_DIRECT) {
         const int ys = y - s.oy, xs = x - s.ox;
         if ((unsigned)ys >= (unsigned)s.H || (unsigned)xs >= (unsigned)s.W) return 0.f;
-        return s.ptr[b * s.bstride + c * s.cstride + (int64_t)ys * s.rstride + xs];
+        return pc_src_at(s, b * s.bstride + c * s.cstride + (int64_t)ys * s.rstride + xs);
     } else if (s.mode == PC_SRC_POOL2) {
-        const float* p = s.ptr + b * s.bstride + c * s.cstride + (int64_t)(2 * y) * s.rstride + 2 * x;
+        const int64_t o = b * s.bstride + c * s.cstride + (int64_t)(2 * y) * s.rstride + 2 * x;
         // nn.MaxPool2d(2): floor mode, windows never cross the source extent for y < H/2, x < W/2
-        return fmaxf(fmaxf(p[0], p[1]), fmaxf(p[s.rstride], p[s.rstride + 1]));
+        return fmaxf(fmaxf(pc_src_at(s, o), pc_src_at(s, o + 1)), fmaxf(pc_src_at(s, o + s.rstride), pc_src_at(s, o + s.rstride + 1)));
     } else {
         const int ys = pc_reflect(y - s.oy, s.H), xs = pc_reflect(x - s.ox, s.W);
-        return s.ptr[b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + xs];
+        return pc_src_at(s, b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + xs);
     }
 }
 

@@ -61,6 +61,7 @@ struct ConvProb {
     const float* act;     // DGRAD: post-ReLU activations of the producer (NULL = plain)
     int64_t act_bstride, act_cstride;
     int act_rstride;
+    int act_dtype;
     int fast_a, fast_b;   // pc_src_fast_mode of the two sources (generic loader)
     pc_dst out;
     pc_dst pool_out;      // FWD: 2x2-max-pooled copy of the output (ptr NULL = not wanted)
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     const int l_r = lane / 10, l_seg = lane - l_r * 10;
     const bool l_act = lane < 60;
     const int CA = q.a.C;
-    const float* const a_ptr = q.a.ptr;
-    const float* const b_ptr = q.b.ptr;
+    // BF instantiations: activation / gradient tensors are bf16 CONTAINERS (2-byte elements; strides in elements)
+    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
+    const act_t* const a_ptr = reinterpret_cast<const act_t*>(q.a.ptr);
+    const act_t* const b_ptr = reinterpret_cast<const act_t*>(q.b.ptr);
     const int64_t a_cstr = q.a.cstride, b_cstr = q.b.cstride;
     const int64_t my_bs = q.a.bstride;
     const int my_rs = q.a.rstride;                       // launch_conv guarantees identical layouts for both sources
@@ -158,17 +161,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int cg = ch * CHUNK + it;
-                const float* cp = cg < CA ? a_ptr + cg * a_cstr : b_ptr + (cg - CA) * b_cstr;
-                R[it] = *reinterpret_cast<const f32x4*>(cp + off);
+                const act_t* cp = cg < CA ? a_ptr + cg * a_cstr : b_ptr + (cg - CA) * b_cstr;
+                R[it] = pc_ld4(cp + off);          // fp32: one 16-byte load; bf16: one 8-byte load (same 4 pixels)
             }
         } else if (LD == LD_POOL) {
             const int64_t off = ok ? b * my_bs + (int64_t)(2 * y) * my_rs + 2 * xg : 0;
             const int rs1 = ok ? my_rs : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const float* s0 = a_ptr + (ch * CHUNK + it) * a_cstr + off;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + rs1), b1 = *reinterpret_cast<const f32x4*>(s0 + rs1 + 4);
+                const act_t* s0 = a_ptr + (ch * CHUNK + it) * a_cstr + off;
+                const f32x4 a0 = pc_ld4(s0), a1 = pc_ld4(s0 + 4);
+                const f32x4 b0 = pc_ld4(s0 + rs1), b1 = pc_ld4(s0 + rs1 + 4);
                 f32x4 v;
                 v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
                 v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // instead of overlapping: tools/ablate_conv.py).  An empty asm use forces the one wait to happen before the loop.
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) asm volatile("" : : "v"(e_scale[nb]), "v"(e_shift[nb]));
-    const float* const act = q.act;
-    float* const outp = q.out.ptr;
+    const act_t* const act = reinterpret_cast<const act_t*>(q.act);
+    act_t* const outp = reinterpret_cast<act_t*>(q.out.ptr);
     const int64_t o_bs = q.out.bstride, o_cs = q.out.cstride, a_bs = q.act_bstride, a_cs = q.act_cstride;
     const int o_rs = q.out.rstride, a_rs = q.act_rstride;
 
@@ -378,15 +381,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 for (int nb = 0; nb < NB; ++nb) {
                     const int co = nb * 8 + col;
                     const f32x4 v = pacc[u][nb];
-                    const float* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs + 2 * x;
-                    float* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs + 2 * x;
+                    const act_t* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs + 2 * x;
+                    act_t* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs + 2 * x;
                     f32x4 A[2][2], O[2][2];
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            A[rr][h] = *reinterpret_cast<const f32x4*>(a0 + rr * a_rs + 4 * h);
-                            O[rr][h] = *reinterpret_cast<const f32x4*>(o0 + rr * o_rs + 4 * h);
+                            A[rr][h] = pc_ld4(a0 + rr * a_rs + 4 * h);
+                            O[rr][h] = pc_ld4(o0 + rr * o_rs + 4 * h);
                         }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(o0 + rr * o_rs + 4 * h) = BF ? pc_bf16r4(O[rr][h]) : O[rr][h];
+                        for (int h = 0; h < 2; ++h) pc_st4(o0 + rr * o_rs + 4 * h, O[rr][h]);       // (the bf16 store rounds)
                 }
             }
             return;
@@ -414,14 +417,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         const bool full = !POOLB && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W);
         if (full) {
             // interior strip, aligned tensors: no bounds checks, 16-byte accesses only
-            float* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0 + 4 * lk;
-            const float* ab = act ? act + eb * a_bs + col * a_cs + (int64_t)(ey0 + s_row) * a_rs + ex0 + 4 * lk : nullptr;
+            act_t* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0 + 4 * lk;
+            const act_t* ab = act ? act + eb * a_bs + col * a_cs + (int64_t)(ey0 + s_row) * a_rs + ex0 + 4 * lk : nullptr;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x4 v = pacc[u][nb];
-                    float* op = ob + nb * 8 * o_cs + (int64_t)((u >> 1) * 2) * o_rs + (u & 1) * 16;
+                    act_t* op = ob + nb * 8 * o_cs + (int64_t)((u >> 1) * 2) * o_rs + (u & 1) * 16;
                     if (MODE == MODE_FWD) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -430,12 +433,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         }
                     } else {
                         if (ab) {
-                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + nb * 8 * a_cs + (int64_t)((u >> 1) * 2) * a_rs + (u & 1) * 16);
+                            const f32x4 a4 = pc_ld4(ab + nb * 8 * a_cs + (int64_t)((u >> 1) * 2) * a_rs + (u & 1) * 16);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb] : 0.f;
                         }
                         if (p.accumulate) {
-                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(op);
+                            const f32x4 o4 = pc_ld4(op);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += o4[r];
                         }
@@ -458,16 +461,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                                                       (int64_t)(ey0 + s_row + (u >> 1) * 2) * q.dot_out.rstride + ex0 + (u & 1) * 16 + 4 * lk) = t;
                         continue;
                     }
-                    *reinterpret_cast<f32x4*>(op) = v;
+                    pc_st4(op, v);
                     if (EPI == EPI_POOL && MODE == MODE_FWD && q.pool_out.ptr) {
                         // MaxPool2d(2): the x pairs are in the lane, the row pair (s_row 0 / 1) sits 8 lanes apart
                         float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
                         m0 = fmaxf(m0, __shfl_xor(m0, 8));
                         m1 = fmaxf(m1, __shfl_xor(m1, 8));
                         if (s_row == 0) {
-                            float* pp = q.pool_out.ptr + eb * q.pool_out.bstride + (nb * 8 + col) * q.pool_out.cstride +
+                            act_t* pp = reinterpret_cast<act_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride + (nb * 8 + col) * q.pool_out.cstride +
                                         (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride + (ex0 >> 1) + (u & 1) * 8 + 2 * lk;
-                            *reinterpret_cast<float2*>(pp) = make_float2(m0, m1);
+                            pc_st2(pp, m0, m1);
                         }
                     }
                 }
@@ -483,45 +486,45 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 const int co = nb * 8 + col;
                 const f32x4 v = pacc[u][nb];
                 if (MODE == MODE_FWD) {
-                    float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
+                    act_t* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float o = v[r] * e_scale[nb] + e_shift[nb];
-                        if (x + r < p.W) op[r] = rnd(p.relu ? fmaxf(o, 0.f) : o);
+                        if (x + r < p.W) pc_st1(op + r, p.relu ? fmaxf(o, 0.f) : o);
                     }
                 } else if (!POOLB) {
-                    float* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
-                    const float* ap = act ? act + eb * a_bs + co * a_cs + (int64_t)y * a_rs + x : nullptr;
+                    act_t* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
+                    const act_t* ap = act ? act + eb * a_bs + co * a_cs + (int64_t)y * a_rs + x : nullptr;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (x + r < p.W) {
                             float o = v[r];
-                            if (ap) o = ap[r] > 0.f ? o * e_scale[nb] : 0.f;
-                            if (p.accumulate) o += op[r];
-                            op[r] = rnd(o);
+                            if (ap) o = pc_ld1(ap + r) > 0.f ? o * e_scale[nb] : 0.f;
+                            if (p.accumulate) o += pc_ld1(op + r);
+                            pc_st1(op + r, o);
                         }
                     }
                 } else {
                     // MaxPool2d(2) backward: (y,x) is a pooled coordinate; route to the first arg-max of the window.
-                    const float* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs;
-                    const float* a1 = a0 + a_rs;
-                    float* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs;
-                    float* o1 = o0 + o_rs;
+                    const act_t* a0 = act + eb * a_bs + co * a_cs + (int64_t)(2 * y) * a_rs;
+                    const act_t* a1 = a0 + a_rs;
+                    act_t* o0 = outp + eb * o_bs + co * o_cs + (int64_t)(2 * y) * o_rs;
+                    act_t* o1 = o0 + o_rs;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int xx = x + r;
                         if (xx < p.W) {
-                            const float w00 = a0[2 * xx], w01 = a0[2 * xx + 1], w10 = a1[2 * xx], w11 = a1[2 * xx + 1];
+                            const float w00 = pc_ld1(a0 + 2 * xx), w01 = pc_ld1(a0 + 2 * xx + 1), w10 = pc_ld1(a1 + 2 * xx), w11 = pc_ld1(a1 + 2 * xx + 1);
                             int am = 0;
                             float m = w00;
                             if (w01 > m) { m = w01; am = 1; }
                             if (w10 > m) { m = w10; am = 2; }
                             if (w11 > m) { m = w11; am = 3; }
                             const float g = m > 0.f ? v[r] * e_scale[nb] : 0.f;
-                            o0[2 * xx] = rnd(o0[2 * xx] + (am == 0 ? g : 0.f));
-                            o0[2 * xx + 1] = rnd(o0[2 * xx + 1] + (am == 1 ? g : 0.f));
-                            o1[2 * xx] = rnd(o1[2 * xx] + (am == 2 ? g : 0.f));
-                            o1[2 * xx + 1] = rnd(o1[2 * xx + 1] + (am == 3 ? g : 0.f));
+                            pc_st1(o0 + 2 * xx, pc_ld1(o0 + 2 * xx) + (am == 0 ? g : 0.f));
+                            pc_st1(o0 + 2 * xx + 1, pc_ld1(o0 + 2 * xx + 1) + (am == 1 ? g : 0.f));
+                            pc_st1(o1 + 2 * xx, pc_ld1(o1 + 2 * xx) + (am == 2 ? g : 0.f));
+                            pc_st1(o1 + 2 * xx + 1, pc_ld1(o1 + 2 * xx + 1) + (am == 3 ? g : 0.f));
                         }
                     }
                 }
@@ -660,6 +663,17 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     return launch_conv_po<CIN, COUT, MODE, LD, EPI_NONE>(p, nprob, stream);
 }
 
+// staged-loader classification of a source (1 = aligned DIRECT, 2 = aligned POOL2, 0 = generic), for either container type
+int conv_src_mode(const pc_src& s, int H, int W) {
+    if (s.C == 0) return 0;
+    const uintptr_t amask = s.dtype == PC_BF16 ? 7 : 15;
+    const bool al = ((reinterpret_cast<uintptr_t>(s.ptr) & amask) == 0) && (s.rstride % 4 == 0) && (s.cstride % 4 == 0) && (s.bstride % 4 == 0);
+    if (!al) return 0;
+    if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W && (W % 4) == 0) return 1;
+    if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && (W % 4) == 0) return 2;
+    return 0;
+}
+
 bool same_layout(const pc_src& a, const pc_src& b) { return b.C == 0 || (a.bstride == b.bstride && a.rstride == b.rstride); }
 
 template <int CIN, int COUT, int MODE>
@@ -676,17 +690,26 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     // loader choice: all problems of the group must qualify for a staged loader
     bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
     bool vec = (p.W % 4) == 0;
+    // container types must match the arithmetic mode: bf16 mode = bf16 activation / gradient tensors (the reflect-padded model
+    // input and the partial-logit output stay fp32), fp32 mode = fp32 everywhere
+    const bool bfm = g_pc_precision == PC_PREC_BF16;
+    const int want = bfm ? PC_BF16 : PC_F32;
+    const uintptr_t amask = bfm ? 7 : 15;              // a 4-pixel vector access: 8 bytes of bf16, 16 bytes of fp32
     for (int i = 0; i < nprob; ++i) {
         ConvProb& q = p.pr[i];
-        q.fast_a = pc_src_fast_mode(q.a, p.H, p.W);
-        q.fast_b = pc_src_fast_mode(q.b, p.H, p.W);
+        if (q.a.dtype != (q.a.mode == PC_SRC_REFLECT ? PC_F32 : want) || (q.b.C && q.b.dtype != want)) return PC_EINVAL;
+        if ((q.out.ptr != reinterpret_cast<float*>(q.dot_out.ptr) && q.out.dtype != want) || (q.pool_out.ptr && q.pool_out.dtype != want) ||
+            (q.dot_out.ptr && q.dot_out.dtype != PC_F32) || (q.act && q.act_dtype != want))
+            return PC_EINVAL;
+        q.fast_a = conv_src_mode(q.a, p.H, p.W);
+        q.fast_b = conv_src_mode(q.b, p.H, p.W);
         const bool lay = same_layout(q.a, q.b);
         direct = direct && q.fast_a == 1 && (q.b.C == 0 || q.fast_b == 1) && lay && (CIN <= 16 || q.a.C == 16);
         pool = pool && q.fast_a == 2 && q.b.C == 0;
         vec = vec && (q.out.rstride % 4 == 0) && (q.out.cstride % 4 == 0) && (q.out.bstride % 4 == 0) &&
-              ((reinterpret_cast<uintptr_t>(q.out.ptr) & 15) == 0);
+              ((reinterpret_cast<uintptr_t>(q.out.ptr) & amask) == 0);
         if (q.act) vec = vec && (q.act_rstride % 4 == 0) && (q.act_cstride % 4 == 0) && (q.act_bstride % 4 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(q.act) & 15) == 0);
+                         ((reinterpret_cast<uintptr_t>(q.act) & amask) == 0);
         reflect = reflect && q.a.mode == PC_SRC_REFLECT && q.b.C == 0;
     }
     p.vec_ok = vec ? 1 : 0;
@@ -737,6 +760,7 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
         q.act_bstride = act->bstride;
         q.act_cstride = act->cstride;
         q.act_rstride = act->rstride;
+        q.act_dtype = act->dtype;
     }
     q.out = *out;
     return 0;
@@ -745,7 +769,7 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
 // the pooled second output needs every strip on the vector epilogue: full 32 x 4 strips, 16-byte aligned output
 bool pool_out_geometry_ok(const pc_dst& out, int H, int W) {
     return W % 32 == 0 && H % 4 == 0 && out.rstride % 4 == 0 && out.cstride % 4 == 0 && out.bstride % 4 == 0 &&
-           (reinterpret_cast<uintptr_t>(out.ptr) & 15) == 0;
+           (reinterpret_cast<uintptr_t>(out.ptr) & (out.dtype == PC_BF16 ? 7 : 15)) == 0;
 }
 
 }  // namespace

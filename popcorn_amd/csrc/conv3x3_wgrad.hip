@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
                 const int64_t goff = gok ? b * p.g.bstride + (int64_t)yy * p.g.rstride + xx : 0;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
-                    G[rpi][mb][h] = *reinterpret_cast<const f32x4*>(p.g.ptr + (mb * 8 + g_c) * p.g.cstride + goff);
+                    G[rpi][mb][h] = p.g.dtype == PC_BF16      // (bf16 mode: the first-layer launches run this kernel on a bf16 gradient)
+                        ? pc_ld4(reinterpret_cast<const pc_bf16_t*>(p.g.ptr) + (mb * 8 + g_c) * p.g.cstride + goff)
+                        : *reinterpret_cast<const f32x4*>(p.g.ptr + (mb * 8 + g_c) * p.g.cstride + goff);
             }
         }
         gvalid = gm;
@@ -398,8 +400,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
 // v_mfma_f32_16x16x32_bf16: the reduction over pixels rides on K = 32 = one whole strip row, so a strip is 2 x 3 x MB x
 // CINC/4 instructions instead of 16 x MB x CINC*12/16 fp32 ones.  The horizontal tap moves to the GRADIENT operand:
 //     D_dx[(s,co)][(ci,v)] += sum_x' g[co][yp+s][x' - dx + 1] * in[ci][yp+v-1][x'],   x' = x0 .. x0+31
-// A (M = (s, co8)): the lane's 8 k-slots are g at x0 + 8*lk + j - dx + 1, cut from ten consecutive floats that sit in
-//    registers (two 16-byte loads + the two neighbours) -- three shifted packings, no LDS;
+// A (M = (s, co8)): the lane's 8 k-slots are g at x0 + 8*lk + j - dx + 1, cut from ten consecutive pixels that sit in
+//    registers (one 16-byte load of 8 bf16 + the two neighbours) -- three shifted packings, no LDS;
 // B (N = (ci, v), 4 channels x 4 input rows per block): in at x0 + 8*lk + j, UNshifted, one aligned ds_read_b128 from the
 //    strip kept in LDS as bf16 ([ci][6 rows][16 B pad + 32 px]); no x halo is needed at all.
 // dW[co][ci][dy][dx] = D_dx[(0,co)][(ci,dy)] + D_dx[(1,co)][(ci,dy+1)]; same compacted partial as the fp32 kernels.
@@ -433,12 +435,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
     const int CA = p.a.C;
     const int64_t in_bs = p.a.bstride;
     const int in_rs = p.a.rstride;
-    f32x4 R[NIT];
+    uint2 R[NIT];             // four bf16 pixels of one channel row
     bool rvalid = false;
+    const pc_bf16_t* const a_ptr = reinterpret_cast<const pc_bf16_t*>(p.a.ptr);
+    const pc_bf16_t* const b_ptr = reinterpret_cast<const pc_bf16_t*>(p.b.ptr);
+    const pc_bf16_t* const g_ptr = reinterpret_cast<const pc_bf16_t*>(p.g.ptr);
     // ---- gradient operand: lane (i = (s, co8), k group lk): ten floats g[x0 + 8*lk - 1 .. x0 + 8*lk + 8] of row y0 + 2*rpi + s
     const int g_s = li >> 3, g_c = li & 7;
-    f32x4 G0[2][MB], G1[2][MB];
-    float GL[2][MB], GR[2][MB];
+    u32x4w G8[2][MB];          // eight bf16 pixels from x0 + 8*lk
+    pc_bf16_t GL[2][MB], GR[2][MB];
     unsigned gvalid = 0;      // bit rpi*4 + {0: first 4, 1: second 4, 2: left neighbour, 3: right neighbour}
 
     auto issue = [&](int b, int y0, int x0) {
@@ -450,23 +455,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int cg = cbase + it;
-                const float* cp = cg < CA ? p.a.ptr + cg * p.a.cstride : p.b.ptr + (cg - CA) * p.b.cstride;
-                R[it] = *reinterpret_cast<const f32x4*>(cp + off);
+                const pc_bf16_t* cp = cg < CA ? a_ptr + cg * p.a.cstride : b_ptr + (cg - CA) * p.b.cstride;
+                R[it] = *reinterpret_cast<const uint2*>(cp + off);
             }
         } else {
             const int64_t off = ok ? b * in_bs + (int64_t)(2 * y) * in_rs + 2 * xg : 0;
             const int rs1 = ok ? in_rs : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const float* s0 = p.a.ptr + (cbase + it) * p.a.cstride + off;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + rs1), b1 = *reinterpret_cast<const f32x4*>(s0 + rs1 + 4);
-                f32x4 v;
-                v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
-                v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
-                v[2] = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1]));
-                v[3] = fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]));
-                R[it] = v;
+                const pc_bf16_t* s0 = a_ptr + (cbase + it) * p.a.cstride + off;
+                const f32x4 a0 = pc_ld4(s0), a1 = pc_ld4(s0 + 4);
+                const f32x4 b0 = pc_ld4(s0 + rs1), b1 = pc_ld4(s0 + rs1 + 4);
+                R[it] = make_uint2(pc_pack_bf16(fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1])), fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]))),
+                                   pc_pack_bf16(fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1])), fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]))));
             }
         }
         unsigned gm = 0;
@@ -475,17 +476,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
         for (int rpi = 0; rpi < 2; ++rpi) {
             const int yy = y0 + 2 * rpi + g_s;
             const bool rowok = yy < p.H;
-            const bool ok0 = rowok && xx < p.W, ok1 = rowok && xx + 4 < p.W;
+            // the 8-pixel piece is loaded whole when its first pixel is inside the image (W % 8 == 0 on this path)
+            const bool ok0 = rowok && xx < p.W, ok1 = ok0;
             const bool okl = rowok && xx - 1 >= 0 && xx - 1 < p.W, okr = rowok && xx + 8 < p.W;
             gm |= (ok0 ? 1u : 0u) << (rpi * 4) | (ok1 ? 2u : 0u) << (rpi * 4) | (okl ? 4u : 0u) << (rpi * 4) | (okr ? 8u : 0u) << (rpi * 4);
             const int64_t rowoff = rowok ? b * p.g.bstride + (int64_t)yy * p.g.rstride : 0;
-            const int64_t o0 = ok0 ? rowoff + xx : 0, o1 = ok1 ? rowoff + xx + 4 : 0;
+            const int64_t o0 = ok0 ? rowoff + xx : 0;
             const int64_t ol = okl ? rowoff + xx - 1 : 0, orr = okr ? rowoff + xx + 8 : 0;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const float* gp = p.g.ptr + (mb * 8 + g_c) * p.g.cstride;
-                G0[rpi][mb] = *reinterpret_cast<const f32x4*>(gp + o0);
-                G1[rpi][mb] = *reinterpret_cast<const f32x4*>(gp + o1);
+                const pc_bf16_t* gp = g_ptr + (mb * 8 + g_c) * p.g.cstride;
+                G8[rpi][mb] = *reinterpret_cast<const u32x4w*>(gp + o0);
                 GL[rpi][mb] = gp[ol];
                 GR[rpi][mb] = gp[orr];
             }
@@ -497,10 +498,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
         if (l_act && l_seg >= 1 && l_seg <= 8) {
             unsigned char* d = wl + l_r * BW_ROWB + 16 + 8 * (l_seg - 1);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const f32x4 v = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<uint2*>(d + it * 6 * BW_ROWB) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
-            }
+            for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint2*>(d + it * 6 * BW_ROWB) = rvalid ? R[it] : make_uint2(0u, 0u);
         }
     };
 
@@ -537,12 +535,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
             for (int mb = 0; mb < MB; ++mb) {
                 const unsigned m = gvalid >> (rpi * 4);
                 float f[10];
-                f[0] = (m & 4u) ? GL[rpi][mb] : 0.f;
-                f[9] = (m & 8u) ? GR[rpi][mb] : 0.f;
+                f[0] = (m & 4u) ? pc_bf2f(GL[rpi][mb]) : 0.f;
+                f[9] = (m & 8u) ? pc_bf2f(GR[rpi][mb]) : 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    f[1 + e] = (m & 1u) ? G0[rpi][mb][e] : 0.f;
-                    f[5 + e] = (m & 2u) ? G1[rpi][mb][e] : 0.f;
+                    const unsigned dw = G8[rpi][mb][e];
+                    f[1 + 2 * e] = (m & 1u) ? __uint_as_float(dw << 16) : 0.f;
+                    f[2 + 2 * e] = (m & 1u) ? __uint_as_float(dw & 0xffff0000u) : 0.f;
                 }
                 bsum[mb] += ((f[1] + f[2]) + (f[3] + f[4])) + ((f[5] + f[6]) + (f[7] + f[8]));
 #pragma unroll
@@ -679,14 +678,30 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
     if (nwg < 1) nwg = 1;
     p.partial = reinterpret_cast<float*>(ws);
     p.ci0 = 0;
-    p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);
+    p.bf = g_pc_precision == PC_PREC_BF16;
+    // container types follow the mode: bf16 mode = bf16 activations and gradients (the reflect-padded model input stays fp32)
+    const int want = p.bf ? PC_BF16 : PC_F32;
+    if (p.a.dtype != (p.a.mode == PC_SRC_REFLECT ? PC_F32 : want) || (p.b.C && p.b.dtype != want) || p.g.dtype != want) return -1;
+    auto mode_of = [&](const pc_src& s) -> int {      // 1 = aligned DIRECT, 2 = aligned POOL2 (either container type)
+        if (s.C == 0) return 0;
+        const uintptr_t amask = s.dtype == PC_BF16 ? 7 : 15;
+        if ((reinterpret_cast<uintptr_t>(s.ptr) & amask) || s.rstride % 4 || s.cstride % 4 || s.bstride % 4) return 0;
+        if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == p.H && s.W == p.W && (p.W % 4) == 0) return 1;
+        if (s.mode == PC_SRC_POOL2 && s.W == 2 * p.W && s.H >= 2 * p.H && (p.W % 4) == 0) return 2;
+        return 0;
+    };
+    const int ma = mode_of(p.a), mbb = mode_of(p.b), mg = mode_of(p.g);
+    p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);      // (fp32 only: the generic kernel's vector paths)
     p.fast_b = pc_src_fast_mode(p.b, p.H, p.W);
     p.fast_g = pc_src_fast_mode(p.g, p.H, p.W) == 1;
-    p.bf = g_pc_precision == PC_PREC_BF16;
+    const bool gok = mg == 1;
     const bool lay = p.b.C == 0 || (p.a.bstride == p.b.bstride && p.a.rstride == p.b.rstride);
-    if (p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && p.fast_g && CINC <= 4) return 3;
-    if (p.fast_a == 1 && (p.b.C == 0 || p.fast_b == 1) && lay && p.fast_g) return 1;
-    if (p.fast_a == 2 && p.b.C == 0 && p.fast_g) return 2;
+    if (p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && gok && CINC <= 4) return 3;
+    if (p.bf && (CINC < 8 || (p.W % 8) != 0 || (reinterpret_cast<uintptr_t>(p.g.ptr) & 15) || p.g.rstride % 8 || p.g.cstride % 8 ||
+                 p.g.bstride % 8))
+        return 0;                                      // bf16 wave kernel: 16-byte pieces of 8 gradient pixels
+    if (ma == 1 && (p.b.C == 0 || mbb == 1) && lay && gok) return 1;
+    if (ma == 2 && p.b.C == 0 && gok) return 2;
     return 0;
 }
 
@@ -746,6 +761,7 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
     using Cfg = WgradCfg<CINC, COUT>;
     int nwg, nchunk;
     const int kind = prepare_wgrad<CINC, COUT>(p, Cin, ws, nwg, nchunk);
+    if (kind < 0) return PC_EINVAL;
     if (kind != 0) {
         // A single-problem launch (the first layers: their Cin differs per stream, so they cannot be grouped) gets the
         // workgroups a grouped launch would spread over its problems -- as many partials as the workspace slice holds
@@ -792,6 +808,7 @@ int launch_wgrad_group(WgradArgs* ps, void* const* wss, int n, int Cin, hipStrea
     for (int i = 0; i < n; ++i) {
         int w, c;
         const int k = prepare_wgrad<CINC, COUT>(ps[i], Cin, wss[i], w, c);
+        if (k < 0) return PC_EINVAL;
         if (i == 0) { kind0 = k; nwg = w; nchunk = c; }
         same = same && k == kind0 && w == nwg;
         g.pr[i] = ps[i];

@@ -35,8 +35,12 @@ struct CtGroup {
     CtArgs pr[PC_MAX_GROUP];
 };
 
-template <int C>
+// BF (all three kernels): PC_PREC_BF16 -- x / g / out / act are bf16 CONTAINERS (typed accessors of common.h), weights are
+// rounded when loaded, the bf16 store rounds the result; the MFMA stays the fp32 one on bf16-representable operands (these
+// kernels are HBM-bound).
+template <int C, bool BF>
 __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
+    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int KS = C / 4, NBK = C / 4;
     const int lane = threadIdx.x & 63;
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const float wv = p.w[(4 * ks + lk) * 4 * C + ng];
-            bw[ks][nb] = p.bf ? pc_bf16r(wv) : wv;
+            bw[ks][nb] = BF ? pc_bf16r(wv) : wv;
         }
     }
 
@@ -64,9 +68,9 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
         const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
         float av[KS];
-        const float* xp = p.x.ptr + b * p.x.bstride + (int64_t)i * p.x.rstride + j0 + li;
+        const act_t* xp = reinterpret_cast<const act_t*>(p.x.ptr) + b * p.x.bstride + (int64_t)i * p.x.rstride + j0 + li;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) av[ks] = (j0 + li < p.W) ? xp[(4 * ks + lk) * p.x.cstride] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) av[ks] = (j0 + li < p.W) ? pc_ld1(xp + (4 * ks + lk) * p.x.cstride) : 0.f;
         f32x4 acc[NBK];
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) acc[nb] = f32x4{binit[nb], binit[nb], binit[nb], binit[nb]};
@@ -86,25 +90,25 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(mine[r], 1);
             // bb = 0 writes x = 2*jb + {0,1,2,3} (pixels r = 0,1); bb = 1 writes x = 2*jb + {4,5,6,7} (pixels r = 2,3)
-            f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
-            if (p.bf) v = pc_bf16r4(v);
+            const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
             const int jb = j0 + 4 * lk;
-            float* op = p.out.ptr + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + 2 * jb + 4 * bb;
-            if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
-                *reinterpret_cast<f32x4*>(op) = v;
+            act_t* op = reinterpret_cast<act_t*>(p.out.ptr) + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + 2 * jb + 4 * bb;
+            if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & (BF ? 7 : 15)) == 0)) {
+                pc_st4(op, v);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int xo = 2 * jb + 4 * bb + e;            // output x
-                    if ((xo >> 1) < p.W) op[e] = v[e];
+                    if ((xo >> 1) < p.W) pc_st1(op + e, v[e]);
                 }
             }
         }
     }
 }
 
-template <int C>
+template <int C, bool BF>
 __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_) {
+    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
     const CtArgs& p = grp_.pr[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
 #pragma unroll
     for (int co = 0; co < C; ++co) {
         const float wv = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
-        bw[co] = p.bf ? pc_bf16r(wv) : wv;
+        bw[co] = BF ? pc_bf16r(wv) : wv;
     }
     float e_scale = 1.f, e_shift = 0.f;
     if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
@@ -127,37 +131,36 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
         const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
         // A[pixel li][k = (a,b) = lk] of k-step co
-        const float* gp = p.x.ptr + b * p.x.bstride + (int64_t)(2 * i + (lk >> 1)) * p.x.rstride + 2 * (j0 + li) + (lk & 1);
+        const act_t* gp = reinterpret_cast<const act_t*>(p.x.ptr) + b * p.x.bstride + (int64_t)(2 * i + (lk >> 1)) * p.x.rstride + 2 * (j0 + li) + (lk & 1);
         const bool ok = j0 + li < p.W;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int co = 0; co < C; ++co) {
-            const float av = ok ? gp[co * p.x.cstride] : 0.f;
+            const float av = ok ? pc_ld1(gp + co * p.x.cstride) : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[co], acc, 0, 0, 0);
         }
         if (li < C) {
             const int j = j0 + 4 * lk;
-            float* op = p.out.ptr + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j;
-            const float* ap = p.act ? p.act + b * p.act_bstride + li * p.act_cstride + (int64_t)i * p.act_rstride + j : nullptr;
-            const bool vec = j + 3 < p.W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0) &&
-                             (!ap || (reinterpret_cast<uintptr_t>(ap) & 15) == 0);
+            act_t* op = reinterpret_cast<act_t*>(p.out.ptr) + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j;
+            const act_t* ap = p.act ? reinterpret_cast<const act_t*>(p.act) + b * p.act_bstride + li * p.act_cstride + (int64_t)i * p.act_rstride + j : nullptr;
+            const bool vec = j + 3 < p.W && ((reinterpret_cast<uintptr_t>(op) & (BF ? 7 : 15)) == 0) &&
+                             (!ap || (reinterpret_cast<uintptr_t>(ap) & (BF ? 7 : 15)) == 0);
             if (vec) {
                 // the lane's 4 consecutive x of one channel row: one 16-byte load of the mask, one 16-byte store
                 f32x4 o = acc;
                 if (ap) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap);
+                    const f32x4 a4 = pc_ld4(ap);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = a4[r] > 0.f ? o[r] * e_scale : 0.f;
                 }
-                if (p.bf) o = pc_bf16r4(o);
-                *reinterpret_cast<f32x4*>(op) = o;
+                pc_st4(op, o);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (j + r < p.W) {
                         float o = acc[r];
-                        if (ap) o = ap[r] > 0.f ? o * e_scale : 0.f;
-                        op[r] = p.bf ? pc_bf16r(o) : o;
+                        if (ap) o = pc_ld1(ap + r) > 0.f ? o * e_scale : 0.f;
+                        pc_st1(op + r, o);
                     }
                 }
             }
@@ -175,8 +178,9 @@ struct CtWgradCfg {
 // both operands use it: lane (., lk) takes pixels 4*lk .. 4*lk+3 of the 16-pixel group, so k-step ks holds pixel 4*lk + ks
 // and a lane's four A values are ONE 16-byte load of x, its four B values the even or odd floats of TWO 16-byte loads of
 // the g row (4 + 4*C/4 scalar gathers before: 12 / 20 four-byte loads per group and lane).
-template <int C, bool VEC>
+template <int C, bool VEC, bool BF>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_) {
+    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
@@ -199,18 +203,19 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_)
         const int i = (int)pc_div((uint32_t)rem, p.div_gx);
         const int gx = rem - i * p.groups_x;
         const int j0 = gx * 16;
-        const float* xp = p.x.ptr + b * p.x.bstride + li * p.x.cstride + (int64_t)i * p.x.rstride;
+        const act_t* xp = reinterpret_cast<const act_t*>(p.x.ptr) + b * p.x.bstride + li * p.x.cstride + (int64_t)i * p.x.rstride;
+        const act_t* gbase = reinterpret_cast<const act_t*>(p.g.ptr);
         float av[4], bv[4][NBK];
         if (VEC) {
-            const f32x4 xv = li < C ? *reinterpret_cast<const f32x4*>(xp + j0 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 xv = li < C ? pc_ld4(xp + j0 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) av[ks] = xv[ks];
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) {
                 const int ng = nb * 16 + li;
                 const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
-                const float* gp = p.g.ptr + b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j0 + 8 * lk;
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const act_t* gp = gbase + b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j0 + 8 * lk;
+                const f32x4 g0 = pc_ld4(gp), g1 = pc_ld4(gp + 4);
                 bv[0][nb] = bb ? g0[1] : g0[0];
                 bv[1][nb] = bb ? g0[3] : g0[2];
                 bv[2][nb] = bb ? g1[1] : g1[0];
@@ -220,12 +225,12 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int j = j0 + 4 * ks + lk;
-                av[ks] = (li < C && j < p.W) ? xp[j] : 0.f;
+                av[ks] = (li < C && j < p.W) ? pc_ld1(xp + j) : 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb) {
                     const int ng = nb * 16 + li;
                     const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
-                    bv[ks][nb] = j < p.W ? p.g.ptr[b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j + bb]
+                    bv[ks][nb] = j < p.W ? pc_ld1(gbase + b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j + bb)
                                          : 0.f;
                 }
             }
@@ -330,8 +335,13 @@ extern "C" int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, i
         nwg = fill_groups(p);
     }
     nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;     // keep the total grid size roughly constant
-    if (C == 16) hipLaunchKernelGGL(convt2x2_fwd_kernel<16>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8) hipLaunchKernelGGL(convt2x2_fwd_kernel<8>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    const bool bf = g_pc_precision == PC_PREC_BF16;
+    for (int i = 0; i < n; ++i)
+        if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].out.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
+    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_fwd_kernel<16, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 16) hipLaunchKernelGGL((convt2x2_fwd_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_fwd_kernel<8, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL((convt2x2_fwd_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
@@ -355,13 +365,19 @@ extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int 
             if (!d[i].act_bn) return PC_EINVAL;
             p.act = d[i].act->ptr; p.act_bstride = d[i].act->bstride; p.act_cstride = d[i].act->cstride;
             p.act_rstride = d[i].act->rstride;
+            if (d[i].act->dtype != (g_pc_precision == PC_PREC_BF16 ? PC_BF16 : PC_F32)) return PC_EINVAL;
             p.bn = *d[i].act_bn;
         }
         nwg = fill_groups(p);
     }
     nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;
-    if (C == 16) hipLaunchKernelGGL(convt2x2_dgrad_kernel<16>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8) hipLaunchKernelGGL(convt2x2_dgrad_kernel<8>, dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    const bool bf = g_pc_precision == PC_PREC_BF16;
+    for (int i = 0; i < n; ++i)
+        if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].out.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
+    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 16) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
@@ -381,20 +397,25 @@ extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {
 namespace {
 bool ct_wgrad_vec_ok(const CtArgs& p) {
     auto al = [](const pc_src& s) {
-        return ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && s.rstride % 4 == 0 && s.cstride % 4 == 0 && s.bstride % 4 == 0;
+        return ((reinterpret_cast<uintptr_t>(s.ptr) & (s.dtype == PC_BF16 ? 7 : 15)) == 0) && s.rstride % 4 == 0 && s.cstride % 4 == 0 &&
+               s.bstride % 4 == 0;
     };
     return p.W % 16 == 0 && al(p.x) && al(p.g);
 }
 int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t st) {
     bool vec = true;
-    for (int i = 0; i < n; ++i) vec = vec && ct_wgrad_vec_ok(g.pr[i]);
+    const bool bf = g_pc_precision == PC_PREC_BF16;
+    for (int i = 0; i < n; ++i) {
+        vec = vec && ct_wgrad_vec_ok(g.pr[i]);
+        if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].g.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
+    }
+#define PC_CTW(CC, VV, BB) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV, BB>), dim3(nwg, n), dim3(256), 0, st, g)
     if (C == 16) {
-        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, true>), dim3(nwg, n), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<16, false>), dim3(nwg, n), dim3(256), 0, st, g);
+        if (vec && bf) PC_CTW(16, true, true); else if (vec) PC_CTW(16, true, false); else if (bf) PC_CTW(16, false, true); else PC_CTW(16, false, false);
     } else if (C == 8) {
-        if (vec) hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, true>), dim3(nwg, n), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((convt2x2_wgrad_kernel<8, false>), dim3(nwg, n), dim3(256), 0, st, g);
+        if (vec && bf) PC_CTW(8, true, true); else if (vec) PC_CTW(8, true, false); else if (bf) PC_CTW(8, false, true); else PC_CTW(8, false, false);
     } else return PC_EINVAL;
+#undef PC_CTW
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -1097,10 +1097,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
         const int qc = valid ? q : 0;
         sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
-        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+        const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = fp[(4 * j + lk) * p.feat.cstride];
+            const float v = pc_ld1(fp + (4 * j + lk) * p.feat.cstride);
             xv[j] = valid ? v : 0.f;
         }
     };
@@ -1187,16 +1187,16 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         const int right0 = p.px + p.W;
         for (int j = hw; j < njobs; j += nhw) {
             const int row = j % Hp;
-            float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
+            pc_bf16_t* rp = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
             if (row < p.py || row >= p.py + p.H) {
-                if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
-                else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) pc_st4(rp + x4, f32x4{0.f, 0.f, 0.f, 0.f});
+                else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0;
             } else if (p.px <= 16 && Wp - right0 <= 16) {
                 const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
-                if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0.f;
+                if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0;
             } else {
-                for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
-                for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0;
+                for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0;
             }
         }
     }
@@ -1228,7 +1228,9 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
     for (int mb = 0; mb < 4; ++mb) {
         b0o2[mb] = lf[16 * mb + li]; b2o2[mb] = lf[64 + 16 * mb + li]; b4o2[mb] = lf[128 + 16 * mb + li]; w6o2[mb] = lf[192 + 16 * mb + li];
     }
-    const bool quad_ok = (p.W & 3) == 0;        // pixel quads 4*lk .. 4*lk+3 of a group never straddle a row
+    // pixel quads 4*lk .. 4*lk+3 of a group never straddle a row, and start at an even element (dword loads of bf16 pairs)
+    const bool quad_ok = (p.W & 3) == 0 && (p.px & 1) == 0 && (p.feat.rstride & 1) == 0 && (p.feat.cstride & 1) == 0 && (p.feat.bstride & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.feat.ptr) & 3) == 0;
 
     // per-group inputs, fetched one group ahead
     float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
@@ -1240,11 +1242,12 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
         const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+        const pc_bf16_t* fbase = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr);
+        const pc_bf16_t* fp = fbase + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            n_xv[j] = fp[(4 * j + lk) * p.feat.cstride];
-            n_fv[j] = !a.fuse_feat_bn ? 1.f : fp[(4 * lk + j) * p.feat.cstride];
+            n_xv[j] = pc_ld1(fp + (4 * j + lk) * p.feat.cstride);
+            n_fv[j] = !a.fuse_feat_bn ? 1.f : pc_ld1(fp + (4 * lk + j) * p.feat.cstride);
         }
         n_msk = p.mask ? p.mask[pix] : 1;
         n_bld = p.building[pix];
@@ -1256,16 +1259,19 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         if (quad_ok) {
             const bool v2 = q2 < HW;
             const int y2 = v2 ? (int)pc_div((uint32_t)q2, p.div_w) : 0, x2 = v2 ? q2 - y2 * p.W : 0;
-            const f32x4u t = *reinterpret_cast<const f32x4u*>(p.feat.ptr + b * p.feat.bstride + li * p.feat.cstride +
-                                                              (int64_t)(p.py + y2) * p.feat.rstride + p.px + x2);
-            n_xq = v2 ? f32x4{t[0], t[1], t[2], t[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            // four bf16 pixels = two dwords (the quad starts at an even element: 4-byte aligned)
+            const unsigned* q2p = reinterpret_cast<const unsigned*>(fbase + b * p.feat.bstride + li * p.feat.cstride +
+                                                                    (int64_t)(p.py + y2) * p.feat.rstride + p.px + x2);
+            const unsigned d0 = q2p[0], d1 = q2p[1];
+            n_xq = v2 ? f32x4{__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u), __uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)}
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qq = q2 + e;
                 const bool vv = qq < HW;
                 const int yy = vv ? (int)pc_div((uint32_t)qq, p.div_w) : 0, xx = vv ? qq - yy * p.W : 0;
-                const float t = p.feat.ptr[b * p.feat.bstride + li * p.feat.cstride + (int64_t)(p.py + yy) * p.feat.rstride + p.px + xx];
+                const float t = pc_ld1(fbase + b * p.feat.bstride + li * p.feat.cstride + (int64_t)(p.py + yy) * p.feat.rstride + p.px + xx);
                 n_xq[e] = vv ? t : 0.f;
             }
         }
@@ -1294,9 +1300,9 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         if (gg + gstep < a.total_groups) fetch(gg + gstep);
         auto store_zero = [&]() {
             if (a.zero_in_kernel && valid) {
-                float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+                pc_bf16_t* op = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0.f;
+                for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0;
             }
         };
         if (!__any(sel)) { store_zero(); continue; }
@@ -1463,12 +1469,12 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
 #pragma unroll
         for (int t = 0; t < 2; ++t) gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T1, 0, t, lane_o), gb1[t], gx, 0, 0, 0);
         if (valid) {
-            float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+            pc_bf16_t* op = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float o = gx[r];
                 if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                op[(4 * lk + r) * a.g_feat.cstride] = pc_bf16r(o);
+                pc_st1(op + (4 * lk + r) * a.g_feat.cstride, o);
             }
         }
     }
@@ -1583,11 +1589,11 @@ __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, 
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)W;
         const int x = (int)(i - row * (unsigned)W), y = (int)(row % (unsigned)H), b = (int)(row / (unsigned)H);
-        const float* fp = feat.ptr + b * feat.bstride + (int64_t)(py + y) * feat.rstride + px + x;
+        const int64_t fo = b * feat.bstride + (int64_t)(py + y) * feat.rstride + px + x;
         float s = bv;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c < feat.C) s = fmaf(fp[c * feat.cstride], wv[c], s);
+            if (c < feat.C) s = fmaf(pc_src_at(feat, fo + c * feat.cstride), wv[c], s);
         out.ptr[b * out.bstride + (int64_t)y * out.rstride + x] = 1.f / (1.f + expf(-s));
     }
 }
@@ -1675,7 +1681,8 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     }
     const float bv = a.bias[0];
     int nsel = 0, nreg = 0;
-    const bool vec4 = (a.W & 3) == 0 && (a.out.rstride & 3) == 0 && (a.out.bstride & 3) == 0 &&
+    const bool vec4 = a.feat.dtype == PC_F32 &&      // (a bf16 feature map -- the non-dot fallback of bf16 mode -- takes the scalar loop)
+                      (a.W & 3) == 0 && (a.out.rstride & 3) == 0 && (a.out.bstride & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(a.out.ptr) | reinterpret_cast<uintptr_t>(a.admin) |
                         reinterpret_cast<uintptr_t>(a.mask)) & 15) == 0;
     if (vec4) {
@@ -1716,11 +1723,11 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)a.W;
         const int x = (int)(i - row * (unsigned)a.W), y = (int)(row % (unsigned)a.H), b = (int)(row / (unsigned)a.H);
-        const float* fp = a.feat.ptr + b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + a.px + x;
+        const int64_t fo = b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + a.px + x;
         float s = bv;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c < a.feat.C) s = fmaf(fp[c * a.feat.cstride], wv[c], s);
+            if (c < a.feat.C) s = fmaf(pc_src_at(a.feat, fo + c * a.feat.cstride), wv[c], s);
         const float building = 1.f / (1.f + expf(-s));
         a.out.ptr[b * a.out.bstride + (int64_t)y * a.out.rstride + x] = building;
         const bool region = a.admin[i] == (float)a.census[b];
@@ -1982,13 +1989,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.groups_per_wave < 8) p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
-    static int bf_mfma = -1;          // POPCORN_HEAD_BF16_MFMA=0: bf16 mode on the fp32-MFMA kernels (A/B switch)
-    if (bf_mfma < 0) {
-        const char* ev = getenv("POPCORN_HEAD_BF16_MFMA");
-        bf_mfma = (ev && ev[0] == '0') ? 0 : 1;
-    }
-    if (p.bf && bf_mfma) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
-    else if (p.bf) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
+    if (feat->dtype != (p.bf ? PC_BF16 : PC_F32)) return PC_EINVAL;      // bf16 mode: the feature map is a bf16 container
+    if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
@@ -2093,7 +2095,9 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         use_pc = (ev && ev[0] == '1') ? 0 : 1;
     }
     const char* zv = getenv("POPCORN_HEAD_ZERO_FILL");            // A/B switch: 1 = the round-1 separate zero-fill launch
-    const bool zero_launch = !use_pc || (zv && zv[0] == '1');
+    const bool bfmode = g_pc_precision == PC_PREC_BF16;          // bf16 mode: feat and g_feat are bf16 containers
+    if (feat->dtype != (bfmode ? PC_BF16 : PC_F32) || g_feat->dtype != feat->dtype) return PC_EINVAL;
+    const bool zero_launch = !bfmode && (!use_pc || (zv && zv[0] == '1'));
     if (zero_launch) {
         // zero fill by a kernel, not a memset node (see zero_fill_kernel)
         const int64_t n4 = (int64_t)B * 16 * Hp * Wp / 4, rem = (int64_t)B * 16 * Hp * Wp - 4 * n4;
@@ -2132,21 +2136,16 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
-        if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    static int bf_mfma = -1;
-    if (bf_mfma < 0) {
-        const char* ev = getenv("POPCORN_HEAD_BF16_MFMA");
-        bf_mfma = (ev && ev[0] == '0') ? 0 : 1;
+    static bool bf_attr = false;
+    if (!bf_attr) {
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, HB_RED);
         if (e3 != hipSuccess) return (int)e3;
+        bf_attr = true;
     }
-    if (use_pc && p.bf && bf_mfma) hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nwg), dim3(256), HB_RED, st, a);
-    else if (use_pc && p.bf) hipLaunchKernelGGL(head_bwd_pc_kernel<true>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    if (p.bf) hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nwg), dim3(256), HB_RED, st, a);
     else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel<false>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();

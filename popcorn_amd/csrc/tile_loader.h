@@ -14,7 +14,7 @@
 
 // host side: can the vector path be used for this source on a conv domain of H x W?
 static inline int pc_src_fast_mode(const pc_src& s, int H, int W) {
-    if (s.C == 0) return 0;
+    if (s.C == 0 || s.dtype != PC_F32) return 0;      // bf16 containers: staged paths have their own check, the rest is pc_fetch
     const bool al = ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && (s.rstride % 4 == 0) && (s.cstride % 4 == 0) &&
                     (s.bstride % 4 == 0);
     if (!al) return 0;

@@ -13,7 +13,8 @@ fp32 sum lands within rounding of a bf16 tie (a 2^-8 = 0.4 % step on that elemen
       gradients, worst tensor      4.7e-3   -> bound 1.5e-2      5.2e-2 .. 5.6e-2
       gradients, median tensor     9e-4     -> bound 3e-3        1.0e-2
     and every HIP-vs-oracle distance must stay below HALF the rounding band of the same quantity.
-Index paths (mask, Nsel) stay exact; stored activations must be bf16-representable; master weights / Adam stay fp32."""
+Index paths (mask, Nsel) stay exact; activations and activation gradients are bf16 CONTAINERS (torch.bfloat16 tensors, half
+the HBM bytes of the fp32 mode); master weights, weight gradients and Adam stay fp32."""
 import os
 import socket
 
@@ -47,7 +48,15 @@ def _sample():
 
 
 def _is_bf16(t):
+    """bf16 container, or fp32 values that are all bf16-representable"""
+    if t.dtype == torch.bfloat16:
+        return True
     return bool(((t.contiguous().view(torch.int32) & 0xFFFF) == 0).all())
+
+
+def _dev(x):
+    """activation / gradient operand of a bf16-mode op: a bf16 container on the GPU"""
+    return x.cuda().to(torch.bfloat16)
 
 
 @pytest.mark.parametrize("padding", [True, False])
@@ -83,12 +92,12 @@ def test_bf16_stored_activations_are_bf16_values_and_fp32_mode_is_untouched():
         feats, saved = eng.forward(x, 14, 14, 128, 128, save=True)
     for s in ("sar_stream", "optical_stream"):
         for k in ("a1", "a2", "b1", "b2", "c1", "c2", "u2", "e1", "e2", "u1", "f1", "pa2", "pb2"):
-            assert _is_bf16(saved[s][k]), (s, k)
-    assert _is_bf16(feats)
+            assert saved[s][k].dtype == torch.bfloat16, (s, k)
+    assert feats.dtype == torch.bfloat16 and saved["X"].dtype == torch.float32
     assert L.lib().pc_get_precision() == L.PC_PREC_FP32                               # the context restored the mode
     with torch.no_grad():
         feats32, _ = eng.forward(x, 14, 14, 128, 128, save=False)
-    assert not _is_bf16(feats32)
+    assert feats32.dtype == torch.float32 and not _is_bf16(feats32)
     ref = O.dualstream_features(sd, "unetmodel", O.reorder_channels(O.add_padding(x.cpu(), True)[0]))
     assert rel(feats32.cpu(), ref) < 1e-4                                             # fp32 path unchanged by the bf16 build
 
@@ -227,8 +236,8 @@ def _close_bf16(out, ref_fp32):
     """out must equal round_bf16(ref) up to the ties an fp32 summation order can flip: every element within one bf16 step
     (2^-7 relative, or a tiny absolute floor around zero), almost all of them exactly equal."""
     want = _bf(ref_fp32)
-    assert _is_bf16(out.cuda() if not out.is_cuda else out)
-    o = out.cpu()
+    assert out.dtype == torch.bfloat16
+    o = out.float().cpu()
     err = (o - want).abs()
     assert bool((err <= 2.0 ** -7 * want.abs() + 1e-6).all()), err.max().item()
     assert float((err == 0).float().mean()) > 0.98
@@ -247,7 +256,9 @@ def test_bf16_conv_fwd_op(cin, cout, shape):
     y = F.conv2d(x.double(), _bf(w).double(), b.double(), padding=1)
     ref = F.relu(F.batch_norm(y, mean.double(), var.double(), gamma.double(), beta.double(), training=False, eps=1e-5)).float()
     with L.precision("bf16"):
-        out = ops.conv3x3_bn_relu(x.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())
+        out = ops.conv3x3_bn_relu(_dev(x), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())
+        with pytest.raises(RuntimeError):               # an fp32 container in bf16 mode is refused, not converted
+            ops.conv3x3_bn_relu(x.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())
     _close_bf16(out, ref)
 
 
@@ -262,14 +273,14 @@ def test_bf16_conv_asymmetric_taps_and_loaders():
             w = torch.zeros(8, 16, 3, 3)
             w[co, ci, dy, dx] = 1.0
             ref = F.conv2d(x, w, None, padding=1)
-            out = ops.conv3x3_bn_relu(x.cuda(), w.cuda(), None, relu=False)
-            assert torch.equal(out.cpu(), ref), (co, ci, dy, dx)
+            out = ops.conv3x3_bn_relu(_dev(x), w.cuda(), None, relu=False)
+            assert torch.equal(out.float().cpu(), ref), (co, ci, dy, dx)
         # pool loader
         xs = _bf(_mk(2, 8, 64, 64, seed=6))
         w = _mk(16, 8, 3, 3, seed=7, scale=0.2)
         b = _mk(16, seed=8, scale=0.1)
         ref = F.relu(F.conv2d(F.max_pool2d(xs, 2).double(), _bf(w).double(), b.double(), padding=1)).float()
-        out = ops.conv3x3_bn_relu(xs.cuda(), w.cuda(), b.cuda(), a_mode=L.PC_SRC_POOL2)
+        out = ops.conv3x3_bn_relu(_dev(xs), w.cuda(), b.cuda(), a_mode=L.PC_SRC_POOL2)
         _close_bf16(out, ref)
         # concat loader (aligned: staged path) and with an offset up tensor (generic path)
         for (hs, ws, hu, wu) in [(32, 64, 32, 64), (23, 35, 22, 34)]:
@@ -279,7 +290,7 @@ def test_bf16_conv_asymmetric_taps_and_loaders():
             dy, dx = hs - hu, ws - wu
             upp = F.pad(upt, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
             ref = F.relu(F.conv2d(torch.cat([skip, upp], 1).double(), _bf(w).double(), b.double(), padding=1)).float()
-            out = ops.conv3x3_bn_relu(skip.cuda(), w.cuda(), b.cuda(), b=upt.cuda(), b_offset=(dy // 2, dx // 2))
+            out = ops.conv3x3_bn_relu(_dev(skip), w.cuda(), b.cuda(), b=_dev(upt), b_offset=(dy // 2, dx // 2))
             _close_bf16(out, ref)
         # reflect loader: un-rounded 6-channel input, channel gather
         X = _mk(2, 6, 100, 100, seed=14)
@@ -294,13 +305,13 @@ def test_bf16_conv_asymmetric_taps_and_loaders():
         # data gradient with the ReLU / BN epilogue of the producing layer
         g = _bf(_mk(2, 8, 32, 64, seed=17))
         w = _mk(8, 16, 3, 3, seed=18, scale=0.2)
-        act = F.relu(_mk(2, 8, 32, 64, seed=19))
+        act = _bf(F.relu(_mk(2, 8, 32, 64, seed=19)))
         gamma, beta, mean, var = _bn(8, 20)
         scale = gamma / torch.sqrt(var + 1e-5)
         full = F.conv_transpose2d(g.double(), _bf(w).double(), padding=1)[:, 8:16]
         ref = (full * (act > 0) * scale.view(1, 8, 1, 1).double()).float()
-        out = torch.empty(2, 8, 32, 64, device="cuda")
-        ops.conv3x3_dgrad(g.cuda(), w.cuda(), 8, 8, out, act=act.cuda(), act_bn=L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()))
+        out = torch.empty(2, 8, 32, 64, device="cuda", dtype=torch.bfloat16)
+        ops.conv3x3_dgrad(_dev(g), w.cuda(), 8, 8, out, act=_dev(act), act_bn=L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()))
         _close_bf16(out, ref)
 
 
@@ -319,13 +330,13 @@ def test_bf16_conv_wgrad_op(cin, cout, shape):
     g = _bf(_mk(B, cout, H, W, seed=42))
     F.conv2d(x.double(), w, bias, padding=1).backward(g.double())
     with L.precision("bf16"):
-        dw, db = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
-        dw2, db2 = ops.conv3x3_wgrad(x.cuda(), g.cuda(), cout)
+        dw, db = ops.conv3x3_wgrad(_dev(x), _dev(g), cout)
+        dw2, db2 = ops.conv3x3_wgrad(_dev(x), _dev(g), cout)
     sw, sb = w.grad.abs().max().item(), bias.grad.abs().max().item()
     assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * sw
     assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * max(sb, 1.0)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)                            # deterministic
-    assert not _is_bf16(dw)
+    assert dw.dtype == torch.float32 and not _is_bf16(dw)
 
 
 def test_bf16_conv_wgrad_pool_and_concat_loaders():
@@ -337,12 +348,12 @@ def test_bf16_conv_wgrad_pool_and_concat_loaders():
         y = F.conv2d(F.max_pool2d(xs, 2).double(), w, None, padding=1)
         g = _bf(_mk(*y.shape, seed=45))
         y.backward(g.double())
-        dw, _ = ops.conv3x3_wgrad(xs.cuda(), g.cuda(), 16, a_mode=L.PC_SRC_POOL2)
+        dw, _ = ops.conv3x3_wgrad(_dev(xs), _dev(g), 16, a_mode=L.PC_SRC_POOL2)
         assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * w.grad.abs().max().item()
         skip, upt = _bf(_mk(2, 16, 32, 64, seed=46)), _bf(_mk(2, 16, 32, 64, seed=47))
         w = _mk(8, 32, 3, 3, seed=48, scale=0.1).double().requires_grad_(True)
         y = F.conv2d(torch.cat([skip, upt], 1).double(), w, None, padding=1)
         g = _bf(_mk(*y.shape, seed=49))
         y.backward(g.double())
-        dw, _ = ops.conv3x3_wgrad(skip.cuda(), g.cuda(), 8, b=upt.cuda(), b_offset=(0, 0))
+        dw, _ = ops.conv3x3_wgrad(_dev(skip), _dev(g), 8, b=_dev(upt), b_offset=(0, 0))
         assert (dw.cpu().double() - w.grad).abs().max().item() <= 2e-5 * w.grad.abs().max().item()

@@ -89,7 +89,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     selected pixel (data + weight gradients).  The kernel also recomputes the forward chain in registers
     instead of reading a 491 MB hidden-activation buffer: it ISSUES 56,064 flop per pixel -- reported separately as the
     executed-MFMA fraction, never as `frac`."""
-    from popcorn_amd import ops
+    from popcorn_amd import ops, _lib as L
     m = trainer.model
     X = sample["input"]
     B, _, H, W = X.shape
@@ -100,7 +100,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     g_pc = torch.ones(B, device=X.device)
     gsc = torch.full((1,), 1e-3, device=X.device)
     grads = [torch.empty_like(t) for t in m.head_tensors()]
-    g_feat = torch.empty(B, 16, H + 28, W + 28, device=X.device, dtype=feats.dtype)
+    g_feat = L.empty_act(B, 16, H + 28, W + 28, X.device)
     bf = feats.dtype == torch.bfloat16
     peak = BF16_MATRIX_PEAK if bf else FP32_MATRIX_PEAK
     esz = feats.element_size()
@@ -125,7 +125,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     achieved = flops / dur / 1e12
     pmc = _pmc("r2_pmc_head_bwd.json") or _pmc("r1_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    kname = ("head_bwd_bf16_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, bf16 feature + gradient maps)" if bf else
+    kname = ("head_bwd_bf16_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, channels-last bf16 feature + gradient maps)" if bf else
              "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
     if bf:
         pmc = _pmc("r2_pmc_head_bwd_bf16.json")
@@ -156,8 +156,8 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
         probs = []
         for _ in range(4):
             bias = torch.zeros(8, device="cuda")
-            probs.append({"a": torch.randn(B, 8, 128, 128, device="cuda").to(adt), "w": torch.randn(8, 8, 3, 3, device="cuda") * 0.1,
-                          "bn": L.bn(bias), "out": torch.empty(B, 8, 128, 128, device="cuda", dtype=adt), "_keep": bias})
+            probs.append({"a": L.as_act(torch.randn(B, 8, 128, 128, device="cuda")), "w": torch.randn(8, 8, 3, 3, device="cuda") * 0.1,
+                          "bn": L.bn(bias), "out": L.empty_act(B, 8, 128, 128, "cuda"), "_keep": bias})
         sets.append(probs)
     for s in sets:
         ops.conv3x3_fwd_group(s)
@@ -181,7 +181,7 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
     pmc = _pmc("r2_pmc_conv_8to8_bf16.json" if esz == 2 else "r2_pmc_conv_8to8.json")
-    return {"bound": "hbm", "kernel": f"conv3x3_mfma_kernel<8,8,fwd,{'bf16' if esz == 2 else 'fp32'}> grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
+    return {"bound": "hbm", "kernel": f"{'conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)' if esz == 2 else 'conv3x3_mfma_kernel<8,8,fwd> (fp32)'} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
             "traffic": pmc["traffic_bytes"] if pmc and B == 64 else None, "launch_us": round(dur * 1e6, 2),
             "alg_bytes_per_launch": nbytes,

@@ -53,7 +53,8 @@ typedef struct pc_src {
     int32_t oy, ox;      /* DIRECT: placement of the source origin in the conv domain; REFLECT: top/left pad */
     int32_t chmap[4];    /* REFLECT only: conv channel c reads source channel chmap[c] */
     int32_t dtype;       /* enum pc_dtype */
-    int32_t _pad;
+    int32_t xstride;     /* elements between x-neighbours: 0 or 1 = planar rows (NCHW); a channels-last tensor
+                            (bf16 mode, see below) has cstride = 1 and xstride = its channel count */
 } pc_src;
 
 typedef struct pc_dst {
@@ -61,6 +62,8 @@ typedef struct pc_dst {
     int64_t bstride, cstride;
     int32_t rstride;
     int32_t dtype;       /* enum pc_dtype */
+    int32_t xstride;     /* as pc_src.xstride */
+    int32_t _pad;
 } pc_dst;
 
 /* folded BatchNorm2d(eval) + conv bias of one layer: y = relu(conv * scale + shift) with

@@ -19,12 +19,12 @@ PC_SRC_DIRECT, PC_SRC_POOL2, PC_SRC_REFLECT = 0, 1, 2
 class PcSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32), ("mode", C.c_int32),
-                ("oy", C.c_int32), ("ox", C.c_int32), ("chmap", C.c_int32 * 4), ("dtype", C.c_int32), ("_pad", C.c_int32)]
+                ("oy", C.c_int32), ("ox", C.c_int32), ("chmap", C.c_int32 * 4), ("dtype", C.c_int32), ("xstride", C.c_int32)]
 
 
 class PcDst(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bstride", C.c_int64), ("cstride", C.c_int64), ("rstride", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("xstride", C.c_int32), ("_pad", C.c_int32)]
 
 
 class PcBn(C.Structure):
@@ -107,6 +107,22 @@ def act_dtype():
     return torch.bfloat16 if lib().pc_get_precision() == PC_PREC_BF16 else torch.float32
 
 
+def empty_act(B, C_, H, W, device, zero=False):
+    """Activation / activation-gradient tensor (B, C, H, W) in the layout of the current arithmetic mode: planar fp32, or
+    channels-last bf16 (one aligned 16-byte slot per pixel and 8-channel group; include/popcorn_hip.h)."""
+    mk = torch.zeros if zero else torch.empty
+    if lib().pc_get_precision() == PC_PREC_BF16:
+        return mk(B, C_, H, W, device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    return mk(B, C_, H, W, device=device, dtype=torch.float32)
+
+
+def as_act(t):
+    """Copy of a (B, C, H, W) tensor in the container type and layout of the current arithmetic mode (tests, tools)."""
+    if lib().pc_get_precision() == PC_PREC_BF16:
+        return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return t.float().contiguous()
+
+
 class precision:
     """``with precision("bf16"):`` -- the arithmetic mode of every call enqueued inside the block (pc_set_precision; the
     mode is read at enqueue time, so a HIP graph captured inside the block keeps it).  Restores the previous mode."""
@@ -147,9 +163,11 @@ def ptr(t) -> C.c_void_p:
 
 
 def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2, 3)) -> PcSrc:
-    """Descriptor of a (B, C, H, W) fp32 or bf16 tensor (any batch/channel/row stride, unit x stride; strides in elements)."""
-    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.stride(3) == 1
+    """Descriptor of a (B, C, H, W) fp32 or bf16 tensor, planar (unit x stride) or channels-last (unit channel stride);
+    strides in elements."""
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and (t.stride(3) == 1 or t.stride(1) == 1)
     s = PcSrc()
+    s.xstride = t.stride(3)
     s.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
     s.ptr = t.data_ptr()
     s.C = t.shape[1] if C_ is None else C_
@@ -161,8 +179,9 @@ def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2
 
 
 def dst(t: torch.Tensor) -> PcDst:
-    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.stride(3) == 1
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and (t.stride(3) == 1 or t.stride(1) == 1)
     d = PcDst()
+    d.xstride = t.stride(3)
     d.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
     d.ptr = t.data_ptr()
     d.bstride, d.cstride, d.rstride = t.stride(0), t.stride(1), t.stride(2)

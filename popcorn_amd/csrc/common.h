@@ -44,6 +44,19 @@ __device__ __forceinline__ void pc_st4(pc_bf16_t* p, f32x4 v) {
 __device__ __forceinline__ void pc_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 __device__ __forceinline__ void pc_st2(pc_bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pc_pack_bf16(a, b); }
 // element i of a source described by a pc_src (run-time dtype: generic / fallback paths only)
+// x stride of a descriptor (0 / 1 = planar rows), and whether it describes a planar tensor -- the only form the fp32 kernels take
+__host__ __device__ __forceinline__ int pc_xs(const pc_src& s) { return s.xstride > 1 ? s.xstride : 1; }
+__host__ __device__ __forceinline__ int pc_xs(const pc_dst& d) { return d.xstride > 1 ? d.xstride : 1; }
+__host__ __device__ __forceinline__ bool pc_planar(const pc_src& s) { return s.xstride <= 1; }
+__host__ __device__ __forceinline__ bool pc_planar(const pc_dst& d) { return d.xstride <= 1; }
+// channels-last bf16: one aligned 16-byte slot per (pixel, 8-channel group)
+__host__ __device__ __forceinline__ bool pc_cl_ok(const void* ptr, int dtype, int64_t bstride, int64_t cstride, int rstride, int xstride) {
+    return dtype == PC_BF16 && cstride == 1 && xstride >= 8 && xstride % 8 == 0 && rstride % 8 == 0 && bstride % 8 == 0 &&
+           (reinterpret_cast<uintptr_t>(ptr) & 15) == 0;
+}
+__host__ __device__ __forceinline__ bool pc_cl_ok(const pc_src& s) { return pc_cl_ok(s.ptr, s.dtype, s.bstride, s.cstride, s.rstride, s.xstride); }
+__host__ __device__ __forceinline__ bool pc_cl_ok(const pc_dst& d) { return pc_cl_ok(d.ptr, d.dtype, d.bstride, d.cstride, d.rstride, d.xstride); }
+
 __device__ __forceinline__ float pc_src_at(const pc_src& s, int64_t i) {
     return s.dtype == PC_BF16 ? pc_bf2f(reinterpret_cast<const pc_bf16_t*>(s.ptr)[i]) : s.ptr[i];
 }
@@ -122,14 +135,15 @@ __device__ __forceinline__ float pc_fetch(const pc_src& s, int b, int c, int y, 
     if (s.mode == PC_SRC_DIRECT) {
         const int ys = y - s.oy, xs = x - s.ox;
         if ((unsigned)ys >= (unsigned)s.H || (unsigned)xs >= (unsigned)s.W) return 0.f;
-        return pc_src_at(s, b * s.bstride + c * s.cstride + (int64_t)ys * s.rstride + xs);
+        return pc_src_at(s, b * s.bstride + c * s.cstride + (int64_t)ys * s.rstride + (int64_t)xs * pc_xs(s));
     } else if (s.mode == PC_SRC_POOL2) {
-        const int64_t o = b * s.bstride + c * s.cstride + (int64_t)(2 * y) * s.rstride + 2 * x;
+        const int xst = pc_xs(s);
+        const int64_t o = b * s.bstride + c * s.cstride + (int64_t)(2 * y) * s.rstride + (int64_t)(2 * x) * xst;
         // nn.MaxPool2d(2): floor mode, windows never cross the source extent for y < H/2, x < W/2
-        return fmaxf(fmaxf(pc_src_at(s, o), pc_src_at(s, o + 1)), fmaxf(pc_src_at(s, o + s.rstride), pc_src_at(s, o + s.rstride + 1)));
+        return fmaxf(fmaxf(pc_src_at(s, o), pc_src_at(s, o + xst)), fmaxf(pc_src_at(s, o + s.rstride), pc_src_at(s, o + s.rstride + xst)));
     } else {
         const int ys = pc_reflect(y - s.oy, s.H), xs = pc_reflect(x - s.ox, s.W);
-        return pc_src_at(s, b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + xs);
+        return pc_src_at(s, b * s.bstride + s.chmap[c & 3] * s.cstride + (int64_t)ys * s.rstride + (int64_t)xs * pc_xs(s));
     }
 }
 

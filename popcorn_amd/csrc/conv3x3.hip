@@ -62,6 +62,7 @@ struct ConvProb {
     int64_t act_bstride, act_cstride;
     int act_rstride;
     int act_dtype;
+    int act_xstride;
     int fast_a, fast_b;   // pc_src_fast_mode of the two sources (generic loader)
     pc_dst out;
     pc_dst pool_out;      // FWD: 2x2-max-pooled copy of the output (ptr NULL = not wanted)
@@ -638,9 +639,439 @@ int launch_conv_bf(ConvArgs& p, int nprob, hipStream_t stream) {
     return 0;
 }
 
+
+// =====================================================================================================================
+// Channels-last bf16 kernel (PC_PREC_BF16).  Activations / gradients are bf16 tensors with the channels of a pixel
+// contiguous (cstride = 1, xstride = C: torch.channels_last), i.e. ONE aligned 16-byte slot per (pixel, 8-channel group)
+// in HBM -- exactly the slot of the LDS strip image and of the MFMA operand:
+//   * the loader is a masked copy: 6 x 34 slots of a strip = 204 16-byte pieces, 4 per lane, in 544-byte runs per row
+//     (the planar layout moved 48 pieces of 80 bytes per strip and transposed them with 16 pack instructions per lane;
+//     tools/layout_bw.hip: 28 us instead of 50 us for the loads + stores of the grouped 8 -> 8 @128x128 launch);
+//   * the MFMA operands are swapped against the planar kernels: A = weights (M = (row of pair s, co)), B = pixels
+//     (N = 16 x), so D hands every lane FOUR CONSECUTIVE CHANNELS of one pixel:
+//         lane (x = lane & 15, lk = lane >> 4), register r:  s = lk >> 1,  co = 4 * (lk & 1) + r
+//     = one 8-byte store per pixel, 256 contiguous bytes per 16 lanes, and every epilogue (BN + ReLU, ReLU-mask * BN scale,
+//     accumulate, 2x2 max-pool copy, max-pool backward scatter, 1x1 partial logit) is per-pixel with a plain bounds
+//     predicate: no separate "aligned interior" and "generic edge" paths, and no generic loader either (any placement
+//     offset of a source keeps its slots aligned).
+// Same wave-private strips, register-staged prefetch, deferred epilogue and persistent XCD-aware grid as above.
+constexpr int CL_PX = 34;                 // pixels per strip row incl. the one-pixel halo
+constexpr int CL_PIECES = SROWS * CL_PX;  // 16-byte pieces per strip and 8-channel chunk
+
+__device__ __forceinline__ u32x4 cl_max8(u32x4 a, u32x4 b) {      // elementwise max of 8 bf16 (exact: no rounding involved)
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = fmaxf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16));
+        const float hi = fmaxf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u));
+        o[e] = (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+    }
+    return o;
+}
+__device__ __forceinline__ f32x4 cl_ld4(const pc_bf16_t* p) {     // 4 consecutive channels of one pixel
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void cl_st4(pc_bf16_t* p, f32x4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
+}
+
+template <int CIN, int COUT, int MODE, int LD, int EPI>
+__global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
+    constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
+    constexpr int NB = COUT / 8;
+    constexpr int NIT = CIN < 8 ? CIN : 1;               // REFLECT loader: planar fp32 rows, one 16-byte segment per channel
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const ConvProb& q = p.pr[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    if (p.dbg & 8) return;
+    u32x4* const wl = reinterpret_cast<u32x4*>(lds) + wave * (SROWS * BSLOTS);       // this wave's strip: [6 rows][48 slots]
+
+    // ---- loader: piece id = lane + 64 * i -> (strip row, pixel of the 34-pixel row)
+    int l_slot[4];            // LDS slot of the piece, -1 = the lane has no such piece
+    int l_r[4], l_px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = lane + 64 * i;
+        l_r[i] = id / CL_PX;
+        l_px[i] = id - l_r[i] * CL_PX;
+        l_slot[i] = id < CL_PIECES ? l_r[i] * BSLOTS + (COL0 - 1) + l_px[i] : -1;
+    }
+    const int CA = q.a.C;
+    u32x4 R[LD == LD_POOL ? 16 : 4];
+    f32x4 RF[LD == LD_REFLECT ? NIT : 1];
+    unsigned rvalid = 0;
+    const int r_r = lane / 10, r_seg = lane - r_r * 10;  // REFLECT: lane = (row, 4-pixel segment of the 40-pixel row)
+    auto issue = [&](int ch, int b, int y0, int x0) {
+        if constexpr (LD == LD_REFLECT) {
+            rvalid = lane < 60 ? 1u : 0u;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                RF[it] = lane < 60 ? pc_fetch_reflect_seg(q.a, b, it, y0 - 1 + r_r, x0 - 4 + 4 * r_seg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const bool useb = LD == LD_DIRECT && 8 * ch >= CA;
+            const pc_src& s = useb ? q.b : q.a;
+            const pc_bf16_t* base = reinterpret_cast<const pc_bf16_t*>(s.ptr) + b * s.bstride + (useb ? 8 * ch - CA : 8 * ch);
+            const int rs = s.rstride, xs = s.xstride;
+            unsigned vm = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = y0 - 1 + l_r[i], x = x0 - 1 + l_px[i];
+                bool ok = l_slot[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                if constexpr (LD == LD_DIRECT) {
+                    const int ys = y - s.oy, xq = x - s.ox;
+                    ok = ok && (unsigned)ys < (unsigned)s.H && (unsigned)xq < (unsigned)s.W;
+                    const int64_t off = ok ? (int64_t)ys * rs + (int64_t)xq * xs : 0;
+                    R[i] = *reinterpret_cast<const u32x4*>(base + off);
+                } else {      // LD_POOL: the 2x2 window of a source at twice the resolution (floor mode: always inside)
+                    const int64_t off = ok ? (int64_t)(2 * y) * rs + (int64_t)(2 * x) * xs : 0;
+                    const int rs1 = ok ? rs : 0, xs1 = ok ? xs : 0;
+                    R[4 * i + 0] = *reinterpret_cast<const u32x4*>(base + off);
+                    R[4 * i + 1] = *reinterpret_cast<const u32x4*>(base + off + xs1);
+                    R[4 * i + 2] = *reinterpret_cast<const u32x4*>(base + off + rs1);
+                    R[4 * i + 3] = *reinterpret_cast<const u32x4*>(base + off + rs1 + xs1);
+                }
+                vm |= (ok ? 1u : 0u) << i;
+            }
+            rvalid = vm;
+        }
+    };
+    auto commit = [&]() {
+        if constexpr (LD == LD_REFLECT) {
+            // planar fp32 model input: round + pack here (the one operand no producer has rounded); channel slots >= CIN are zero
+            if (lane < 60) {
+                u32x4* d = wl + r_r * BSLOTS + 4 * r_seg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 t = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int h = 0; h < (NIT + 1) / 2; ++h)
+                        t[h] = pc_pack_bf16(RF[2 * h][e], 2 * h + 1 < NIT ? RF[(2 * h + 1) % NIT][e] : 0.f);
+                    d[e] = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (l_slot[i] >= 0) {
+                    u32x4 v;
+                    if constexpr (LD == LD_POOL) v = cl_max8(cl_max8(R[4 * i], R[4 * i + 1]), cl_max8(R[4 * i + 2], R[4 * i + 3]));
+                    else v = R[i];
+                    wl[l_slot[i]] = ((rvalid >> i) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+    };
+
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nstages = my_tiles * NCHUNK;
+    auto strip_coords = [&](int stage, int& b, int& y0, int& x0) {
+        const int t = blockIdx.x + (stage / NCHUNK) * gridDim.x;
+        const int tile = pc_xcd_remap(t, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (nstages > 0) {
+        strip_coords(0, b, y0, x0);
+        if (!(p.dbg & 1)) issue(0, b, y0, x0);
+    }
+
+    // ---- weight image [dy plane 0..3][co][chunk][dx][8 ci] bf16 (plane 3 all zero), as in the planar bf16 path; a lane's
+    // A fragment for (chunk, dx): the 8 input channels of tap (dy = lk - s, dx) of output channel co = li & 7, s = li >> 3
+    unsigned short* const w2h = reinterpret_cast<unsigned short*>(lds + 4 * BWAVE_F);
+    constexpr int BW_CO = NCHUNK * 24;
+    constexpr int BW_DYS = COUT * BW_CO;
+    constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
+    float wreg[NWR];
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+        const int e = tid + k * 256;
+        const int ec = e < COUT * CIN * 9 ? e : 0;
+        const int tap = ec % 9, ci = (ec / 9) % CIN, co = ec / (9 * CIN);
+        wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+    }
+    // per-lane epilogue constants for co = nb*8 + 4*(lk&1) + r
+    const bool has_bn = MODE == MODE_FWD || q.act != nullptr;
+    const int c4 = 4 * (lk & 1);
+    float e_scale[NB][4], e_shift[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = nb * 8 + c4 + r;
+            const float cb = has_bn && q.bn.conv_bias ? q.bn.conv_bias[c] : 0.f;
+            if (has_bn && q.bn.gamma) {
+                e_scale[nb][r] = q.bn.gamma[c] * (1.0f / sqrtf(q.bn.var[c] + q.bn.eps));
+                e_shift[nb][r] = (cb - q.bn.mean[c]) * e_scale[nb][r] + q.bn.beta[c];
+            } else {
+                e_scale[nb][r] = 1.f;
+                e_shift[nb][r] = cb;
+            }
+        }
+    float dotw[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_DOT) {
+        if (q.dot_w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dotw[r] = pc_bf16r(q.dot_w[c4 + r]);
+        }
+    }
+    for (int e = tid; e < 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+        const int e = tid + k * 256;
+        if (e < COUT * CIN * 9) {
+            const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
+            w2h[(tap / 3) * BW_DYS + co * BW_CO + (ci / 8) * 24 + (tap % 3) * 8 + (ci % 8)] = pc_f2bf(wreg[k]);
+        }
+    }
+    __syncthreads();
+    // (see the planar kernel: consume the constants before the loop so that no vmcnt(0) lands in front of the epilogue)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : : "v"(e_scale[nb][r]), "v"(e_shift[nb][r]));
+    const int a_s = li >> 3, a_co = li & 7;
+    const unsigned short* const wlane_h = w2h + (((unsigned)(lk - a_s) <= 2u) ? lk - a_s : 3) * BW_DYS + a_co * BW_CO;
+    bf16x8 bwh[3][NB];
+    auto load_bwh = [&](int ch) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                bwh[dx][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane_h + nb * 8 * BW_CO + ch * 24 + dx * 8));
+    };
+
+    const pc_bf16_t* const act = reinterpret_cast<const pc_bf16_t*>(q.act);
+    pc_bf16_t* const outp = reinterpret_cast<pc_bf16_t*>(q.out.ptr);
+    const int64_t o_bs = q.out.bstride, a_bs = q.act_bstride;
+    const int o_rs = q.out.rstride, o_xs = q.out.xstride, a_rs = q.act_rstride, a_xs = q.act_xstride;
+
+    f32x4 pacc[4][NB];
+    int eb = 0, ey0 = 0, ex0 = 0;
+    bool have_prev = false;
+    const int e_s = lk >> 1;
+    auto epilogue = [&]() {
+        // lane holds pixel (y = ey0 + 2*(u>>1) + e_s, x = ex0 + (u&1)*16 + li), channels nb*8 + c4 + r
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int y = ey0 + 2 * (u >> 1) + e_s, x = ex0 + (u & 1) * 16 + li;
+            const bool ok = y < p.H && x < p.W;
+            if constexpr (MODE == MODE_FWD) {
+                float dsum = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 v = pacc[u][nb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float o = v[r] * e_scale[nb][r] + e_shift[nb][r];
+                        v[r] = pc_bf16r(p.relu ? fmaxf(o, 0.f) : o);
+                    }
+                    if (EPI == EPI_DOT && q.dot_w) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dsum += v[r] * dotw[r];
+                        continue;
+                    }
+                    if (ok) cl_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
+                    if (EPI == EPI_POOL && q.pool_out.ptr) {
+                        // MaxPool2d(2) (full strips only, pc_conv3x3_pool_out_ok): x pair = lane ^ 1, row pair = lane ^ 32
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float m = fmaxf(v[r], __shfl_xor(v[r], 1));
+                            v[r] = fmaxf(m, __shfl_xor(m, 32));
+                        }
+                        if ((li & 1) == 0 && e_s == 0)
+                            cl_st4(reinterpret_cast<pc_bf16_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride +
+                                       (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride +
+                                       (int64_t)((ex0 >> 1) + (u & 1) * 8 + (li >> 1)) * q.pool_out.xstride + nb * 8 + c4, v);
+                    }
+                }
+                if (EPI == EPI_DOT && q.dot_w) {
+                    dsum += __shfl_xor(dsum, 16);          // the other four channels of the pixel
+                    if ((lk & 1) == 0 && ok)
+                        q.dot_out.ptr[eb * q.dot_out.bstride + (int64_t)y * q.dot_out.rstride + x] = dsum;
+                }
+            } else if constexpr (EPI != EPI_POOLBWD) {
+                if (!ok) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 v = pacc[u][nb];
+                    pc_bf16_t* op = outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4;
+                    if (act) {
+                        const f32x4 a4 = cl_ld4(act + eb * a_bs + (int64_t)y * a_rs + (int64_t)x * a_xs + nb * 8 + c4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb][r] : 0.f;
+                    }
+                    if (p.accumulate) {
+                        const f32x4 o4 = cl_ld4(op);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                    }
+                    cl_st4(op, v);
+                }
+            } else {
+                // MaxPool2d(2) backward: (y, x) is a pooled coordinate; the gradient goes to the first arg-max of the 2x2 window
+                if (!ok) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 v = pacc[u][nb];
+                    const pc_bf16_t* a0 = act + eb * a_bs + (int64_t)(2 * y) * a_rs + (int64_t)(2 * x) * a_xs + nb * 8 + c4;
+                    pc_bf16_t* o0 = outp + eb * o_bs + (int64_t)(2 * y) * o_rs + (int64_t)(2 * x) * o_xs + nb * 8 + c4;
+                    const f32x4 A00 = cl_ld4(a0), A01 = cl_ld4(a0 + a_xs), A10 = cl_ld4(a0 + a_rs), A11 = cl_ld4(a0 + a_rs + a_xs);
+                    f32x4 O00 = cl_ld4(o0), O01 = cl_ld4(o0 + o_xs), O10 = cl_ld4(o0 + o_rs), O11 = cl_ld4(o0 + o_rs + o_xs);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int am = 0;
+                        float m = A00[r];
+                        if (A01[r] > m) { m = A01[r]; am = 1; }
+                        if (A10[r] > m) { m = A10[r]; am = 2; }
+                        if (A11[r] > m) { m = A11[r]; am = 3; }
+                        const float g = m > 0.f ? v[r] * e_scale[nb][r] : 0.f;
+                        O00[r] += am == 0 ? g : 0.f;
+                        O01[r] += am == 1 ? g : 0.f;
+                        O10[r] += am == 2 ? g : 0.f;
+                        O11[r] += am == 3 ? g : 0.f;
+                    }
+                    cl_st4(o0, O00); cl_st4(o0 + o_xs, O01); cl_st4(o0 + o_rs, O10); cl_st4(o0 + o_rs + o_xs, O11);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[4][NB];
+    for (int stage = 0; stage < nstages; ++stage) {
+        const int ch = stage % NCHUNK;
+        if (!(p.dbg & 1)) commit();
+        int nb_ = b, ny0 = y0, nx0 = x0;
+        if (stage + 1 < nstages) {
+            if ((stage + 1) % NCHUNK == 0) strip_coords(stage + 1, nb_, ny0, nx0);
+            if (!(p.dbg & 1)) issue((stage + 1) % NCHUNK, nb_, ny0, nx0);
+        }
+        if (have_prev) {
+            if (!(p.dbg & 4)) epilogue();
+            have_prev = false;
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!(p.dbg & 2)) {
+            load_bwh(ch);
+            const u32x4* lrow = wl + lk * BSLOTS + (COL0 - 1) + li;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    av[u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSLOTS + (u & 1) * 16 + dx]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bwh[dx][nb], av[u], acc[u][nb], 0, 0, 0);
+            }
+        }
+        if (ch == NCHUNK - 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) pacc[u][nb] = acc[u][nb];
+            eb = b; ey0 = y0; ex0 = x0;
+            have_prev = true;
+        }
+        b = nb_; y0 = ny0; x0 = nx0;
+    }
+    if (have_prev && !(p.dbg & 4)) epilogue();
+}
+
+template <int CIN, int COUT, int MODE, int LD, int EPI>
+int launch_conv_cl(ConvArgs& p, int nprob, hipStream_t stream) {
+    constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
+    const size_t lds = (size_t)4 * BWAVE_F * sizeof(float) + (size_t)4 * COUT * NCHUNK * 24 * sizeof(unsigned short);
+    static int resident = 0;
+    if (!resident) {
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, lds);
+        if (getenv("POPCORN_CONV_DBG"))
+            fprintf(stderr, "conv3x3_cl<%d,%d,%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD, EPI,
+                    fa.numRegs, lds, resident);
+    }
+    int max_grid = g_conv_max_grid > 0 ? g_conv_max_grid : resident / nprob;
+    if (max_grid < 1) max_grid = 1;
+    int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
+    const int rounds = (p.ntiles + grid - 1) / grid;
+    grid = (p.ntiles + rounds - 1) / rounds;
+    hipLaunchKernelGGL((conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int CIN, int COUT, int MODE, int LD>
+int launch_conv_cl_epi(ConvArgs& p, int nprob, hipStream_t stream) {
+    if constexpr (MODE == MODE_FWD && CIN >= 8) {
+        bool po = false;
+        for (int i = 0; i < nprob; ++i) po = po || p.pr[i].pool_out.ptr != nullptr;
+        if (po) return launch_conv_cl<CIN, COUT, MODE, LD, EPI_POOL>(p, nprob, stream);
+    }
+    if constexpr (MODE == MODE_FWD && CIN == 8 && COUT == 8) {
+        bool dot = false;
+        for (int i = 0; i < nprob; ++i) dot = dot || p.pr[i].dot_w != nullptr;
+        if (dot) return launch_conv_cl<CIN, COUT, MODE, LD, EPI_DOT>(p, nprob, stream);
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+        if (p.pool) return launch_conv_cl<CIN, COUT, MODE, LD, EPI_POOLBWD>(p, nprob, stream);
+    }
+    return launch_conv_cl<CIN, COUT, MODE, LD, EPI_NONE>(p, nprob, stream);
+}
+
+// bf16 mode: validate the channels-last descriptors and pick the loader
+template <int CIN, int COUT, int MODE>
+int launch_conv_bf16(ConvArgs& p, int nprob, hipStream_t stream) {
+    int mode = -1;
+    for (int i = 0; i < nprob; ++i) {
+        ConvProb& q = p.pr[i];
+        const int m = q.a.mode;
+        if (mode >= 0 && m != mode) return PC_EINVAL;
+        mode = m;
+        if (m == PC_SRC_REFLECT) {       // the model input: planar fp32
+            if (CIN > 4 || q.b.C || q.a.dtype != PC_F32 || !pc_planar(q.a)) return PC_EINVAL;
+        } else {
+            if (CIN < 8 || !pc_cl_ok(q.a) || q.a.C % 8 != 0 || q.a.xstride < q.a.C) return PC_EINVAL;
+            if (m == PC_SRC_POOL2 && (q.b.C || CIN > 16 || q.a.W < 2 * p.W || q.a.H < 2 * p.H)) return PC_EINVAL;
+            if (q.b.C && (!pc_cl_ok(q.b) || q.b.mode != PC_SRC_DIRECT || q.b.C % 8 != 0)) return PC_EINVAL;
+        }
+        const bool own_out = q.out.ptr != reinterpret_cast<float*>(q.dot_out.ptr);
+        if (own_out && !pc_cl_ok(q.out)) return PC_EINVAL;
+        if (q.pool_out.ptr && !pc_cl_ok(q.pool_out)) return PC_EINVAL;
+        if (q.dot_out.ptr && (q.dot_out.dtype != PC_F32 || !pc_planar(q.dot_out))) return PC_EINVAL;
+        if (q.act && !pc_cl_ok(q.act, q.act_dtype, q.act_bstride, q.act_cstride, q.act_rstride, q.act_xstride)) return PC_EINVAL;
+    }
+    if (mode == PC_SRC_REFLECT) {
+        if constexpr (CIN <= 4) return launch_conv_cl_epi<CIN, COUT, MODE, LD_REFLECT>(p, nprob, stream);
+    } else if (mode == PC_SRC_POOL2) {
+        if constexpr (CIN >= 8 && CIN <= 16) return launch_conv_cl_epi<CIN, COUT, MODE, LD_POOL>(p, nprob, stream);
+    } else {
+        if constexpr (CIN >= 8) return launch_conv_cl_epi<CIN, COUT, MODE, LD_DIRECT>(p, nprob, stream);
+    }
+    return PC_EINVAL;
+}
+
 template <int CIN, int COUT, int MODE, int LD, int EPI>
 int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
-    if (g_pc_precision == PC_PREC_BF16) return launch_conv_bf<CIN, COUT, MODE, LD, EPI, true>(p, nprob, stream);
     return launch_conv_bf<CIN, COUT, MODE, LD, EPI, false>(p, nprob, stream);
 }
 
@@ -687,6 +1118,7 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     p.dbg = g_conv_dbg;
     p.ts = g_conv_ts;
+    if (g_pc_precision == PC_PREC_BF16) return launch_conv_bf16<CIN, COUT, MODE>(p, nprob, stream);
     // loader choice: all problems of the group must qualify for a staged loader
     bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
     bool vec = (p.W % 4) == 0;
@@ -761,6 +1193,7 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
         q.act_cstride = act->cstride;
         q.act_rstride = act->rstride;
         q.act_dtype = act->dtype;
+        q.act_xstride = act->xstride;
     }
     q.out = *out;
     return 0;
@@ -768,6 +1201,7 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
 
 // the pooled second output needs every strip on the vector epilogue: full 32 x 4 strips, 16-byte aligned output
 bool pool_out_geometry_ok(const pc_dst& out, int H, int W) {
+    if (out.dtype == PC_BF16) return W % 32 == 0 && H % 4 == 0 && pc_cl_ok(out);      // channels-last bf16 (bf16 mode)
     return W % 32 == 0 && H % 4 == 0 && out.rstride % 4 == 0 && out.cstride % 4 == 0 && out.bstride % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(out.ptr) & (out.dtype == PC_BF16 ? 7 : 15)) == 0;
 }
@@ -808,9 +1242,10 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
         }
         if (d[i].pool_out) {
             const pc_dst& po = *d[i].pool_out;
-            if (Cin < 8 || !pool_out_geometry_ok(*d[i].out, H, W) || !po.ptr || po.rstride % 2 != 0 || po.cstride % 2 != 0 ||
-                po.bstride % 2 != 0 || (reinterpret_cast<uintptr_t>(po.ptr) & 7) != 0)
-                return PC_EINVAL;
+            const bool po_ok = po.dtype == PC_BF16 ? pc_cl_ok(po)
+                                                   : (po.rstride % 2 == 0 && po.cstride % 2 == 0 && po.bstride % 2 == 0 &&
+                                                      (reinterpret_cast<uintptr_t>(po.ptr) & 7) == 0 && pc_planar(po));
+            if (Cin < 8 || !pool_out_geometry_ok(*d[i].out, H, W) || !po.ptr || !po_ok) return PC_EINVAL;
             p.pr[i].pool_out = po;
         }
     }

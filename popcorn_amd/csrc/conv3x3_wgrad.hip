@@ -610,6 +610,280 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const Wgra
     }
 }
 
+
+// ---- channels-last bf16 kernel (PC_PREC_BF16) -------------------------------------------------------------------------------
+// Activations and gradients are channels-last bf16 (one 16-byte slot per pixel and 8-channel group, conv3x3.hip), but the
+// weight gradient contracts over PIXELS: both MFMA operands need "8 pixels of one channel" per lane, the transpose of what
+// memory holds.  The strips (input: 6 rows x 34 pixels, gradient: 4 rows x 32 pixels) are therefore copied slot by slot into
+// the wave's LDS region and read back with ds_read_b64_tr_b16, the gfx950 transposing LDS read: the 16 lanes of a group
+// hand in 16 addresses of 4 contiguous bf16 (lane L: row L / 4, column quad L % 4 of a 4 x 16 block) and lane c receives
+// column c of the block.  With rows = 4 consecutive pixels:
+//     A (M = (s, co8)):  quad q = (s = q >> 1, channels 4 * (q & 1) ..) of gradient row yp + s           -> lane (s * 8 + co)
+//     B (N = (v, ci4)):  quad q = input row yp + v - 1, channels 4 * (nb & 1) .. of chunk nb >> 1, pixel + dx -> lane (4 * v + ci)
+// two reads (pixels 8 * lk + 0..3 and + 4..7) make the 8 k-slots of a lane for v_mfma_f32_16x16x32_bf16 (K = 32 = a strip row):
+//     D_dx[(s,co)][(v,ci)] += sum_x g[co][yp+s][x] * in[ci][yp+v-1][x+dx-1];   dW[co][ci][dy][dx] = D_dx[(0,co)][(dy,ci)] + D_dx[(1,co)][(dy+1,ci)]
+// Bank layout: rows sit 16 dwords apart (row strides 52 / 36 slots) and the two 8-byte halves of a slot are swapped for pixels
+// with bit 3 set, so the two lane groups of a pass (pixels 8 apart) hit different banks.
+// Same compacted per-workgroup partial as the other kernels; the first layers (reflect loader, planar fp32 model input, 2 / 4
+// channels) use channel slots 0..3 of one block.
+constexpr int CLW_IN_RS = 52, CLW_G_RS = 36;        // slots per strip row
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 clw_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 clw_pair(s16x4 a, s16x4 b) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ u32x4w clw_swz(u32x4w v, bool sw) { return sw ? u32x4w{v[2], v[3], v[0], v[1]} : v; }
+__device__ __forceinline__ u32x4w clw_max8(u32x4w a, u32x4w b) {
+    u32x4w o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = fmaxf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16));
+        const float hi = fmaxf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u));
+        o[e] = (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+    }
+    return o;
+}
+
+template <int CINC, int COUT>
+struct WgradClCfg {
+    static constexpr int MB = COUT / 8;
+    static constexpr int NCH = CINC <= 8 ? 1 : CINC / 8;      // 8-channel images of the input strip
+    static constexpr int NBP = CINC <= 4 ? 1 : CINC / 4;      // N blocks (4 rows x 4 channels) per tap
+    static constexpr int NBLK = 3 * NBP;
+    static constexpr int IN_B = 6 * CLW_IN_RS * 16, G_B = 4 * CLW_G_RS * 16;      // bytes of one image
+    static constexpr size_t WAVE_B = (size_t)NCH * IN_B + (size_t)MB * G_B;
+    static constexpr size_t RED_B = (size_t)4 * NBLK * 256 * sizeof(float);
+    static constexpr size_t LDS_B = 4 * WAVE_B > RED_B ? 4 * WAVE_B : RED_B;
+};
+
+template <int CINC, int COUT, int LD>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_cl_kernel(const WgradGroup grp_) {
+    const WgradArgs& p = grp_.pr[blockIdx.z];
+    using Cfg = WgradCfg<CINC, COUT>;
+    using Cl = WgradClCfg<CINC, COUT>;
+    constexpr int MB = Cl::MB, NCH = Cl::NCH, NBP = Cl::NBP, NBLK = Cl::NBLK;
+    constexpr int NIT = CINC < 8 ? CINC : 1;      // REFLECT loader: one 16-byte segment of a planar fp32 row per channel
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int cbase = p.ci0 + chunk * CINC;
+    unsigned char* const win = reinterpret_cast<unsigned char*>(lds) + wave * Cl::WAVE_B;
+    unsigned char* const wg = win + NCH * Cl::IN_B;
+
+    // ---- loaders: input pieces id = lane + 64 * i -> (row of 6, pixel of 34); gradient pieces -> (mb, row of 4, pixel of 32)
+    int i_r[4], i_px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = lane + 64 * i;
+        i_r[i] = id / 34;
+        i_px[i] = id - i_r[i] * 34;
+    }
+    const int CA = p.a.C;
+    u32x4w R[NCH][LD == 2 ? 16 : 4];
+    f32x4 RF[LD == 3 ? NIT : 1];
+    u32x4w G[2 * MB];
+    unsigned rvalid = 0, gvalid = 0;
+    const int r_r = lane / 10, r_seg = lane - r_r * 10;
+    const pc_bf16_t* const g_ptr = reinterpret_cast<const pc_bf16_t*>(p.g.ptr);
+    auto issue = [&](int b, int y0, int x0) {
+        if constexpr (LD == 3) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                RF[it] = lane < 60 ? pc_fetch_reflect_seg(p.a, b, cbase + it, y0 - 1 + r_r, x0 - 4 + 4 * r_seg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            unsigned vm = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int cg = cbase + 8 * c;
+                const bool useb = LD == 1 && cg >= CA;
+                const pc_src& s = useb ? p.b : p.a;
+                const pc_bf16_t* base = reinterpret_cast<const pc_bf16_t*>(s.ptr) + b * s.bstride + (useb ? cg - CA : cg);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int y = y0 - 1 + i_r[i], x = x0 - 1 + i_px[i];
+                    bool ok = lane + 64 * i < 204 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    if constexpr (LD == 1) {
+                        const int ys = y - s.oy, xq = x - s.ox;
+                        ok = ok && (unsigned)ys < (unsigned)s.H && (unsigned)xq < (unsigned)s.W;
+                        const int64_t off = ok ? (int64_t)ys * s.rstride + (int64_t)xq * s.xstride : 0;
+                        R[c][i] = *reinterpret_cast<const u32x4w*>(base + off);
+                    } else {
+                        const int64_t off = ok ? (int64_t)(2 * y) * s.rstride + (int64_t)(2 * x) * s.xstride : 0;
+                        const int rs1 = ok ? s.rstride : 0, xs1 = ok ? s.xstride : 0;
+                        R[c][4 * i + 0] = *reinterpret_cast<const u32x4w*>(base + off);
+                        R[c][4 * i + 1] = *reinterpret_cast<const u32x4w*>(base + off + xs1);
+                        R[c][4 * i + 2] = *reinterpret_cast<const u32x4w*>(base + off + rs1);
+                        R[c][4 * i + 3] = *reinterpret_cast<const u32x4w*>(base + off + rs1 + xs1);
+                    }
+                    vm |= (ok ? 1u : 0u) << (4 * c + i);
+                }
+            }
+            rvalid = vm;
+        }
+        unsigned gm = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * MB; ++i) {
+            const int id = lane + 64 * i;
+            const int mb = id >> 7, r = (id >> 5) & 3, px = id & 31;
+            const int y = y0 + r, x = x0 + px;
+            const bool ok = y < p.H && x < p.W;
+            const int64_t off = ok ? b * p.g.bstride + (int64_t)y * p.g.rstride + (int64_t)x * p.g.xstride + 8 * mb : 0;
+            G[i] = *reinterpret_cast<const u32x4w*>(g_ptr + off);
+            gm |= (ok ? 1u : 0u) << i;
+        }
+        gvalid = gm;
+    };
+    auto commit = [&]() {
+        if constexpr (LD == 3) {
+            if (lane < 60) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pi = 4 * r_seg - 3 + e;          // pixel x0 - 4 + 4 * seg + e  ->  strip pixel index (x0 - 1 = 0)
+                    if (pi >= 0 && pi < 34) {
+                        u32x4w t = u32x4w{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int h = 0; h < (NIT + 1) / 2; ++h)
+                            t[h] = pc_pack_bf16(RF[2 * h][e], 2 * h + 1 < NIT ? RF[(2 * h + 1) % NIT][e] : 0.f);
+                        *reinterpret_cast<u32x4w*>(win + (r_r * CLW_IN_RS + pi) * 16) = clw_swz(t, (pi >> 3) & 1);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (lane + 64 * i < 204) {
+                        u32x4w v;
+                        if constexpr (LD == 2) v = clw_max8(clw_max8(R[c][4 * i], R[c][4 * i + 1]), clw_max8(R[c][4 * i + 2], R[c][4 * i + 3]));
+                        else v = R[c][i];
+                        if (!((rvalid >> (4 * c + i)) & 1u)) v = u32x4w{0u, 0u, 0u, 0u};
+                        *reinterpret_cast<u32x4w*>(win + c * Cl::IN_B + (i_r[i] * CLW_IN_RS + i_px[i]) * 16) = clw_swz(v, (i_px[i] >> 3) & 1);
+                    }
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * MB; ++i) {
+            const int id = lane + 64 * i;
+            const int mb = id >> 7, r = (id >> 5) & 3, px = id & 31;
+            const u32x4w v = ((gvalid >> i) & 1u) ? G[i] : u32x4w{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4w*>(wg + mb * Cl::G_B + (r * CLW_G_RS + px) * 16) = clw_swz(v, (px >> 3) & 1);
+        }
+    };
+
+    // ---- transposing-read addresses of this lane: pixel row j = li >> 2 of the 4 x 16 block, column quad q = li & 3
+    const int t_j = li >> 2, t_q = li & 3;
+    // A: quad = (s = q >> 1, channel half q & 1), pixels 8 * lk + 4 * e + j  (bit 3 of the pixel = lk & 1)
+    const int a_off = ((t_q >> 1) * CLW_G_RS + 8 * lk + t_j) * 16 + 8 * ((t_q & 1) ^ (lk & 1));
+    // B: quad = input row v = q; pixel index 8 * lk + 4 * e + j + dx, channel half (nb & 1) of image nb >> 1
+    const int b_row = t_q * CLW_IN_RS;
+
+    f32x4 acc[MB][NBLK];
+    float bsum[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) {
+        strip_coords(0, b, y0, x0);
+        issue(b, y0, x0);
+    }
+    for (int k = 0; k < my_tiles; ++k) {
+        commit();
+        if (k + 1 < my_tiles) {
+            strip_coords(k + 1, b, y0, x0);
+            issue(b, y0, x0);
+        }
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            bf16x8 av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned char* ga = wg + mb * Cl::G_B + 2 * rpi * CLW_G_RS * 16 + a_off;
+                const s16x4 lo = clw_tr(ga), hi = clw_tr(ga + 4 * 16);
+                av[mb] = clw_pair(lo, hi);
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t += __uint_as_float((unsigned)(unsigned short)lo[e] << 16) + __uint_as_float((unsigned)(unsigned short)hi[e] << 16);
+                bsum[mb] += t;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    // pixel index of read e: 8 * lk + 4 * e + j + dx  (the swizzle bit is bit 3 of THAT index)
+                    const int p0 = 8 * lk + t_j + dx, p1 = p0 + 4;
+                    const unsigned char* ib = win + (nb >> 1) * Cl::IN_B + (2 * rpi * CLW_IN_RS + b_row) * 16;
+                    const s16x4 lo = clw_tr(ib + p0 * 16 + 8 * ((nb & 1) ^ ((p0 >> 3) & 1)));
+                    const s16x4 hi = clw_tr(ib + p1 * 16 + 8 * ((nb & 1) ^ ((p1 >> 3) & 1)));
+                    const bf16x8 bv = clw_pair(lo, hi);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][dx * NBP + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb], bv, acc[mb][dx * NBP + nb], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS (fixed order), one compacted partial per workgroup (layout of the fp32 kernels)
+    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+            *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
+        __syncthreads();
+        for (int idx = tid; idx < 8 * CINC * 9; idx += 256) {
+            const int c8 = idx / (CINC * 9), rem = idx - c8 * (CINC * 9);
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            // D_dx[m = s*8 + c8][n = 4*v + (cil & 3)] in block dx*NBP + (cil >> 2); D register layout: lane = (m>>2)*16 + n, reg = m&3
+            const int blk = dx * NBP + (cil >> 2);
+            const int n0 = 4 * dy + (cil & 3), n1 = n0 + 4;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
+            const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * (CINC * 9) + rem] = wsum(e0) + wsum(e1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
+    __syncthreads();
+    if (tid < COUT) {
+        const int mb = tid >> 3, c8 = tid & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int lk2 = 0; lk2 < 4; ++lk2) {
+            const int ea = mb * 64 + lk2 * 16 + c8, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[MB * 64 + ea]) + lds[2 * MB * 64 + ea]) + lds[3 * MB * 64 + ea];
+            const float sb = ((lds[eb] + lds[MB * 64 + eb]) + lds[2 * MB * 64 + eb]) + lds[3 * MB * 64 + eb];
+            t += sa + sb;
+        }
+        part[COUT * CINC * 9 + tid] = t;
+    }
+}
+
 struct WreduceArgs {
     const float* partial;
     int nwg;              // partials per chunk
@@ -682,6 +956,16 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
     // container types follow the mode: bf16 mode = bf16 activations and gradients (the reflect-padded model input stays fp32)
     const int want = p.bf ? PC_BF16 : PC_F32;
     if (p.a.dtype != (p.a.mode == PC_SRC_REFLECT ? PC_F32 : want) || (p.b.C && p.b.dtype != want) || p.g.dtype != want) return -1;
+    if (p.bf) {
+        // bf16 mode: channels-last operands (the model input: planar fp32 through the reflect loader); every geometry and
+        // placement offset runs on the channels-last kernel -- kind 1 direct (+ concat), 2 pooled, 3 reflect
+        if (!pc_cl_ok(p.g) || p.g.C != COUT) return -1;
+        if (p.a.mode == PC_SRC_REFLECT) return (CINC <= 4 && p.b.C == 0 && pc_planar(p.a)) ? 3 : -1;
+        if (CINC < 8 || !pc_cl_ok(p.a) || p.a.C % 8 != 0 || (p.b.C && (!pc_cl_ok(p.b) || p.b.C % 8 != 0 || p.b.mode != PC_SRC_DIRECT))) return -1;
+        if (p.a.mode == PC_SRC_POOL2) return (p.b.C == 0 && p.a.W >= 2 * p.W && p.a.H >= 2 * p.H) ? 2 : -1;
+        return 1;
+    }
+    if (!pc_planar(p.a) || !pc_planar(p.b) || !pc_planar(p.g)) return -1;
     auto mode_of = [&](const pc_src& s) -> int {      // 1 = aligned DIRECT, 2 = aligned POOL2 (either container type)
         if (s.C == 0) return 0;
         const uintptr_t amask = s.dtype == PC_BF16 ? 7 : 15;
@@ -711,8 +995,7 @@ int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk
     const size_t lred = (size_t)4 * Cfg::NBLK * 256 * sizeof(float);     // staging of the cross-wave reduction (same buffer)
     size_t lw_f32 = (size_t)4 * CINC * WIN_CSW * sizeof(float);          // fp32 strips
     if (lw_f32 < lred) lw_f32 = lred;
-    size_t lw_bf = (size_t)4 * CINC * 6 * BW_ROWB;                       // bf16 strips
-    if (lw_bf < lred) lw_bf = lred;
+    const size_t lw_bf = WgradClCfg<CINC, COUT>::LDS_B;                   // channels-last bf16 strips / reduction staging
     static int resident[5] = {0, 0, 0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
     auto go = [&](auto kern, int slot) -> int {
         const size_t lw = slot >= 3 ? lw_bf : lw_f32;
@@ -738,14 +1021,18 @@ int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk
     int rc = 0;
     bool bf = true;
     for (int i = 0; i < n; ++i) bf = bf && g.pr[i].bf != 0;
-    if constexpr (CINC >= 8) {
-        if (bf && (kind == 1 || kind == 2)) {
-            if (kind == 1) rc = go(&conv3x3_wgrad_wave_bf16_kernel<CINC, COUT, 1>, 3);
-            else rc = go(&conv3x3_wgrad_wave_bf16_kernel<CINC, COUT, 2>, 4);
-            if (rc) return rc;
-            PC_CHECK_LAUNCH();
-            return 0;
+    if (bf) {
+        if constexpr (CINC >= 8) {
+            if (kind == 1) rc = go(&conv3x3_wgrad_cl_kernel<CINC, COUT, 1>, 3);
+            else if (kind == 2) rc = go(&conv3x3_wgrad_cl_kernel<CINC, COUT, 2>, 4);
+            else return PC_EINVAL;
+        } else {
+            if (kind == 3) rc = go(&conv3x3_wgrad_cl_kernel<CINC, COUT, 3>, 3);
+            else return PC_EINVAL;
         }
+        if (rc) return rc;
+        PC_CHECK_LAUNCH();
+        return 0;
     }
     if (kind == 3) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 3>, 2);
     else if (kind == 1) rc = go(&conv3x3_wgrad_wave_kernel<CINC, COUT, 1>, 0);

@@ -21,7 +21,7 @@ struct CtArgs {
     const float* bias;     // fwd
     const float* act;      // dgrad: post-ReLU activations of the layer that produced x (mask), same geometry as out
     int64_t act_bstride, act_cstride;
-    int act_rstride;
+    int act_rstride, act_xstride, act_dtype;
     pc_bn bn;              // dgrad: BN of that layer
     pc_dst out;
     float* partial;        // wgrad
@@ -173,6 +173,253 @@ struct CtWgradCfg {
     static constexpr int NBK = C / 4;
     static constexpr int E = NBK * 256 + NBK * 64;
 };
+
+// =====================================================================================================================
+// Channels-last bf16 kernels (PC_PREC_BF16): x / g / out / act are channels-last bf16 tensors (one 16-byte slot per pixel and
+// 8 channels, conv3x3.hip).  bf16 MFMA with the pixel on N, so that D hands a lane 4 consecutive channels of one pixel:
+//   fwd   : A = weights (M = 16 columns of (a, b, co)), B = 16 input pixels x K = ci: the lane's k-slots are 4 channels of its
+//           pixel = one 8-byte load; one v_mfma_f32_16x16x16_bf16 per M tile, 8-byte stores
+//   dgrad : K = (a, b, co): k-group lk = the output pixel (a, b) of the 2x2 block, slots = 8 channels = ONE 16-byte load of g;
+//           A = w[ci][co][a][b] (M = ci); v_mfma_f32_16x16x32_bf16 per 8 output channels
+//   wgrad : contraction over pixels -> both operands are transposed through the wave's LDS region with ds_read_b64_tr_b16
+//           (see conv3x3_wgrad.hip): group = 32 input pixels of a row and their 2 x 64 gradient pixels
+typedef short ct_s4 __attribute__((ext_vector_type(4)));
+typedef short ct_s8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ct_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned ct_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ short ct_bf(float x) { return (short)pc_f2bf(x); }
+__device__ __forceinline__ f32x4 ct_ld4(const pc_bf16_t* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void ct_st4(pc_bf16_t* p, f32x4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_fwd_cl_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
+    constexpr int NT = C / 4;                 // M tiles of the (a, b, co) space: C = 8: tile = a, m = b*8 + co;  C = 16: tile = (a, b), m = co
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    // A fragments: lane (m = li, k-group lk): ci = 4*lk + e
+    ct_s4 aw[NT];
+    float binit[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int a = C == 8 ? t : t >> 1, b = C == 8 ? li >> 3 : t & 1, co = C == 8 ? li & 7 : li;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = 4 * lk + e;
+            aw[t][e] = ci < C ? ct_bf(p.w[((ci * C + co) * 2 + a) * 2 + b]) : (short)0;
+        }
+        // D rows of this lane: m = 4*lk + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * lk + r;
+            binit[t][r] = p.bias ? p.bias[C == 8 ? (m & 7) : m] : 0.f;
+        }
+    }
+    const pc_bf16_t* const xb = reinterpret_cast<const pc_bf16_t*>(p.x.ptr);
+    pc_bf16_t* const ob = reinterpret_cast<pc_bf16_t*>(p.out.ptr);
+    for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
+        const int b = (int)pc_div((uint32_t)grp, p.div_gimg);
+        const int rem = grp - b * p.groups_x * p.H;
+        const int i = (int)pc_div((uint32_t)rem, p.div_gx);
+        const int j = (rem - i * p.groups_x) * 16 + li;
+        const bool ok = j < p.W;
+        const bool kok = ok && 4 * lk < C;
+        const uint2 xv = *reinterpret_cast<const uint2*>(xb + b * p.x.bstride + (int64_t)i * p.x.rstride + (kok ? (int64_t)j * p.x.xstride + 4 * lk : 0));
+        ct_s4 bv;
+        bv[0] = kok ? (short)(xv.x & 0xffffu) : (short)0; bv[1] = kok ? (short)(xv.x >> 16) : (short)0;
+        bv[2] = kok ? (short)(xv.y & 0xffffu) : (short)0; bv[3] = kok ? (short)(xv.y >> 16) : (short)0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 acc = f32x4{binit[t][0], binit[t][1], binit[t][2], binit[t][3]};
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aw[t], bv, acc, 0, 0, 0);
+            const int a = C == 8 ? t : t >> 1, bb = C == 8 ? lk >> 1 : t & 1, co4 = C == 8 ? 4 * (lk & 1) : 4 * lk;
+            if (ok) ct_st4(ob + b * p.out.bstride + (int64_t)(2 * i + a) * p.out.rstride + (int64_t)(2 * j + bb) * p.out.xstride + co4, acc);
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_dgrad_cl_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
+    constexpr int NH = C / 8;                 // 8-channel halves of co = MFMAs per group
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    // A fragments: lane (m = ci = li, k-group lk = (a, b)): slots e = co 8*h + e
+    ct_bf8 aw[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        ct_s8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = li < C ? ct_bf(p.w[(li * C + 8 * h + e) * 4 + lk]) : (short)0;
+        aw[h] = __builtin_bit_cast(ct_bf8, t);
+    }
+    // D rows of this lane: ci = 4*lk + r
+    float e_scale[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sh;
+        e_scale[r] = 1.f;
+        if (p.act && 4 * lk + r < C) pc_bn_fold(p.bn, 4 * lk + r, e_scale[r], sh);
+    }
+    const pc_bf16_t* const gb = reinterpret_cast<const pc_bf16_t*>(p.x.ptr);
+    const pc_bf16_t* const ab = reinterpret_cast<const pc_bf16_t*>(p.act);
+    pc_bf16_t* const ob = reinterpret_cast<pc_bf16_t*>(p.out.ptr);
+    for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
+        const int b = (int)pc_div((uint32_t)grp, p.div_gimg);
+        const int rem = grp - b * p.groups_x * p.H;
+        const int i = (int)pc_div((uint32_t)rem, p.div_gx);
+        const int j = (rem - i * p.groups_x) * 16 + li;
+        const bool ok = j < p.W;
+        const pc_bf16_t* gp = gb + b * p.x.bstride + (ok ? (int64_t)(2 * i + (lk >> 1)) * p.x.rstride + (int64_t)(2 * j + (lk & 1)) * p.x.xstride : 0);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            ct_u4 gv = *reinterpret_cast<const ct_u4*>(gp + 8 * h);
+            if (!ok) gv = ct_u4{0u, 0u, 0u, 0u};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[h], __builtin_bit_cast(ct_bf8, gv), acc, 0, 0, 0);
+        }
+        if (ok && 4 * lk < C) {
+            if (ab) {
+                const f32x4 a4 = ct_ld4(ab + b * p.act_bstride + (int64_t)i * p.act_rstride + (int64_t)j * p.act_xstride + 4 * lk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = a4[r] > 0.f ? acc[r] * e_scale[r] : 0.f;
+            }
+            ct_st4(ob + b * p.out.bstride + (int64_t)i * p.out.rstride + (int64_t)j * p.out.xstride + 4 * lk, acc);
+        }
+    }
+}
+
+__device__ __forceinline__ ct_s4 ct_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ct_s4*)(p));
+}
+
+// group = 32 consecutive input pixels of one row.  LDS per wave: x [32 px][C] and g [2 rows][64 px][C] (bf16), plain copies.
+template <int C>
+__global__ __launch_bounds__(256) void convt2x2_wgrad_cl_kernel(const CtGroup grp_) {
+    const CtArgs& p = grp_.pr[blockIdx.y];
+    constexpr int NBK = C / 4, NT = C / 4;    // N tiles: C = 8: tile = a, n = b*8 + co;  C = 16: tile = (a, b), n = co
+    constexpr int PB = 2 * C;                 // bytes per pixel
+    constexpr int XB = 32 * PB, GB = 2 * 64 * PB, WB = XB + GB;
+    using Cfg = CtWgradCfg<C>;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsb[4 * WB > 4 * NBK * 256 * 4 ? 4 * WB : 4 * NBK * 256 * 4];
+    float* const lds = reinterpret_cast<float*>(ldsb);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int gwave = (blockIdx.x * blockDim.x + tid) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    unsigned char* const wx = ldsb + wave * WB;
+    unsigned char* const wg = wx + XB;
+    const int groups32 = (p.W + 31) / 32, ngroups = p.B * p.H * groups32;
+
+    f32x4 acc[NT];
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[t] = 0.f; }
+    constexpr int NXP = XB / 16 / 64 > 0 ? XB / 16 / 64 : 1;       // 16-byte pieces per lane: x (32 or 64 pieces), g (128 or 256)
+    constexpr int NGP = GB / 16 / 64;
+    ct_u4 RX[NXP], RG[NGP];
+    const pc_bf16_t* const xb = reinterpret_cast<const pc_bf16_t*>(p.x.ptr);
+    const pc_bf16_t* const gb = reinterpret_cast<const pc_bf16_t*>(p.g.ptr);
+    auto issue = [&](int grp) {
+        const int b = grp / (p.H * groups32);
+        const int rem = grp - b * p.H * groups32;
+        const int i = rem / groups32, j0 = (rem - i * groups32) * 32;
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) {
+            const int id = lane + 64 * k;                    // piece = (pixel, 8-channel half)
+            const int px = id / (C / 8), hf = id % (C / 8);
+            const bool ok = id < 32 * (C / 8) && j0 + px < p.W;
+            RX[k] = *reinterpret_cast<const ct_u4*>(xb + b * p.x.bstride + (int64_t)i * p.x.rstride + (ok ? (int64_t)(j0 + px) * p.x.xstride + 8 * hf : 0));
+            if (!ok) RX[k] = ct_u4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < NGP; ++k) {
+            const int id = lane + 64 * k;
+            const int a = id / (64 * (C / 8)), r2 = id % (64 * (C / 8));
+            const int px = r2 / (C / 8), hf = r2 % (C / 8);
+            const bool ok = 2 * j0 + px < 2 * p.W;
+            RG[k] = *reinterpret_cast<const ct_u4*>(gb + b * p.g.bstride + (int64_t)(2 * i + a) * p.g.rstride + (ok ? (int64_t)(2 * j0 + px) * p.g.xstride + 8 * hf : 0));
+            if (!ok) RG[k] = ct_u4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NXP; ++k)
+            if (lane + 64 * k < 32 * (C / 8)) *reinterpret_cast<ct_u4*>(wx + (lane + 64 * k) * 16) = RX[k];
+#pragma unroll
+        for (int k = 0; k < NGP; ++k) *reinterpret_cast<ct_u4*>(wg + (lane + 64 * k) * 16) = RG[k];
+    };
+    // transposing reads: lane supplies row jj = li >> 2 (pixel 8*lk + 4*e + jj) and column quad q = li & 3
+    const int t_j = li >> 2, t_q = li & 3;
+    int grp = gwave;
+    if (grp < ngroups) issue(grp);
+    for (; grp < ngroups; grp += nwaves) {
+        commit();
+        if (grp + nwaves < ngroups) issue(grp + nwaves);
+        // A (M = ci): columns 4q .. 4q+3 of pixel j; for C = 8 the quads 2, 3 repeat 0, 1 (rows 8..15 of D are not used)
+        const unsigned char* xa = wx + (8 * lk + t_j) * PB + 8 * (C == 8 ? (t_q & 1) : t_q);
+        const ct_s4 alo = ct_tr(xa), ahi = ct_tr(xa + 4 * PB);
+        const ct_bf8 av = __builtin_bit_cast(ct_bf8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // B (N tile t): C = 8: quad -> (b = q >> 1, channels 4*(q&1)..) of gradient row 2i + t; C = 16: (a, b) = t, channels 4q..
+            const int a = C == 8 ? t : t >> 1;
+            const int bq = C == 8 ? t_q >> 1 : t & 1, c4 = C == 8 ? 4 * (t_q & 1) : 4 * t_q;
+            const unsigned char* gp = wg + (a * 64 + 2 * (8 * lk + t_j) + bq) * PB + 2 * c4;
+            const ct_s4 blo = ct_tr(gp), bhi = ct_tr(gp + 8 * PB);
+            float sb = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sb += __uint_as_float((unsigned)(unsigned short)blo[e] << 16) + __uint_as_float((unsigned)(unsigned short)bhi[e] << 16);
+            bsum[t] += sb;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(ct_bf8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[t], 0, 0, 0);
+        }
+    }
+
+    // one partial per workgroup in the layout of the planar kernels: D[m = ci][n = ng & 15] of tile ng >> 4, ng = co*4 + a*2 + b
+    float* part = p.partial + (int64_t)blockIdx.x * Cfg::E;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(&lds[((wave * NT + t) * 64 + lane) * 4]) = acc[t];
+    __syncthreads();
+    for (int e = tid; e < NBK * 256; e += 256) {
+        const int r = e & 3, ln = (e >> 2) & 63, nb = e >> 8;
+        const int ci = (ln >> 4) * 4 + r, ng = nb * 16 + (ln & 15);
+        const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
+        const int t = C == 8 ? a : a * 2 + bb, n = C == 8 ? bb * 8 + co : co;
+        const int e2 = ((t * 64) + (ci >> 2) * 16 + n) * 4 + (ci & 3);
+        part[e] = ((lds[e2] + lds[NT * 256 + e2]) + lds[2 * NT * 256 + e2]) + lds[3 * NT * 256 + e2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lds[(wave * NT + t) * 64 + lane] = bsum[t];
+    __syncthreads();
+    for (int e = tid; e < NBK * 64; e += 256) {
+        const int nb = e >> 6, lk2 = (e >> 4) & 3, ng = nb * 16 + (e & 15);
+        const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
+        const int t = C == 8 ? a : a * 2 + bb, n = C == 8 ? bb * 8 + co : co;
+        const int e2 = t * 64 + lk2 * 16 + n;
+        part[NBK * 256 + e] = ((lds[e2] + lds[NT * 64 + e2]) + lds[2 * NT * 64 + e2]) + lds[3 * NT * 64 + e2];
+    }
+}
+
+bool ct_cl_ok(const CtArgs& p, bool with_g) {
+    if (!pc_cl_ok(p.x)) return false;
+    if (with_g) return pc_cl_ok(p.g);
+    if (!pc_cl_ok(p.out)) return false;
+    if (p.act && !pc_cl_ok(p.act, p.act_dtype, p.act_bstride, p.act_cstride, p.act_rstride, p.act_xstride)) return false;
+    return true;
+}
 
 // VEC: aligned tensors with W % 16 == 0.  The K dimension of the GEMM is "pixels", and any pixel order works as long as
 // both operands use it: lane (., lk) takes pixels 4*lk .. 4*lk+3 of the 16-pixel group, so k-step ks holds pixel 4*lk + ks
@@ -336,11 +583,13 @@ extern "C" int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, i
     }
     nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;     // keep the total grid size roughly constant
     const bool bf = g_pc_precision == PC_PREC_BF16;
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].out.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
-    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_fwd_kernel<16, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+        if (bf ? !ct_cl_ok(g.pr[i], false) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].out))) return PC_EINVAL;
+    }
+    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_fwd_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 16) hipLaunchKernelGGL((convt2x2_fwd_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_fwd_kernel<8, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_fwd_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 8) hipLaunchKernelGGL((convt2x2_fwd_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
@@ -364,7 +613,7 @@ extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int 
         if (d[i].act) {
             if (!d[i].act_bn) return PC_EINVAL;
             p.act = d[i].act->ptr; p.act_bstride = d[i].act->bstride; p.act_cstride = d[i].act->cstride;
-            p.act_rstride = d[i].act->rstride;
+            p.act_rstride = d[i].act->rstride; p.act_xstride = d[i].act->xstride; p.act_dtype = d[i].act->dtype;
             if (d[i].act->dtype != (g_pc_precision == PC_PREC_BF16 ? PC_BF16 : PC_F32)) return PC_EINVAL;
             p.bn = *d[i].act_bn;
         }
@@ -372,11 +621,13 @@ extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int 
     }
     nwg = (nwg + n - 1) / n < 64 ? nwg : (nwg + n - 1) / n;
     const bool bf = g_pc_precision == PC_PREC_BF16;
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].out.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
-    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+        if (bf ? !ct_cl_ok(g.pr[i], false) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].out) && g.pr[i].act_xstride <= 1)) return PC_EINVAL;
+    }
+    if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_dgrad_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 16) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8, true>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_dgrad_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 8) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
@@ -408,12 +659,20 @@ int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t s
     for (int i = 0; i < n; ++i) {
         vec = vec && ct_wgrad_vec_ok(g.pr[i]);
         if (g.pr[i].x.dtype != (bf ? PC_BF16 : PC_F32) || g.pr[i].g.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
+        if (bf ? !ct_cl_ok(g.pr[i], true) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].g))) return PC_EINVAL;
+    }
+    if (bf) {
+        if (C == 16) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, st, g);
+        else if (C == 8) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, st, g);
+        else return PC_EINVAL;
+        PC_CHECK_LAUNCH();
+        return 0;
     }
 #define PC_CTW(CC, VV, BB) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV, BB>), dim3(nwg, n), dim3(256), 0, st, g)
     if (C == 16) {
-        if (vec && bf) PC_CTW(16, true, true); else if (vec) PC_CTW(16, true, false); else if (bf) PC_CTW(16, false, true); else PC_CTW(16, false, false);
+        if (vec) PC_CTW(16, true, false); else PC_CTW(16, false, false);
     } else if (C == 8) {
-        if (vec && bf) PC_CTW(8, true, true); else if (vec) PC_CTW(8, true, false); else if (bf) PC_CTW(8, false, true); else PC_CTW(8, false, false);
+        if (vec) PC_CTW(8, true, false); else PC_CTW(8, false, false);
     } else return PC_EINVAL;
 #undef PC_CTW
     PC_CHECK_LAUNCH();

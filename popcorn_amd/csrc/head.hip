@@ -1097,10 +1097,12 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
         const int qc = valid ? q : 0;
         sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
-        const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+        // channels-last feature map: the 16 channels of the pixel are contiguous
+        const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride +
+                              (int64_t)(p.px + x) * p.feat.xstride;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = pc_ld1(fp + (4 * j + lk) * p.feat.cstride);
+            const float v = pc_ld1(fp + 4 * j + lk);
             xv[j] = valid ? v : 0.f;
         }
     };
@@ -1182,21 +1184,23 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         const int Hp = a.Hp, Wp = a.Wp;
         const int l32 = tid & 31;
         const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + (tid >> 5);
-        const int njobs = p.B * 16 * Hp;
-        const bool v4 = (Wp & 3) == 0;
+        // channels-last: a pixel is two 16-byte pieces; one (b, row) job per half-wave
+        const int njobs = p.B * Hp;
         const int right0 = p.px + p.W;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
         for (int j = hw; j < njobs; j += nhw) {
             const int row = j % Hp;
-            pc_bf16_t* rp = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
+            pc_bf16_t* rp = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + (int64_t)(j / Hp) * a.g_feat.bstride + (int64_t)row * a.g_feat.rstride;
+            const int xs = a.g_feat.xstride;
             if (row < p.py || row >= p.py + p.H) {
-                if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) pc_st4(rp + x4, f32x4{0.f, 0.f, 0.f, 0.f});
-                else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0;
-            } else if (p.px <= 16 && Wp - right0 <= 16) {
-                const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
-                if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0;
+                for (int i = l32; i < 2 * Wp; i += 32) *reinterpret_cast<uint4*>(rp + (int64_t)(i >> 1) * xs + 8 * (i & 1)) = z4;
             } else {
-                for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0;
-                for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0;
+                const int nl = 2 * p.px, nr = 2 * (Wp - right0);
+                for (int i = l32; i < nl + nr; i += 32) {
+                    const int k = i < nl ? i : i - nl;
+                    const int xpix = i < nl ? (k >> 1) : right0 + (k >> 1);
+                    *reinterpret_cast<uint4*>(rp + (int64_t)xpix * xs + 8 * (k & 1)) = z4;
+                }
             }
         }
     }
@@ -1229,8 +1233,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         b0o2[mb] = lf[16 * mb + li]; b2o2[mb] = lf[64 + 16 * mb + li]; b4o2[mb] = lf[128 + 16 * mb + li]; w6o2[mb] = lf[192 + 16 * mb + li];
     }
     // pixel quads 4*lk .. 4*lk+3 of a group never straddle a row, and start at an even element (dword loads of bf16 pairs)
-    const bool quad_ok = (p.W & 3) == 0 && (p.px & 1) == 0 && (p.feat.rstride & 1) == 0 && (p.feat.cstride & 1) == 0 && (p.feat.bstride & 1) == 0 &&
-                         (reinterpret_cast<uintptr_t>(p.feat.ptr) & 3) == 0;
+    const bool quad_ok = (p.W & 3) == 0;
 
     // per-group inputs, fetched one group ahead
     float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
@@ -1243,11 +1246,14 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
         const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
         const pc_bf16_t* fbase = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr);
-        const pc_bf16_t* fp = fbase + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+        const int fxs = p.feat.xstride;
+        const pc_bf16_t* fp = fbase + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + (int64_t)(p.px + x) * fxs;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            n_xv[j] = pc_ld1(fp + (4 * j + lk) * p.feat.cstride);
-            n_fv[j] = !a.fuse_feat_bn ? 1.f : pc_ld1(fp + (4 * lk + j) * p.feat.cstride);
+        for (int j = 0; j < 4; ++j) n_xv[j] = pc_ld1(fp + 4 * j + lk);
+        {
+            const f32x4 f4 = pc_ld4(fp + 4 * lk);          // channels 4*lk .. +3 of the pixel: one 8-byte load
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n_fv[j] = !a.fuse_feat_bn ? 1.f : f4[j];
         }
         n_msk = p.mask ? p.mask[pix] : 1;
         n_bld = p.building[pix];
@@ -1259,19 +1265,17 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         if (quad_ok) {
             const bool v2 = q2 < HW;
             const int y2 = v2 ? (int)pc_div((uint32_t)q2, p.div_w) : 0, x2 = v2 ? q2 - y2 * p.W : 0;
-            // four bf16 pixels = two dwords (the quad starts at an even element: 4-byte aligned)
-            const unsigned* q2p = reinterpret_cast<const unsigned*>(fbase + b * p.feat.bstride + li * p.feat.cstride +
-                                                                    (int64_t)(p.py + y2) * p.feat.rstride + p.px + x2);
-            const unsigned d0 = q2p[0], d1 = q2p[1];
-            n_xq = v2 ? f32x4{__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u), __uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)}
-                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            // four consecutive pixels of one row, channel li
+            const pc_bf16_t* q2p = fbase + b * p.feat.bstride + (int64_t)(p.py + y2) * p.feat.rstride + (int64_t)(p.px + x2) * fxs + li;
+            const float t0 = pc_ld1(q2p), t1 = pc_ld1(q2p + fxs), t2 = pc_ld1(q2p + 2 * fxs), t3 = pc_ld1(q2p + 3 * fxs);
+            n_xq = v2 ? f32x4{t0, t1, t2, t3} : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qq = q2 + e;
                 const bool vv = qq < HW;
                 const int yy = vv ? (int)pc_div((uint32_t)qq, p.div_w) : 0, xx = vv ? qq - yy * p.W : 0;
-                const float t = pc_ld1(fbase + b * p.feat.bstride + li * p.feat.cstride + (int64_t)(p.py + yy) * p.feat.rstride + p.px + xx);
+                const float t = pc_ld1(fbase + b * p.feat.bstride + (int64_t)(p.py + yy) * p.feat.rstride + (int64_t)(p.px + xx) * fxs + li);
                 n_xq[e] = vv ? t : 0.f;
             }
         }
@@ -1299,11 +1303,9 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         }
         if (gg + gstep < a.total_groups) fetch(gg + gstep);
         auto store_zero = [&]() {
-            if (a.zero_in_kernel && valid) {
-                pc_bf16_t* op = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0;
-            }
+            if (a.zero_in_kernel && valid)
+                *reinterpret_cast<uint2*>(reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride +
+                                          (int64_t)(p.px + x) * a.g_feat.xstride + 4 * lk) = make_uint2(0u, 0u);
         };
         if (!__any(sel)) { store_zero(); continue; }
         int lane_o = lane;
@@ -1469,13 +1471,16 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
 #pragma unroll
         for (int t = 0; t < 2; ++t) gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T1, 0, t, lane_o), gb1[t], gx, 0, 0, 0);
         if (valid) {
-            pc_bf16_t* op = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+            // channels 4*lk .. +3 of the pixel: one 8-byte store
+            f32x4 o4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float o = gx[r];
                 if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                pc_st1(op + (4 * lk + r) * a.g_feat.cstride, o);
+                o4[r] = o;
             }
+            pc_st4(reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride +
+                       (int64_t)(p.px + x) * a.g_feat.xstride + 4 * lk, o4);
         }
     }
 
@@ -1589,7 +1594,7 @@ __global__ __launch_bounds__(256) void outconv_sigmoid_crop_kernel(pc_src feat, 
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)W;
         const int x = (int)(i - row * (unsigned)W), y = (int)(row % (unsigned)H), b = (int)(row / (unsigned)H);
-        const int64_t fo = b * feat.bstride + (int64_t)(py + y) * feat.rstride + px + x;
+        const int64_t fo = b * feat.bstride + (int64_t)(py + y) * feat.rstride + (int64_t)(px + x) * pc_xs(feat);
         float s = bv;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -1681,7 +1686,7 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     }
     const float bv = a.bias[0];
     int nsel = 0, nreg = 0;
-    const bool vec4 = a.feat.dtype == PC_F32 &&      // (a bf16 feature map -- the non-dot fallback of bf16 mode -- takes the scalar loop)
+    const bool vec4 = a.feat.dtype == PC_F32 && pc_planar(a.feat) &&      // (a bf16 feature map -- the non-dot fallback of bf16 mode -- takes the scalar loop)
                       (a.W & 3) == 0 && (a.out.rstride & 3) == 0 && (a.out.bstride & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(a.out.ptr) | reinterpret_cast<uintptr_t>(a.admin) |
                         reinterpret_cast<uintptr_t>(a.mask)) & 15) == 0;
@@ -1723,7 +1728,7 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
         const unsigned row = i / (unsigned)a.W;
         const int x = (int)(i - row * (unsigned)a.W), y = (int)(row % (unsigned)a.H), b = (int)(row / (unsigned)a.H);
-        const int64_t fo = b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + a.px + x;
+        const int64_t fo = b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + (int64_t)(a.px + x) * pc_xs(a.feat);
         float s = bv;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -1989,7 +1994,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.groups_per_wave < 8) p.groups_per_wave = 8;
     p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
-    if (feat->dtype != (p.bf ? PC_BF16 : PC_F32)) return PC_EINVAL;      // bf16 mode: the feature map is a bf16 container
+    // bf16 mode: the feature map is a channels-last bf16 tensor (16 contiguous channels per pixel); fp32 mode: planar fp32
+    if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
@@ -2086,7 +2092,15 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
                            int Hp, int Wp, void* ws, int B, int H, int W, void* stream) {
     if (!feat || !hw || !building || !dhw || !g_feat || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
-    if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
+    const bool bfmode = g_pc_precision == PC_PREC_BF16;          // bf16 mode: feat and g_feat are channels-last bf16 tensors
+    if (bfmode) {
+        if (!pc_cl_ok(*feat) || feat->xstride < 16 || !pc_cl_ok(*g_feat) || g_feat->xstride != 16 || g_feat->rstride != 16 * Wp ||
+            g_feat->bstride != (int64_t)16 * Hp * Wp)
+            return PC_EINVAL;
+    } else {
+        if (feat->dtype != PC_F32 || g_feat->dtype != PC_F32 || !pc_planar(*feat) || !pc_planar(*g_feat)) return PC_EINVAL;
+        if (g_feat->cstride != (int64_t)Hp * Wp || g_feat->bstride != (int64_t)16 * Hp * Wp || g_feat->rstride != Wp) return PC_EINVAL;
+    }
     hipStream_t st = (hipStream_t)stream;
     if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
     static int use_pc = -1;
@@ -2095,8 +2109,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         use_pc = (ev && ev[0] == '1') ? 0 : 1;
     }
     const char* zv = getenv("POPCORN_HEAD_ZERO_FILL");            // A/B switch: 1 = the round-1 separate zero-fill launch
-    const bool bfmode = g_pc_precision == PC_PREC_BF16;          // bf16 mode: feat and g_feat are bf16 containers
-    if (feat->dtype != (bfmode ? PC_BF16 : PC_F32) || g_feat->dtype != feat->dtype) return PC_EINVAL;
     const bool zero_launch = !bfmode && (!use_pc || (zv && zv[0] == '1'));
     if (zero_launch) {
         // zero fill by a kernel, not a memset node (see zero_fill_kernel)

@@ -169,7 +169,7 @@ class UNetEngine:
         dev = X.device
         H1, W1 = Hp // 2, Wp // 2
         H2, W2 = H1 // 2, W1 // 2
-        E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=L.act_dtype())  # noqa: E731
+        E = lambda c, h, w: L.empty_act(B, c, h, w, dev)  # noqa: E731
         S = [s for s, _, _, _ in self.streams]
         A = {s: saved[s] for s in S}
         ly = lambda s, t: self.layers[(s, t)]  # noqa: E731
@@ -309,8 +309,8 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
                   for e, lo in enumerate(logit_only)]
     feats = [f if f is not None else
              (torch.empty(B, 2, Hp, Wp, device=dev, dtype=torch.float32) if logit_only[e] else
-              mk(B, 16, Hp, Wp, device=dev, dtype=L.act_dtype())) for e, f in enumerate(feats_list)]
-    E = lambda c, h, w: torch.empty(B, c, h, w, device=dev, dtype=L.act_dtype())  # noqa: E731
+              L.empty_act(B, 16, Hp, Wp, dev, zero=mk is torch.zeros)) for e, f in enumerate(feats_list)]
+    E = lambda c, h, w: L.empty_act(B, c, h, w, dev)  # noqa: E731
     streams = engines[0].streams
     assert all([st[0] for st in e.streams] == [st[0] for st in streams] for e in engines)
     keys = [(e, s) for e in range(nE) for s, _, _, _ in streams]

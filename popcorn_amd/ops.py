@@ -32,7 +32,7 @@ def conv3x3_raw(a, w, bnd, relu=True, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 
     sa = L.src(a, C_=Ca, mode=a_mode, oy=a_pad[0], ox=a_pad[1], chmap=chmap)
     sb = L.src(b, oy=b_offset[0], ox=b_offset[1]) if b is not None else None
     if out is None:
-        out = torch.empty(B, Cout, H, W, device=a.device, dtype=L.act_dtype())
+        out = L.empty_act(B, Cout, H, W, a.device)
     d = L.dst(out)
     code = L.lib().pc_conv3x3_bn_relu_fwd(C.byref(sa), C.byref(sb) if sb is not None else None, L.ptr(w), C.byref(bnd),
                                           int(relu), C.byref(d), B, H, W, Ca + Cb, Cout, L.stream_ptr())
@@ -92,7 +92,7 @@ def pool_out_like(out):
     d = L.dst(out)
     if not L.lib().pc_conv3x3_pool_out_ok(C.byref(d), H, W):
         return None
-    return torch.empty(B, Cc, H // 2, W // 2, device=out.device, dtype=out.dtype)
+    return L.empty_act(B, Cc, H // 2, W // 2, out.device)
 
 
 def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):
@@ -178,7 +178,7 @@ def convt2x2(x, w, bias, out=None):
     L.require_device(x, w)
     B, Cc, H, W = x.shape
     if out is None:
-        out = torch.empty(B, Cc, 2 * H, 2 * W, device=x.device, dtype=L.act_dtype())
+        out = L.empty_act(B, Cc, 2 * H, 2 * W, x.device)
     sx, d = L.src(x), L.dst(out)
     L.check(L.lib().pc_convt2x2_fwd(C.byref(sx), L.ptr(w), L.ptr(bias), C.byref(d), B, H, W, Cc, L.stream_ptr()),
             "pc_convt2x2_fwd")
@@ -359,7 +359,7 @@ def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     if grads is None:
         grads = [torch.empty_like(t) for t in head_tensors]
     if g_feat is None:
-        g_feat = torch.empty(B, 16, Hp, Wp, device=dev, dtype=L.act_dtype())
+        g_feat = L.empty_act(B, 16, Hp, Wp, dev)
     ws = _workspace(L.lib().pc_head_ws_bytes(B, H, W), dev)
     sf, d = L.src(feat), L.dst(g_feat)
     hw = _hw_array(head_tensors)

@@ -10,6 +10,10 @@ import torch
 from popcorn_amd import ops, _lib as L
 
 lib = L.lib()
+PREC = os.environ.get("ABL_PREC", "fp32")          # bf16: the bf16-container instantiations (half the bytes)
+lib.pc_set_precision(L.PRECISIONS[PREC])
+ADT = L.act_dtype()
+ESZ = 2 if PREC == "bf16" else 4
 B, NSETS, REPS = 64, 4, 10
 cfgs = [(8, 8, 128), (16, 8, 128), (16, 16, 64), (32, 8, 64)]
 if len(sys.argv) == 4:
@@ -28,15 +32,15 @@ for (cin, cout, hw) in cfgs:
         for i in range(4):
             ca = cin if cin <= 8 else cin // 2
             mk = torch.zeros if os.environ.get("ABL_ZERO") else torch.randn       # zero operands: the power-limit test
-            a = mk(B, ca, hw, hw, device="cuda")
-            b = mk(B, cin - ca, hw, hw, device="cuda") if cin > ca else None
+            a = L.as_act(mk(B, ca, hw, hw, device="cuda"))
+            b = L.as_act(mk(B, cin - ca, hw, hw, device="cuda")) if cin > ca else None
             w = mk(cout, cin, 3, 3, device="cuda") * 0.1
             bias = torch.zeros(cout, device="cuda")
-            probs.append({"a": a, "b": b, "w": w, "bn": L.bn(bias), "out": torch.empty(B, cout, hw, hw, device="cuda"),
+            probs.append({"a": a, "b": b, "w": w, "bn": L.bn(bias), "out": L.empty_act(B, cout, hw, hw, "cuda"),
                           "_keep": bias})
         sets.append(probs)
     flop = 4 * B * hw * hw * 2 * 9 * cin * cout
-    byts = 4 * B * hw * hw * 4 * (cin + cout)
+    byts = 4 * B * hw * hw * ESZ * (cin + cout)
     for dbg, grid, tag in variants:
         lib.pc_debug_conv(dbg, grid)
         for s in sets:

@@ -37,9 +37,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// bf16 mode (BF instantiations): the MFMA is v_mfma_f32_16x16x32_bf16 with K = 32 = (4 input rows v) x (8 input channels):
-// one instruction per (horizontal tap dx, 16-px block) and 8-channel chunk instead of 8 fp32 ones.  The wave's strip lives
-// in LDS as [6 rows][48 slots][8 channels] bf16 (one 16-byte slot per pixel), so an A operand -- lane (x, v): the 8
+// bf16 mode (the channels-last kernel below): the MFMA is v_mfma_f32_16x16x32_bf16 with K = 32 = (4 input rows v) x (8 input
+// channels): one instruction per (horizontal tap dx, 16-px block) and 8-channel chunk instead of 8 fp32 ones.  The wave's strip
+// lives in LDS as [6 rows][48 slots][8 channels] bf16 (one 16-byte slot per pixel), so a pixel operand -- lane (x, v): the 8
 // channels of pixel (row v, x + dx) -- is ONE ds_read_b128; weights are an image [dy plane][co][chunk][dx][8 ci] bf16
 // with an all-zero plane for the (row, output row) pairs that are not a tap.  Both operands enumerate K as
 // slot(lane >> 4, j) = (row, channel j), so the products pair up whatever the hardware's internal K order is.
@@ -100,10 +100,7 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 // count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
 // write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
 enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3 };   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
-// BF: PC_PREC_BF16 rounding points (popcorn_hip.h) as their own instantiations -- the fp32 kernels compile to the same code
-// as before.  Weights and the first layer's input (the only operand no producer has rounded yet) are rounded when staged,
-// results when stored; the MFMA stays v_mfma_f32_16x16x4_f32 on bf16-representable operands (exact products, fp32 sums).
-template <int CIN, int COUT, int MODE, int LD, int EPI, bool BF>
+template <int CIN, int COUT, int MODE, int LD, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
@@ -112,7 +109,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
     constexpr int W_RL = CIN * 3 + 4;                    // weight image: floats per (dy, co) row (== 4 mod 8: spreads banks)
     constexpr int W_DYS = COUT * W_RL + 16;              // ... and per dy plane
-    auto rnd = [](float x) { return BF ? pc_bf16r(x) : x; };
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const ConvProb& q = p.pr[blockIdx.y];
@@ -127,15 +123,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 
-    constexpr int WAVE_F = BF ? BWAVE_F : CHUNK * CSW;   // floats of one wave's LDS region
+    constexpr int WAVE_F = CHUNK * CSW;                  // floats of one wave's LDS region
     float* const wl = lds + wave * WAVE_F;               // this wave's LDS region
 
     // ---- staged loader: lane = (row r of the 6-row strip, 16-byte segment seg of the 40-float row)
     const int l_r = lane / 10, l_seg = lane - l_r * 10;
     const bool l_act = lane < 60;
     const int CA = q.a.C;
-    // BF instantiations: activation / gradient tensors are bf16 CONTAINERS (2-byte elements; strides in elements)
-    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
+    using act_t = float;
     const act_t* const a_ptr = reinterpret_cast<const act_t*>(q.a.ptr);
     const act_t* const b_ptr = reinterpret_cast<const act_t*>(q.b.ptr);
     const int64_t a_cstr = q.a.cstride, b_cstr = q.b.cstride;
@@ -163,7 +158,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             for (int it = 0; it < NIT; ++it) {
                 const int cg = ch * CHUNK + it;
                 const act_t* cp = cg < CA ? a_ptr + cg * a_cstr : b_ptr + (cg - CA) * b_cstr;
-                R[it] = pc_ld4(cp + off);          // fp32: one 16-byte load; bf16: one 8-byte load (same 4 pixels)
+                R[it] = pc_ld4(cp + off);
             }
         } else if (LD == LD_POOL) {
             const int64_t off = ok ? b * my_bs + (int64_t)(2 * y) * my_rs + 2 * xg : 0;
@@ -183,23 +178,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         }
     };
     auto commit = [&]() {
-        if constexpr (BF) {
-            // the lane holds 4 consecutive pixels of every channel of the chunk: one 16-byte slot (8 channels) per pixel
-            if (l_act) {
-                u32x4* d = reinterpret_cast<u32x4*>(wl) + l_r * BSLOTS + 4 * l_seg;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u32x4 s;
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const float lo = (2 * h < NIT && rvalid) ? R[(2 * h) % NIT][e] : 0.f;
-                        const float hi = (2 * h + 1 < NIT && rvalid) ? R[(2 * h + 1) % NIT][e] : 0.f;
-                        s[h] = pc_pack_bf16(lo, hi);
-                    }
-                    d[e] = s;
-                }
-            }
-        } else if (l_act) {
+        if (l_act) {
             float* d = wl + l_r * RS + 4 * l_seg;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
@@ -212,18 +191,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             const int cg = ch * CHUNK + ci;
             const float v = cg < CA ? pc_fetch(q.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
                                     : pc_fetch(q.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-            if constexpr (BF) {
-                reinterpret_cast<unsigned short*>(wl)[(r * BSLOTS + (COL0 - 1) + c) * 8 + ci] =
-                    (unsigned short)(__float_as_uint(rnd(v)) >> 16);
-            } else {
-                wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
-            }
-        }
-        if constexpr (BF && CHUNK < 8) {      // channel slots the layer does not have
-            for (int idx = lane; idx < (8 - CHUNK) * SROWS * 34; idx += 64) {
-                const int c = idx % 34, r = (idx / 34) % SROWS, ci = CHUNK + idx / (34 * SROWS);
-                reinterpret_cast<unsigned short*>(wl)[(r * BSLOTS + (COL0 - 1) + c) * 8 + ci] = 0;
-            }
+            wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
         }
     };
 
@@ -258,10 +226,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // trip, in flight together with the first strip), the LDS image is zeroed meanwhile, and only then are they consumed
     // -- the prologue used to be three dependent round trips (zero fill + barrier, weights, BN), ~4.6 us of every launch.
     float* const w2 = lds + 4 * WAVE_F;
-    // bf16 image: [dy plane 0..3][co][chunk][dx][8 ci] halves, plane 3 all zero
-    constexpr int BW_CO = NCHUNK * 24;                   // halves per (dy plane, co)
-    constexpr int BW_DYS = COUT * BW_CO;                 // halves per dy plane
-    unsigned short* const w2h = reinterpret_cast<unsigned short*>(w2);
     constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
     float wreg[NWR];
 #pragma unroll
@@ -269,7 +233,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         const int e = tid + k * 256;
         const int ec = e < COUT * CIN * 9 ? e : 0;
         const int tap = ec % 9, ci = (ec / 9) % CIN, co = ec / (9 * CIN);
-        wreg[k] = rnd(q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)]);
+        wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
     }
     const bool has_bn = MODE == MODE_FWD || q.act != nullptr;
     float bn_raw[NB][5];            // {conv bias, gamma, var, mean, beta} of channel nb*8 + col
@@ -282,21 +246,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         bn_raw[nb][3] = has_bn && q.bn.gamma ? q.bn.mean[c] : 0.f;
         bn_raw[nb][4] = has_bn && q.bn.gamma ? q.bn.beta[c] : 0.f;
     }
-    if constexpr (BF) {
-        // whole image zeroed first (plane 3, and the channel slots a CIN < 8 layer does not have), then the taps
-        for (int e = tid; e < 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NWR; ++k) {
-            const int e = tid + k * 256;
-            if (e < COUT * CIN * 9) {
-                const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-                w2h[(tap / 3) * BW_DYS + co * BW_CO + (ci / 8) * 24 + (tap % 3) * 8 + (ci % 8)] =
-                    (unsigned short)(__float_as_uint(wreg[k]) >> 16);          // wreg is already rounded to bf16
-            }
-        }
-        __syncthreads();
-    } else {
+    {
         // only the dy = 3 plane has to be zero (the pad floats of the other planes are never read): disjoint from the weight
         // writes below, so one barrier covers both
         for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
@@ -311,15 +261,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         __syncthreads();
     }
     const float* const wlane = w2 + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * W_DYS + col * W_RL;
-    const unsigned short* const wlane_h = w2h + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * BW_DYS + col * BW_CO;
-    bf16x8 bwh[3][NB];
-    auto load_bwh = [&](int ch) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-                bwh[dx][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane_h + nb * 8 * BW_CO + ch * 24 + dx * 8));
-    };
     float bw[CHUNK][3][NB];
     auto load_bw = [&](int ch) {
         if constexpr (CHUNK == 8) {
@@ -410,7 +351,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) pc_st4(o0 + rr * o_rs + 4 * h, O[rr][h]);       // (the bf16 store rounds)
+                        for (int h = 0; h < 2; ++h) pc_st4(o0 + rr * o_rs + 4 * h, O[rr][h]);
                 }
             }
             return;
@@ -444,10 +385,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                             for (int r = 0; r < 4; ++r) v[r] += o4[r];
                         }
                     }
-                    if (BF) v = pc_bf16r4(v);
                     if (EPI == EPI_DOT && MODE == MODE_FWD && q.dot_w) {
                         // sum over the 8 channels = the 8 lanes `col` of a 16-lane group half; lane col == 0 stores
-                        const float wl = rnd(q.dot_w[nb * 8 + col]);
+                        const float wl = q.dot_w[nb * 8 + col];
                         f32x4 t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -555,24 +495,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (BF) {
-            if (!(p.dbg & 2)) {
-                load_bwh(ch);
-                const u32x4* lrow = reinterpret_cast<const u32x4*>(wl) + lk * BSLOTS + (COL0 - 1) + li;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    bf16x8 av[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        av[u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSLOTS + (u & 1) * 16 + dx]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], bwh[dx][nb], acc[u][nb], 0, 0, 0);
-                }
-            }
-        } else if (!(p.dbg & 2)) {
+        if (!(p.dbg & 2)) {
             load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
             const float* lrow = wl + lk * RS + (COL0 - 1) + li;
 #pragma unroll
@@ -604,14 +527,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-template <int CIN, int COUT, int MODE, int LD, int EPI, bool BF>
-int launch_conv_bf(ConvArgs& p, int nprob, hipStream_t stream) {
+template <int CIN, int COUT, int MODE, int LD, int EPI>
+int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
-    const size_t lds = BF ? ((size_t)4 * BWAVE_F * sizeof(float) + (size_t)4 * COUT * (CIN / CHUNK) * 24 * sizeof(unsigned short))
-                          : ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
+    const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, BF>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -634,7 +556,7 @@ int launch_conv_bf(ConvArgs& p, int nprob, hipStream_t stream) {
         grid = 768 / nprob < 128 ? 128 : 768 / nprob;
         if (grid > p.ntiles) grid = p.ntiles;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, BF>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -1070,11 +992,6 @@ int launch_conv_bf16(ConvArgs& p, int nprob, hipStream_t stream) {
     return PC_EINVAL;
 }
 
-template <int CIN, int COUT, int MODE, int LD, int EPI>
-int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
-    return launch_conv_bf<CIN, COUT, MODE, LD, EPI, false>(p, nprob, stream);
-}
-
 template <int CIN, int COUT, int MODE, int LD>
 int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     if constexpr (MODE == MODE_FWD && CIN >= 8) {       // the layers in front of a Down block: inc.conv.3 (8->8), down1 conv.3 (16->16)
@@ -1094,11 +1011,10 @@ int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
     return launch_conv_po<CIN, COUT, MODE, LD, EPI_NONE>(p, nprob, stream);
 }
 
-// staged-loader classification of a source (1 = aligned DIRECT, 2 = aligned POOL2, 0 = generic), for either container type
+// staged-loader classification of a planar fp32 source (1 = aligned DIRECT, 2 = aligned POOL2, 0 = generic)
 int conv_src_mode(const pc_src& s, int H, int W) {
     if (s.C == 0) return 0;
-    const uintptr_t amask = s.dtype == PC_BF16 ? 7 : 15;
-    const bool al = ((reinterpret_cast<uintptr_t>(s.ptr) & amask) == 0) && (s.rstride % 4 == 0) && (s.cstride % 4 == 0) && (s.bstride % 4 == 0);
+    const bool al = ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && (s.rstride % 4 == 0) && (s.cstride % 4 == 0) && (s.bstride % 4 == 0);
     if (!al) return 0;
     if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W && (W % 4) == 0) return 1;
     if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && (W % 4) == 0) return 2;
@@ -1122,16 +1038,14 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     // loader choice: all problems of the group must qualify for a staged loader
     bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
     bool vec = (p.W % 4) == 0;
-    // container types must match the arithmetic mode: bf16 mode = bf16 activation / gradient tensors (the reflect-padded model
-    // input and the partial-logit output stay fp32), fp32 mode = fp32 everywhere
-    const bool bfm = g_pc_precision == PC_PREC_BF16;
-    const int want = bfm ? PC_BF16 : PC_F32;
-    const uintptr_t amask = bfm ? 7 : 15;              // a 4-pixel vector access: 8 bytes of bf16, 16 bytes of fp32
+    // fp32 mode: planar fp32 tensors everywhere
+    const uintptr_t amask = 15;                        // a 4-pixel vector access: 16 bytes
     for (int i = 0; i < nprob; ++i) {
         ConvProb& q = p.pr[i];
-        if (q.a.dtype != (q.a.mode == PC_SRC_REFLECT ? PC_F32 : want) || (q.b.C && q.b.dtype != want)) return PC_EINVAL;
-        if ((q.out.ptr != reinterpret_cast<float*>(q.dot_out.ptr) && q.out.dtype != want) || (q.pool_out.ptr && q.pool_out.dtype != want) ||
-            (q.dot_out.ptr && q.dot_out.dtype != PC_F32) || (q.act && q.act_dtype != want))
+        if (q.a.dtype != PC_F32 || !pc_planar(q.a) || (q.b.C && (q.b.dtype != PC_F32 || !pc_planar(q.b)))) return PC_EINVAL;
+        if ((q.out.ptr != reinterpret_cast<float*>(q.dot_out.ptr) && (q.out.dtype != PC_F32 || !pc_planar(q.out))) ||
+            (q.pool_out.ptr && (q.pool_out.dtype != PC_F32 || !pc_planar(q.pool_out))) ||
+            (q.dot_out.ptr && (q.dot_out.dtype != PC_F32 || !pc_planar(q.dot_out))) || (q.act && (q.act_dtype != PC_F32 || q.act_xstride > 1)))
             return PC_EINVAL;
         q.fast_a = conv_src_mode(q.a, p.H, p.W);
         q.fast_b = conv_src_mode(q.b, p.H, p.W);
@@ -1202,8 +1116,8 @@ int fill_dgrad(ConvProb& q, const pc_src* g, const float* w, int c0, const pc_sr
 // the pooled second output needs every strip on the vector epilogue: full 32 x 4 strips, 16-byte aligned output
 bool pool_out_geometry_ok(const pc_dst& out, int H, int W) {
     if (out.dtype == PC_BF16) return W % 32 == 0 && H % 4 == 0 && pc_cl_ok(out);      // channels-last bf16 (bf16 mode)
-    return W % 32 == 0 && H % 4 == 0 && out.rstride % 4 == 0 && out.cstride % 4 == 0 && out.bstride % 4 == 0 &&
-           (reinterpret_cast<uintptr_t>(out.ptr) & (out.dtype == PC_BF16 ? 7 : 15)) == 0;
+    return W % 32 == 0 && H % 4 == 0 && pc_planar(out) && out.rstride % 4 == 0 && out.cstride % 4 == 0 && out.bstride % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(out.ptr) & 15) == 0;
 }
 
 }  // namespace

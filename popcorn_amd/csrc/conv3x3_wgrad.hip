@@ -39,8 +39,7 @@ struct WgradArgs {
     int tiles_x, tiles_y, ntiles;
     pc_fastdiv div_tx, div_tpi;
     int fast_a, fast_b, fast_g;
-    int bf;               // PC_PREC_BF16: the input operand is rounded to bf16 when staged by the reflect / generic loaders
-                          // (the model input; every other operand was rounded by its producer).  dW / db stay fp32.
+    int bf;               // PC_PREC_BF16: channels-last bf16 operands, conv3x3_wgrad_cl_kernel (dW / db stay fp32)
 };
 
 template <int CINC, int COUT>
@@ -96,8 +95,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs p) {
         const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
         const int x0 = (rem - ty * p.tiles_x) * TW, y0 = ty * TH;
         __syncthreads();
-        pc_load_halo_tile<CINC, IN_RS, IN_CS, IN_COL0, true>(lin, p.a, p.b, p.fast_a, p.fast_b, cbase, b, y0, x0, p.H, p.W, tid,
-                                                              p.bf != 0);
+        pc_load_halo_tile<CINC, IN_RS, IN_CS, IN_COL0, true>(lin, p.a, p.b, p.fast_a, p.fast_b, cbase, b, y0, x0, p.H, p.W, tid);
         // gradient tile: COUT x 16 rows x 32 cols, no halo; 8 lanes x float4 per row
         for (int job = tid >> 3; job < COUT * 16; job += 32) {
             const int co = job >> 4, r = job & 15, l8 = tid & 7;
@@ -238,10 +236,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 R[it] = l_act ? pc_fetch_reflect_seg(p.a, b, cbase + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bf) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) R[it] = pc_bf16r4(R[it]);
-            }
         } else if (LD == 1) {
             const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
 #pragma unroll
@@ -278,9 +272,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
                 const int64_t goff = gok ? b * p.g.bstride + (int64_t)yy * p.g.rstride + xx : 0;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
-                    G[rpi][mb][h] = p.g.dtype == PC_BF16      // (bf16 mode: the first-layer launches run this kernel on a bf16 gradient)
-                        ? pc_ld4(reinterpret_cast<const pc_bf16_t*>(p.g.ptr) + (mb * 8 + g_c) * p.g.cstride + goff)
-                        : *reinterpret_cast<const f32x4*>(p.g.ptr + (mb * 8 + g_c) * p.g.cstride + goff);
+                    G[rpi][mb][h] = *reinterpret_cast<const f32x4*>(p.g.ptr + (mb * 8 + g_c) * p.g.cstride + goff);
             }
         }
         gvalid = gm;
@@ -395,221 +387,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGrou
         part[COUT * CINC * 9 + tid] = t;
     }
 }
-
-// ---- bf16 variant of the wave-private kernel (PC_PREC_BF16; aligned DIRECT / POOL2 sources, CINC = 8 or 16) --------------
-// v_mfma_f32_16x16x32_bf16: the reduction over pixels rides on K = 32 = one whole strip row, so a strip is 2 x 3 x MB x
-// CINC/4 instructions instead of 16 x MB x CINC*12/16 fp32 ones.  The horizontal tap moves to the GRADIENT operand:
-//     D_dx[(s,co)][(ci,v)] += sum_x' g[co][yp+s][x' - dx + 1] * in[ci][yp+v-1][x'],   x' = x0 .. x0+31
-// A (M = (s, co8)): the lane's 8 k-slots are g at x0 + 8*lk + j - dx + 1, cut from ten consecutive pixels that sit in
-//    registers (one 16-byte load of 8 bf16 + the two neighbours) -- three shifted packings, no LDS;
-// B (N = (ci, v), 4 channels x 4 input rows per block): in at x0 + 8*lk + j, UNshifted, one aligned ds_read_b128 from the
-//    strip kept in LDS as bf16 ([ci][6 rows][16 B pad + 32 px]); no x halo is needed at all.
-// dW[co][ci][dy][dx] = D_dx[(0,co)][(ci,dy)] + D_dx[(1,co)][(ci,dy+1)]; same compacted partial as the fp32 kernels.
-constexpr int BW_ROWB = 80;                  // bytes of one (channel, row) of the bf16 strip: 16 pad + 64
-
-template <int CINC, int COUT, int LD>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_wave_bf16_kernel(const WgradGroup grp_) {
-    const WgradArgs& p = grp_.pr[blockIdx.z];
-    using Cfg = WgradCfg<CINC, COUT>;
-    constexpr int MB = Cfg::MB;
-    constexpr int NBP = CINC / 4;                // N blocks of (4 channels x 4 rows) per tap
-    constexpr int NBLK = 3 * NBP;                // accumulator blocks per mb: [dx][nbp]  (== Cfg::NBLK for CINC = 8, 16)
-    static_assert(NBLK == Cfg::NBLK, "staging buffer of the cross-wave reduction is sized by Cfg::NBLK");
-    constexpr int NIT = CINC;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int chunk = blockIdx.y;
-    const int cbase = p.ci0 + chunk * CINC;
-    unsigned char* const wl = reinterpret_cast<unsigned char*>(lds) + wave * (CINC * 6 * BW_ROWB);
-
-    // B operand address: lane n = (ci4 = li >> 2, v = li & 3), 8 pixels from x0 + 8*lk
-    int boff[NBP];
-#pragma unroll
-    for (int nb = 0; nb < NBP; ++nb) boff[nb] = ((nb * 4 + (li >> 2)) * 6 + (li & 3)) * BW_ROWB + 16 + 16 * lk;
-
-    // ---- input-strip loader (as in the fp32 kernel): lane = (row r of 6, 16-byte segment of the 40-float row)
-    const int l_r = lane / 10, l_seg = lane - l_r * 10;
-    const bool l_act = lane < 60;
-    const int CA = p.a.C;
-    const int64_t in_bs = p.a.bstride;
-    const int in_rs = p.a.rstride;
-    uint2 R[NIT];             // four bf16 pixels of one channel row
-    bool rvalid = false;
-    const pc_bf16_t* const a_ptr = reinterpret_cast<const pc_bf16_t*>(p.a.ptr);
-    const pc_bf16_t* const b_ptr = reinterpret_cast<const pc_bf16_t*>(p.b.ptr);
-    const pc_bf16_t* const g_ptr = reinterpret_cast<const pc_bf16_t*>(p.g.ptr);
-    // ---- gradient operand: lane (i = (s, co8), k group lk): ten floats g[x0 + 8*lk - 1 .. x0 + 8*lk + 8] of row y0 + 2*rpi + s
-    const int g_s = li >> 3, g_c = li & 7;
-    u32x4w G8[2][MB];          // eight bf16 pixels from x0 + 8*lk
-    pc_bf16_t GL[2][MB], GR[2][MB];
-    unsigned gvalid = 0;      // bit rpi*4 + {0: first 4, 1: second 4, 2: left neighbour, 3: right neighbour}
-
-    auto issue = [&](int b, int y0, int x0) {
-        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
-        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
-        rvalid = ok;
-        if (LD == 1) {
-            const int64_t off = ok ? b * in_bs + (int64_t)y * in_rs + xg : 0;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int cg = cbase + it;
-                const pc_bf16_t* cp = cg < CA ? a_ptr + cg * p.a.cstride : b_ptr + (cg - CA) * p.b.cstride;
-                R[it] = *reinterpret_cast<const uint2*>(cp + off);
-            }
-        } else {
-            const int64_t off = ok ? b * in_bs + (int64_t)(2 * y) * in_rs + 2 * xg : 0;
-            const int rs1 = ok ? in_rs : 0;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const pc_bf16_t* s0 = a_ptr + (cbase + it) * p.a.cstride + off;
-                const f32x4 a0 = pc_ld4(s0), a1 = pc_ld4(s0 + 4);
-                const f32x4 b0 = pc_ld4(s0 + rs1), b1 = pc_ld4(s0 + rs1 + 4);
-                R[it] = make_uint2(pc_pack_bf16(fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1])), fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]))),
-                                   pc_pack_bf16(fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1])), fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]))));
-            }
-        }
-        unsigned gm = 0;
-        const int xx = x0 + 8 * lk;
-#pragma unroll
-        for (int rpi = 0; rpi < 2; ++rpi) {
-            const int yy = y0 + 2 * rpi + g_s;
-            const bool rowok = yy < p.H;
-            // the 8-pixel piece is loaded whole when its first pixel is inside the image (W % 8 == 0 on this path)
-            const bool ok0 = rowok && xx < p.W, ok1 = ok0;
-            const bool okl = rowok && xx - 1 >= 0 && xx - 1 < p.W, okr = rowok && xx + 8 < p.W;
-            gm |= (ok0 ? 1u : 0u) << (rpi * 4) | (ok1 ? 2u : 0u) << (rpi * 4) | (okl ? 4u : 0u) << (rpi * 4) | (okr ? 8u : 0u) << (rpi * 4);
-            const int64_t rowoff = rowok ? b * p.g.bstride + (int64_t)yy * p.g.rstride : 0;
-            const int64_t o0 = ok0 ? rowoff + xx : 0;
-            const int64_t ol = okl ? rowoff + xx - 1 : 0, orr = okr ? rowoff + xx + 8 : 0;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const pc_bf16_t* gp = g_ptr + (mb * 8 + g_c) * p.g.cstride;
-                G8[rpi][mb] = *reinterpret_cast<const u32x4w*>(gp + o0);
-                GL[rpi][mb] = gp[ol];
-                GR[rpi][mb] = gp[orr];
-            }
-        }
-        gvalid = gm;
-    };
-    auto commit = [&]() {
-        // segments 1..8 = the strip's own 32 pixels; four pixels of a channel row -> four bf16 = one 8-byte store
-        if (l_act && l_seg >= 1 && l_seg <= 8) {
-            unsigned char* d = wl + l_r * BW_ROWB + 16 + 8 * (l_seg - 1);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint2*>(d + it * 6 * BW_ROWB) = rvalid ? R[it] : make_uint2(0u, 0u);
-        }
-    };
-
-    f32x4 acc[MB][NBLK];
-    float bsum[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        bsum[mb] = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
-        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
-        b = (int)pc_div((uint32_t)tile, p.div_tpi);
-        const int rem = tile - b * p.tiles_x * p.tiles_y;
-        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
-        x0 = (rem - ty * p.tiles_x) * TW;
-        y0 = ty * TH + 4 * wave;
-    };
-    int b = 0, y0 = 0, x0 = 0;
-    if (my_tiles > 0) {
-        strip_coords(0, b, y0, x0);
-        issue(b, y0, x0);
-    }
-    for (int k = 0; k < my_tiles; ++k) {
-        commit();
-        // A operands of this strip: f[t] = g[x0 + 8*lk - 1 + t], t = 0..9 (masked); tap dx takes f[2 - dx + j], j = 0..7
-        bf16x8 av[2][MB][3];
-#pragma unroll
-        for (int rpi = 0; rpi < 2; ++rpi)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const unsigned m = gvalid >> (rpi * 4);
-                float f[10];
-                f[0] = (m & 4u) ? pc_bf2f(GL[rpi][mb]) : 0.f;
-                f[9] = (m & 8u) ? pc_bf2f(GR[rpi][mb]) : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned dw = G8[rpi][mb][e];
-                    f[1 + 2 * e] = (m & 1u) ? __uint_as_float(dw << 16) : 0.f;
-                    f[2 + 2 * e] = (m & 1u) ? __uint_as_float(dw & 0xffff0000u) : 0.f;
-                }
-                bsum[mb] += ((f[1] + f[2]) + (f[3] + f[4])) + ((f[5] + f[6]) + (f[7] + f[8]));
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    u32x4w q;
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) q[h] = pc_pack_bf16(f[2 - dx + 2 * h], f[3 - dx + 2 * h]);
-                    av[rpi][mb][dx] = __builtin_bit_cast(bf16x8, q);
-                }
-            }
-        if (k + 1 < my_tiles) {
-            strip_coords(k + 1, b, y0, x0);
-            issue(b, y0, x0);
-        }
-#pragma unroll
-        for (int rpi = 0; rpi < 2; ++rpi) {
-#pragma unroll
-            for (int nb = 0; nb < NBP; ++nb) {
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4w*>(wl + boff[nb] + 2 * rpi * BW_ROWB));
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[mb][dx * NBP + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rpi][mb][dx], bv, acc[mb][dx * NBP + nb], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- cross-wave reduction through LDS (fixed order), one compacted partial per workgroup (layout of the fp32 kernels)
-    float* part = p.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * Cfg::EC;
-    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        __syncthreads();
-#pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb)
-            *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = acc[mb][nb];
-        __syncthreads();
-        for (int idx = tid; idx < 8 * CINC * 9; idx += 256) {
-            const int c8 = idx / (CINC * 9), rem = idx - c8 * (CINC * 9);
-            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
-            // D_dx[m = s*8 + c8][n = (cil & 3)*4 + v] in block dx*NBP + (cil >> 2); lane = (m>>2)*16 + n, reg = m&3
-            const int blk = dx * NBP + (cil >> 2);
-            const int n0 = (cil & 3) * 4 + dy, n1 = n0 + 1;
-            const int m0 = c8, m1 = 8 + c8;
-            const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
-            const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
-            part[(mb * 8 + c8) * (CINC * 9) + rem] = wsum(e0) + wsum(e1);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) lds[(wave * MB + mb) * 64 + lane] = bsum[mb];
-    __syncthreads();
-    if (tid < COUT) {
-        const int mb = tid >> 3, c8 = tid & 7;
-        float t = 0.f;
-#pragma unroll
-        for (int lk2 = 0; lk2 < 4; ++lk2) {
-            const int ea = mb * 64 + lk2 * 16 + c8, eb = ea + 8;
-            const float sa = ((lds[ea] + lds[MB * 64 + ea]) + lds[2 * MB * 64 + ea]) + lds[3 * MB * 64 + ea];
-            const float sb = ((lds[eb] + lds[MB * 64 + eb]) + lds[2 * MB * 64 + eb]) + lds[3 * MB * 64 + eb];
-            t += sa + sb;
-        }
-        part[COUT * CINC * 9 + tid] = t;
-    }
-}
-
 
 // ---- channels-last bf16 kernel (PC_PREC_BF16) -------------------------------------------------------------------------------
 // Activations and gradients are channels-last bf16 (one 16-byte slot per pixel and 8-channel group, conv3x3.hip), but the
@@ -966,24 +743,20 @@ int prepare_wgrad(WgradArgs& p, int Cin, void* ws, int& nwg, int& nchunk) {
         return 1;
     }
     if (!pc_planar(p.a) || !pc_planar(p.b) || !pc_planar(p.g)) return -1;
-    auto mode_of = [&](const pc_src& s) -> int {      // 1 = aligned DIRECT, 2 = aligned POOL2 (either container type)
+    auto mode_of = [&](const pc_src& s) -> int {      // 1 = aligned DIRECT, 2 = aligned POOL2
         if (s.C == 0) return 0;
-        const uintptr_t amask = s.dtype == PC_BF16 ? 7 : 15;
-        if ((reinterpret_cast<uintptr_t>(s.ptr) & amask) || s.rstride % 4 || s.cstride % 4 || s.bstride % 4) return 0;
+        if ((reinterpret_cast<uintptr_t>(s.ptr) & 15) || s.rstride % 4 || s.cstride % 4 || s.bstride % 4) return 0;
         if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == p.H && s.W == p.W && (p.W % 4) == 0) return 1;
         if (s.mode == PC_SRC_POOL2 && s.W == 2 * p.W && s.H >= 2 * p.H && (p.W % 4) == 0) return 2;
         return 0;
     };
     const int ma = mode_of(p.a), mbb = mode_of(p.b), mg = mode_of(p.g);
-    p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);      // (fp32 only: the generic kernel's vector paths)
+    p.fast_a = pc_src_fast_mode(p.a, p.H, p.W);      // (the generic kernel's vector paths)
     p.fast_b = pc_src_fast_mode(p.b, p.H, p.W);
     p.fast_g = pc_src_fast_mode(p.g, p.H, p.W) == 1;
     const bool gok = mg == 1;
     const bool lay = p.b.C == 0 || (p.a.bstride == p.b.bstride && p.a.rstride == p.b.rstride);
     if (p.a.mode == PC_SRC_REFLECT && p.b.C == 0 && gok && CINC <= 4) return 3;
-    if (p.bf && (CINC < 8 || (p.W % 8) != 0 || (reinterpret_cast<uintptr_t>(p.g.ptr) & 15) || p.g.rstride % 8 || p.g.cstride % 8 ||
-                 p.g.bstride % 8))
-        return 0;                                      // bf16 wave kernel: 16-byte pieces of 8 gradient pixels
     if (ma == 1 && (p.b.C == 0 || mbb == 1) && lay && gok) return 1;
     if (ma == 2 && p.b.C == 0 && gok) return 2;
     return 0;

@@ -28,19 +28,17 @@ struct CtArgs {
     int B, H, W;           // input resolution
     int groups_x, ngroups;
     pc_fastdiv div_gx, div_gimg;   // by groups_x, by groups per image
-    int bf;                // PC_PREC_BF16: weights rounded to bf16 when loaded, results when stored (popcorn_hip.h)
+    int bf;                // PC_PREC_BF16: the channels-last bf16 kernels
 };
 
 struct CtGroup {
     CtArgs pr[PC_MAX_GROUP];
 };
 
-// BF (all three kernels): PC_PREC_BF16 -- x / g / out / act are bf16 CONTAINERS (typed accessors of common.h), weights are
-// rounded when loaded, the bf16 store rounds the result; the MFMA stays the fp32 one on bf16-representable operands (these
-// kernels are HBM-bound).
-template <int C, bool BF>
+// fp32 kernels (planar tensors); the channels-last bf16 kernels of PC_PREC_BF16 follow below
+template <int C>
 __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
-    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
+    using act_t = float;
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int KS = C / 4, NBK = C / 4;
     const int lane = threadIdx.x & 63;
@@ -57,7 +55,7 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const float wv = p.w[(4 * ks + lk) * 4 * C + ng];
-            bw[ks][nb] = BF ? pc_bf16r(wv) : wv;
+            bw[ks][nb] = wv;
         }
     }
 
@@ -93,7 +91,7 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
             const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
             const int jb = j0 + 4 * lk;
             act_t* op = reinterpret_cast<act_t*>(p.out.ptr) + b * p.out.bstride + co * p.out.cstride + (int64_t)(2 * i + a) * p.out.rstride + 2 * jb + 4 * bb;
-            if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & (BF ? 7 : 15)) == 0)) {
+            if (jb + 3 < p.W && ((p.out.rstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
                 pc_st4(op, v);
             } else {
 #pragma unroll
@@ -106,9 +104,9 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
     }
 }
 
-template <int C, bool BF>
+template <int C>
 __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_) {
-    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
+    using act_t = float;
     const CtArgs& p = grp_.pr[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
 #pragma unroll
     for (int co = 0; co < C; ++co) {
         const float wv = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
-        bw[co] = BF ? pc_bf16r(wv) : wv;
+        bw[co] = wv;
     }
     float e_scale = 1.f, e_shift = 0.f;
     if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
@@ -143,8 +141,8 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_)
             const int j = j0 + 4 * lk;
             act_t* op = reinterpret_cast<act_t*>(p.out.ptr) + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j;
             const act_t* ap = p.act ? reinterpret_cast<const act_t*>(p.act) + b * p.act_bstride + li * p.act_cstride + (int64_t)i * p.act_rstride + j : nullptr;
-            const bool vec = j + 3 < p.W && ((reinterpret_cast<uintptr_t>(op) & (BF ? 7 : 15)) == 0) &&
-                             (!ap || (reinterpret_cast<uintptr_t>(ap) & (BF ? 7 : 15)) == 0);
+            const bool vec = j + 3 < p.W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0) &&
+                             (!ap || (reinterpret_cast<uintptr_t>(ap) & 15) == 0);
             if (vec) {
                 // the lane's 4 consecutive x of one channel row: one 16-byte load of the mask, one 16-byte store
                 f32x4 o = acc;
@@ -425,9 +423,9 @@ bool ct_cl_ok(const CtArgs& p, bool with_g) {
 // both operands use it: lane (., lk) takes pixels 4*lk .. 4*lk+3 of the 16-pixel group, so k-step ks holds pixel 4*lk + ks
 // and a lane's four A values are ONE 16-byte load of x, its four B values the even or odd floats of TWO 16-byte loads of
 // the g row (4 + 4*C/4 scalar gathers before: 12 / 20 four-byte loads per group and lane).
-template <int C, bool VEC, bool BF>
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_) {
-    using act_t = std::conditional_t<BF, pc_bf16_t, float>;
+    using act_t = float;
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
@@ -588,9 +586,9 @@ extern "C" int pc_convt2x2_fwd_group(int n, const pc_convt_fwd_desc* d, int B, i
         if (bf ? !ct_cl_ok(g.pr[i], false) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].out))) return PC_EINVAL;
     }
     if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_fwd_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 16) hipLaunchKernelGGL((convt2x2_fwd_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 16) hipLaunchKernelGGL((convt2x2_fwd_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_fwd_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8) hipLaunchKernelGGL((convt2x2_fwd_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL((convt2x2_fwd_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
@@ -626,9 +624,9 @@ extern "C" int pc_convt2x2_dgrad_group(int n, const pc_convt_dgrad_desc* d, int 
         if (bf ? !ct_cl_ok(g.pr[i], false) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].out) && g.pr[i].act_xstride <= 1)) return PC_EINVAL;
     }
     if (C == 16 && bf) hipLaunchKernelGGL((convt2x2_dgrad_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 16) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 16) hipLaunchKernelGGL((convt2x2_dgrad_kernel<16>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else if (C == 8 && bf) hipLaunchKernelGGL((convt2x2_dgrad_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
-    else if (C == 8) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8, false>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
+    else if (C == 8) hipLaunchKernelGGL((convt2x2_dgrad_kernel<8>), dim3(nwg, n), dim3(256), 0, (hipStream_t)stream, g);
     else return PC_EINVAL;
     PC_CHECK_LAUNCH();
     return 0;
@@ -648,7 +646,7 @@ extern "C" int64_t pc_convt2x2_wgrad_ws_bytes(int C) {
 namespace {
 bool ct_wgrad_vec_ok(const CtArgs& p) {
     auto al = [](const pc_src& s) {
-        return ((reinterpret_cast<uintptr_t>(s.ptr) & (s.dtype == PC_BF16 ? 7 : 15)) == 0) && s.rstride % 4 == 0 && s.cstride % 4 == 0 &&
+        return ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && s.rstride % 4 == 0 && s.cstride % 4 == 0 &&
                s.bstride % 4 == 0;
     };
     return p.W % 16 == 0 && al(p.x) && al(p.g);
@@ -668,11 +666,11 @@ int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t s
         PC_CHECK_LAUNCH();
         return 0;
     }
-#define PC_CTW(CC, VV, BB) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV, BB>), dim3(nwg, n), dim3(256), 0, st, g)
+#define PC_CTW(CC, VV) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV>), dim3(nwg, n), dim3(256), 0, st, g)
     if (C == 16) {
-        if (vec) PC_CTW(16, true, false); else PC_CTW(16, false, false);
+        if (vec) PC_CTW(16, true); else PC_CTW(16, false);
     } else if (C == 8) {
-        if (vec) PC_CTW(8, true, false); else PC_CTW(8, false, false);
+        if (vec) PC_CTW(8, true); else PC_CTW(8, false);
     } else return PC_EINVAL;
 #undef PC_CTW
     PC_CHECK_LAUNCH();

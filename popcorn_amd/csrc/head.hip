@@ -60,21 +60,21 @@ __device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
         const float t = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)];
-        lds[L_A1 + e] = p.bf ? pc_bf16r(t) : t;
+        lds[L_A1 + e] = t;
     }
     for (int e = tid; e < 64 * 64; e += blockDim.x) {
         const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8, mb = f & 3, mb2 = f >> 2;
         const int col = 16 * mb + 4 * (lane >> 4) + r;
         const int row = 16 * mb2 + (lane & 15);
         const float t2 = p.w2[row * HID + col], t4 = p.w4[row * HID + col];
-        lds[L_A2 + e] = p.bf ? pc_bf16r(t2) : t2;
-        lds[L_A3 + e] = p.bf ? pc_bf16r(t4) : t4;
+        lds[L_A2 + e] = t2;
+        lds[L_A3 + e] = t4;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[L_B0 + e] = p.b0[e];
         lds[L_B2 + e] = p.b2[e];
         lds[L_B4 + e] = p.b4[e];
-        lds[L_W6 + e] = p.bf ? pc_bf16r(p.w6[e]) : p.w6[e];   // row 0 of the [2][64] last layer: only channel 0 is used (popcorn.py:162,164)
+        lds[L_W6 + e] = p.w6[e];   // row 0 of the [2][64] last layer: only channel 0 is used (popcorn.py:162,164)
     }
     if (tid == 0) lds[L_W6 + 64] = p.b6[0];
 }
@@ -109,19 +109,14 @@ __device__ __forceinline__ void head_layer1(const float* lds, int a_off, int b_o
     }
 }
 
-__device__ __forceinline__ void relu4(f32x4 (&h)[4], int bf = 0) {
+__device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
-    if (bf) {       // bf16 mode: the hidden activation is an operand of the next layer
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h[mb] = pc_bf16r4(h[mb]);
-    }
 }
 
-// BF: PC_PREC_BF16 rounding points as a separate instantiation (a run-time flag in this loop cost the fp32 kernel 9 %)
-template <bool BF>
+// fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     head_stage_weights(lds, p);
@@ -167,11 +162,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         if (__any(sel)) {
             f32x4 h[4], acc[4];
             head_layer1(lds, L_A1, L_B0, lane, lk, xv, h);
-            relu4(h, BF);
+            relu4(h);
             head_layer64(lds, L_A2, L_B2, lane, lk, h, acc);
-            relu4(acc, BF);
+            relu4(acc);
             head_layer64(lds, L_A3, L_B4, lane, lk, acc, h);
-            relu4(h, BF);
+            relu4(h);
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -351,20 +346,20 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
         const int col = 16 * mi + (l & 15);                           // i
         const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
-        lds[LB_T3 + e] = p.bf ? pc_bf16r(t4) : t4;
-        lds[LB_T2 + e] = p.bf ? pc_bf16r(t2) : t2;
+        lds[LB_T3 + e] = t4;
+        lds[LB_T2 + e] = t2;
     }
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
         const int row = 16 * mb + 4 * (l >> 4) + r;
         const float t0 = p.w0[row * 16 + (l & 15)];
-        lds[LB_T1 + e] = p.bf ? pc_bf16r(t0) : t0;
+        lds[LB_T1 + e] = t0;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[LB_B0 + e] = p.b0[e];
         lds[LB_B2 + e] = p.b2[e];
         lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = p.bf ? pc_bf16r(p.w6[e]) : p.w6[e];
+        lds[LB_W6 + e] = p.w6[e];
     }
     if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
     __syncthreads();
@@ -421,11 +416,11 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         // ---- forward recompute
         f32x4 h1[4], h2[4], h3[4];
         head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-        relu4(h1, p.bf);
+        relu4(h1);
         head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
-        relu4(h2, p.bf);
+        relu4(h2);
         head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
-        relu4(h3, p.bf);
+        relu4(h3);
         float s = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -448,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                g3[mb][r] = h3[mb][r] > 0.f ? (p.bf ? pc_bf16r(w[r] * gout) : w[r] * gout) : 0.f;
+                g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
                 db4[mb][r] += g3[mb][r];
             }
         }
@@ -463,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g2[mb][r] = h2[mb][r] > 0.f ? (p.bf ? pc_bf16r(g2[mb][r]) : g2[mb][r]) : 0.f;
+                g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
                 db2[mb][r] += g2[mb][r];
             }
         // ---- layer 2 (W2)
@@ -477,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g1[mb][r] = h1[mb][r] > 0.f ? (p.bf ? pc_bf16r(g1[mb][r]) : g1[mb][r]) : 0.f;
+                g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
                 db0[mb][r] += g1[mb][r];
             }
         // ---- layer 1 (W0: 64 x 16)
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
                     const float fv = fvv[r];
                     o = fv > 0.f ? o * fscale[r] : 0.f;
                 }
-                op[(4 * lk + r) * a.g_feat.cstride] = p.bf ? pc_bf16r(o) : o;
+                op[(4 * lk + r) * a.g_feat.cstride] = o;
             }
         }
     }
@@ -594,7 +589,6 @@ constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is sha
 constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
 constexpr int LP_END = LP_FLAGS + 16;
 
-template <bool BF>
 __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const HeadArgs& p = a.f;
@@ -609,20 +603,20 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
         const int col = 16 * mi + (l & 15);                           // i
         const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
-        lds[LB_T3 + e] = BF ? pc_bf16r(t4) : t4;
-        lds[LB_T2 + e] = BF ? pc_bf16r(t2) : t2;
+        lds[LB_T3 + e] = t4;
+        lds[LB_T2 + e] = t2;
     }
     for (int e = tid; e < 16 * 64; e += blockDim.x) {
         const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
         const int row = 16 * mb + 4 * (l >> 4) + r;
         const float t0 = p.w0[row * 16 + (l & 15)];
-        lds[LB_T1 + e] = BF ? pc_bf16r(t0) : t0;
+        lds[LB_T1 + e] = t0;
     }
     for (int e = tid; e < 64; e += blockDim.x) {
         lds[LB_B0 + e] = p.b0[e];
         lds[LB_B2 + e] = p.b2[e];
         lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = BF ? pc_bf16r(p.w6[e]) : p.w6[e];
+        lds[LB_W6 + e] = p.w6[e];
     }
     if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
     int* flags = reinterpret_cast<int*>(lds + LP_FLAGS);
@@ -733,11 +727,11 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             if (!__any(sel)) { store_zero(); continue; }
             f32x4 h1[4], h2[4], h3[4];
             head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-            relu4(h1, BF);
+            relu4(h1);
             head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
-            relu4(h2, BF);
+            relu4(h2);
             head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
-            relu4(h3, BF);
+            relu4(h3);
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -759,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                    g3[mb][r] = h3[mb][r] > 0.f ? (BF ? pc_bf16r(w[r] * gout) : w[r] * gout) : 0.f;
+                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
                 }
             }
             if (!(a.dbg & 2)) {   // slot kind 0: (G3, H2) -> dW4, db4
@@ -772,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? (BF ? pc_bf16r(g2[mb][r]) : g2[mb][r]) : 0.f;
+                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
             if (!(a.dbg & 2)) {   // slot kind 1: (G2, H1) -> dW2, db2
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g2);
@@ -783,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? (BF ? pc_bf16r(g1[mb][r]) : g1[mb][r]) : 0.f;
+                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
             if (!(a.dbg & 2)) {   // slot kind 2: (G1, X) -> dW0, db0
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g1);
@@ -810,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 for (int r = 0; r < 4; ++r) {
                     float o = gx[r];
                     if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                    op[(4 * lk + r) * a.g_feat.cstride] = BF ? pc_bf16r(o) : o;
+                    op[(4 * lk + r) * a.g_feat.cstride] = o;
                 }
             }
         }
@@ -1982,7 +1976,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     static int resident = 0;
     if (!resident) {
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel<false>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
     }
@@ -1997,7 +1991,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     // bf16 mode: the feature map is a channels-last bf16 tensor (16 contiguous channels per pixel); fp32 mode: planar fp32
     if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
-    else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
+    else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
                        p.nchunk, stats, nsel_counts, (double)B * H * W);
@@ -2145,7 +2139,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel<false>),
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
@@ -2158,7 +2152,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         bf_attr = true;
     }
     if (p.bf) hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nwg), dim3(256), HB_RED, st, a);
-    else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel<false>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
     HeadReduceArgs r{};

@@ -25,7 +25,7 @@ static inline int pc_src_fast_mode(const pc_src& s, int H, int W) {
 
 template <int RS, int CS, int COL0, bool VEC_STORE>
 __device__ __forceinline__ void pc_load_row_job(float* lds, const pc_src& s, int fast, int b, int c, int ci, int r,
-                                                int y0, int x0, int H, int W, int lane16, bool bf = false) {
+                                                int y0, int x0, int H, int W, int lane16) {
     const int y = y0 - 1 + r;
     float* dst = lds + ci * CS + r * RS + COL0;
     if (lane16 < 8) {
@@ -48,7 +48,6 @@ __device__ __forceinline__ void pc_load_row_job(float* lds, const pc_src& s, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = pc_fetch(s, b, c, y, x + e, H, W);
         }
-        if (bf) v = pc_bf16r4(v);
         if (VEC_STORE) {
             *reinterpret_cast<f32x4*>(dst + 4 * lane16) = v;
         } else {
@@ -57,24 +56,24 @@ __device__ __forceinline__ void pc_load_row_job(float* lds, const pc_src& s, int
         }
     } else if (lane16 == 8) {
         const float t = pc_fetch(s, b, c, y, x0 - 1, H, W);
-        dst[-1] = bf ? pc_bf16r(t) : t;
+        dst[-1] = t;
     } else if (lane16 == 9) {
         const float t = pc_fetch(s, b, c, y, x0 + 32, H, W);
-        dst[32] = bf ? pc_bf16r(t) : t;
+        dst[32] = t;
     }
 }
 
 // channels [c_begin, c_begin + NCH) of cat[A, B] -> lds[ci][r][COL0 + (x - x0)], rows y0-1 .. y0+16, cols x0-1 .. x0+32
 template <int NCH, int RS, int CS, int COL0, bool VEC_STORE>
 __device__ __forceinline__ void pc_load_halo_tile(float* lds, const pc_src& A, const pc_src& Bs, int fastA, int fastB,
-                                                  int c_begin, int b, int y0, int x0, int H, int W, int tid, bool bf = false) {
+                                                  int c_begin, int b, int y0, int x0, int H, int W, int tid) {
     const int lane16 = tid & 15, grp = tid >> 4;
     const int CA = A.C;
     for (int job = grp; job < NCH * 18; job += 16) {
         const int ci = job / 18, r = job - ci * 18;
         const int cg = c_begin + ci;
-        if (cg < CA) pc_load_row_job<RS, CS, COL0, VEC_STORE>(lds, A, fastA, b, cg, ci, r, y0, x0, H, W, lane16, bf);
-        else pc_load_row_job<RS, CS, COL0, VEC_STORE>(lds, Bs, fastB, b, cg - CA, ci, r, y0, x0, H, W, lane16, bf);
+        if (cg < CA) pc_load_row_job<RS, CS, COL0, VEC_STORE>(lds, A, fastA, b, cg, ci, r, y0, x0, H, W, lane16);
+        else pc_load_row_job<RS, CS, COL0, VEC_STORE>(lds, Bs, fastB, b, cg - CA, ci, r, y0, x0, H, W, lane16);
     }
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
         for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
 }
 
-// fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_kernel below, channels-last bf16 feature map)
+// fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     head_stage_weights(lds, p);
@@ -967,18 +967,15 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 }
 
 // ---- bf16 mode (PC_PREC_BF16): the head on v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 ---------------------------------------
-// The 64-wide contractions take 2 instructions of K = 32 instead of 16 fp32 ones, so the matrix pipe stops being the limit and
-// the structure changes: ONE role, no LDS hand-off.  The trick that removes the hand-off: a layer computed as
-// D = mfma(A = W fragment, B = packed activations) leaves lane = pixel, registers = hidden units (the operand layout of the
-// NEXT layer); the same two operands swapped, D' = mfma(A = packed activations, B = W fragment), give the transpose: lane =
-// hidden unit, registers = 4 consecutive pixels -- exactly the operand layout of the weight-gradient GEMM dW = G . H^T
-// (contraction over pixels, 16x16x16, K-slots (lk, j) = pixel 4*lk + j).  In bf16 the second orientation costs 36 cheap
-// instructions per 16 pixels and saves the 192 LDS writes + 48 reads + two counters of the producer / consumer ring.
+// The 64-wide contractions take 2 instructions of K = 32 instead of 16 fp32 ones, so the matrix pipe stops being the limit.
+// A layer computed as D = mfma(A = W fragment, B = packed activations) leaves lane = pixel, registers = hidden units -- the
+// operand layout of the NEXT layer, so the forward and backward chains stay in registers; the weight gradients (contraction
+// over pixels) take their operands through an LDS exchange and transposing reads (head_bwd_bf16_coop_kernel).
 // K-slot conventions (identical for both operands, so the hardware's internal K order is irrelevant):
 //   64-wide contraction, instruction t of 2:  slot (lk, j) -> hidden unit 16*(2t + (j >> 2)) + 4*lk + (j & 3)
 //       (= D-layout registers h[2t][0..3], h[2t+1][0..3] of the lane, packed in order)
 //   16-wide feature contraction (layer 1):    slot (lk, j) -> feature channel 4*j + lk       (the gather order of `fetch`)
-//   16-pixel contraction (weight gradients):  slot (lk, j) -> pixel 4*lk + j
+//   32-pixel contraction (weight gradients):  slot (lk, j) -> pixel 8*lk + j of a pair of 16-pixel groups
 typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
 typedef short hs16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
@@ -991,7 +988,6 @@ constexpr int HB_T2 = HB_T3 + 8 * 64 * 16;        // same for W2
 constexpr int HB_T1 = HB_T2 + 8 * 64 * 16;        // [2 t][64][8]               W0[unit(t,lk,j)][c = i]
 constexpr int HB_F32 = HB_T1 + 2 * 64 * 16;       // floats: b0[64] b2[64] b4[64] w6[64] (rounded) b6
 constexpr int HB_END = HB_F32 + (4 * 64 + 4) * 4;
-constexpr int HB_RED = 16384 * 4;                 // the cross-wave reduction tail reuses the buffer: 4 x 4096 floats
 
 __device__ __forceinline__ int hb_unit(int t, int lk, int j) { return 16 * (2 * t + (j >> 2)) + 4 * lk + (j & 3); }
 
@@ -1045,22 +1041,16 @@ __device__ __forceinline__ hs16x4 hb_frag4(const unsigned char* lds, int off, in
     return __builtin_bit_cast(hs16x4, *reinterpret_cast<const uint2*>(lds + off + blk * 512 + lane * 8));
 }
 
-// one 64 -> 64 layer in both orientations.  hb[t]: packed input (lane = pixel).  o1[mb2]: D = W . h (lane = pixel, regs =
-// hidden 16*mb2 + 4*lk + r), initialised with the bias; o2[mb2] (optional): the transpose (lane = hidden 16*mb2 + li, regs =
-// pixels 4*lk + r), initialised with the per-lane bias bo2[mb2].
-template <bool O2>
+// one 64 -> 64 layer.  hb[t]: packed input (lane = pixel).  o1[mb2]: D = W . h (lane = pixel, regs = hidden 16*mb2 + 4*lk + r),
+// initialised with the bias.
 __device__ __forceinline__ void hb_layer64(const unsigned char* lds, int a_off, const float* bias, int lane, int lk,
-                                           const hbf16x8 (&hb)[2], f32x4 (&o1)[4], f32x4 (&o2)[4], const float (&bo2)[4]) {
+                                           const hbf16x8 (&hb)[2], f32x4 (&o1)[4]) {
 #pragma unroll
     for (int mb2 = 0; mb2 < 4; ++mb2) {
         o1[mb2] = *reinterpret_cast<const f32x4*>(&bias[16 * mb2 + 4 * lk]);
-        if (O2) o2[mb2] = f32x4{bo2[mb2], bo2[mb2], bo2[mb2], bo2[mb2]};      // accumulators of both orientations start from the bias
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const hbf16x8 w = hb_frag8(lds, a_off, mb2, t, lane);
-            o1[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hb[t], o1[mb2], 0, 0, 0);
-            if (O2) o2[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb[t], w, o2[mb2], 0, 0, 0);
-        }
+        for (int t = 0; t < 2; ++t)
+            o1[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(lds, a_off, mb2, t, lane), hb[t], o1[mb2], 0, 0, 0);
     }
 }
 
@@ -1114,7 +1104,7 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
         if (__any(sel)) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));          // opaque: keeps the fragment reads in the loop
-            f32x4 h[4], acc[4], dummy[4];
+            f32x4 h[4], acc[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 h[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
@@ -1122,11 +1112,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
             }
             hb_relu_round(h);
             hbf16x8 hb[2] = {hb_pack8(h[0], h[1]), hb_pack8(h[2], h[3])};
-            const float nob[4] = {0.f, 0.f, 0.f, 0.f};
-            hb_layer64<false>(ldsb, HB_A2, lf + 64, lane_o, lk, hb, acc, dummy, nob);
+            hb_layer64(ldsb, HB_A2, lf + 64, lane_o, lk, hb, acc);
             hb_relu_round(acc);
             hb[0] = hb_pack8(acc[0], acc[1]); hb[1] = hb_pack8(acc[2], acc[3]);
-            hb_layer64<false>(ldsb, HB_A3, lf + 128, lane_o, lk, hb, h, dummy, nob);
+            hb_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb, h);
             hb_relu_round(h);
             float s = 0.f;
 #pragma unroll
@@ -1160,25 +1149,56 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     }
 }
 
-// backward, one role per wave, both orientations (see the header of this section).  Same outputs and workgroup-partial
-// layout as head_bwd_pc_kernel (head_bwd_reduce_kernel finishes both).
-__global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs a) {
+// ---- bf16 backward, cooperative form -------------------------------------------------------------------------------------
+// The first bf16 kernel kept all 160 weight-gradient accumulator registers in every wave and computed every chain twice (a
+// second, transposed orientation: mfma with swapped operands) to get their operands: one wave per SIMD, 116 MFMAs and two sets
+// of bias / ReLU / pack epilogues per 16 pixels, nothing to overlap with (198 us per launch at B = 64; this one 118 us).
+// Here the 8 waves of a workgroup SHARE the weight gradients: every wave runs the
+// forward + backward chain of its own 16-pixel group in the first orientation only (lane = pixel), writes the packed
+// operands H1, H2, G3, G2, G1, X as [pixel][channel] rows into its slot of an LDS exchange area, and after a barrier
+// accumulates only ITS blocks of dW4 / dW2 / dW0 (2 + 2 + at most 1 of the 36 16x16 blocks) over all 8 groups = 128 pixels:
+// the contraction over pixels takes both operands through ds_read_b64_tr_b16 ([4 pixels][16 channels] -> lane = channel,
+// 4 pixels), K = 32 pixels per v_mfma_f32_16x16x32_bf16.  Per wave and group: 38 chain + 18 weight-gradient MFMAs, 36
+// accumulator registers, two waves per SIMD.  Bias gradients are row sums of the same A operands.
+constexpr int HC_ROW = 136;                       // bytes per pixel row of a 64-channel exchange tensor (128 + 8: the 16 pixel rows of a
+                                                  // lane group hit 16 different bank pairs when written)
+constexpr int HC_T = 16 * HC_ROW;                 // one tensor of one group
+constexpr int HC_H1 = 0, HC_H2 = HC_T, HC_G3 = 2 * HC_T, HC_G2 = 3 * HC_T, HC_G1 = 4 * HC_T, HC_X = 5 * HC_T;
+constexpr int HC_XROW = 40;                       // bytes per pixel row of the 16 feature channels
+constexpr int HC_SLOT = HC_X + 16 * HC_XROW;      // 11520 bytes per group
+constexpr int HC_WAVES = 8;
+constexpr int HC_EX = (HB_END + 15) & ~15;        // exchange area behind the weight images
+constexpr int HC_END = HC_EX + HC_WAVES * HC_SLOT;
+
+__device__ __forceinline__ hs16x4 hc_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(p));
+}
+__device__ __forceinline__ hbf16x8 hc_pair(hs16x4 a, hs16x4 b) {
+    return __builtin_bit_cast(hbf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ float hc_sum4(hs16x4 v) {
+    const uint2 q = __builtin_bit_cast(uint2, v);
+    return (__uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xffff0000u)) + (__uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const HeadArgs& p = a.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     head_stage_weights_bf16(ldsb, p, true);
+    // the exchange area starts as zeros: a slot that was never written must not feed NaN bit patterns into 0 * x
+    for (int e = tid; e < HC_WAVES * HC_SLOT / 16; e += 512) reinterpret_cast<uint4*>(ldsb + HC_EX)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
     float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
     const int HW = p.H * p.W;
 
     if (a.zero_in_kernel) {
-        // padding frame of g_feat (the crop is written below, zeros included): one (b, c, row) job per half-wave
+        // padding frame of the channels-last gradient map (the crop is written below, zeros included): one (b, row) job per half-wave
         const int Hp = a.Hp, Wp = a.Wp;
         const int l32 = tid & 31;
-        const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + (tid >> 5);
-        // channels-last: a pixel is two 16-byte pieces; one (b, row) job per half-wave
+        const int nhw = gridDim.x * 16, hw = blockIdx.x * 16 + (tid >> 5);
         const int njobs = p.B * Hp;
         const int right0 = p.px + p.W;
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
@@ -1199,16 +1219,15 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         }
     }
 
-    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4];
-    float dbs[3][4];
+    // ---- this wave's blocks: dW4 / dW2 blocks (mb = wave >> 1, nb = 2 * (wave & 1) + {0, 1}); dW0 block mb = wave for waves 0..3
+    const int my_mb = wave >> 1, my_nb0 = 2 * (wave & 1);
+    f32x4 dW4[2], dW2[2], dW0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    dW4[0] = dW4[1] = dW2[0] = dW2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db4 = 0.f, db2 = 0.f, db0 = 0.f;         // row sums of G3 / G2 / G1 for hidden unit 16 * mb + li (even waves / waves 0..3)
+    f32x4 dw6[4];
     float db6 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dW0[i] = dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < 4; ++i) dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
     float fscale[4];
 #pragma unroll
@@ -1220,18 +1239,16 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
             pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
         }
     }
-    // biases in the second orientation are per lane (hidden unit 16*mb + li)
-    float b0o2[4], b2o2[4], b4o2[4], w6o2[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        b0o2[mb] = lf[16 * mb + li]; b2o2[mb] = lf[64 + 16 * mb + li]; b4o2[mb] = lf[128 + 16 * mb + li]; w6o2[mb] = lf[192 + 16 * mb + li];
-    }
-    // pixel quads 4*lk .. 4*lk+3 of a group never straddle a row, and start at an even element (dword loads of bf16 pairs)
-    const bool quad_ok = (p.W & 3) == 0;
+    unsigned char* const ex = ldsb + HC_EX;
+    unsigned char* const my = ex + wave * HC_SLOT;
+    // transposing reads: lane supplies pixel row j = li >> 2 and column quad q = li & 3 of a [4 pixels][16 channels] block;
+    // k-group lk = pixels 8 * lk .. + 7 of a 32-pixel pair of groups
+    const int t_off = (lk >> 1) * HC_SLOT + (8 * (lk & 1) + (li >> 2)) * HC_ROW + 8 * (li & 3);
+    const int t_offx = (lk >> 1) * HC_SLOT + HC_X + (8 * (lk & 1) + (li >> 2)) * HC_XROW + 8 * (li & 3);
 
     // per-group inputs, fetched one group ahead
-    float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
-    f32x4 n_xq = f32x4{0.f, 0.f, 0.f, 0.f};    // second orientation: feature channel li, pixels 4*lk .. +3
+    float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
+    uint2 n_f4 = make_uint2(0u, 0u);
     unsigned n_msk = 1;
     auto fetch = [&](int gg) {
         const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
@@ -1239,298 +1256,250 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(const HeadBwdArgs
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
         const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-        const pc_bf16_t* fbase = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr);
-        const int fxs = p.feat.xstride;
-        const pc_bf16_t* fp = fbase + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + (int64_t)(p.px + x) * fxs;
+        const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride +
+                              (int64_t)(p.px + x) * p.feat.xstride;
 #pragma unroll
         for (int j = 0; j < 4; ++j) n_xv[j] = pc_ld1(fp + 4 * j + lk);
-        {
-            const f32x4 f4 = pc_ld4(fp + 4 * lk);          // channels 4*lk .. +3 of the pixel: one 8-byte load
-#pragma unroll
-            for (int j = 0; j < 4; ++j) n_fv[j] = !a.fuse_feat_bn ? 1.f : f4[j];
-        }
+        n_f4 = *reinterpret_cast<const uint2*>(fp + 4 * lk);          // channels 4*lk .. +3: mask of the fused ReLU backward AND the dW0 operand
         n_msk = p.mask ? p.mask[pix] : 1;
         n_bld = p.building[pix];
         if (p.admin) n_adm = p.admin[pix];
         if (a.g_popdense) n_gpd = a.g_popdense[pix];
         if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
-        // the same features with pixels in the registers: channel li, pixels q2 .. q2+3
-        const int q2 = g * 16 + 4 * lk;
-        if (quad_ok) {
-            const bool v2 = q2 < HW;
-            const int y2 = v2 ? (int)pc_div((uint32_t)q2, p.div_w) : 0, x2 = v2 ? q2 - y2 * p.W : 0;
-            // four consecutive pixels of one row, channel li
-            const pc_bf16_t* q2p = fbase + b * p.feat.bstride + (int64_t)(p.py + y2) * p.feat.rstride + (int64_t)(p.px + x2) * fxs + li;
-            const float t0 = pc_ld1(q2p), t1 = pc_ld1(q2p + fxs), t2 = pc_ld1(q2p + 2 * fxs), t3 = pc_ld1(q2p + 3 * fxs);
-            n_xq = v2 ? f32x4{t0, t1, t2, t3} : f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int qq = q2 + e;
-                const bool vv = qq < HW;
-                const int yy = vv ? (int)pc_div((uint32_t)qq, p.div_w) : 0, xx = vv ? qq - yy * p.W : 0;
-                const float t = pc_ld1(fbase + b * p.feat.bstride + (int64_t)(p.py + yy) * p.feat.rstride + (int64_t)(p.px + xx) * fxs + li);
-                n_xq[e] = vv ? t : 0.f;
-            }
-        }
     };
-    const int gstep = gridDim.x * 4;
-    int gg = blockIdx.x * 4 + wave;
+    const int gstep = gridDim.x * HC_WAVES;
+    const int niter = (a.total_groups + gstep - 1) / gstep;
+    int gg = blockIdx.x * HC_WAVES + wave;
     if (gg < a.total_groups) fetch(gg);
-    for (; gg < a.total_groups; gg += gstep) {
-        const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
-        const int q = g * 16 + li;
-        const bool valid = q < HW;
-        const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-        const bool sel = valid && n_msk != 0;
-        float xv[4], fvv[4];
+    for (int it = 0; it < niter; ++it, gg += gstep) {
+        const bool live = gg < a.total_groups;
+        bool wrote = false;
+        if (live) {
+            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+            const int q = g * 16 + li;
+            const bool valid = q < HW;
+            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
+            const bool sel = valid && n_msk != 0;
+            float xv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = valid ? n_fv[j] : 1.f; }
-        const f32x4 xq = n_xq;
-        float gup = 0.f;
-        if (sel) {
-            const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
-            gup = gsc;
-            if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
-            if (a.g_popdense) gup += n_gpd * n_bld;
-            if (a.g_scale_map) gup += n_gsm;
-        }
-        if (gg + gstep < a.total_groups) fetch(gg + gstep);
-        auto store_zero = [&]() {
-            if (a.zero_in_kernel && valid)
-                *reinterpret_cast<uint2*>(reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride +
-                                          (int64_t)(p.px + x) * a.g_feat.xstride + 4 * lk) = make_uint2(0u, 0u);
-        };
-        if (!__any(sel)) { store_zero(); continue; }
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));              // opaque: keeps the weight-fragment reads inside the loop
-
-        // ---- forward, both orientations.  h*: lane = pixel; H*: lane = hidden unit, registers = pixels 4*lk + r.
-        // Only what the backward needs stays live, and in its packed form: hb1 / hb2 (operands of the next layer AND the ReLU
-        // masks of this one: a post-ReLU bf16 is positive iff its bits are non-zero), H1p / H2p (operands of the weight-
-        // gradient GEMMs and masks of the second orientation), h3 in fp32 (dw6), a 16-bit mask of H3.
-        const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
-        hbf16x8 hb1[2], hb2[2];
-        hs16x4 H1p[4], H2p[4];
-        f32x4 h3[4];
-        unsigned M3 = 0;
-        {
-            f32x4 h1[4], H1[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const hs16x4 w = hb_frag4(ldsb, HB_A1, mb, lane_o);
-                h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
-                h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, xb, h1[mb], 0, 0, 0);
-                H1[mb] = f32x4{b0o2[mb], b0o2[mb], b0o2[mb], b0o2[mb]};
-                H1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xb, w, H1[mb], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) xv[j] = valid ? n_xv[j] : 0.f;
+            const uint2 f4 = valid ? n_f4 : make_uint2(0u, 0u);
+            float gup = 0.f;
+            if (sel) {
+                const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
+                gup = gsc;
+                if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
+                if (a.g_popdense) gup += n_gpd * n_bld;
+                if (a.g_scale_map) gup += n_gsm;
             }
+            if (gg + gstep < a.total_groups) fetch(gg + gstep);
+            pc_bf16_t* const gxp = reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride +
+                                   (int64_t)(p.px + x) * a.g_feat.xstride + 4 * lk;
+            bool active = __any(sel);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));              // opaque: keeps the weight-fragment reads inside the loop
+            hbf16x8 hb1[2], hb2[2];
+            f32x4 h3[4];
+            float gout = 0.f;
+            if (active) {
+                // ---- forward chain (lane = pixel, registers = hidden 16*mb + 4*lk + r)
+                const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
+                {
+                    f32x4 h1[4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+                    for (int mb = 0; mb < 4; ++mb) {
+                        h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
+                        h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb_frag4(ldsb, HB_A1, mb, lane_o), xb, h1[mb], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { h1[mb][r] = fmaxf(h1[mb][r], 0.f); H1[mb][r] = fmaxf(H1[mb][r], 0.f); }
-            hb1[0] = hb_pack8(h1[0], h1[1]); hb1[1] = hb_pack8(h1[2], h1[3]);            // the pack rounds to bf16
+                        for (int r = 0; r < 4; ++r) h1[mb][r] = fmaxf(h1[mb][r], 0.f);
+                    }
+                    hb1[0] = hb_pack8(h1[0], h1[1]); hb1[1] = hb_pack8(h1[2], h1[3]);            // the pack rounds to bf16
+                }
+                {
+                    f32x4 h2[4];
+                    hb_layer64(ldsb, HB_A2, lf + 64, lane_o, lk, hb1, h2);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) H1p[mb] = hb_pack4(H1[mb][0], H1[mb][1], H1[mb][2], H1[mb][3]);
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h2[mb][r] = fmaxf(h2[mb][r], 0.f);
+                    hb2[0] = hb_pack8(h2[0], h2[1]); hb2[1] = hb_pack8(h2[2], h2[3]);
+                    hb_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb2, h3);
+                    hb_relu_round(h3);
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
+                }
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float outv = s + lf[256];
+                gout = (sel && outv > 0.f) ? gup : 0.f;
+                active = __any(gout != 0.f);
+            }
+            if (active) {
+                auto nz8 = [](const hbf16x8& v, int e) { return ((__builtin_bit_cast(hu32x4, v)[e >> 1] >> (16 * (e & 1))) & 0xffffu) != 0u; };
+                if (lk == 0) db6 += gout;
+                // ---- backward chain: G3 = relu'(h3) . w6 . gout;  G2 = relu'(h2) . (W4^T G3);  G1 = relu'(h1) . (W2^T G2);  g_x = W0^T G1
+                hbf16x8 gb3[2], gb2[2], gb1[2];
+                {
+                    f32x4 g3[4];
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                            g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                        }
+                    }
+                    gb3[0] = hb_pack8(g3[0], g3[1]); gb3[1] = hb_pack8(g3[2], g3[3]);
+                }
+                {
+                    f32x4 g2[4];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            g2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T3, mi, t, lane_o), gb3[t], g2[mi], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g2[mi][r] = nz8(hb2[mi >> 1], 4 * (mi & 1) + r) ? g2[mi][r] : 0.f;
+                    }
+                    gb2[0] = hb_pack8(g2[0], g2[1]); gb2[1] = hb_pack8(g2[2], g2[3]);
+                }
+                {
+                    f32x4 g1[4];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            g1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T2, mi, t, lane_o), gb2[t], g1[mi], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g1[mi][r] = nz8(hb1[mi >> 1], 4 * (mi & 1) + r) ? g1[mi][r] : 0.f;
+                    }
+                    gb1[0] = hb_pack8(g1[0], g1[1]); gb1[1] = hb_pack8(g1[2], g1[3]);
+                }
+                f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T1, 0, t, lane_o), gb1[t], gx, 0, 0, 0);
+                if (valid) {
+                    const f32x4 fv = f32x4{__uint_as_float(f4.x << 16), __uint_as_float(f4.x & 0xffff0000u), __uint_as_float(f4.y << 16),
+                                           __uint_as_float(f4.y & 0xffff0000u)};
+                    f32x4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float o = gx[r];
+                        if (a.fuse_feat_bn) o = fv[r] > 0.f ? o * fscale[r] : 0.f;
+                        o4[r] = o;
+                    }
+                    pc_st4(gxp, o4);
+                }
+                // ---- operands of the weight gradients into this wave's slot: rows = pixels, 8-byte pieces of 4 channels
+                // (pack t holds hidden 16*(2t) + 4*lk .. +3 and 16*(2t+1) + 4*lk .. +3)
+                auto put = [&](int tensor, const hbf16x8 (&v)[2]) {
+                    unsigned char* d = my + tensor + li * HC_ROW + 8 * lk;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const hu32x4 q4 = __builtin_bit_cast(hu32x4, v[t]);
+                        *reinterpret_cast<uint2*>(d + 32 * (2 * t)) = make_uint2(q4[0], q4[1]);
+                        *reinterpret_cast<uint2*>(d + 32 * (2 * t + 1)) = make_uint2(q4[2], q4[3]);
+                    }
+                };
+                put(HC_H1, hb1); put(HC_H2, hb2); put(HC_G3, gb3); put(HC_G2, gb2); put(HC_G1, gb1);
+                *reinterpret_cast<uint2*>(my + HC_X + li * HC_XROW + 8 * lk) = f4;
+                wrote = true;
+            } else if (a.zero_in_kernel && valid) {
+                *reinterpret_cast<uint2*>(gxp) = make_uint2(0u, 0u);
+            }
         }
-        {
-            f32x4 h2[4], H2[4];
-            hb_layer64<true>(ldsb, HB_A2, lf + 64, lane_o, lk, hb1, h2, H2, b2o2);
+        if (!wrote) {
+            // nothing to contribute: zero gradients in the slot (the H / X rows of an earlier group stay: finite values times zero)
+            const uint2 z2 = make_uint2(0u, 0u);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int tz = 0; tz < 3; ++tz) {
+                unsigned char* d = my + HC_G3 + tz * HC_T + li * HC_ROW + 8 * lk;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { h2[mb][r] = fmaxf(h2[mb][r], 0.f); H2[mb][r] = fmaxf(H2[mb][r], 0.f); }
-            hb2[0] = hb_pack8(h2[0], h2[1]); hb2[1] = hb_pack8(h2[2], h2[3]);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) H2p[mb] = hb_pack4(H2[mb][0], H2[mb][1], H2[mb][2], H2[mb][3]);
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(d + 32 * k) = z2;
+            }
         }
-        {
-            f32x4 H3[4];
-            hb_layer64<true>(ldsb, HB_A3, lf + 128, lane_o, lk, hb2, h3, H3, b4o2);
-            hb_relu_round(h3);
+        __syncthreads();
+        // ---- weight gradients over the 8 groups: 4 K-steps of 32 pixels (slots 2*ks, 2*ks + 1)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned char* base = ex + 2 * ks * HC_SLOT;
+            {
+                const unsigned char* ap = base + HC_G3 + t_off + 32 * my_mb;
+                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
+                const hbf16x8 av = hc_pair(lo, hi);
+                if ((wave & 1) == 0) db4 += hc_sum4(lo) + hc_sum4(hi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) M3 |= (pc_bf16r(H3[mb][r]) > 0.f ? 1u : 0u) << (4 * mb + r);
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float outv = s + lf[256];
-        const float gout = (sel && outv > 0.f) ? gup : 0.f;
-        if (!__any(gout != 0.f)) { store_zero(); continue; }
-
-        // masks out of the packed operands: element e of an 8-pack (o1: hidden 16*(2t + (e >> 2)) + 4*lk + (e & 3)) / of a 4-pack
-        auto nz8 = [](const hbf16x8& v, int e) { return ((__builtin_bit_cast(hu32x4, v)[e >> 1] >> (16 * (e & 1))) & 0xffffu) != 0u; };
-        auto nz4 = [](const hs16x4& v, int e) { const uint2 q = __builtin_bit_cast(uint2, v); return (((e >> 1) ? q.y : q.x) >> (16 * (e & 1)) & 0xffffu) != 0u; };
-        // upstream gradient of the group's pixels 4*lk + r for the second orientation
-        float go2[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) go2[r] = __shfl(gout, 4 * lk + r, 16);
-        if (lk == 0) db6 += gout;
-        // ---- layer 4 -> G3 (both orientations), dw6;  dW4 += G3 . H2^T, db4 += rowsum(G3)
-        hbf16x8 gb3[2];
-        {
-            f32x4 g3[4], G3[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
-                    G3[mb][r] = ((M3 >> (4 * mb + r)) & 1u) ? pc_bf16r(w6o2[mb] * go2[r]) : 0.f;
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const unsigned char* bp = base + HC_H2 + t_off + 32 * (my_nb0 + n2);
+                    dW4[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_ROW)), dW4[n2], 0, 0, 0);
                 }
             }
-            gb3[0] = hb_pack8(g3[0], g3[1]); gb3[1] = hb_pack8(g3[2], g3[3]);
-            hs16x4 ga[4];
+            {
+                const unsigned char* ap = base + HC_G2 + t_off + 32 * my_mb;
+                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
+                const hbf16x8 av = hc_pair(lo, hi);
+                if ((wave & 1) == 0) db2 += hc_sum4(lo) + hc_sum4(hi);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                ga[q4] = hb_pack4(G3[q4][0], G3[q4][1], G3[q4][2], G3[q4][3]);
-                dbs[2][q4] += (G3[q4][0] + G3[q4][1]) + (G3[q4][2] + G3[q4][3]);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    dW4[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[mb], H2p[nb], dW4[mb][nb], 0, 0, 0);
-        }
-        // ---- G2 = relu'(h2) . (W4^T G3), both orientations;  dW2 += G2 . H1^T
-        hbf16x8 gb2[2];
-        {
-            f32x4 g2[4], G2[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                g2[mi] = G2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const hbf16x8 w = hb_frag8(ldsb, HB_T3, mi, t, lane_o);
-                    g2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, gb3[t], g2[mi], 0, 0, 0);
-                    G2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb3[t], w, G2[mi], 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    g2[mi][r] = nz8(hb2[mi >> 1], 4 * (mi & 1) + r) ? g2[mi][r] : 0.f;
-                    G2[mi][r] = nz4(H2p[mi], r) ? pc_bf16r(G2[mi][r]) : 0.f;
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const unsigned char* bp = base + HC_H1 + t_off + 32 * (my_nb0 + n2);
+                    dW2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_ROW)), dW2[n2], 0, 0, 0);
                 }
             }
-            gb2[0] = hb_pack8(g2[0], g2[1]); gb2[1] = hb_pack8(g2[2], g2[3]);
-            hs16x4 ga[4];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                ga[q4] = hb_pack4(G2[q4][0], G2[q4][1], G2[q4][2], G2[q4][3]);
-                dbs[1][q4] += (G2[q4][0] + G2[q4][1]) + (G2[q4][2] + G2[q4][3]);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    dW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga[mb], H1p[nb], dW2[mb][nb], 0, 0, 0);
-        }
-        // ---- G1 = relu'(h1) . (W2^T G2), both orientations;  dW0 += G1 . X^T
-        hbf16x8 gb1[2];
-        {
-            f32x4 g1[4], G1[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                g1[mi] = G1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const hbf16x8 w = hb_frag8(ldsb, HB_T2, mi, t, lane_o);
-                    g1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, gb2[t], g1[mi], 0, 0, 0);
-                    G1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb2[t], w, G1[mi], 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    g1[mi][r] = nz8(hb1[mi >> 1], 4 * (mi & 1) + r) ? g1[mi][r] : 0.f;
-                    G1[mi][r] = nz4(H1p[mi], r) ? pc_bf16r(G1[mi][r]) : 0.f;
-                }
-            }
-            gb1[0] = hb_pack8(g1[0], g1[1]); gb1[1] = hb_pack8(g1[2], g1[3]);
-            const hs16x4 xo2 = hb_pack4(xq[0], xq[1], xq[2], xq[3]);        // lane = feature channel li, 4 pixels
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const hs16x4 ga = hb_pack4(G1[q4][0], G1[q4][1], G1[q4][2], G1[q4][3]);
-                dbs[0][q4] += (G1[q4][0] + G1[q4][1]) + (G1[q4][2] + G1[q4][3]);
-                dW0[q4] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga, xo2, dW0[q4], 0, 0, 0);
+            if (wave < 4) {
+                const unsigned char* ap = base + HC_G1 + t_off + 32 * wave;
+                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
+                db0 += hc_sum4(lo) + hc_sum4(hi);
+                const unsigned char* bp = base + t_offx;
+                dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hc_pair(lo, hi), hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_XROW)), dW0, 0, 0, 0);
             }
         }
-        // ---- g_x = W0^T G1 (lane = pixel, registers = feature channels 4*lk + r)
-        f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 2; ++t) gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T1, 0, t, lane_o), gb1[t], gx, 0, 0, 0);
-        if (valid) {
-            // channels 4*lk .. +3 of the pixel: one 8-byte store
-            f32x4 o4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o = gx[r];
-                if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                o4[r] = o;
-            }
-            pc_st4(reinterpret_cast<pc_bf16_t*>(a.g_feat.ptr) + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride +
-                       (int64_t)(p.px + x) * a.g_feat.xstride + 4 * lk, o4);
-        }
+        __syncthreads();
     }
 
-    // ---- reductions (layout of head_bwd_pc_kernel's partial: every wave here owns what a producer AND its consumer own there)
+    // ---- workgroup partial (layout of head_bwd_pc_kernel): every 16x16 block has ONE owner; dw6 / db6 are summed over the waves
+    // D layout of a block: lane = (m >> 2) * 16 + n, register = m & 3  (m = row = gradient's hidden unit, n = column)
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+        *reinterpret_cast<f32x4*>(&part[PE_W4 + ((my_mb * 4 + my_nb0 + n2) * 64 + lane) * 4]) = dW4[n2];
+        *reinterpret_cast<f32x4*>(&part[PE_W2 + ((my_mb * 4 + my_nb0 + n2) * 64 + lane) * 4]) = dW2[n2];
+    }
+    if (wave < 4) *reinterpret_cast<f32x4*>(&part[PE_W0 + (wave * 64 + lane) * 4]) = dW0;
+    // bias gradients: lane (m = li, k-group lk) holds a partial row sum -> sum over the 4 k-groups
+    db4 += __shfl_xor(db4, 16); db4 += __shfl_xor(db4, 32);
+    db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
+    db0 += __shfl_xor(db0, 16); db0 += __shfl_xor(db0, 32);
+    if (lk == 0) {
+        if ((wave & 1) == 0) { part[PE_B4 + 16 * my_mb + li] = db4; part[PE_B2 + 16 * my_mb + li] = db2; }
+        if (wave < 4) part[PE_B0 + 16 * wave + li] = db0;
+    }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
     db6 = lane_sum16(db6);
-#pragma unroll
-    for (int l3 = 0; l3 < 3; ++l3)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float v = dbs[l3][q4];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            dbs[l3][q4] = v;
-        }
-    float* lds = reinterpret_cast<float*>(ldsb);
+    float* red = reinterpret_cast<float*>(ldsb);
     __syncthreads();
-#pragma unroll
-    for (int stage = 0; stage < 2; ++stage) {
+    if (li == 0) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                *reinterpret_cast<f32x4*>(&lds[wave * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
-        __syncthreads();
-        for (int e = tid; e < 4096; e += 256)
-            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
-        __syncthreads();
+            for (int r = 0; r < 4; ++r) red[wave * 65 + 16 * mb + 4 * lk + r] = dw6[mb][r];
+        if (lk == 0) red[wave * 65 + 64] = db6;
     }
-    {
-        float* w = lds + wave * 1344;       // [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1]
+    __syncthreads();
+    if (tid < 65) {
+        float t = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
-        if (lk == 0) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                w[1088 + 16 * q4 + li] = dbs[0][q4];
-                w[1152 + 16 * q4 + li] = dbs[1][q4];
-                w[1216 + 16 * q4 + li] = dbs[2][q4];
-            }
-        }
-        if (li == 0) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[1024 + 16 * mb + 4 * lk + r] = dw6[mb][r];
-            if (lk == 0) w[1280] = db6;
-        }
-        __syncthreads();
-        for (int e = tid; e < 1281; e += 256) {
-            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
-            part[PE_W0 + e] = t;
-        }
+        for (int w = 0; w < HC_WAVES; ++w) t += red[w * 65 + tid];
+        part[(tid < 64 ? PE_W6 + tid : PE_B6)] = t;
     }
 }
 
@@ -2144,14 +2113,19 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    static bool bf_attr = false;
-    if (!bf_attr) {
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, HB_RED);
-        if (e3 != hipSuccess) return (int)e3;
-        bf_attr = true;
+    static bool coop_attr = false;
+    if (!coop_attr) {
+        hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_coop_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, HC_END);
+        if (e4 != hipSuccess) return (int)e4;
+        coop_attr = true;
     }
-    if (p.bf) hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nwg), dim3(256), HB_RED, st, a);
+    if (p.bf) {
+        nwg = (a.total_groups + HC_WAVES - 1) / HC_WAVES;       // one 8-wave workgroup per CU at most (130 KB of LDS)
+        if (nwg > 256) nwg = 256;
+        if (nwg < 1) nwg = 1;
+        hipLaunchKernelGGL(head_bwd_bf16_coop_kernel, dim3(nwg), dim3(512), HC_END, st, a);
+    }
     else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();

@@ -419,3 +419,68 @@ def test_bf16_convt_fwd_dgrad_wgrad_op(C_, shape):
     assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
     assert (db.cpu().double() - bd.grad).abs().max().item() <= 2e-5 * bd.grad.abs().max().item()
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+# ---- op level: the bf16 head kernels (channels-last feature / gradient maps) -------------------------------------------
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("shape", [(3, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17), (40, 100, 100, 128, 128, 14, 14)])
+def test_bf16_head_fwd_bwd_vs_bf16_oracle_autograd(sparse, shape):
+    """Head forward and backward in bf16 mode against torch autograd through the oracle head with the bf16 rounding points;
+    all four upstream-gradient routes.  The B = 40 case (25,000 pixel groups) runs the cooperative backward kernel through
+    several rounds of its workgroup exchange (more groups than 256 workgroups x 8 waves)."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    B, H, W, Hp, Wp, py, px = shape
+    sd = O.load_golden_state(G)
+    names = [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+    work = dict(sd)
+    for n in names:
+        work[n] = sd[n].clone().requires_grad_(True)
+    feat = _bf(_mk(B, 16, Hp, Wp, seed=21)).requires_grad_(True)             # the feature map arrives rounded from its producers
+    gen = torch.Generator().manual_seed(22)
+    building = torch.rand(B, 1, H, W, generator=gen)
+    admin = (torch.rand(B, H, W, generator=gen) < 0.6).float() * 5.0
+    census = torch.full((B,), 5, dtype=torch.int64)
+    mask = (torch.rand(B, H, W, generator=gen) < 0.5) & (admin == 5.0)
+    g_pc = torch.randn(B, generator=gen)
+    g_pd = torch.randn(B, H, W, generator=gen) * 0.1
+    g_sm = torch.randn(B, H, W, generator=gen) * 0.1
+    g_const = 0.37
+    headin = feat[:, :, py:py + H, px:px + W]
+    with O.bf16_mode():
+        if sparse:
+            out = O.sparse_head_forward(work, headin, mask)[:, 0]
+            selmask = mask
+        else:
+            out = O.head_forward(work, headin)[:, 0]
+            selmask = torch.ones(B, H, W, dtype=torch.bool)
+        scale = F.relu(out)
+        pd = scale * building[:, 0]
+        pc = (pd * (admin == census.view(-1, 1, 1))).sum((1, 2))
+        loss = (pc * g_pc).sum() + (pd * g_pd).sum() + (scale * g_sm).sum() + g_const * scale[selmask].sum()
+        loss.backward()
+    ht = [sd[n].cuda() for n in names]
+    kw = dict(mask=mask.to(torch.uint8).cuda() if sparse else None, admin_mask=admin.cuda(), census_idx=census.cuda())
+    with L.precision("bf16"):
+        s_map, pd_gpu, pc_gpu = ops.head_fwd(_dev(feat.detach()), py, px, H, W, ht, building.cuda(), **kw)
+        grads, g_feat = ops.head_bwd(_dev(feat.detach()), py, px, H, W, ht, building.cuda(), g_popcount=g_pc.cuda(),
+                                     g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
+                                     g_scale_const=torch.tensor([g_const], device="cuda"), **kw)
+        grads2, g_feat2 = ops.head_bwd(_dev(feat.detach()), py, px, H, W, ht, building.cuda(), g_popcount=g_pc.cuda(),
+                                       g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
+                                       g_scale_const=torch.tensor([g_const], device="cuda"), **kw)
+    # forward: fp32 evaluation of the same bf16 definition -- differences only where an fp32 sum sits on a bf16 tie
+    assert rel(s_map.cpu(), scale.detach()) < TOL_MAP and rel(pc_gpu.cpu(), pc.detach()) < 5 * TOL_COUNT
+    assert g_feat.dtype == torch.bfloat16 and g_feat.is_contiguous(memory_format=torch.channels_last)
+    worst = {n: rel(gr.cpu(), work[n].grad) for n, gr in zip(names, grads)}
+    assert max(worst.values()) < TOL_GRAD_WORST, worst
+    gf = g_feat.float().cpu()
+    # the gradient map is rounded per element: a bf16 step (2^-7) on its largest entries, and a rare ReLU-mask flip of a hidden
+    # unit at a pixel, bound the maximum; almost all elements agree to two bf16 steps
+    assert rel(gf, feat.grad) < 2 * TOL_MAP
+    off = (gf - feat.grad).abs() > 2.0 ** -6 * feat.grad.abs() + 1e-4 * feat.grad.abs().max()
+    assert off.float().mean().item() < 1e-3
+    assert torch.equal(gf[:, :, :py], torch.zeros_like(gf[:, :, :py])) and torch.equal(gf[:, :, :, :px], torch.zeros_like(gf[:, :, :, :px]))
+    assert torch.equal(gf[:, :, py + H:], torch.zeros_like(gf[:, :, py + H:])) and torch.equal(gf[:, :, :, px + W:], torch.zeros_like(gf[:, :, :, px + W:]))
+    assert torch.all(grads[6][1] == 0) and grads[7][1].item() == 0.0
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2)) and torch.equal(g_feat, g_feat2)       # deterministic

@@ -24,37 +24,40 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-step = collections.defaultdict(dict)
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for n, cs in per_kernel(f"{OUT}/pmc_{c}/**/*counter_collection.csv").items():
-        if c in cs:
-            step[n][c] = (mean(cs[c]), len(cs[c]))
-rows = []
-for n, d in sorted(step.items()):
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
-        rows.append({"kernel": n, "launches": d["FETCH_SIZE"][1], "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
-                     "traffic_bytes": (2 * f + w) * 1024})
-json.dump(rows, open(f"{OUT}/{tag}_pmc_step_kernels.json", "w"), indent=1)
-for r in rows:
-    print(f"{r['kernel'][:70]:70s} n={r['launches']:3d} fetch {r['FETCH_SIZE_KB'] / 1024:8.1f} MiB write {r['WRITE_SIZE_KB'] / 1024:8.1f} MiB")
-hb = [r for r in rows if r["kernel"].startswith("head_bwd_pc_kernel")]
-if hb:
-    r = dict(hb[0])
-    r["note"] = ("traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction; upper estimate: the feature loads are 4-byte "
-                 "gathers); separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --no-graph, B=64 100x100")
-    json.dump(r, open(f"{OUT}/{tag}_pmc_head_bwd.json", "w"), indent=1)
-conv = collections.defaultdict(dict)
-for d in glob.glob(f"{OUT}/pmcc_*"):
-    for n, cs in per_kernel(f"{d}/**/*counter_collection.csv").items():
-        if n.startswith("conv3x3_mfma_kernel"):
-            for c, v in cs.items():
-                conv[n][c] = mean(v)
-for n, d in conv.items():
-    print(n, {k: round(v, 1) for k, v in d.items()})
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        out = {"kernel": n, "counters": d, "traffic_bytes": (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024,
-               "alg_bytes": 4 * 64 * 128 * 128 * 4 * 16,
-               "note": "grouped conv 8->8 @128x128 x4 (tools/ablate_conv_group.py 8 8 128, ABL_ONE=0), mean per launch; traffic = "
-                       "2*FETCH_SIZE + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (4 * GRBM_GUI_ACTIVE * 256 CUs) ~ MFMA pipe utilisation"}
-        json.dump(out, open(f"{OUT}/{tag}_pmc_conv_8to8.json", "w"), indent=1)
+for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kernel", "conv3x3_mfma_kernel", 4),
+                                                 ("bf16", "_bf16", "head_bwd_bf16_coop_kernel", "conv3x3_cl_kernel", 2)):
+    step = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for n, cs in per_kernel(f"{OUT}/pmc_{prec}_{c}/**/*counter_collection.csv").items():
+            if c in cs:
+                step[n][c] = (mean(cs[c]), len(cs[c]))
+    rows = []
+    for n, d in sorted(step.items()):
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
+            rows.append({"kernel": n, "launches": d["FETCH_SIZE"][1], "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                         "traffic_bytes": (2 * f + w) * 1024})
+    json.dump(rows, open(f"{OUT}/{tag}_pmc_step_kernels{sfx}.json", "w"), indent=1)
+    print(f"---- {prec}")
+    for r in rows:
+        print(f"{r['kernel'][:70]:70s} n={r['launches']:3d} fetch {r['FETCH_SIZE_KB'] / 1024:8.1f} MiB write {r['WRITE_SIZE_KB'] / 1024:8.1f} MiB")
+    hb = [r for r in rows if r["kernel"].startswith(head_kernel)]
+    if hb:
+        r = dict(hb[0])
+        r["note"] = ("traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction for 16-byte-per-lane streams; an upper estimate "
+                     "where loads are narrower); separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --no-graph, B=64 100x100")
+        json.dump(r, open(f"{OUT}/{tag}_pmc_head_bwd{sfx}.json", "w"), indent=1)
+    conv = collections.defaultdict(dict)
+    for d in glob.glob(f"{OUT}/pmcc_{prec}_*"):
+        for n, cs in per_kernel(f"{d}/**/*counter_collection.csv").items():
+            if n.startswith(conv_kernel):
+                for c, v in cs.items():
+                    conv[n][c] = mean(v)
+    for n, d in conv.items():
+        print(n, {k: round(v, 1) for k, v in d.items()})
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            out = {"kernel": n, "counters": d, "traffic_bytes": (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024,
+                   "alg_bytes": 4 * 64 * 128 * 128 * esz * 16,
+                   "note": "grouped conv 8->8 @128x128 x4 (tools/ablate_conv_group.py 8 8 128, ABL_ONE=0), mean per launch; traffic = "
+                           "2*FETCH_SIZE + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (4 * GRBM_GUI_ACTIVE * 256 CUs) ~ MFMA pipe utilisation"}
+            json.dump(out, open(f"{OUT}/{tag}_pmc_conv_8to8{sfx}.json", "w"), indent=1)

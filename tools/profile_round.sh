@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats of the bench (fp32 and bf16 lines, graph replay) and the FETCH_SIZE /
-# WRITE_SIZE PMC passes (separate runs, --kernel-trace only, eager dispatches) that feed `roofline.traffic`.
+# WRITE_SIZE PMC passes (separate runs, --kernel-trace only, eager dispatches) that feed `roofline.traffic`, for both modes.
 #   usage: tools/profile_round.sh r2        -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
 TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -12,18 +12,22 @@ for prec in fp32 bf16; do
       python3 bench.py --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-class-sweep --precision $prec > $OUT/${TAG}_${prec}_bench_under_profiler.json 2> $OUT/prof_$prec.err
   f=$(find $OUT/prof_$prec -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_${prec}_graph_kernel_stats.csv
+  # PMC: one counter set per run (FETCH_SIZE costs 3 of the 4 TCC slots), eager launches so that every kernel is a dispatch
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/pmc_${prec}_$c
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${prec}_$c -o b -- \
+        python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-class-sweep --precision $prec > $OUT/pmc_${prec}_$c.log 2>&1
+  done
 done
-# PMC: one counter set per run (FETCH_SIZE costs 3 of the 4 TCC slots), eager launches so that every kernel is a dispatch
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $OUT/pmc_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o b -- \
-      python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-class-sweep > $OUT/pmc_$c.log 2>&1
-done
-# the standalone grouped conv 8->8 @128x128 x4 launch (roofline_conv)
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
-  n=$(echo $c | cut -d' ' -f1)
-  rm -rf $OUT/pmcc_$n
-  ABL_ONE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcc_$n -o c -- \
-      python3 tools/ablate_conv_group.py 8 8 128 > $OUT/pmcc_$n.log 2>&1
+# the standalone grouped conv 8->8 @128x128 x4 launch (roofline_conv): the precision goes through a file, not the environment
+# (the profiled program must be the one after `--`)
+for prec in fp32 bf16; do
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+    n=$(echo $c | cut -d' ' -f1)
+    rm -rf $OUT/pmcc_${prec}_$n
+    export ABL_ONE=0 ABL_PREC=$prec
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcc_${prec}_$n -o c -- \
+        python3 tools/ablate_conv_group.py 8 8 128 > $OUT/pmcc_${prec}_$n.log 2>&1
+  done
 done
 python3 tools/pmc_round_summary.py $TAG

@@ -99,9 +99,12 @@ int pc_sizeof(int which);
  *     - everything else stays fp32: BN folding, partial logits and the building score, masks, occupancy product, census
  *       sums, loss, all WEIGHT gradients, the gradient all-reduce, clip, Adam and the master weights.
  *   Activation / activation-gradient tensors (everything a conv, transposed-conv or head kernel hands to another kernel:
- *   pc_src / pc_dst operands) are bf16 CONTAINERS in this mode (dtype = PC_BF16, half the HBM bytes); the model input, the
- *   partial logits / building score, masks, popdensemap, scale map, all parameters and all weight gradients stay fp32.  A
- *   call whose descriptors do not match the mode returns PC_EINVAL.  The mode is read when a call is enqueued.
+ *   pc_src / pc_dst operands) are CHANNELS-LAST bf16 tensors in this mode: dtype = PC_BF16, cstride = 1, xstride = number
+ *   of channels of the tensor (8 or 16; a slice of 8 channels of a 16-channel tensor is fine), ptr / rstride / bstride
+ *   multiples of 8 elements -- one aligned 16-byte slot per pixel and 8-channel group (torch.channels_last of a bf16 tensor).
+ *   The model input (PC_SRC_REFLECT sources), the partial logits / building score, masks, popdensemap, scale map, all
+ *   parameters and all weight gradients stay planar fp32.  In PC_PREC_FP32 every tensor is planar fp32 (xstride 0 / 1).
+ *   A call whose descriptors do not match the mode returns PC_EINVAL.  The mode is read when a call is enqueued.
  * Process-global; returns the previous mode (pc_set_precision) / the current one. */
 enum pc_precision { PC_PREC_FP32 = 0, PC_PREC_BF16 = 1 };
 int pc_set_precision(int mode);

@@ -484,3 +484,35 @@ def test_bf16_head_fwd_bwd_vs_bf16_oracle_autograd(sparse, shape):
     assert torch.equal(gf[:, :, py + H:], torch.zeros_like(gf[:, :, py + H:])) and torch.equal(gf[:, :, :, px + W:], torch.zeros_like(gf[:, :, :, px + W:]))
     assert torch.all(grads[6][1] == 0) and grads[7][1].item() == 0.0
     assert all(torch.equal(a, b) for a, b in zip(grads, grads2)) and torch.equal(g_feat, g_feat2)       # deterministic
+
+
+# ---- other tile geometries than 100 x 100 through the whole bf16 train step ---------------------------------------------
+@pytest.mark.parametrize("geom", [(2, 64, 48, "full"), (3, 37, 53, "disc"), (1, 131, 77, "disc"), (2, 32, 32, "full")])
+def test_bf16_train_step_other_geometries(geom):
+    """Ragged / small tiles take the partial-strip paths of every channels-last kernel (bounds predicates, fallback pooling
+    loader when the pooled second output does not qualify, placement offsets of the up-sampled halves).  Loss and census
+    counts against the bf16 oracle at the bounds of this file; every gradient tensor within TOL_GRAD_WORST or, where a few
+    hundred selected pixels make single ReLU-tie flips visible, well inside the band bf16 rounding itself spans."""
+    from popcorn_amd.train import FusedTrainStep
+    from popcorn_amd.data.synthetic import make_raw_batch
+    B, H, W, region = geom
+    m, sd = _model()
+    batch = make_raw_batch(B, H, W, seed=7, region=region)
+    x = O.select_normalize(batch["raw"])
+    s = {"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}
+    torch.manual_seed(3)
+    l32, out32, g32, _ = O.train_step_grads(sd, dict(s))
+    with O.bf16_mode():
+        torch.manual_seed(3)
+        l16, out16, g16, _ = O.train_step_grads(sd, dict(s))
+    m.set_precision("bf16")
+    tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+    torch.manual_seed(3)
+    loss = tr.step({k: v.cuda() for k, v in s.items()})
+    torch.cuda.synchronize()
+    assert abs(loss[0].item() - l16.item()) < 2 * TOL_LOSS * max(1.0, abs(l16.item()))
+    assert rel(tr.last["popcount"].cpu(), out16["popcount"]) < 2 * TOL_COUNT
+    assert int(tr.stats[0].item()) == out16["scale"].numel()
+    for n in g16:
+        e, band = rel(tr.grads[n].cpu(), g16[n]), rel(g16[n], g32[n])
+        assert e < max(TOL_GRAD_WORST, 0.75 * band), (n, e, band)

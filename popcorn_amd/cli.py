@@ -78,6 +78,8 @@ def train_parser():
     p.add_argument("--test_raster_hw", type=int, nargs=2, default=[384, 448], help="synthetic target-test raster (test_target)")
     p.add_argument("--test_patchsize", type=int, default=256)
     p.add_argument("--test_overlap", type=int, default=32)
+    p.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                   help="bf16: mixed precision (bf16 MFMA operands + channels-last bf16 activations, fp32 master weights; DESIGN.md 7)")
     return p
 
 
@@ -101,6 +103,7 @@ def eval_parser():
     p.add_argument("--patchsize", type=int, default=2048)
     p.add_argument("--overlap", type=int, default=128)
     p.add_argument("--ensemble", type=int, default=1, help="members to instantiate when no --resume checkpoints are given")
+    p.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="arithmetic mode of the kernels (DESIGN.md 7)")
     return p
 
 
@@ -177,6 +180,7 @@ class Trainer:
             batch_size=args.weak_val_batch_size, shuffle=False, collate_fn=Population_Dataset_collate_fn, drop_last=False)
         self._test_raster = None
         self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)   # same seed: same init on every rank
+        self.model.set_precision(args.precision)
         # from here on the CPU generators feed per-rank randomness (augmentation coins, the 60x60 sparsity grid of
         # get_sparsity_mask): every rank gets its own stream, rank 0 keeps the single-process one
         seed_all(args.seed + 2 + 1000 * self.rank)
@@ -436,7 +440,7 @@ def run_eval(argv=None):
         m = model_dict[args.model](**get_model_kwargs(args, args.model)).to(dev)
         if j < len(args.resume):
             m.load_state_dict(torch.load(args.resume[j], map_location="cpu", weights_only=False)["model"])   # run_eval.py:243-257
-        models.append(m.eval())
+        models.append(m.eval().set_precision(args.precision))
     data = SyntheticTestRaster(args.raster_hw[0], args.raster_hw[1], seasons=4 if args.fourseasons else 1, device=dev)
     reducer = FlatReducer()
     t0 = time.time()

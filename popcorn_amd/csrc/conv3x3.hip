@@ -36,6 +36,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // bf16 mode (the channels-last kernel below): the MFMA is v_mfma_f32_16x16x32_bf16 with K = 32 = (4 input rows v) x (8 input
 // channels): one instruction per (horizontal tap dx, 16-px block) and 8-channel chunk instead of 8 fp32 ones.  The wave's strip
@@ -803,11 +804,13 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                     }
                     if (ok) cl_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
                     if (EPI == EPI_POOL && q.pool_out.ptr) {
-                        // MaxPool2d(2) (full strips only, pc_conv3x3_pool_out_ok): x pair = lane ^ 1, row pair = lane ^ 32
+                        // MaxPool2d(2) (full strips only, pc_conv3x3_pool_out_ok): x pair = lane ^ 1 (DPP quad permute), row pair =
+                        // lane ^ 32 (v_permlane32_swap: both halves' values in every lane) -- no trip through the LDS crossbar
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float m = fmaxf(v[r], __shfl_xor(v[r], 1));
-                            v[r] = fmaxf(m, __shfl_xor(m, 32));
+                            const float m = fmaxf(v[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[r]), 0xB1, 0xF, 0xF, false)));
+                            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                            v[r] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                         }
                         if ((li & 1) == 0 && e_s == 0)
                             cl_st4(reinterpret_cast<pc_bf16_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride +

@@ -516,3 +516,27 @@ def test_bf16_train_step_other_geometries(geom):
     for n in g16:
         e, band = rel(tr.grads[n].cpu(), g16[n]), rel(g16[n], g32[n])
         assert e < max(TOL_GRAD_WORST, 0.75 * band), (n, e, band)
+
+
+def test_bf16_che_recipe_through_the_clis(tmp_path):
+    """BASELINE config 4's recipe flags (README.md:182: -wd 5e-7 --biasinit 0.2267) through the run_train / run_eval
+    counterparts with --precision bf16: the fused bf16 step trains (finite, logged, checkpoint in the reference's format with
+    fp32 parameters), validation + the in-training target test run in bf16, and run_eval stitches a raster from the checkpoint."""
+    import json as _json
+    from popcorn_amd import cli
+    from popcorn_amd.cli import Trainer, train_parser
+    base = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 5e-7 --biasinit 0.2267 --synthetic_regions 8 -wb 4 "
+            f"--save_dir {tmp_path} -lt 1 -wv -val 1 --fixed_hw 64 64 --precision bf16 -e 2").split()
+    t = Trainer(train_parser().parse_args(base))
+    assert t.model.precision == "bf16"
+    t.train()
+    recs = [_json.loads(l) for l in open(os.path.join(t.exp, "train_log.jsonl"))]
+    losses = [r["loss"] for r in recs if "loss" in r and "iter" in r]
+    assert len(losses) >= 2 and all(np.isfinite(losses))
+    assert any(any(k.endswith("/val") for k in r) for r in recs) and any(any(k.endswith("/targettest") for k in r) for r in recs)
+    ck = os.path.join(t.exp, "last_model.pth")
+    d = torch.load(ck, weights_only=False)
+    assert all(v.dtype in (torch.float32, torch.int64) for v in d["model"].values())          # master weights stay fp32
+    res = cli.run_eval(("-S2 -NIR -S1 -occmodel -senbuilds -pret --biasinit 0.2267 --raster_hw 300 420 --patchsize 256 --overlap 32 "
+                        f"--seed 1600 --precision bf16 --save_dir {tmp_path} -r {ck}").split())
+    assert np.isfinite(res["Population_MainCensus_synthetic_fine/r2"]) and np.isfinite(res["Population_AdjCensus_synthetic_fine/l1_loss"])

@@ -42,6 +42,7 @@ struct HeadArgs {
     float* scale_map;
     float* popdense;
     float* partial;        // [B][nchunk][2]  {popcount partial, scale-sum partial}
+    const void* wimage;    // the kernel's LDS weight image, assembled once per call by head_pack_kernel (workgroups copy it)
     int B, H, W;
     int groups, nchunk, groups_per_wave;
     pc_fastdiv div_w, div_groups;
@@ -55,14 +56,13 @@ struct HeadArgs {
 // sits on the MFMA issue path).
 //   layer 1 (W0 64x16):  [mb][lane][j]            = W0[16*mb + i][4*j + k]
 //   64x64 layers:        [mb2][mb][lane][r]       = W[16*mb2 + i][16*mb + 4*k + r]      (lane = k*16 + i)
-__device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 16 * 64; e += blockDim.x) {
+__device__ __forceinline__ void head_stage_a(float* lds, const HeadArgs& p, int tid, int nt) {
+    for (int e = tid; e < 16 * 64; e += nt) {
         const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
         const float t = p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)];
         lds[L_A1 + e] = t;
     }
-    for (int e = tid; e < 64 * 64; e += blockDim.x) {
+    for (int e = tid; e < 64 * 64; e += nt) {
         const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8, mb = f & 3, mb2 = f >> 2;
         const int col = 16 * mb + 4 * (lane >> 4) + r;
         const int row = 16 * mb2 + (lane & 15);
@@ -70,13 +70,21 @@ __device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p
         lds[L_A2 + e] = t2;
         lds[L_A3 + e] = t4;
     }
-    for (int e = tid; e < 64; e += blockDim.x) {
+}
+__device__ __forceinline__ void head_stage_weights(float* lds, const HeadArgs& p, int tid, int nt) {
+    head_stage_a(lds, p, tid, nt);
+    for (int e = tid; e < 64; e += nt) {
         lds[L_B0 + e] = p.b0[e];
         lds[L_B2 + e] = p.b2[e];
         lds[L_B4 + e] = p.b4[e];
         lds[L_W6 + e] = p.w6[e];   // row 0 of the [2][64] last layer: only channel 0 is used (popcorn.py:162,164)
     }
     if (tid == 0) lds[L_W6 + 64] = p.b6[0];
+}
+// every workgroup starts by copying the ready-made image (16-byte pieces, coalesced) instead of gathering ~9,000 weights
+// itself: 1024 workgroups doing that gather at once cost the bf16 forward kernel 10 of its 47 us
+__device__ __forceinline__ void head_copy_image(void* lds, const void* img, int nbytes) {
+    for (int e = threadIdx.x; e < nbytes / 16; e += blockDim.x) reinterpret_cast<uint4*>(lds)[e] = reinterpret_cast<const uint4*>(img)[e];
 }
 
 // One 64-wide layer: acc[mb2] = bias + W * h  (h in D layout of the previous layer), ReLU applied by the caller.
@@ -119,7 +127,7 @@ __device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
 // fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    head_stage_weights(lds, p);
+    head_copy_image(lds, p.wimage, L_END * (int)sizeof(float));
     __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -262,6 +270,32 @@ constexpr int LB_SCR = LB_W6 + 64 + 4;           // per wave: Gm[64][18] + Hm[64
 constexpr int SCR_LD = 20;    // multiple of 4 (ds_read_b128) and 5 x 16 B: the 16 rows of a fragment hit 16 distinct slots
 constexpr int SCR_WAVE = 2 * 64 * SCR_LD;
 constexpr int LB_END = LB_SCR + 4 * SCR_WAVE;
+// weight image of the fp32 backward kernels: forward fragments, transposed fragments, biases  (LB_A1 .. LB_W6; LB_SCR floats)
+__device__ __forceinline__ void head_stage_weights_bwd(float* lds, const HeadArgs& p, int tid, int nt) {
+    head_stage_a(lds, p, tid, nt);                      // LB_A1..LB_A3 coincide with L_A1..L_A3
+    for (int e = tid; e < 64 * 64; e += nt) {
+        const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
+        const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
+        const int col = 16 * mi + (l & 15);                           // i
+        const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
+        lds[LB_T3 + e] = t4;
+        lds[LB_T2 + e] = t2;
+    }
+    for (int e = tid; e < 16 * 64; e += nt) {
+        const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
+        const int row = 16 * mb + 4 * (l >> 4) + r;
+        const float t0 = p.w0[row * 16 + (l & 15)];
+        lds[LB_T1 + e] = t0;
+    }
+    for (int e = tid; e < 64; e += nt) {
+        lds[LB_B0 + e] = p.b0[e];
+        lds[LB_B2 + e] = p.b2[e];
+        lds[LB_B4 + e] = p.b4[e];
+        lds[LB_W6 + e] = p.w6[e];
+    }
+    if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
+}
+
 // workgroup partial layout
 constexpr int PE_W4 = 0, PE_W2 = 4096, PE_W0 = 8192, PE_W6 = 9216, PE_B0 = 9280, PE_B2 = 9344, PE_B4 = 9408, PE_B6 = 9472;
 constexpr int PE_TOTAL = 9480;
@@ -339,29 +373,7 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
     const HeadArgs& p = a.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    head_stage_weights(lds, p);     // LB_A1..LB_A3 coincide with L_A1..L_A3
-    __syncthreads();                // its bias block (L_B0..) overlaps LB_T3: let it land before T3 is filled
-    for (int e = tid; e < 64 * 64; e += blockDim.x) {
-        const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
-        const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
-        const int col = 16 * mi + (l & 15);                           // i
-        const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
-        lds[LB_T3 + e] = t4;
-        lds[LB_T2 + e] = t2;
-    }
-    for (int e = tid; e < 16 * 64; e += blockDim.x) {
-        const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
-        const int row = 16 * mb + 4 * (l >> 4) + r;
-        const float t0 = p.w0[row * 16 + (l & 15)];
-        lds[LB_T1 + e] = t0;
-    }
-    for (int e = tid; e < 64; e += blockDim.x) {
-        lds[LB_B0 + e] = p.b0[e];
-        lds[LB_B2 + e] = p.b2[e];
-        lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = p.w6[e];
-    }
-    if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
+    head_copy_image(lds, p.wimage, LB_SCR * (int)sizeof(float));     // forward + transposed fragments, biases (head_stage_weights_bwd)
     __syncthreads();
 
     float* gm = lds + LB_SCR + wave * SCR_WAVE;
@@ -596,29 +608,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
     const int li = lane & 15, lk = lane >> 4;
     const int pair = wave & 3;
     const bool producer = wave < 4;
-    head_stage_weights(lds, p);
-    __syncthreads();                // its bias block (L_B0..) overlaps LB_T3: let it land before T3 is filled
-    for (int e = tid; e < 64 * 64; e += blockDim.x) {
-        const int r = e & 3, l = (e >> 2) & 63, f = e >> 8, mb = f & 3, mi = f >> 2;
-        const int row = 16 * mb + 4 * (l >> 4) + r;                   // o
-        const int col = 16 * mi + (l & 15);                           // i
-        const float t4 = p.w4[row * HID + col], t2 = p.w2[row * HID + col];
-        lds[LB_T3 + e] = t4;
-        lds[LB_T2 + e] = t2;
-    }
-    for (int e = tid; e < 16 * 64; e += blockDim.x) {
-        const int r = e & 3, l = (e >> 2) & 63, mb = e >> 8;
-        const int row = 16 * mb + 4 * (l >> 4) + r;
-        const float t0 = p.w0[row * 16 + (l & 15)];
-        lds[LB_T1 + e] = t0;
-    }
-    for (int e = tid; e < 64; e += blockDim.x) {
-        lds[LB_B0 + e] = p.b0[e];
-        lds[LB_B2 + e] = p.b2[e];
-        lds[LB_B4 + e] = p.b4[e];
-        lds[LB_W6 + e] = p.w6[e];
-    }
-    if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
+    head_copy_image(lds, p.wimage, LB_SCR * (int)sizeof(float));     // forward + transposed fragments, biases (head_stage_weights_bwd)
     int* flags = reinterpret_cast<int*>(lds + LP_FLAGS);
     if (tid < 16) flags[tid] = 0;
     __syncthreads();
@@ -991,8 +981,7 @@ constexpr int HB_END = HB_F32 + (4 * 64 + 4) * 4;
 
 __device__ __forceinline__ int hb_unit(int t, int lk, int j) { return 16 * (2 * t + (j >> 2)) + 4 * lk + (j & 3); }
 
-__device__ __forceinline__ void head_stage_weights_bf16(unsigned char* lds, const HeadArgs& p, bool backward) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void head_stage_weights_bf16(unsigned char* lds, const HeadArgs& p, bool backward, int tid, int nt) {
     unsigned short* h = reinterpret_cast<unsigned short*>(lds);
     auto bits = [](float x) { return (unsigned short)(__float_as_uint(pc_bf16r(x)) >> 16); };
     for (int e = tid; e < 4 * 64 * 4; e += nt) {
@@ -1063,7 +1052,7 @@ __device__ __forceinline__ void hb_relu_round(f32x4 (&h)[4]) {
 
 __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    head_stage_weights_bf16(ldsb, p, false);
+    head_copy_image(ldsb, p.wimage, HB_END);
     __syncthreads();
     const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1186,7 +1175,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
     const HeadArgs& p = a.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    head_stage_weights_bf16(ldsb, p, true);
+    head_copy_image(ldsb, p.wimage, HB_END);
     // the exchange area starts as zeros: a slot that was never written must not feed NaN bit patterns into 0 * x
     for (int e = tid; e < HC_WAVES * HC_SLOT / 16; e += 512) reinterpret_cast<uint4*>(ldsb + HC_EX)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -1501,6 +1490,24 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         for (int w = 0; w < HC_WAVES; ++w) t += red[w * 65 + tid];
         part[(tid < 64 ? PE_W6 + tid : PE_B6)] = t;
     }
+}
+
+// assembles the LDS weight image of the head kernel that follows, once, in global memory (kind 0: fp32 forward, 1: fp32
+// backward, 2: bf16 forward, 3: bf16 backward)
+__global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* img, int kind) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (kind == 0) head_stage_weights(reinterpret_cast<float*>(img), p, tid, nt);
+    else if (kind == 1) head_stage_weights_bwd(reinterpret_cast<float*>(img), p, tid, nt);
+    else head_stage_weights_bf16(reinterpret_cast<unsigned char*>(img), p, kind == 3, tid, nt);
+}
+constexpr int HEAD_IMG_BYTES = 96 * 1024;      // room for the largest image (fp32 backward: LB_SCR floats = 72 KB)
+static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES, "weight image slot");
+// the images live in the unused tail of the backward partial area of the workspace (pc_head_ws_bytes reserves 512 x 12288
+// floats, the backward uses at most 256 x PE_TOTAL): slot 0 forward, slot 1 backward
+__host__ inline void* head_image_slot(void* ws, int B, int H, int W, int slot) {
+    const int groups = (H * W + 15) / 16;
+    const int64_t nchunk = (groups + 31) / 32 + 1;
+    return reinterpret_cast<char*>(ws) + (int64_t)B * nchunk * 2 * sizeof(float) + (int64_t)300 * 12288 * sizeof(float) + (int64_t)slot * HEAD_IMG_BYTES;
 }
 
 struct HeadReduceArgs {
@@ -1959,6 +1966,10 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     hipStream_t st = (hipStream_t)stream;
     // bf16 mode: the feature map is a channels-last bf16 tensor (16 contiguous channels per pixel); fp32 mode: planar fp32
     if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
+    void* img = head_image_slot(ws, B, H, W, 0);
+    p.wimage = img;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 2 : 0);
+    PC_CHECK_LAUNCH();
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
@@ -2119,6 +2130,12 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
                                             hipFuncAttributeMaxDynamicSharedMemorySize, HC_END);
         if (e4 != hipSuccess) return (int)e4;
         coop_attr = true;
+    }
+    {
+        void* img = head_image_slot(ws, B, H, W, 1);
+        p.wimage = img;
+        hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 3 : 1);
+        PC_CHECK_LAUNCH();
     }
     if (p.bf) {
         nwg = (a.total_groups + HC_WAVES - 1) / HC_WAVES;       // one 8-wave workgroup per CU at most (130 KB of LDS)

@@ -1741,6 +1741,10 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     if (threadIdx.x == 0) {
         a.counts[0] = (int32_t)(tot_sel ? tot_sel : tot_reg);
         a.counts[1] = (int32_t)tot_reg;
+        // this block is the last one alive: leave the accumulator and the ticket at zero for the next call (which is ordered
+        // behind this kernel on the stream), instead of a zeroing launch in front of every call
+        a.scratch[0] = 0u; a.scratch[1] = 0u; a.scratch[2] = 0u;
+        __threadfence();
     }
 }
 
@@ -1999,13 +2003,16 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     if (!feat || !w || !bias || !building_out || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !counts ||
         feat->C < 1 || feat->C > 16)
         return PC_EINVAL;
-    static unsigned* scratch = nullptr;     // {acc nsel, acc nregion, ticket, -}: device-scope atomics only, never reused
+    static unsigned* scratch = nullptr;     // {acc nsel, acc nregion, ticket, -}: device-scope atomics only; zero between calls (the
+                                            // kernel's last block resets it), zeroed once here
     if (!scratch) {
         hipError_t e = hipMalloc(&scratch, 4 * sizeof(unsigned));
         if (e != hipSuccess) return (int)e;
+        e = hipMemset(scratch, 0, 4 * sizeof(unsigned));
+        if (e != hipSuccess) return (int)e;
+        e = hipDeviceSynchronize();            // the first kernel may run on a non-blocking stream
+        if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(scratch), 4);
-    PC_CHECK_LAUNCH();
     ScoreMaskArgs a{};
     a.feat = *feat; a.w = w; a.bias = bias; a.out = *building_out; a.admin = admin_mask; a.census = census_idx;
     a.rowsel = rowsel; a.colsel = colsel; a.occ = occupancymodel; a.mask = mask; a.counts = counts; a.scratch = scratch;

@@ -82,6 +82,8 @@ class FusedTrainStep:
         self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.use_graph = use_graph
         self._graphs = None
+        self._graph_cache = {}          # key -> captured step; a few recurring shapes (e.g. the smaller last batch of an epoch,
+        self._graph_cache_max = 6       # alternating truncation regimes) replay instead of being captured over and over
         self._static = None
         self._static = None
         self.last = {}
@@ -275,8 +277,14 @@ class FusedTrainStep:
     def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
         key = (tuple(sample["input"].shape), encoder_no_grad, unet_no_grad, self.model.precision)
         if self._graphs is None or self._graphs[0] != key:
-            with L.precision(self.model.precision):      # the mode is read when a launch is enqueued = captured
-                self._capture(sample, sel_host, key)
+            if key in self._graph_cache:
+                self._graphs, self.last = self._graph_cache.pop(key)      # (re-inserted below: most recently used last)
+            else:
+                with L.precision(self.model.precision):      # the mode is read when a launch is enqueued = captured
+                    self._capture(sample, sel_host, key)
+            self._graph_cache[key] = (self._graphs, self.last)
+            while len(self._graph_cache) > self._graph_cache_max:
+                self._graph_cache.pop(next(iter(self._graph_cache)))
         _, st, sel, graphs = self._graphs
         for k in ("input", "admin_mask", "census_idx", "y"):
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy

@@ -257,3 +257,35 @@ def test_api_extras_add_padding_scatter_and_sparse_unet_mask(pair):
         mk, ratio = m.get_sparsity_mask(inp, sparse_unet=True)
         assert np.array_equal(mk.cpu().numpy(), gold[f"{name}/mask"]), name                 # index path: exact
         np.testing.assert_allclose(ratio.cpu().numpy(), gold[f"{name}/ratio"], rtol=1e-6)
+
+
+def test_graph_cache_alternating_shapes_and_regimes_equals_eager():
+    """The fused step keeps a few captured graphs (a smaller last batch of an epoch, alternating truncation regimes): a
+    sequence that switches between three batch shapes / regimes and comes back to each gives bit-identical losses,
+    parameters and outputs through graph replay and through eager launches, and captures each key once."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    samples = []
+    for (B, H, W, seed) in [(4, 64, 64, 11), (2, 64, 64, 12), (3, 96, 64, 13)]:
+        b = make_raw_batch(B, H, W, seed=seed, device="cuda", region="disc")
+        samples.append({"input": ops.select_normalize(b["raw"], stats.BAND6, stats.MEAN6, stats.STD6), "admin_mask": b["admin_mask"],
+                        "census_idx": b["census_idx"], "y": b["y"]})
+    order = [(0, False), (1, False), (0, False), (2, True), (1, False), (2, True), (0, False), (0, True)]
+    runs = []
+    for use_graph in (False, True):
+        tr = _fresh_trainer(use_graph)
+        ncap = [0]
+        if use_graph:
+            orig = tr._capture
+            tr._capture = lambda *a, **k: (ncap.__setitem__(0, ncap[0] + 1), orig(*a, **k))[1]
+        torch.manual_seed(21)
+        out = []
+        for i, enc_ng in order:
+            loss = tr.step(dict(samples[i]), encoder_no_grad=enc_ng)
+            out.append((loss.tolist(), tr.last["popcount"].tolist()))
+        torch.cuda.synchronize()
+        runs.append((out, tr.flat_p.clone(), ncap[0]))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert runs[1][2] == 4                      # four distinct (shape, regime) keys, eight steps

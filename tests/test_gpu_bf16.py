@@ -542,3 +542,25 @@ def test_bf16_che_recipe_through_the_clis(tmp_path):
     res = cli.run_eval(("-S2 -NIR -S1 -occmodel -senbuilds -pret --biasinit 0.2267 --raster_hw 300 420 --patchsize 256 --overlap 32 "
                         f"--seed 1600 --precision bf16 --save_dir {tmp_path} -r {ck}").split())
     assert np.isfinite(res["Population_MainCensus_synthetic_fine/r2"]) and np.isfinite(res["Population_AdjCensus_synthetic_fine/l1_loss"])
+
+
+def test_bf16_sliding_window_inference_tracks_fp32():
+    """BASELINE config 5's path in bf16 mode: the stitched population map of a small raster (overlapping windows, two ensemble
+    members) stays inside the bf16 rounding band of the fp32 map; window bookkeeping (count map = finite everywhere) unchanged."""
+    from popcorn_amd.eval import evaluate_raster
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    models = [POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda().eval()
+              for _ in range(2)]
+    g = torch.Generator().manual_seed(5)
+    raster = torch.randn(1, 6, 600, 700, generator=g).cuda()
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        for m in models:
+            m.set_precision(prec)
+        mean, std, smean, sstd = evaluate_raster(models, raster, patchsize=256, overlap=32)
+        outs[prec] = (mean.cpu(), smean.cpu())
+    for a, b in zip(outs["bf16"], outs["fp32"]):
+        assert torch.isfinite(a).all()
+        assert rel(a, b) < 5e-2                                                     # per-pixel bf16 rounding of a deep chain
+        assert ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item() < 3e-2

@@ -20,7 +20,6 @@ __device__ __forceinline__ unsigned pc_pack_bf16(float lo, float hi) {
     const pc_bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, p);
 }
-__device__ __forceinline__ f32x4 pc_bf16r4(f32x4 v) { return f32x4{pc_bf16r(v[0]), pc_bf16r(v[1]), pc_bf16r(v[2]), pc_bf16r(v[3])}; }
 extern int g_pc_precision;      // api.hip: pc_set_precision()
 
 // ---- element access for fp32 / bf16 containers (bf16 = unsigned short bits) -------------------------------------------------
@@ -30,8 +29,7 @@ __device__ __forceinline__ unsigned short pc_f2bf(float x) { return (unsigned sh
 __device__ __forceinline__ float pc_ld1(const float* p) { return *p; }
 __device__ __forceinline__ float pc_ld1(const pc_bf16_t* p) { return pc_bf2f(*p); }
 __device__ __forceinline__ void pc_st1(float* p, float v) { *p = v; }
-__device__ __forceinline__ void pc_st1(pc_bf16_t* p, float v) { *p = pc_f2bf(v); }
-// four consecutive elements; the bf16 forms need 8-byte alignment, the fp32 forms 16-byte
+// four consecutive elements (bf16: four channels of a channels-last pixel); the bf16 forms need 8-byte alignment, the fp32 forms 16-byte
 __device__ __forceinline__ f32x4 pc_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 pc_ld4(const pc_bf16_t* p) {
     const uint2 q = *reinterpret_cast<const uint2*>(p);
@@ -42,7 +40,6 @@ __device__ __forceinline__ void pc_st4(pc_bf16_t* p, f32x4 v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
 }
 __device__ __forceinline__ void pc_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
-__device__ __forceinline__ void pc_st2(pc_bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pc_pack_bf16(a, b); }
 // element i of a source described by a pc_src (run-time dtype: generic / fallback paths only)
 // x stride of a descriptor (0 / 1 = planar rows), and whether it describes a planar tensor -- the only form the fp32 kernels take
 __host__ __device__ __forceinline__ int pc_xs(const pc_src& s) { return s.xstride > 1 ? s.xstride : 1; }

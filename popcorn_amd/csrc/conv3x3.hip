@@ -591,14 +591,6 @@ __device__ __forceinline__ u32x4 cl_max8(u32x4 a, u32x4 b) {      // elementwise
     }
     return o;
 }
-__device__ __forceinline__ f32x4 cl_ld4(const pc_bf16_t* p) {     // 4 consecutive channels of one pixel
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
-}
-__device__ __forceinline__ void cl_st4(pc_bf16_t* p, f32x4 v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
-}
-
 template <int CIN, int COUT, int MODE, int LD, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
@@ -802,7 +794,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                         for (int r = 0; r < 4; ++r) dsum += v[r] * dotw[r];
                         continue;
                     }
-                    if (ok) cl_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
+                    if (ok) pc_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
                     if (EPI == EPI_POOL && q.pool_out.ptr) {
                         // MaxPool2d(2) (full strips only, pc_conv3x3_pool_out_ok): x pair = lane ^ 1 (DPP quad permute), row pair =
                         // lane ^ 32 (v_permlane32_swap: both halves' values in every lane) -- no trip through the LDS crossbar
@@ -813,7 +805,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                             v[r] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                         }
                         if ((li & 1) == 0 && e_s == 0)
-                            cl_st4(reinterpret_cast<pc_bf16_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride +
+                            pc_st4(reinterpret_cast<pc_bf16_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride +
                                        (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride +
                                        (int64_t)((ex0 >> 1) + (u & 1) * 8 + (li >> 1)) * q.pool_out.xstride + nb * 8 + c4, v);
                     }
@@ -830,16 +822,16 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                     f32x4 v = pacc[u][nb];
                     pc_bf16_t* op = outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4;
                     if (act) {
-                        const f32x4 a4 = cl_ld4(act + eb * a_bs + (int64_t)y * a_rs + (int64_t)x * a_xs + nb * 8 + c4);
+                        const f32x4 a4 = pc_ld4(act + eb * a_bs + (int64_t)y * a_rs + (int64_t)x * a_xs + nb * 8 + c4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb][r] : 0.f;
                     }
                     if (p.accumulate) {
-                        const f32x4 o4 = cl_ld4(op);
+                        const f32x4 o4 = pc_ld4(op);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += o4[r];
                     }
-                    cl_st4(op, v);
+                    pc_st4(op, v);
                 }
             } else {
                 // MaxPool2d(2) backward: (y, x) is a pooled coordinate; the gradient goes to the first arg-max of the 2x2 window
@@ -849,8 +841,8 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                     const f32x4 v = pacc[u][nb];
                     const pc_bf16_t* a0 = act + eb * a_bs + (int64_t)(2 * y) * a_rs + (int64_t)(2 * x) * a_xs + nb * 8 + c4;
                     pc_bf16_t* o0 = outp + eb * o_bs + (int64_t)(2 * y) * o_rs + (int64_t)(2 * x) * o_xs + nb * 8 + c4;
-                    const f32x4 A00 = cl_ld4(a0), A01 = cl_ld4(a0 + a_xs), A10 = cl_ld4(a0 + a_rs), A11 = cl_ld4(a0 + a_rs + a_xs);
-                    f32x4 O00 = cl_ld4(o0), O01 = cl_ld4(o0 + o_xs), O10 = cl_ld4(o0 + o_rs), O11 = cl_ld4(o0 + o_rs + o_xs);
+                    const f32x4 A00 = pc_ld4(a0), A01 = pc_ld4(a0 + a_xs), A10 = pc_ld4(a0 + a_rs), A11 = pc_ld4(a0 + a_rs + a_xs);
+                    f32x4 O00 = pc_ld4(o0), O01 = pc_ld4(o0 + o_xs), O10 = pc_ld4(o0 + o_rs), O11 = pc_ld4(o0 + o_rs + o_xs);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int am = 0;
@@ -864,7 +856,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                         O10[r] += am == 2 ? g : 0.f;
                         O11[r] += am == 3 ? g : 0.f;
                     }
-                    cl_st4(o0, O00); cl_st4(o0 + o_xs, O01); cl_st4(o0 + o_rs, O10); cl_st4(o0 + o_rs + o_xs, O11);
+                    pc_st4(o0, O00); pc_st4(o0 + o_xs, O01); pc_st4(o0 + o_rs, O10); pc_st4(o0 + o_rs + o_xs, O11);
                 }
             }
         }

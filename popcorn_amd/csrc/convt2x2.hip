@@ -187,14 +187,6 @@ typedef __bf16 ct_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned ct_u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ short ct_bf(float x) { return (short)pc_f2bf(x); }
-__device__ __forceinline__ f32x4 ct_ld4(const pc_bf16_t* p) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
-}
-__device__ __forceinline__ void ct_st4(pc_bf16_t* p, f32x4 v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]));
-}
-
 template <int C>
 __global__ __launch_bounds__(256) void convt2x2_fwd_cl_kernel(const CtGroup grp_) {
     const CtArgs& p = grp_.pr[blockIdx.y];
@@ -239,7 +231,7 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_cl_kernel(const CtGroup grp_
             f32x4 acc = f32x4{binit[t][0], binit[t][1], binit[t][2], binit[t][3]};
             acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aw[t], bv, acc, 0, 0, 0);
             const int a = C == 8 ? t : t >> 1, bb = C == 8 ? lk >> 1 : t & 1, co4 = C == 8 ? 4 * (lk & 1) : 4 * lk;
-            if (ok) ct_st4(ob + b * p.out.bstride + (int64_t)(2 * i + a) * p.out.rstride + (int64_t)(2 * j + bb) * p.out.xstride + co4, acc);
+            if (ok) pc_st4(ob + b * p.out.bstride + (int64_t)(2 * i + a) * p.out.rstride + (int64_t)(2 * j + bb) * p.out.xstride + co4, acc);
         }
     }
 }
@@ -288,11 +280,11 @@ __global__ __launch_bounds__(256) void convt2x2_dgrad_cl_kernel(const CtGroup gr
         }
         if (ok && 4 * lk < C) {
             if (ab) {
-                const f32x4 a4 = ct_ld4(ab + b * p.act_bstride + (int64_t)i * p.act_rstride + (int64_t)j * p.act_xstride + 4 * lk);
+                const f32x4 a4 = pc_ld4(ab + b * p.act_bstride + (int64_t)i * p.act_rstride + (int64_t)j * p.act_xstride + 4 * lk);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = a4[r] > 0.f ? acc[r] * e_scale[r] : 0.f;
             }
-            ct_st4(ob + b * p.out.bstride + (int64_t)i * p.out.rstride + (int64_t)j * p.out.xstride + 4 * lk, acc);
+            pc_st4(ob + b * p.out.bstride + (int64_t)i * p.out.rstride + (int64_t)j * p.out.xstride + 4 * lk, acc);
         }
     }
 }

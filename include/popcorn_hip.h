@@ -157,6 +157,18 @@ typedef struct pc_conv_dgrad_desc {
 } pc_conv_dgrad_desc;
 int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Cin_total, int c0, int Cn, int pool,
                            int accumulate, int B, int H, int W, int Cg, void* stream);
+/* ---- backward of one 8 -> 8 channel conv3x3 in ONE launch (PC_PREC_BF16 only): data gradient AND weight / bias gradient
+ * partials from one pass over the layer's output gradient g and input x (both channels-last bf16, 8 channels).
+ *   out (=|+=) relu'(x) * bn_scale(x_bn) * conv^T(g, w[:, c0:c0+8])      (x_bn NULL: no ReLU / BN factor)
+ *   ws <- per-workgroup partials of dW[:, c0:c0+8] and db, to be finished by pc_wgrad_reduce_batch (Cin = 8, Cout = 8,
+ *         dw = &dW[0][c0][0][0], dw_co_stride = Cin_total * 9; *nwg_out partials per problem)
+ * x may be one half of a concatenated input: x->oy / ox = its placement in the conv domain (zero outside).  Replaces a
+ * pc_conv3x3_dgrad + pc_conv3x3_wgrad_partial pair (5 tensor reads + 1 write) by 2 reads + 1 write. */
+typedef struct pc_conv_bwd_desc {
+    const pc_src* g; const pc_src* x; const float* w; const pc_bn* x_bn; const pc_dst* out; void* ws;
+} pc_conv_bwd_desc;
+int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
+                         int* nwg_out, void* stream);
 /* ablation switches for tools/ablate_conv.py (0,0 = normal operation) */
 void pc_debug_conv(int dbg, int max_grid);
 
@@ -188,7 +200,8 @@ typedef struct pc_wgrad_reduce_desc {
     int32_t nwg, Cin, Cout; /* convT: Cin = Cout = C */
     int32_t kind;           /* 0: conv3x3, 1: convT 2x2 */
     int32_t accumulate;
-    int32_t _pad;
+    int32_t dw_co_stride;   /* conv3x3: elements between output channels of dw (0 = Cin * 9); > Cin * 9 when the entry is one
+                               8-channel column block of a wider weight gradient (dw then points at its first column) */
 } pc_wgrad_reduce_desc;
 int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void* stream);
 

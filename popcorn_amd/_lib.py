@@ -61,7 +61,12 @@ class PcConvtWgradDesc(C.Structure):
 
 class PcWgradReduceDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
-                ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+                ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("dw_co_stride", C.c_int32)]
+
+
+class PcConvBwdDesc(C.Structure):
+    _fields_ = [("g", C.POINTER(PcSrc)), ("x", C.POINTER(PcSrc)), ("w", C.c_void_p), ("x_bn", C.POINTER(PcBn)),
+                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p)]
 
 
 PC_MAX_GROUP = 4

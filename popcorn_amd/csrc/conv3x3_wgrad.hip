@@ -893,6 +893,7 @@ constexpr int RB_MAX = 32;
 struct RbEntry {
     const float* partial; float* dw; float* db;
     int nwg, Cin, Cout, kind, accumulate;     // kind 0: conv3x3, 1: convT 2x2 (C = Cin)
+    int dw_co_stride;                         // conv3x3: elements between output channels of dw (0 = Cin * 9)
 };
 struct RbArgs { RbEntry e[RB_MAX]; };
 
@@ -960,7 +961,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
-        float* dstp = o < n_w ? q.dw + o : q.db + (o - n_w);
+        int64_t od = o;
+        if (q.kind == 0 && q.dw_co_stride > 0 && o < n_w) od = (int64_t)(o / (q.Cin * 9)) * q.dw_co_stride + o % (q.Cin * 9);
+        float* dstp = o < n_w ? q.dw + od : q.db + (o - n_w);
         if (o >= n_w && q.db == nullptr) return;
         *dstp = q.accumulate ? *dstp + tot : tot;
     }
@@ -984,7 +987,7 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
         for (int i = 0; i < m; ++i) {
             const pc_wgrad_reduce_desc& s = d[base + i];
             if (!s.partial || !s.dw || s.nwg < 1) return PC_EINVAL;
-            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate};
+            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride};
             const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : s.Cin * s.Cin * 4 + s.Cin;
             if (n_out > max_out) max_out = n_out;
         }

@@ -63,6 +63,11 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
     return names
 
 
+# bf16 mode: data gradient + weight gradient of the 8 -> 8 conv layers in one launch each (POPCORN_FUSED_CONV_BWD=0: separate
+# launches; A/B switch)
+FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
+
+
 class _Layer:
     __slots__ = ("w", "b", "bn", "bn_nobias", "wname", "bname", "_keep")
 
@@ -218,13 +223,38 @@ class UNetEngine:
             ops.conv3x3_dgrad_group(probs, c0, cn, pool=pool, accumulate=acc)
             return outs
 
+        # bf16 mode: the data gradient and the weight gradient of an 8 -> 8 layer (or of an 8-channel column block of a concat
+        # layer) read the same two tensors -- one launch for both (pc_conv3x3_bwd_group)
+        fuse = FUSED_CONV_BWD and L.act_dtype() == torch.bfloat16
+
+        def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True):
+            probs = []
+            for s in S:
+                lay = ly(s, tag)
+                pr = {"g": gs[s], "x": A[s][x_key], "w": lay.w, "out": outs[s], "dw": grads[prefix + lay.wname],
+                      "db": grads[prefix + lay.bname] if with_db else None}
+                if act_tag is not None:
+                    pr["x_bn"] = ly(s, act_tag).bn_nobias
+                if off_key is not None:
+                    pr["x_offset"] = A[s][off_key]
+                probs.append(pr)
+            wb.conv3x3_bwd_group(probs, cin_total, c0)
+            return outs
+
         G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
-        wgs("up1b", "f1", G_f2)
-        G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
-        wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
-        if not encoder_no_grad:
-            G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
-        g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
+        if fuse:
+            G_f1 = bwd8("up1b", G_f2, "f1", "up1a", {s: E(8, Hp, Wp) for s in S})
+        else:
+            wgs("up1b", "f1", G_f2)
+            G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
+        if fuse and not encoder_no_grad:
+            G_a2 = bwd8("up1a", G_f1, "a2", "inc2", {s: E(8, Hp, Wp) for s in S}, c0=0, cin_total=16)
+            g_u1 = bwd8("up1a", G_f1, "u1", None, {s: E(8, Hp, Wp) for s in S}, c0=8, cin_total=16, off_key="o1", with_db=False)
+        else:
+            wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
+            if not encoder_no_grad:
+                G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
+            g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
         G_e2, probs = {}, []
         g_u1vs = {}
         for s in S:
@@ -234,8 +264,11 @@ class UNetEngine:
             probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
         wgts("up1t", {s: A[s]["e2"] for s in S}, g_u1vs)
         ops.convt2x2_dgrad_group(probs)
-        wgs("up2b", "e1", G_e2)
-        G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
+        if fuse:
+            G_e1 = bwd8("up2b", G_e2, "e1", "up2a", {s: E(8, H1, W1) for s in S})
+        else:
+            wgs("up2b", "e1", G_e2)
+            G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
         wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
         if not encoder_no_grad:
             G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
@@ -269,8 +302,11 @@ class UNetEngine:
         else:
             wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
         dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
-        wgs("inc2", "a1", G_a2)
-        G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
+        if fuse:
+            G_a1 = bwd8("inc2", G_a2, "a1", "inc1", {s: E(8, Hp, Wp) for s in S})
+        else:
+            wgs("inc2", "a1", G_a2)
+            G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
         for s, chmap, cin, f0 in self.streams:
             wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
         finish()

@@ -502,6 +502,28 @@ class WgradBatch:
         for ws, pr in zip(slots, problems):
             self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
 
+    def conv3x3_bwd_group(self, problems, cin_total, c0, accumulate=False):
+        """bf16 mode, 8 -> 8 channels: data gradient + weight-gradient partials of a conv layer in ONE launch.  problems: list of
+        dicts {g, x, w, out, dw (the full [8][cin_total][3][3] gradient), db (or None), x_bn (opt: ReLU / BN factor of x's producer),
+        x_offset (opt)}; the partials cover the columns [c0, c0 + 8) of dw."""
+        n = len(problems)
+        g0 = problems[0]["g"]
+        B, Cg, H, W = g0.shape
+        keep, descs, slots = [], (L.PcConvBwdDesc * n)(), []
+        for i, pr in enumerate(problems):
+            xo = pr.get("x_offset", (0, 0))
+            sg, sx, d = L.src(pr["g"]), L.src(pr["x"], oy=xo[0], ox=xo[1]), L.dst(pr["out"])
+            ws = self._slice()
+            keep += [sg, sx, d]
+            slots.append(ws)
+            descs[i].g, descs[i].x, descs[i].w, descs[i].out, descs[i].ws = C.pointer(sg), C.pointer(sx), pr["w"].data_ptr(), C.pointer(d), ws
+            descs[i].x_bn = C.pointer(pr["x_bn"]) if pr.get("x_bn") is not None else None
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_conv3x3_bwd_group(n, descs, cin_total, c0, int(accumulate), B, H, W, C.byref(nwg), L.stream_ptr()),
+                "pc_conv3x3_bwd_group")
+        for ws, pr in zip(slots, problems):
+            self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, 8, 8, 0, cin_total * 9, c0 * 9))
+
     def convt2x2(self, x, g, dw, db):
         B, Cc, H, W = x.shape
         sx, sg = L.src(x), L.src(g)
@@ -535,9 +557,11 @@ class WgradBatch:
         if n == 0:
             return
         d = (L.PcWgradReduceDesc * n)()
-        for i, (ws, dw, db, nwg, cin, cout, kind) in enumerate(self.entries):
+        for i, ent in enumerate(self.entries):
+            ws, dw, db, nwg, cin, cout, kind = ent[:7]
             d[i].partial = ws
-            d[i].dw = dw.data_ptr()
+            d[i].dw = dw.data_ptr() + (4 * ent[8] if len(ent) > 7 else 0)        # first column of an 8-channel column block
+            d[i].dw_co_stride = ent[7] if len(ent) > 7 else 0
             d[i].db = 0 if db is None else db.data_ptr()
             d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate = nwg, cin, cout, kind, int(self.accumulate)
         L.check(L.lib().pc_wgrad_reduce_batch(n, d, L.stream_ptr()), "pc_wgrad_reduce_batch")

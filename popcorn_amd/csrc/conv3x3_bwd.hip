@@ -1,4 +1,4 @@
-// conv3x3_bwd.hip -- backward of one 3x3 convolution in ONE launch (PC_PREC_BF16, channels-last bf16 tensors, 8 -> 8 channels):
+// conv3x3_bwd.hip -- backward of one 3x3 convolution in ONE launch (PC_PREC_BF16, channels-last bf16 tensors, 8 / 16 channels):
 // the data gradient (conv3x3_cl_kernel<dgrad>) and the weight / bias gradient (conv3x3_wgrad_cl_kernel) of a layer read the SAME
 // two tensors -- the layer's output gradient g (conv input of the one, pixel-contraction operand of the other) and the layer's
 // input x (ReLU mask of the one, second operand of the other).  As two launches they are 5 tensor reads + 1 write; here each
@@ -21,18 +21,16 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 32, TH = 16;
 constexpr int SROWS = 6, BSLOTS = 48, COL0 = 4, PX = 34, PIECES = SROWS * PX;
 constexpr int IMG_B = SROWS * BSLOTS * 16;              // bytes of one strip image
-constexpr int EC = 8 * 8 * 9 + 8;                       // floats of one workgroup partial: dW[co][ci][tap] + db[co]
-constexpr int NBLK = 6;                                 // weight-gradient accumulator blocks: [dx][4-channel half of x]
 constexpr int MAXG = PC_MAX_GROUP;
 
 struct BwdProb {
     pc_src g, x;            // output gradient (conv domain) and the layer's input (placement offset in oy / ox)
-    const float* w;         // forward weights [Cout = 8][Cin_total][3][3], already offset to input channel c0
+    const float* w;         // forward weights [Cout = GC][Cin_total][3][3], already offset to input channel c0
     int w_ci_stride;        // Cin_total * 9
     int mask;               // 1: gx *= (x > 0) * bn_scale   (x is the post-ReLU output of a conv + BN layer)
     pc_bn bn;               // BN of the layer that produced x (mask = 1)
     pc_dst out;             // gx
-    float* partial;         // [nwg][EC]
+    float* partial;         // [nwg][GC * XC * 9 + GC]
 };
 
 struct BwdArgs {
@@ -52,15 +50,31 @@ __device__ __forceinline__ float bw_sum4(s16x4 v) {
     return (__uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xffff0000u)) + (__uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xffff0000u));
 }
 
+// GC = channels of g (the layer's output channels), XC = channels of x (this block of the layer's input channels): 8 or 16
+template <int GC, int XC>
+struct BwdCfg {
+    static constexpr int NG = GC / 8, NX = XC / 8;           // 8-channel images of the two strips
+    static constexpr int NBP = XC / 4;                        // N blocks (4 rows x 4 channels of x) per tap
+    static constexpr int NBLK = 3 * NBP;                      // weight-gradient accumulator blocks per 8 output channels: [dx][nbp]
+    static constexpr int EC = GC * XC * 9 + GC;               // floats of one workgroup partial: dW[co][ci][tap] + db[co]
+    static constexpr size_t WAVE_B = (size_t)(NG + NX) * IMG_B;
+    static constexpr size_t W_B = (size_t)4 * XC * NG * 24 * 2;          // weight image [dy plane][ci][g chunk][dx][8 co] bf16
+    static constexpr size_t RED_B = (size_t)4 * NBLK * 256 * sizeof(float);
+    static constexpr size_t LDS_B = 4 * WAVE_B + W_B > RED_B ? 4 * WAVE_B + W_B : RED_B;
+};
+
+template <int GC, int XC>
 __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
+    using Cfg = BwdCfg<GC, XC>;
+    constexpr int NG = Cfg::NG, NX = Cfg::NX, NBP = Cfg::NBP, NBLK = Cfg::NBLK, EC = Cfg::EC;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const BwdProb& q = p.pr[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    unsigned char* const wimg = ldsb + wave * 2 * IMG_B;
-    u32x4* const ig = reinterpret_cast<u32x4*>(wimg);                 // g strip
-    u32x4* const ix = reinterpret_cast<u32x4*>(wimg + IMG_B);         // x strip
-    unsigned short* const w2h = reinterpret_cast<unsigned short*>(ldsb + 4 * 2 * IMG_B);     // [dy plane 0..3][ci (dgrad output)][dx][8 co]
+    unsigned char* const wimg = ldsb + wave * Cfg::WAVE_B;
+    u32x4* const ig = reinterpret_cast<u32x4*>(wimg);                       // g strip: NG images
+    u32x4* const ix = reinterpret_cast<u32x4*>(wimg + NG * IMG_B);          // x strip: NX images
+    unsigned short* const w2h = reinterpret_cast<unsigned short*>(ldsb + 4 * Cfg::WAVE_B);
 
     // ---- loaders: piece id = lane + 64 * i -> (strip row, pixel of the 34-pixel row), for both tensors
     int l_slot[4], l_r[4], l_px[4];
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
         l_px[i] = id - l_r[i] * PX;
         l_slot[i] = id < PIECES ? l_r[i] * BSLOTS + (COL0 - 1) + l_px[i] : -1;
     }
-    u32x4 RG[4], RX[4];
+    u32x4 RG[NG][4], RX[NX][4];
     unsigned gvalid = 0, xvalid = 0;
     const pc_bf16_t* const gptr = reinterpret_cast<const pc_bf16_t*>(q.g.ptr);
     const pc_bf16_t* const xptr = reinterpret_cast<const pc_bf16_t*>(q.x.ptr);
@@ -81,10 +95,14 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int y = y0 - 1 + l_r[i], x = x0 - 1 + l_px[i];
             const bool in = l_slot[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            RG[i] = *reinterpret_cast<const u32x4*>(gptr + b * q.g.bstride + (in ? (int64_t)y * q.g.rstride + (int64_t)x * q.g.xstride : 0));
+            const pc_bf16_t* gp = gptr + b * q.g.bstride + (in ? (int64_t)y * q.g.rstride + (int64_t)x * q.g.xstride : 0);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) RG[c][i] = *reinterpret_cast<const u32x4*>(gp + 8 * c);
             const int ys = y - q.x.oy, xs = x - q.x.ox;
             const bool inx = in && (unsigned)ys < (unsigned)q.x.H && (unsigned)xs < (unsigned)q.x.W;
-            RX[i] = *reinterpret_cast<const u32x4*>(xptr + b * q.x.bstride + (inx ? (int64_t)ys * q.x.rstride + (int64_t)xs * q.x.xstride : 0));
+            const pc_bf16_t* xp = xptr + b * q.x.bstride + (inx ? (int64_t)ys * q.x.rstride + (int64_t)xs * q.x.xstride : 0);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) RX[c][i] = *reinterpret_cast<const u32x4*>(xp + 8 * c);
             gm |= (in ? 1u : 0u) << i;
             xm |= (inx ? 1u : 0u) << i;
         }
@@ -94,8 +112,10 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (l_slot[i] >= 0) {
-                ig[l_slot[i]] = ((gvalid >> i) & 1u) ? RG[i] : u32x4{0u, 0u, 0u, 0u};
-                ix[l_slot[i]] = ((xvalid >> i) & 1u) ? RX[i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c = 0; c < NG; ++c) ig[c * SROWS * BSLOTS + l_slot[i]] = ((gvalid >> i) & 1u) ? RG[c][i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c = 0; c < NX; ++c) ix[c * SROWS * BSLOTS + l_slot[i]] = ((xvalid >> i) & 1u) ? RX[c][i] : u32x4{0u, 0u, 0u, 0u};
             }
     };
     const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -114,41 +134,43 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     }
 
     // ---- data-gradient weights: "output" channel = forward input channel ci, "input" channel = g channel co, taps flipped:
-    //      weight(ci, co, tap) = w[co][ci][8 - tap].  Image [dy plane 0..3][ci][dx][8 co] bf16, plane 3 all zero.
-    constexpr int BW_CO = 24, BW_DYS = 8 * BW_CO;
+    //      weight(ci, co, tap) = w[co][ci][8 - tap].  Image [dy plane 0..3][ci][g chunk][dx][8 co] bf16, plane 3 all zero.
+    constexpr int BW_CO = NG * 24, BW_DYS = XC * BW_CO;
+    constexpr int NWR = (GC * XC * 9 + 255) / 256;
     for (int e = tid; e < 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
-    float wreg[3];
+    float wreg[NWR];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NWR; ++k) {
         const int e = tid + k * 256;
-        const int ec = e < 8 * 8 * 9 ? e : 0;
-        const int tap = ec % 9, co = (ec / 9) % 8, ci = ec / 72;
+        const int ec = e < GC * XC * 9 ? e : 0;
+        const int tap = ec % 9, co = (ec / 9) % GC, ci = ec / (9 * GC);
         wreg[k] = q.w[ci * 9 + co * q.w_ci_stride + (8 - tap)];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NWR; ++k) {
         const int e = tid + k * 256;
-        if (e < 8 * 8 * 9) {
-            const int tap = e % 9, co = (e / 9) % 8, ci = e / 72;
-            w2h[(tap / 3) * BW_DYS + ci * BW_CO + (tap % 3) * 8 + co] = pc_f2bf(wreg[k]);
+        if (e < GC * XC * 9) {
+            const int tap = e % 9, co = (e / 9) % GC, ci = e / (9 * GC);
+            w2h[(tap / 3) * BW_DYS + ci * BW_CO + (co / 8) * 24 + (tap % 3) * 8 + (co % 8)] = pc_f2bf(wreg[k]);
         }
     }
     const int c4 = 4 * (lk & 1), e_s = lk >> 1;
-    float e_scale[4];
+    float e_scale[NX][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = c4 + r;
-        e_scale[r] = (q.mask && q.bn.gamma) ? q.bn.gamma[c] * (1.0f / sqrtf(q.bn.var[c] + q.bn.eps)) : 1.f;
-    }
+    for (int nb = 0; nb < NX; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = nb * 8 + c4 + r;
+            e_scale[nb][r] = (q.mask && q.bn.gamma) ? q.bn.gamma[c] * (1.0f / sqrtf(q.bn.var[c] + q.bn.eps)) : 1.f;
+        }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : : "v"(e_scale[r]));
+    for (int nb = 0; nb < NX; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : : "v"(e_scale[nb][r]));
     const int a_s = li >> 3, a_co = li & 7;
     const unsigned short* const wlane = w2h + (((unsigned)(lk - a_s) <= 2u) ? lk - a_s : 3) * BW_DYS + a_co * BW_CO;
-    bf16x8 bwh[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) bwh[dx] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane + dx * 8));
 
     // ---- weight-gradient reads: lane supplies pixel row j = li >> 2 and column quad tq = li & 3 of a [4 pixels][16 columns] block
     const int t_j = li >> 2, t_q = li & 3;
@@ -156,10 +178,14 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     const int a_off = ((1 + (t_q >> 1)) * BSLOTS + (COL0 - 1) + 1 + 8 * lk + t_j) * 16 + 8 * (t_q & 1);
     // B (N = (v, ci4)): quad = input row v = tq (image row 2*rpi + v), pixel index 8*lk + 4*e + j + dx, channel half nb
     const int b_off = (t_q * BSLOTS + (COL0 - 1) + 8 * lk + t_j) * 16;
-    f32x4 wacc[NBLK];
-    float bsum = 0.f;
+    f32x4 wacc[NG][NBLK];
+    float bsum[NG];
 #pragma unroll
-    for (int i = 0; i < NBLK; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < NG; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) wacc[mb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     pc_bf16_t* const outp = reinterpret_cast<pc_bf16_t*>(q.out.ptr);
     const unsigned char* const igb = reinterpret_cast<const unsigned char*>(ig);
     const unsigned char* const ixb = reinterpret_cast<const unsigned char*>(ix);
@@ -172,51 +198,72 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
             issue(nb_, ny0, nx0);
         }
         // ---- data gradient: a 3x3 conv over g (K = 4 rows x 8 channels per MFMA)
-        f32x4 acc[4];
+        f32x4 acc[4][NX];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            const u32x4* lrow = ig + lk * BSLOTS + (COL0 - 1) + li;
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
+            for (int nb = 0; nb < NX; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bwh[dx], __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSLOTS + (u & 1) * 16 + dx]), acc[u], 0, 0, 0);
+        for (int gc = 0; gc < NG; ++gc) {
+            const u32x4* lrow = ig + gc * SROWS * BSLOTS + lk * BSLOTS + (COL0 - 1) + li;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 wq[NX];
+#pragma unroll
+                for (int nb = 0; nb < NX; ++nb)
+                    wq[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane + nb * 8 * BW_CO + gc * 24 + dx * 8));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSLOTS + (u & 1) * 16 + dx]);
+#pragma unroll
+                    for (int nb = 0; nb < NX; ++nb) acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[nb], av, acc[u][nb], 0, 0, 0);
+                }
+            }
         }
         // lane holds pixel (y0 + 2*(u>>1) + e_s, x0 + (u&1)*16 + li), channels c4 + r of gx
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int y = y0 + 2 * (u >> 1) + e_s, x = x0 + (u & 1) * 16 + li;
             if (y < p.H && x < p.W) {
-                f32x4 v = acc[u];
-                if (q.mask) {
-                    // the layer's input at this pixel sits in the x image (row 1 + ..., pixel index 1 + ...)
-                    const f32x4 a4 = pc_ld4(reinterpret_cast<const pc_bf16_t*>(ixb + ((1 + 2 * (u >> 1) + e_s) * BSLOTS + (COL0 - 1) + 1 + (u & 1) * 16 + li) * 16) + c4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[r] : 0.f;
-                }
-                pc_bf16_t* op = outp + b * q.out.bstride + (int64_t)y * q.out.rstride + (int64_t)x * q.out.xstride + c4;
-                if (p.accumulate) {
-                    const f32x4 o4 = pc_ld4(op);
+                for (int nb = 0; nb < NX; ++nb) {
+                    f32x4 v = acc[u][nb];
+                    if (q.mask) {
+                        // the layer's input at this pixel sits in the x image (row 1 + ..., pixel index 1 + ...)
+                        const f32x4 a4 = pc_ld4(reinterpret_cast<const pc_bf16_t*>(ixb + nb * IMG_B + ((1 + 2 * (u >> 1) + e_s) * BSLOTS + (COL0 - 1) + 1 + (u & 1) * 16 + li) * 16) + c4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                        for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb][r] : 0.f;
+                    }
+                    pc_bf16_t* op = outp + b * q.out.bstride + (int64_t)y * q.out.rstride + (int64_t)x * q.out.xstride + nb * 8 + c4;
+                    if (p.accumulate) {
+                        const f32x4 o4 = pc_ld4(op);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                    }
+                    pc_st4(op, v);
                 }
-                pc_st4(op, v);
             }
         }
         // ---- weight gradient of the strip: D_dx[(s,co)][(v,ci)] += sum_x g[co][y0+2rpi+s][x] * x[ci][y0+2rpi+v-1][x+dx-1]
 #pragma unroll
         for (int rpi = 0; rpi < 2; ++rpi) {
-            const unsigned char* ga = igb + 2 * rpi * BSLOTS * 16 + a_off;
-            const s16x4 lo = bw_tr(ga), hi = bw_tr(ga + 4 * 16);
-            const bf16x8 av = bw_pair(lo, hi);
-            bsum += bw_sum4(lo) + bw_sum4(hi);
+            bf16x8 av[NG];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int mb = 0; mb < NG; ++mb) {
+                const unsigned char* ga = igb + mb * IMG_B + 2 * rpi * BSLOTS * 16 + a_off;
+                const s16x4 lo = bw_tr(ga), hi = bw_tr(ga + 4 * 16);
+                av[mb] = bw_pair(lo, hi);
+                bsum[mb] += bw_sum4(lo) + bw_sum4(hi);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const unsigned char* xb = ixb + 2 * rpi * BSLOTS * 16 + b_off + dx * 16 + 8 * nb;
-                    wacc[dx * 2 + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw_pair(bw_tr(xb), bw_tr(xb + 4 * 16)), wacc[dx * 2 + nb], 0, 0, 0);
+                    const unsigned char* xb = ixb + (nb >> 1) * IMG_B + 2 * rpi * BSLOTS * 16 + b_off + dx * 16 + 8 * (nb & 1);
+                    const bf16x8 bv = bw_pair(bw_tr(xb), bw_tr(xb + 4 * 16));
+#pragma unroll
+                    for (int mb = 0; mb < NG; ++mb)
+                        wacc[mb][dx * NBP + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb], bv, wacc[mb][dx * NBP + nb], 0, 0, 0);
                 }
         }
         b = nb_; y0 = ny0; x0 = nx0;
@@ -226,35 +273,67 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     float* lds = reinterpret_cast<float*>(ldsb);
     float* part = q.partial + (int64_t)blockIdx.x * EC;
     auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
-    __syncthreads();
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = wacc[nb];
-    __syncthreads();
-    for (int idx = tid; idx < 8 * 8 * 9; idx += 256) {
-        const int c8 = idx / 72, rem = idx - c8 * 72;
-        const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
-        // D_dx[m = s*8 + c8][n = 4*v + (cil & 3)] in block dx*2 + (cil >> 2); D register layout: lane = (m>>2)*16 + n, reg = m&3
-        const int blk = dx * 2 + (cil >> 2);
-        const int n0 = 4 * dy + (cil & 3), n1 = n0 + 4;
-        const int m0 = c8, m1 = 8 + c8;
-        const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
-        const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
-        part[c8 * 72 + rem] = wsum(e0) + wsum(e1);
+    for (int mb = 0; mb < NG; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = wacc[mb][nb];
+        __syncthreads();
+        for (int idx = tid; idx < 8 * XC * 9; idx += 256) {
+            const int c8 = idx / (XC * 9), rem = idx - c8 * (XC * 9);
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            // D_dx[m = s*8 + c8][n = 4*v + (cil & 3)] in block dx*NBP + (cil >> 2); D register layout: lane = (m>>2)*16 + n, reg = m&3
+            const int blk = dx * NBP + (cil >> 2);
+            const int n0 = 4 * dy + (cil & 3), n1 = n0 + 4;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
+            const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * (XC * 9) + rem] = wsum(e0) + wsum(e1);
+        }
     }
     __syncthreads();
-    lds[wave * 64 + lane] = bsum;
+#pragma unroll
+    for (int mb = 0; mb < NG; ++mb) lds[(wave * NG + mb) * 64 + lane] = bsum[mb];
     __syncthreads();
-    if (tid < 8) {
+    if (tid < GC) {
+        const int mb = tid >> 3, c8 = tid & 7;
         float t = 0.f;
 #pragma unroll
         for (int lk2 = 0; lk2 < 4; ++lk2) {
-            const int ea = lk2 * 16 + tid, eb = ea + 8;
-            const float sa = ((lds[ea] + lds[64 + ea]) + lds[128 + ea]) + lds[192 + ea];
-            const float sb = ((lds[eb] + lds[64 + eb]) + lds[128 + eb]) + lds[192 + eb];
+            const int ea = mb * 64 + lk2 * 16 + c8, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[NG * 64 + ea]) + lds[2 * NG * 64 + ea]) + lds[3 * NG * 64 + ea];
+            const float sb = ((lds[eb] + lds[NG * 64 + eb]) + lds[2 * NG * 64 + eb]) + lds[3 * NG * 64 + eb];
             t += sa + sb;
         }
-        part[8 * 8 * 9 + tid] = t;
+        part[GC * XC * 9 + tid] = t;
     }
+}
+
+template <int GC, int XC>
+int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
+    using Cfg = BwdCfg<GC, XC>;
+    static int resident = 0;
+    if (!resident) {
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_cl_kernel<GC, XC>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_B);
+        if (e != hipSuccess) return (int)e;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, Cfg::LDS_B);
+        if (getenv("POPCORN_CONV_DBG"))
+            fprintf(stderr, "conv3x3_bwd<%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", GC, XC, fa.numRegs, (size_t)Cfg::LDS_B, resident);
+    }
+    int nwg = resident / n;
+    if (nwg > 512) nwg = 512;                // partials per problem (the workspace slice holds more)
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    if (nwg < 1) nwg = 1;
+    const int rounds = (p.ntiles + nwg - 1) / nwg;
+    nwg = (p.ntiles + rounds - 1) / rounds;
+    hipLaunchKernelGGL((conv3x3_bwd_cl_kernel<GC, XC>), dim3(nwg, n), dim3(256), Cfg::LDS_B, stream, p);
+    PC_CHECK_LAUNCH();
+    *nwg_out = nwg;
+    return 0;
 }
 
 }  // namespace
@@ -264,12 +343,14 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     if (n < 1 || n > MAXG || !d || !nwg_out) return PC_EINVAL;
     if (g_pc_precision != PC_PREC_BF16) return PC_EINVAL;
     BwdArgs p{};
+    int GC = 0, XC = 0;
     for (int i = 0; i < n; ++i) {
         if (!d[i].g || !d[i].x || !d[i].w || !d[i].out || !d[i].ws) return PC_EINVAL;
         BwdProb& q = p.pr[i];
         q.g = *d[i].g; q.x = *d[i].x;
-        if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out) || q.g.C != 8 || q.x.C != 8 || q.x.mode != PC_SRC_DIRECT ||
-            q.g.mode != PC_SRC_DIRECT || c0 < 0 || c0 + 8 > Cin_total)
+        if (i == 0) { GC = q.g.C; XC = q.x.C; }
+        if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out) || q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT ||
+            q.g.mode != PC_SRC_DIRECT || c0 < 0 || c0 + XC > Cin_total)
             return PC_EINVAL;
         q.w = d[i].w + (int64_t)c0 * 9;
         q.w_ci_stride = Cin_total * 9;
@@ -286,28 +367,9 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     if (p.ntiles <= 0) { *nwg_out = 0; return 0; }
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
-    const size_t lds_strips = (size_t)4 * 2 * IMG_B + (size_t)4 * 8 * 24 * 2;
-    const size_t lds_red = (size_t)4 * NBLK * 256 * sizeof(float);
-    const size_t lds = lds_strips > lds_red ? lds_strips : lds_red;
-    static int resident = 0;
-    if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_cl_kernel);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, fn);
-        if (e != hipSuccess) return (int)e;
-        resident = pc_resident_workgroups(fa.numRegs, lds);
-        if (getenv("POPCORN_CONV_DBG")) fprintf(stderr, "conv3x3_bwd: %d regs, %zu B LDS -> %d resident workgroups\n", fa.numRegs, lds, resident);
-    }
-    int nwg = resident / n;
-    if (nwg > 512) nwg = 512;                // partials per problem (the workspace slice holds many more)
-    if (nwg > p.ntiles) nwg = p.ntiles;
-    if (nwg < 1) nwg = 1;
-    const int rounds = (p.ntiles + nwg - 1) / nwg;
-    nwg = (p.ntiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL(conv3x3_bwd_cl_kernel, dim3(nwg, n), dim3(256), lds, (hipStream_t)stream, p);
-    PC_CHECK_LAUNCH();
-    *nwg_out = nwg;
-    return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (GC == 8 && XC == 8) return launch_bwd<8, 8>(p, n, nwg_out, st);
+    if (GC == 8 && XC == 16) return launch_bwd<8, 16>(p, n, nwg_out, st);
+    if (GC == 16 && XC == 16) return launch_bwd<16, 16>(p, n, nwg_out, st);
+    return PC_EINVAL;
 }

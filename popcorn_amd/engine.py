@@ -223,8 +223,8 @@ class UNetEngine:
             ops.conv3x3_dgrad_group(probs, c0, cn, pool=pool, accumulate=acc)
             return outs
 
-        # bf16 mode: the data gradient and the weight gradient of an 8 -> 8 layer (or of an 8-channel column block of a concat
-        # layer) read the same two tensors -- one launch for both (pc_conv3x3_bwd_group)
+        # bf16 mode: the data gradient and the weight gradient of a layer (or of one column block of a concat layer) read the
+        # same two tensors -- one launch for both (pc_conv3x3_bwd_group); the pooling layers keep their separate launches
         fuse = FUSED_CONV_BWD and L.act_dtype() == torch.bfloat16
 
         def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True):
@@ -269,10 +269,14 @@ class UNetEngine:
         else:
             wgs("up2b", "e1", G_e2)
             G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
-        wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
-        if not encoder_no_grad:
-            G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
-        g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
+        if fuse and not encoder_no_grad:
+            G_b2 = bwd8("up2a", G_e1, "b2", "d1b", {s: E(16, H1, W1) for s in S}, c0=0, cin_total=32)
+            g_u2 = bwd8("up2a", G_e1, "u2", None, {s: E(16, H1, W1) for s in S}, c0=16, cin_total=32, off_key="o2", with_db=False)
+        else:
+            wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
+            if not encoder_no_grad:
+                G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+            g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
         G_c2, probs = {}, []
         g_u2vs = {}
         for s in S:
@@ -288,15 +292,21 @@ class UNetEngine:
             finish()
             return
         # encoder
-        wgs("d2b", "c1", G_c2)
-        G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
+        if fuse:
+            G_c1 = bwd8("d2b", G_c2, "c1", "d2a", {s: E(16, H2, W2) for s in S}, cin_total=16)
+        else:
+            wgs("d2b", "c1", G_c2)
+            G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
         if all(A[s].get("pb2") is not None for s in S):
             wgs("d2a", "pb2", G_c1)                   # the pooled map was saved by the forward pass
         else:
             wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
         dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
-        wgs("d1b", "b1", G_b2)
-        G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
+        if fuse:
+            G_b1 = bwd8("d1b", G_b2, "b1", "d1a", {s: E(16, H1, W1) for s in S}, cin_total=16)
+        else:
+            wgs("d1b", "b1", G_b2)
+            G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
         if all(A[s].get("pa2") is not None for s in S):
             wgs("d1a", "pa2", G_b1)
         else:

@@ -503,9 +503,10 @@ class WgradBatch:
             self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
 
     def conv3x3_bwd_group(self, problems, cin_total, c0, accumulate=False):
-        """bf16 mode, 8 -> 8 channels: data gradient + weight-gradient partials of a conv layer in ONE launch.  problems: list of
-        dicts {g, x, w, out, dw (the full [8][cin_total][3][3] gradient), db (or None), x_bn (opt: ReLU / BN factor of x's producer),
-        x_offset (opt)}; the partials cover the columns [c0, c0 + 8) of dw."""
+        """bf16 mode: data gradient + weight-gradient partials of a conv layer (g: 8 / 16 channels, x: an 8- or 16-channel column
+        block of the layer's input) in ONE launch.  problems: list of dicts {g, x, w, out, dw (the full [Cg][cin_total][3][3]
+        gradient), db (or None), x_bn (opt: ReLU / BN factor of x's producer), x_offset (opt)}; the partials cover the columns
+        [c0, c0 + x.shape[1]) of dw."""
         n = len(problems)
         g0 = problems[0]["g"]
         B, Cg, H, W = g0.shape
@@ -522,7 +523,7 @@ class WgradBatch:
         L.check(L.lib().pc_conv3x3_bwd_group(n, descs, cin_total, c0, int(accumulate), B, H, W, C.byref(nwg), L.stream_ptr()),
                 "pc_conv3x3_bwd_group")
         for ws, pr in zip(slots, problems):
-            self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, 8, 8, 0, cin_total * 9, c0 * 9))
+            self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, pr["x"].shape[1], Cg, 0, cin_total * 9, c0 * 9))
 
     def convt2x2(self, x, g, dw, db):
         B, Cc, H, W = x.shape

@@ -567,45 +567,47 @@ def test_bf16_sliding_window_inference_tracks_fp32():
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64), (1, 37, 53), (3, 128, 128)])
-@pytest.mark.parametrize("case", ["plain_masked", "concat_up_half", "concat_skip_half_accumulate"])
+@pytest.mark.parametrize("case", ["plain_masked", "concat_up_half", "concat_skip_half_accumulate", "g8_x16_up_half_of_32", "g16_x16_masked"])
 def test_bf16_conv_backward_fused_op(shape, case):
-    """pc_conv3x3_bwd_group: data gradient + weight / bias gradient of an 8 -> 8 (column block of a) conv layer in one launch,
-    against torch on the same rounded operands; incl. a column block of a 16-input-channel layer with a placement offset of the
-    up-sampled half and an accumulating data gradient."""
+    """pc_conv3x3_bwd_group: data gradient + weight / bias gradient of a conv layer (8 / 16 output channels, an 8- or 16-channel
+    column block of its input) in one launch, against torch on the same rounded operands; incl. column blocks of concat layers
+    with a placement offset of the up-sampled half and an accumulating data gradient."""
     from popcorn_amd import ops, _lib as L
     import torch.nn.functional as F
     B, H, W = shape
-    cin_total, c0 = (8, 0) if case == "plain_masked" else (16, 8 if case == "concat_up_half" else 0)
-    hx, wx = (H - 1, W - 1) if case == "concat_up_half" else (H, W)          # the up-sampled half is smaller: zero F.pad, offset (0, 0)
-    x = _bf(F.relu(_mk(B, 8, hx, wx, seed=80)))
+    gc, xc, cin_total, c0 = {"plain_masked": (8, 8, 8, 0), "concat_up_half": (8, 8, 16, 8), "concat_skip_half_accumulate": (8, 8, 16, 0),
+                             "g8_x16_up_half_of_32": (8, 16, 32, 16), "g16_x16_masked": (16, 16, 16, 0)}[case]
+    up_half = "up_half" in case
+    hx, wx = (H - 1, W - 1) if up_half else (H, W)          # the up-sampled half is smaller: zero F.pad, offset (0, 0)
+    x = _bf(F.relu(_mk(B, xc, hx, wx, seed=80)))
     xfull = F.pad(x, (0, W - wx, 0, H - hx))
-    w = _mk(8, cin_total, 3, 3, seed=81, scale=0.2)
-    g = _bf(_mk(B, 8, H, W, seed=82))
-    gamma, beta, mean, var = _bn(8, 83)
+    w = _mk(gc, cin_total, 3, 3, seed=81, scale=0.2)
+    g = _bf(_mk(B, gc, H, W, seed=82))
+    gamma, beta, mean, var = _bn(xc, 83)
     scale = gamma / torch.sqrt(var + 1e-5)
     wd = _bf(w).double().requires_grad_(True)
     xd = torch.zeros(B, cin_total, H, W, dtype=torch.double)
-    xd[:, c0:c0 + 8] = xfull.double()
+    xd[:, c0:c0 + xc] = xfull.double()
     xd.requires_grad_(True)
-    bias = torch.zeros(8, dtype=torch.double, requires_grad=True)
+    bias = torch.zeros(gc, dtype=torch.double, requires_grad=True)
     F.conv2d(xd, wd, bias, padding=1).backward(g.double())
-    gx = xd.grad[:, c0:c0 + 8]
-    masked = case != "concat_up_half"
-    ref = (gx * (xfull > 0) * scale.view(1, 8, 1, 1).double()) if masked else gx
-    prev = _bf(_mk(B, 8, H, W, seed=84))
+    gx = xd.grad[:, c0:c0 + xc]
+    masked = not up_half
+    ref = (gx * (xfull > 0) * scale.view(1, xc, 1, 1).double()) if masked else gx
+    prev = _bf(_mk(B, xc, H, W, seed=84))
     acc = case == "concat_skip_half_accumulate"
     with L.precision("bf16"):
-        out = _dev(prev) if acc else L.empty_act(B, 8, H, W, "cuda")
-        dw = torch.full((8, cin_total, 3, 3), 7.0, device="cuda")
-        db = torch.empty(8, device="cuda")
+        out = _dev(prev) if acc else L.empty_act(B, xc, H, W, "cuda")
+        dw = torch.full((gc, cin_total, 3, 3), 7.0, device="cuda")
+        db = torch.empty(gc, device="cuda")
         wb = ops.WgradBatch(torch.device("cuda"))
         wb.conv3x3_bwd_group([{"g": _dev(g), "x": _dev(x), "w": w.cuda(), "out": out, "dw": dw, "db": db,
                                "x_bn": L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()) if masked else None}],
                              cin_total, c0, accumulate=acc)
         wb.finish()
     _close_bf16(out, (ref + (prev.double() if acc else 0)).float())
-    gw = wd.grad[:, c0:c0 + 8]
-    assert (dw[:, c0:c0 + 8].cpu().double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item()
-    other = [c for c in range(cin_total) if not c0 <= c < c0 + 8]
-    assert bool((dw[:, other] == 7.0).all())                                    # the other column block is not touched
+    gw = wd.grad[:, c0:c0 + xc]
+    assert (dw[:, c0:c0 + xc].cpu().double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item()
+    other = [c for c in range(cin_total) if not c0 <= c < c0 + xc]
+    assert bool((dw[:, other] == 7.0).all())                                    # the other column blocks are not touched
     assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()

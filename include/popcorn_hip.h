@@ -157,15 +157,19 @@ typedef struct pc_conv_dgrad_desc {
 } pc_conv_dgrad_desc;
 int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Cin_total, int c0, int Cn, int pool,
                            int accumulate, int B, int H, int W, int Cg, void* stream);
-/* ---- backward of one 8 -> 8 channel conv3x3 in ONE launch (PC_PREC_BF16 only): data gradient AND weight / bias gradient
- * partials from one pass over the layer's output gradient g and input x (both channels-last bf16, 8 channels).
- *   out (=|+=) relu'(x) * bn_scale(x_bn) * conv^T(g, w[:, c0:c0+8])      (x_bn NULL: no ReLU / BN factor)
- *   ws <- per-workgroup partials of dW[:, c0:c0+8] and db, to be finished by pc_wgrad_reduce_batch (Cin = 8, Cout = 8,
+/* ---- backward of one conv3x3 layer in ONE launch (PC_PREC_BF16 only): data gradient AND weight / bias gradient
+ * partials from one pass over the layer's output gradient g and input x (both channels-last bf16, 8 or 16 channels).
+ *   out (=|+=) relu'(x) * bn_scale(x_bn) * conv^T(g, w[:, c0:c0+XC])     (x_bn NULL: no ReLU / BN factor)
+ *   ws <- per-workgroup partials of dW[:, c0:c0+XC] and db, to be finished by pc_wgrad_reduce_batch (Cin = XC, Cout = GC,
  *         dw = &dW[0][c0][0][0], dw_co_stride = Cin_total * 9; *nwg_out partials per problem)
- * x may be one half of a concatenated input: x->oy / ox = its placement in the conv domain (zero outside).  Replaces a
- * pc_conv3x3_dgrad + pc_conv3x3_wgrad_partial pair (5 tensor reads + 1 write) by 2 reads + 1 write. */
+ * (GC, XC) = channels of g and x: (8,8), (8,16), (16,16); with pool_act (16,8), (16,16).  x may be one column block of a
+ * concatenated input: x->oy / ox = its placement in the conv domain (zero outside).  Replaces a pc_conv3x3_dgrad +
+ * pc_conv3x3_wgrad_partial pair (5 tensor reads + 1 write) by 2 reads + 1 write. */
 typedef struct pc_conv_bwd_desc {
     const pc_src* g; const pc_src* x; const float* w; const pc_bn* x_bn; const pc_dst* out; void* ws;
+    /* optional (Down blocks): x is the 2x2-max-pooled copy of this full-resolution activation; the data gradient is then
+     * scattered (+=) to the first arg-max of every window of `out` (twice the resolution), times relu'(pool_act) * bn_scale(x_bn) */
+    const pc_src* pool_act;
 } pc_conv_bwd_desc;
 int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                          int* nwg_out, void* stream);

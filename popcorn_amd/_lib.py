@@ -66,7 +66,7 @@ class PcWgradReduceDesc(C.Structure):
 
 class PcConvBwdDesc(C.Structure):
     _fields_ = [("g", C.POINTER(PcSrc)), ("x", C.POINTER(PcSrc)), ("w", C.c_void_p), ("x_bn", C.POINTER(PcBn)),
-                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p)]
+                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p), ("pool_act", C.POINTER(PcSrc))]
 
 
 PC_MAX_GROUP = 4

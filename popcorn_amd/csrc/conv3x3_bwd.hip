@@ -29,7 +29,8 @@ struct BwdProb {
     int w_ci_stride;        // Cin_total * 9
     int mask;               // 1: gx *= (x > 0) * bn_scale   (x is the post-ReLU output of a conv + BN layer)
     pc_bn bn;               // BN of the layer that produced x (mask = 1)
-    pc_dst out;             // gx
+    pc_dst out;             // gx (POOL: the gradient map at twice the resolution, accumulated into)
+    pc_src pool_act;        // POOL: the full-resolution activation the pooled x was taken from (arg-max + ReLU mask)
     float* partial;         // [nwg][GC * XC * 9 + GC]
 };
 
@@ -63,7 +64,9 @@ struct BwdCfg {
     static constexpr size_t LDS_B = 4 * WAVE_B + W_B > RED_B ? 4 * WAVE_B + W_B : RED_B;
 };
 
-template <int GC, int XC>
+// POOL: x is the 2x2-max-pooled copy of `pool_act` (the Down block's input, networks.py:289); the data gradient is scattered to the
+// first arg-max of every window of the full-resolution gradient map (+=), with the ReLU / BN factor of pool_act's producer
+template <int GC, int XC, bool POOL>
 __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     using Cfg = BwdCfg<GC, XC>;
     constexpr int NG = Cfg::NG, NX = Cfg::NX, NBP = Cfg::NBP, NBLK = Cfg::NBLK, EC = Cfg::EC;
@@ -225,6 +228,32 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
         for (int u = 0; u < 4; ++u) {
             const int y = y0 + 2 * (u >> 1) + e_s, x = x0 + (u & 1) * 16 + li;
             if (y < p.H && x < p.W) {
+                if constexpr (POOL) {
+                    const pc_bf16_t* const actp = reinterpret_cast<const pc_bf16_t*>(q.pool_act.ptr);
+                    const int a_rs = q.pool_act.rstride, a_xs = q.pool_act.xstride, o_rs = q.out.rstride, o_xs = q.out.xstride;
+#pragma unroll
+                    for (int nb = 0; nb < NX; ++nb) {
+                        const f32x4 v = acc[u][nb];
+                        const pc_bf16_t* a0 = actp + b * q.pool_act.bstride + (int64_t)(2 * y) * a_rs + (int64_t)(2 * x) * a_xs + nb * 8 + c4;
+                        pc_bf16_t* o0 = outp + b * q.out.bstride + (int64_t)(2 * y) * o_rs + (int64_t)(2 * x) * o_xs + nb * 8 + c4;
+                        const f32x4 A00 = pc_ld4(a0), A01 = pc_ld4(a0 + a_xs), A10 = pc_ld4(a0 + a_rs), A11 = pc_ld4(a0 + a_rs + a_xs);
+                        f32x4 O00 = pc_ld4(o0), O01 = pc_ld4(o0 + o_xs), O10 = pc_ld4(o0 + o_rs), O11 = pc_ld4(o0 + o_rs + o_xs);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int am = 0;
+                            float m = A00[r];
+                            if (A01[r] > m) { m = A01[r]; am = 1; }
+                            if (A10[r] > m) { m = A10[r]; am = 2; }
+                            if (A11[r] > m) { m = A11[r]; am = 3; }
+                            const float gv = m > 0.f ? v[r] * e_scale[nb][r] : 0.f;
+                            O00[r] += am == 0 ? gv : 0.f;
+                            O01[r] += am == 1 ? gv : 0.f;
+                            O10[r] += am == 2 ? gv : 0.f;
+                            O11[r] += am == 3 ? gv : 0.f;
+                        }
+                        pc_st4(o0, O00); pc_st4(o0 + o_xs, O01); pc_st4(o0 + o_rs, O10); pc_st4(o0 + o_rs + o_xs, O11);
+                    }
+                } else
 #pragma unroll
                 for (int nb = 0; nb < NX; ++nb) {
                     f32x4 v = acc[u][nb];
@@ -309,12 +338,12 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     }
 }
 
-template <int GC, int XC>
+template <int GC, int XC, bool POOL>
 int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     using Cfg = BwdCfg<GC, XC>;
     static int resident = 0;
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_cl_kernel<GC, XC>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_cl_kernel<GC, XC, POOL>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_B);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -322,7 +351,7 @@ int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, Cfg::LDS_B);
         if (getenv("POPCORN_CONV_DBG"))
-            fprintf(stderr, "conv3x3_bwd<%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", GC, XC, fa.numRegs, (size_t)Cfg::LDS_B, resident);
+            fprintf(stderr, "conv3x3_bwd<%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", GC, XC, (int)POOL, fa.numRegs, (size_t)Cfg::LDS_B, resident);
     }
     int nwg = resident / n;
     if (nwg > 512) nwg = 512;                // partials per problem (the workspace slice holds more)
@@ -330,7 +359,7 @@ int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     if (nwg < 1) nwg = 1;
     const int rounds = (p.ntiles + nwg - 1) / nwg;
     nwg = (p.ntiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL((conv3x3_bwd_cl_kernel<GC, XC>), dim3(nwg, n), dim3(256), Cfg::LDS_B, stream, p);
+    hipLaunchKernelGGL((conv3x3_bwd_cl_kernel<GC, XC, POOL>), dim3(nwg, n), dim3(256), Cfg::LDS_B, stream, p);
     PC_CHECK_LAUNCH();
     *nwg_out = nwg;
     return 0;
@@ -357,6 +386,12 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         q.mask = d[i].x_bn != nullptr;
         if (d[i].x_bn) q.bn = *d[i].x_bn;
         q.out = *d[i].out;
+        if ((d[i].pool_act != nullptr) != (d[0].pool_act != nullptr)) return PC_EINVAL;
+        if (d[i].pool_act) {
+            // the scatter always accumulates and always applies the producer's ReLU / BN factor
+            q.pool_act = *d[i].pool_act;
+            if (!pc_cl_ok(q.pool_act) || !d[i].x_bn || q.pool_act.C != XC || q.pool_act.H < 2 * H || q.pool_act.W < 2 * W) return PC_EINVAL;
+        }
         q.partial = reinterpret_cast<float*>(d[i].ws);
     }
     p.accumulate = accumulate;
@@ -368,8 +403,13 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     hipStream_t st = (hipStream_t)stream;
-    if (GC == 8 && XC == 8) return launch_bwd<8, 8>(p, n, nwg_out, st);
-    if (GC == 8 && XC == 16) return launch_bwd<8, 16>(p, n, nwg_out, st);
-    if (GC == 16 && XC == 16) return launch_bwd<16, 16>(p, n, nwg_out, st);
+    if (d[0].pool_act) {
+        if (GC == 16 && XC == 8) return launch_bwd<16, 8, true>(p, n, nwg_out, st);
+        if (GC == 16 && XC == 16) return launch_bwd<16, 16, true>(p, n, nwg_out, st);
+        return PC_EINVAL;
+    }
+    if (GC == 8 && XC == 8) return launch_bwd<8, 8, false>(p, n, nwg_out, st);
+    if (GC == 8 && XC == 16) return launch_bwd<8, 16, false>(p, n, nwg_out, st);
+    if (GC == 16 && XC == 16) return launch_bwd<16, 16, false>(p, n, nwg_out, st);
     return PC_EINVAL;
 }

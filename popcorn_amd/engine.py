@@ -224,10 +224,10 @@ class UNetEngine:
             return outs
 
         # bf16 mode: the data gradient and the weight gradient of a layer (or of one column block of a concat layer) read the
-        # same two tensors -- one launch for both (pc_conv3x3_bwd_group); the pooling layers keep their separate launches
+        # same two tensors -- one launch for both (pc_conv3x3_bwd_group), the Down blocks' first layers included (pool_act)
         fuse = FUSED_CONV_BWD and L.act_dtype() == torch.bfloat16
 
-        def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True):
+        def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True, pool_key=None):
             probs = []
             for s in S:
                 lay = ly(s, tag)
@@ -237,6 +237,8 @@ class UNetEngine:
                     pr["x_bn"] = ly(s, act_tag).bn_nobias
                 if off_key is not None:
                     pr["x_offset"] = A[s][off_key]
+                if pool_key is not None:               # Down block: x is the saved pooled map, outs the (accumulated) full-resolution gradient
+                    pr["pool_act"] = A[s][pool_key]
                 probs.append(pr)
             wb.conv3x3_bwd_group(probs, cin_total, c0)
             return outs
@@ -297,21 +299,27 @@ class UNetEngine:
         else:
             wgs("d2b", "c1", G_c2)
             G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
-        if all(A[s].get("pb2") is not None for s in S):
-            wgs("d2a", "pb2", G_c1)                   # the pooled map was saved by the forward pass
+        if fuse and all(A[s].get("pb2") is not None for s in S):
+            bwd8("d2a", G_c1, "pb2", "d1b", G_b2, cin_total=16, pool_key="b2")
         else:
-            wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
-        dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
+            if all(A[s].get("pb2") is not None for s in S):
+                wgs("d2a", "pb2", G_c1)               # the pooled map was saved by the forward pass
+            else:
+                wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
+            dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
         if fuse:
             G_b1 = bwd8("d1b", G_b2, "b1", "d1a", {s: E(16, H1, W1) for s in S}, cin_total=16)
         else:
             wgs("d1b", "b1", G_b2)
             G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
-        if all(A[s].get("pa2") is not None for s in S):
-            wgs("d1a", "pa2", G_b1)
+        if fuse and all(A[s].get("pa2") is not None for s in S):
+            bwd8("d1a", G_b1, "pa2", "inc2", G_a2, cin_total=8, pool_key="a2")
         else:
-            wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
-        dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
+            if all(A[s].get("pa2") is not None for s in S):
+                wgs("d1a", "pa2", G_b1)
+            else:
+                wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
+            dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
         if fuse:
             G_a1 = bwd8("inc2", G_a2, "a1", "inc1", {s: E(8, Hp, Wp) for s in S})
         else:

@@ -519,6 +519,10 @@ class WgradBatch:
             slots.append(ws)
             descs[i].g, descs[i].x, descs[i].w, descs[i].out, descs[i].ws = C.pointer(sg), C.pointer(sx), pr["w"].data_ptr(), C.pointer(d), ws
             descs[i].x_bn = C.pointer(pr["x_bn"]) if pr.get("x_bn") is not None else None
+            if pr.get("pool_act") is not None:        # Down blocks: x is the pooled copy of pool_act; out is at twice the resolution (+=)
+                spa = L.src(pr["pool_act"])
+                keep.append(spa)
+                descs[i].pool_act = C.pointer(spa)
         nwg = C.c_int(0)
         L.check(L.lib().pc_conv3x3_bwd_group(n, descs, cin_total, c0, int(accumulate), B, H, W, C.byref(nwg), L.stream_ptr()),
                 "pc_conv3x3_bwd_group")

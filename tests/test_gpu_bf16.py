@@ -611,3 +611,49 @@ def test_bf16_conv_backward_fused_op(shape, case):
     other = [c for c in range(cin_total) if not c0 <= c < c0 + xc]
     assert bool((dw[:, other] == 7.0).all())                                    # the other column blocks are not touched
     assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 37, 53), (3, 50, 50)])
+@pytest.mark.parametrize("xc", [8, 16])
+def test_bf16_conv_backward_fused_pool_op(shape, xc):
+    """pc_conv3x3_bwd_group with pool_act (the first conv of a Down block, networks.py:289 MaxPool2d(2) -> double_conv): x is the
+    saved pooled map, the data gradient is scattered (+=) to the first arg-max of every 2x2 window of the full-resolution
+    gradient with the producer's ReLU / BN factor; against torch autograd through max_pool2d on the same rounded operands
+    (ties between window elements are made impossible by construction: distinct bf16 values per window)."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    B, H2, W2 = shape                                        # full resolution (odd sizes: the last row / column is not pooled)
+    H, W = H2 // 2, W2 // 2
+    gc = 16
+    act = _bf(F.relu(_mk(B, xc, H2, W2, seed=90)))
+    # distinct positive values inside every window where any is positive, so that torch's and the kernel's arg-max agree
+    bump = torch.tensor([[0.0, 1.0], [2.0, 3.0]]).repeat((H2 + 1) // 2, (W2 + 1) // 2)[:H2, :W2] / 64
+    act = _bf(torch.where(act > 0, act + bump, act))
+    for _ in range(3):                                       # re-round until the bumps survive bf16 rounding as distinct values
+        win = F.unfold(act[:, :, :2 * H, :2 * W].reshape(B * xc, 1, 2 * H, 2 * W), 2, stride=2)
+        srt = win.sort(dim=1).values
+        if not bool(((srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] > 0)).any()):
+            break
+        act = _bf(torch.where(act > 0, act * 1.5 + bump, act))
+    pooled = F.max_pool2d(act, 2)
+    w = _mk(gc, xc, 3, 3, seed=91, scale=0.2)
+    g = _bf(_mk(B, gc, H, W, seed=92))
+    gamma, beta, mean, var = _bn(xc, 93)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    ad = act.double().requires_grad_(True)
+    wd = _bf(w).double().requires_grad_(True)
+    bias = torch.zeros(gc, dtype=torch.double, requires_grad=True)
+    F.conv2d(F.max_pool2d(ad, 2), wd, bias, padding=1).backward(g.double())
+    ref = ad.grad * (act > 0) * scale.view(1, xc, 1, 1).double()
+    prev = _bf(_mk(B, xc, H2, W2, seed=94))
+    with L.precision("bf16"):
+        out = _dev(prev)
+        dw = torch.empty(gc, xc, 3, 3, device="cuda")
+        db = torch.empty(gc, device="cuda")
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.conv3x3_bwd_group([{"g": _dev(g), "x": _dev(pooled), "w": w.cuda(), "out": out, "dw": dw, "db": db, "pool_act": _dev(act),
+                               "x_bn": L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())}], xc, 0)
+        wb.finish()
+    _close_bf16(out, (ref + prev.double()).float())
+    assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()

@@ -365,12 +365,245 @@ int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     return 0;
 }
 
+
+// ---- fp32 (planar tensors, PC_PREC_FP32): the same fusion on v_mfma_f32_16x16x4_f32, 8 -> 8 channels -------------------------
+// The data gradient is conv3x3_mfma_kernel<8, 8, dgrad>'s mapping (K = 4 strip rows, N = (row of the output pair, 8 channels)), the
+// weight gradient conv3x3_wgrad_wave_kernel<8, 8>'s (K = 4 pixels, M = (row, g channel), N = (x channel, strip row, dx)); each wave
+// stages its 6 x 40 strip of g (row stride 48, channel stride 292: the pixel-contraction operand is read across channels) and of x
+// (row stride 44, channel stride 264: the conflict-free layout of the weight-gradient kernel) once per strip.  The ReLU mask comes from
+// the x image.  Aligned sources only (W % 4 == 0, no placement offset): the callers keep the separate launches for anything else.
+constexpr int F_RS = 48, F_CSW = 6 * F_RS + 4;
+constexpr int F_XRS = 44, F_XCSW = 6 * F_XRS;
+constexpr int F_WAVE = 8 * (F_CSW + F_XCSW);               // floats of a wave's LDS region
+constexpr int F_WRL = 8 * 3 + 4, F_WDYS = 8 * F_WRL + 16;  // weight image [dy plane][x channel][g channel * 3 + dx] (conv3x3.hip)
+constexpr int F_NBLK = 6, F_EC = 8 * 8 * 9 + 8;
+constexpr size_t F_LDS_B = (size_t)(4 * F_WAVE + 4 * F_WDYS) * sizeof(float);
+
+__global__ __launch_bounds__(256) void conv3x3_bwd_f32_kernel(const BwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    const BwdProb& q = p.pr[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int s_row = li >> 3, col = li & 7;
+    float* const wg = ldsf + wave * F_WAVE;                // g image
+    float* const wx = wg + 8 * F_CSW;                      // x image
+    float* const w2 = ldsf + 4 * F_WAVE;
+
+    // ---- loader: lane = (row of the 6-row strip, 16-byte segment of the 40-float row), both tensors
+    const int l_r = lane / 10, l_seg = lane - l_r * 10;
+    const bool l_act = lane < 60;
+    f32x4 RG[8], RX[8];
+    bool rvalid = false;
+    auto issue = [&](int b, int y0, int x0) {
+        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
+        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
+        rvalid = ok;
+        const float* gp = q.g.ptr + (ok ? b * q.g.bstride + (int64_t)y * q.g.rstride + xg : 0);
+        const float* xp = q.x.ptr + (ok ? b * q.x.bstride + (int64_t)y * q.x.rstride + xg : 0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            RG[it] = *reinterpret_cast<const f32x4*>(gp + it * q.g.cstride);
+            RX[it] = *reinterpret_cast<const f32x4*>(xp + it * q.x.cstride);
+        }
+    };
+    auto commit = [&]() {
+        if (l_act) {
+            float* dg = wg + l_r * F_RS + 4 * l_seg;
+            float* dx_ = wx + l_r * F_XRS + 4 * l_seg;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                *reinterpret_cast<f32x4*>(dg + it * F_CSW) = rvalid ? RG[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dx_ + it * F_XCSW) = rvalid ? RX[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) {
+        strip_coords(0, b, y0, x0);
+        issue(b, y0, x0);
+    }
+
+    // ---- data-gradient weights: output channel = x channel, K channel = g channel, taps flipped (one round trip, see conv3x3.hip)
+    float wreg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = tid + k * 256;
+        const int ec = e < 576 ? e : 0;
+        const int tap = ec % 9, gch = (ec / 9) % 8, xch = ec / 72;
+        wreg[k] = q.w[xch * 9 + gch * q.w_ci_stride + (8 - tap)];
+    }
+    float bn_g = 1.f, bn_v = 1.f;
+    if (q.mask && q.bn.gamma) { bn_g = q.bn.gamma[col]; bn_v = q.bn.var[col]; }
+    for (int e = tid; e < F_WDYS; e += 256) w2[3 * F_WDYS + e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = tid + k * 256;
+        if (e < 576) {
+            const int tap = e % 9, gch = (e / 9) % 8, xch = e / 72;
+            w2[(tap / 3) * F_WDYS + xch * F_WRL + gch * 3 + (tap % 3)] = wreg[k];
+        }
+    }
+    __syncthreads();
+    const float* const wlane = w2 + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * F_WDYS + col * F_WRL;
+    const float e_scale = (q.mask && q.bn.gamma) ? bn_g * (1.0f / sqrtf(bn_v + q.bn.eps)) : 1.f;
+    asm volatile("" : : "v"(e_scale));
+
+    // ---- weight-gradient operand addresses
+    const int koff = ((lk & 1) << 4) | ((lk >> 1) << 3);          // {0,16,8,24}: a lane's 8 k-steps are 8 consecutive floats
+    int boff[F_NBLK];
+#pragma unroll
+    for (int nb = 0; nb < F_NBLK; ++nb) {
+        const int ng = nb * 16 + li;
+        const int ci = ng / 12, rem = ng % 12, v = rem / 3, dx = rem % 3;
+        boff[nb] = ci * F_XCSW + v * F_XRS + (COL0 - 1) + dx + koff;
+    }
+    const float* const ga = wg + col * F_CSW + (1 + s_row) * F_RS + COL0 + koff;      // A: lane (i = (s, g channel), k)
+    f32x4 wacc[F_NBLK];
+    float bsum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < F_NBLK; ++nb) wacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0; k < my_tiles; ++k) {
+        commit();
+        int nb_ = b, ny0 = y0, nx0 = x0;
+        if (k + 1 < my_tiles) {
+            strip_coords(k + 1, nb_, ny0, nx0);
+            issue(nb_, ny0, nx0);
+        }
+        // ---- data gradient
+        {
+            float bw[8][3];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wlane + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bw[(4 * j + e) / 3][(4 * j + e) % 3] = t[e];
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* lrow = wg + lk * F_RS + (COL0 - 1) + li;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = lrow[ci * F_CSW + (u >> 1) * 2 * F_RS + (u & 1) * 16 + dx];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[ci][dx], acc[u], 0, 0, 0);
+                }
+            // lane holds (x channel col, y = y0 + 2*(u>>1) + s_row, x = x0 + (u&1)*16 + 4*lk + r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int y = y0 + 2 * (u >> 1) + s_row, x = x0 + (u & 1) * 16 + 4 * lk;
+                if (y < p.H && x < p.W) {
+                    f32x4 v = acc[u];
+                    if (q.mask) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(wx + col * F_XCSW + (1 + 2 * (u >> 1) + s_row) * F_XRS + COL0 + (u & 1) * 16 + 4 * lk);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale : 0.f;
+                    }
+                    float* op = reinterpret_cast<float*>(q.out.ptr) + b * q.out.bstride + col * q.out.cstride + (int64_t)y * q.out.rstride + x;
+                    if (p.accumulate) {
+                        const f32x4 o4 = pc_ld4(op);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                    }
+                    pc_st4(op, v);
+                }
+            }
+        }
+        // ---- weight gradient: D[(s,co)][(ci,v,dx)] += sum_x g[co][y0+2rpi+s][x] * x[ci][y0+2rpi+v-1][x+dx-1]
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ga + 2 * rpi * F_RS), a1 = *reinterpret_cast<const f32x4*>(ga + 2 * rpi * F_RS + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = j < 4 ? a0[j & 3] : a1[j & 3];
+                float bv[F_NBLK];
+#pragma unroll
+                for (int nb = 0; nb < F_NBLK; ++nb) bv[nb] = wx[boff[nb] + 2 * rpi * F_XRS + j];
+                bsum += a;
+#pragma unroll
+                for (int nb = 0; nb < F_NBLK; ++nb) wacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nb], wacc[nb], 0, 0, 0);
+            }
+        }
+        b = nb_; y0 = ny0; x0 = nx0;
+    }
+
+    // ---- cross-wave reduction through LDS (fixed order), one compacted partial per workgroup (conv3x3_wgrad_wave_kernel's)
+    float* lds = ldsf;
+    float* part = q.partial + (int64_t)blockIdx.x * F_EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[F_NBLK * 256 + e]) + lds[2 * F_NBLK * 256 + e]) + lds[3 * F_NBLK * 256 + e]; };
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < F_NBLK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * F_NBLK + nb) * 64 + lane) * 4]) = wacc[nb];
+    __syncthreads();
+    for (int idx = tid; idx < 8 * 8 * 9; idx += 256) {
+        const int c8 = idx / 72, rem = idx - c8 * 72;
+        const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+        const int ng0 = cil * 12 + dy * 3 + dx, ng1 = ng0 + 3;
+        const int m0 = c8, m1 = 8 + c8;
+        const int e0 = ((ng0 >> 4) * 64 + (m0 >> 2) * 16 + (ng0 & 15)) * 4 + (m0 & 3);
+        const int e1 = ((ng1 >> 4) * 64 + (m1 >> 2) * 16 + (ng1 & 15)) * 4 + (m1 & 3);
+        part[c8 * 72 + rem] = wsum(e0) + wsum(e1);
+    }
+    __syncthreads();
+    lds[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int lk2 = 0; lk2 < 4; ++lk2) {
+            const int ea = lk2 * 16 + tid, eb = ea + 8;
+            const float sa = ((lds[ea] + lds[64 + ea]) + lds[2 * 64 + ea]) + lds[3 * 64 + ea];
+            const float sb = ((lds[eb] + lds[64 + eb]) + lds[2 * 64 + eb]) + lds[3 * 64 + eb];
+            t += sa + sb;
+        }
+        part[8 * 8 * 9 + tid] = t;
+    }
+}
+
+int launch_bwd_f32(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
+    static int resident = 0;
+    if (!resident) {
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_f32_kernel);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_B);
+        if (e != hipSuccess) return (int)e;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, F_LDS_B);
+        if (getenv("POPCORN_CONV_DBG"))
+            fprintf(stderr, "conv3x3_bwd_f32: %d regs, %zu B LDS -> %d resident workgroups\n", fa.numRegs, (size_t)F_LDS_B, resident);
+    }
+    int nwg = resident / n;
+    if (nwg > 512) nwg = 512;
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    if (nwg < 1) nwg = 1;
+    const int rounds = (p.ntiles + nwg - 1) / nwg;
+    nwg = (p.ntiles + rounds - 1) / rounds;
+    hipLaunchKernelGGL(conv3x3_bwd_f32_kernel, dim3(nwg, n), dim3(256), F_LDS_B, stream, p);
+    PC_CHECK_LAUNCH();
+    *nwg_out = nwg;
+    return 0;
+}
 }  // namespace
 
 extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                                     int* nwg_out, void* stream) {
     if (n < 1 || n > MAXG || !d || !nwg_out) return PC_EINVAL;
-    if (g_pc_precision != PC_PREC_BF16) return PC_EINVAL;
+    const bool f32 = g_pc_precision != PC_PREC_BF16;
     BwdArgs p{};
     int GC = 0, XC = 0;
     for (int i = 0; i < n; ++i) {
@@ -378,9 +611,22 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         BwdProb& q = p.pr[i];
         q.g = *d[i].g; q.x = *d[i].x;
         if (i == 0) { GC = q.g.C; XC = q.x.C; }
-        if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out) || q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT ||
-            q.g.mode != PC_SRC_DIRECT || c0 < 0 || c0 + XC > Cin_total)
+        if (q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT || q.g.mode != PC_SRC_DIRECT || c0 < 0 || c0 + XC > Cin_total)
             return PC_EINVAL;
+        if (f32) {
+            // planar fp32, 8 -> 8 channels, 16-byte aligned rows, x placed at (0, 0) with the extent of g
+            auto al = [](const void* ptr, int64_t bs, int64_t cs, int rs) {
+                return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
+            };
+            const pc_dst& o = *d[i].out;
+            if (GC != 8 || XC != 8 || d[i].pool_act || W % 4 != 0 || q.g.dtype != PC_F32 || q.x.dtype != PC_F32 || o.dtype != PC_F32 ||
+                !pc_planar(q.g) || !pc_planar(q.x) || !pc_planar(o) || q.x.oy != 0 || q.x.ox != 0 || q.x.H != H || q.x.W != W ||
+                !al(q.g.ptr, q.g.bstride, q.g.cstride, q.g.rstride) || !al(q.x.ptr, q.x.bstride, q.x.cstride, q.x.rstride) ||
+                !al(o.ptr, o.bstride, o.cstride, o.rstride))
+                return PC_EINVAL;
+        } else if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out)) {
+            return PC_EINVAL;
+        }
         q.w = d[i].w + (int64_t)c0 * 9;
         q.w_ci_stride = Cin_total * 9;
         q.mask = d[i].x_bn != nullptr;
@@ -403,6 +649,7 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     hipStream_t st = (hipStream_t)stream;
+    if (f32) return launch_bwd_f32(p, n, nwg_out, st);
     if (d[0].pool_act) {
         if (GC == 16 && XC == 8) return launch_bwd<16, 8, true>(p, n, nwg_out, st);
         if (GC == 16 && XC == 16) return launch_bwd<16, 16, true>(p, n, nwg_out, st);

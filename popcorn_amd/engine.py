@@ -63,8 +63,8 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
     return names
 
 
-# bf16 mode: data gradient + weight gradient of the 8 -> 8 conv layers in one launch each (POPCORN_FUSED_CONV_BWD=0: separate
-# launches; A/B switch)
+# data gradient + weight gradient of a conv layer in one launch (bf16 mode: every layer; fp32 mode: the 8 -> 8 layers);
+# POPCORN_FUSED_CONV_BWD=0: separate launches (A/B switch)
 FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
 
 
@@ -225,7 +225,22 @@ class UNetEngine:
 
         # bf16 mode: the data gradient and the weight gradient of a layer (or of one column block of a concat layer) read the
         # same two tensors -- one launch for both (pc_conv3x3_bwd_group), the Down blocks' first layers included (pool_act)
-        fuse = FUSED_CONV_BWD and L.act_dtype() == torch.bfloat16
+        bf = L.act_dtype() == torch.bfloat16
+        fuse = FUSED_CONV_BWD and bf
+
+        def fuse8(gs, x_key, off_key=None):
+            """8 -> 8 layers: also in fp32 mode, for planar tensors with 16-byte aligned rows and the input block placed at
+            (0, 0) with the extent of the gradient (anything else keeps the separate launches)"""
+            if not FUSED_CONV_BWD or bf:
+                return FUSED_CONV_BWD
+            for s in S:
+                g, x = gs[s], A[s][x_key]
+                if x.shape[2:] != g.shape[2:] or g.shape[3] % 4 or (off_key is not None and tuple(A[s][off_key]) != (0, 0)):
+                    return False
+                for t in (g, x):
+                    if t.stride(3) != 1 or t.stride(2) % 4 or t.stride(1) % 4 or t.stride(0) % 4 or t.data_ptr() % 16:
+                        return False
+            return True
 
         def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True, pool_key=None):
             probs = []
@@ -244,12 +259,12 @@ class UNetEngine:
             return outs
 
         G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
-        if fuse:
+        if fuse8(G_f2, "f1"):
             G_f1 = bwd8("up1b", G_f2, "f1", "up1a", {s: E(8, Hp, Wp) for s in S})
         else:
             wgs("up1b", "f1", G_f2)
             G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
-        if fuse and not encoder_no_grad:
+        if not encoder_no_grad and fuse8(G_f1, "a2") and fuse8(G_f1, "u1", "o1"):
             G_a2 = bwd8("up1a", G_f1, "a2", "inc2", {s: E(8, Hp, Wp) for s in S}, c0=0, cin_total=16)
             g_u1 = bwd8("up1a", G_f1, "u1", None, {s: E(8, Hp, Wp) for s in S}, c0=8, cin_total=16, off_key="o1", with_db=False)
         else:
@@ -266,7 +281,7 @@ class UNetEngine:
             probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
         wgts("up1t", {s: A[s]["e2"] for s in S}, g_u1vs)
         ops.convt2x2_dgrad_group(probs)
-        if fuse:
+        if fuse8(G_e2, "e1"):
             G_e1 = bwd8("up2b", G_e2, "e1", "up2a", {s: E(8, H1, W1) for s in S})
         else:
             wgs("up2b", "e1", G_e2)
@@ -320,7 +335,7 @@ class UNetEngine:
             else:
                 wgs("d1a", "a2", G_b1, a_mode=L.PC_SRC_POOL2)
             dg("d1a", G_b1, G_a2, 0, 8, {s: A[s]["a2"] for s in S}, "inc2", pool=True, acc=True)
-        if fuse:
+        if fuse8(G_a2, "a1"):
             G_a1 = bwd8("inc2", G_a2, "a1", "inc1", {s: E(8, Hp, Wp) for s in S})
         else:
             wgs("inc2", "a1", G_a2)

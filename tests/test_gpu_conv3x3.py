@@ -245,3 +245,52 @@ def test_conv_fwd_partial_logit_output():
     torch.testing.assert_close(logits[:, 1].cpu(), (ref0 * dw.view(1, 8, 1, 1)).sum(1), rtol=1e-5, atol=5e-5)
     assert torch.isnan(logits[:, 0]).all()                      # the other channel is untouched
     torch.testing.assert_close(out1.cpu(), ref1, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 36, 52), (3, 128, 128), (2, 20, 8)])
+@pytest.mark.parametrize("case", ["plain_masked", "concat_up_half", "concat_skip_half_accumulate"])
+def test_conv_backward_fused_op_fp32(shape, case):
+    """pc_conv3x3_bwd_group in fp32 mode (planar tensors, 8 -> 8 channels): data gradient (+ ReLU / BN factor, += form) and
+    weight / bias gradient of a layer, or of one column block of a concat layer, in one launch, against torch autograd (fp64)."""
+    from popcorn_amd import ops, _lib as L
+    B, H, W = shape
+    cin_total, c0 = {"plain_masked": (8, 0), "concat_up_half": (16, 8), "concat_skip_half_accumulate": (16, 0)}[case]
+    masked = case != "concat_up_half"
+    x = F.relu(_mk(B, 8, H, W, seed=80)) if masked else _mk(B, 8, H, W, seed=80)
+    w = _mk(8, cin_total, 3, 3, seed=81, scale=0.2)
+    g = _mk(B, 8, H, W, seed=82)
+    gamma, beta, mean, var = _bn_params(8, 83)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    wd = w.double().requires_grad_(True)
+    xd = torch.zeros(B, cin_total, H, W, dtype=torch.double)
+    xd[:, c0:c0 + 8] = x.double()
+    xd.requires_grad_(True)
+    bias = torch.zeros(8, dtype=torch.double, requires_grad=True)
+    F.conv2d(xd, wd, bias, padding=1).backward(g.double())
+    gx = xd.grad[:, c0:c0 + 8]
+    ref = (gx * (x > 0) * scale.view(1, 8, 1, 1).double()) if masked else gx
+    acc = case == "concat_skip_half_accumulate"
+    prev = _mk(B, 8, H, W, seed=84)
+    out = prev.cuda() if acc else torch.empty(B, 8, H, W, device="cuda")
+    dw = torch.full((8, cin_total, 3, 3), 7.0, device="cuda")
+    db = torch.empty(8, device="cuda")
+    wb = ops.WgradBatch(torch.device("cuda"))
+    wb.conv3x3_bwd_group([{"g": g.cuda(), "x": x.cuda(), "w": w.cuda(), "out": out, "dw": dw, "db": db,
+                           "x_bn": L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()) if masked else None}],
+                         cin_total, c0, accumulate=acc)
+    wb.finish()
+    torch.testing.assert_close(out.cpu().double(), ref + (prev.double() if acc else 0), rtol=1e-5, atol=2e-5)
+    gw = wd.grad[:, c0:c0 + 8]
+    assert (dw[:, c0:c0 + 8].cpu().double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item()
+    other = [c for c in range(cin_total) if not c0 <= c < c0 + 8]
+    assert bool((dw[:, other] == 7.0).all())
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()
+
+
+def test_conv_backward_fused_op_fp32_refuses_unaligned():
+    from popcorn_amd import ops, _lib as L
+    x = torch.zeros(1, 8, 10, 10, device="cuda")
+    wb = ops.WgradBatch(torch.device("cuda"))
+    with pytest.raises(L.PopcornHipError):
+        wb.conv3x3_bwd_group([{"g": x, "x": x, "w": torch.zeros(8, 8, 3, 3, device="cuda"), "out": torch.empty_like(x),
+                               "dw": torch.empty(8, 8, 3, 3, device="cuda"), "db": torch.empty(8, device="cuda")}], 8, 0)

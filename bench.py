@@ -250,6 +250,16 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         cin = k.get("a_channels") or a.shape[1]
         return 2.0 * 9 * cin * cout * Bn * H * W, nb(g) + Bn * cin * H * W * a.element_size(), f"wgrad {cin}->{cout} @{H}x{W} x1 (reflect loader)"
 
+    def c_bwd(self, problems, cin_total, c0, accumulate=False):
+        # data + weight gradient of one layer (column block) in one launch: g and x read once, the data gradient written once
+        p0 = problems[0]
+        Bn, cg, H, W = p0["g"].shape
+        cx = p0["x"].shape[1]
+        n = len(problems)
+        pool = p0.get("pool_act") is not None
+        by = sum(nb(p["g"]) + nb(p["x"]) + nb(p["out"]) * (2 if (accumulate or pool) else 1) + nb(p.get("pool_act")) for p in problems)
+        return 2.0 * 2 * 9 * cg * cx * Bn * H * W * n, by, f"dgrad+wgrad {cg}<->{cx} @{H}x{W} x{n}{' pool' if pool else ''}"
+
     def c_convt(problems):
         p0 = problems[0]
         Bn, C_, H, W = p0["x"].shape
@@ -276,6 +286,7 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
     trainer.use_graph = False
     patches = [wrap(ops, "conv3x3_fwd_group", "conv_fwd", c_fwd), wrap(ops, "conv3x3_dgrad_group", "conv_dgrad", c_dgrad),
                wrap(ops.WgradBatch, "conv3x3_group", "conv_wgrad", c_wgrad_g), wrap(ops.WgradBatch, "conv3x3", "conv_wgrad", c_wgrad_1),
+               wrap(ops.WgradBatch, "conv3x3_bwd_group", "conv_bwd_fused", c_bwd),
                wrap(ops, "convt2x2_group", "convt", c_convt), wrap(ops, "convt2x2_dgrad_group", "convt", c_convt_d),
                wrap(ops.WgradBatch, "convt2x2_group", "convt", c_convt_w), wrap(ops.WgradBatch, "finish", "conv_wgrad", c_finish)]
     # the engine module holds its own references to the ops functions through `ops.<name>` lookups: patched above

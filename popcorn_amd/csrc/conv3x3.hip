@@ -9,7 +9,8 @@
 //     K (4)   = v: the 4 input rows (y0-1 .. y0+2) that the two output rows touch
 //     one MFMA per (input channel ci, horizontal tap dx);  B[v][(s,co)] = w[co][ci][v-s][dx] (0 when v-s not in 0..2)
 // so 9 useful taps ride on 12 K-slots: 75 % MFMA efficiency at Cout = 8 (a plain im2col with N = Cout = 8 wastes half
-// of every MFMA) and no padding waste in N for any Cout that is a multiple of 8.
+// of every MFMA).  The 16-output layers use the plain im2col instead (N16 below: N = 16 channels, K = 4 consecutive
+// (ci, dy, dx) of a chunk's 72): every issued K-slot is a tap.
 //
 // Data movement: a workgroup (4 waves) owns a 32 x 16 output tile; the (CHUNK x 18 x 40) input halo tile is staged
 // in LDS with row stride 48 (= 16 mod 32 banks), which makes the A-operand read -- lane (i = x, k = row) ->
@@ -110,6 +111,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
     constexpr int W_RL = CIN * 3 + 4;                    // weight image: floats per (dy, co) row (== 4 mod 8: spreads banks)
     constexpr int W_DYS = COUT * W_RL + 16;              // ... and per dy plane
+    // 16 output channels: plain im2col, N = 16 channels, M = 16 x of ONE row, K = 4 consecutive (ci, dy, dx) of a chunk's 72 --
+    // every issued MFMA slot is a tap (the row-pair mapping of the 8-channel blocks spends 12 K-slots on 9 taps)
+    constexpr bool N16 = COUT == 16 && CHUNK == 8;
+    constexpr int W16_S = CIN * 9 + 1;                   // N16 weight image [co][ci * 9 + tap], odd row stride: 16 channels on 16 banks
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const ConvProb& q = p.pr[blockIdx.y];
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     float bn_raw[NB][5];            // {conv bias, gamma, var, mean, beta} of channel nb*8 + col
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int c = nb * 8 + col;
+        const int c = N16 ? li : nb * 8 + col;          // N16: one channel per lane (slot nb = 0 is the one that is used)
         bn_raw[nb][0] = has_bn && q.bn.conv_bias ? q.bn.conv_bias[c] : 0.f;
         bn_raw[nb][1] = has_bn && q.bn.gamma ? q.bn.gamma[c] : 1.f;
         bn_raw[nb][2] = has_bn && q.bn.gamma ? q.bn.var[c] : 1.f;
@@ -250,21 +255,34 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     {
         // only the dy = 3 plane has to be zero (the pad floats of the other planes are never read): disjoint from the weight
         // writes below, so one barrier covers both
-        for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
+        if constexpr (!N16)
+            for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
 #pragma unroll
         for (int k = 0; k < NWR; ++k) {
             const int e = tid + k * 256;
             if (e < COUT * CIN * 9) {
                 const int tap = e % 9, ci = (e / 9) % CIN, co = e / (9 * CIN);
-                w2[(tap / 3) * W_DYS + co * W_RL + ci * 3 + (tap % 3)] = wreg[k];
+                if constexpr (N16) w2[co * W16_S + ci * 9 + tap] = wreg[k];
+                else w2[(tap / 3) * W_DYS + co * W_RL + ci * 3 + (tap % 3)] = wreg[k];
             }
         }
         __syncthreads();
     }
     const float* const wlane = w2 + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * W_DYS + col * W_RL;
     float bw[CHUNK][3][NB];
+    // N16: B fragment of step m = weight (co = li, K-slot 4 * m + lk of the chunk); A = pixel (row + dy, x + dx) of channel ci
+    const float* const wlane16 = w2 + li * W16_S + lk;
+    int aoff16[18];
+#pragma unroll
+    for (int m = 0; m < 18; ++m) {
+        const int kk = 4 * m + lk, ci = kk / 9, t = kk - 9 * ci, dy = t / 3;
+        aoff16[m] = ci * CSW + dy * RS + (t - 3 * dy);
+    }
     auto load_bw = [&](int ch) {
-        if constexpr (CHUNK == 8) {
+        if constexpr (N16) {
+#pragma unroll
+            for (int m = 0; m < 18; ++m) bw[m / 6][(m % 6) / 2][m % 2] = wlane16[ch * 72 + 4 * m];
+        } else if constexpr (CHUNK == 8) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -313,6 +331,130 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + (u&1)*16 + 4*lk + r), r = 0..3
         if (ey0 >= p.H) return;
         constexpr bool POOLB = MODE == MODE_DGRAD && EPI == EPI_POOLBWD;   // p.pool, as a compile-time property
+        if constexpr (N16) {
+            // lane holds (co = li, y = ey0 + r, x = ex0 + h*16 + 4*lk + e) in pacc[r][h][e]
+            const float sc = e_scale[0], sh = e_shift[0];
+            const bool vec = p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W);
+            if (POOLB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int y = ey0 + r, x = ex0 + h * 16 + 4 * lk;
+                        if (y >= p.H || x >= p.W) continue;
+                        const f32x4 v = pacc[r][h];
+                        const act_t* a0 = act + eb * a_bs + li * a_cs + (int64_t)(2 * y) * a_rs + 2 * x;
+                        act_t* o0 = outp + eb * o_bs + li * o_cs + (int64_t)(2 * y) * o_rs + 2 * x;
+                        if (vec) {
+                            f32x4 A[2][2], O[2][2];
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                                for (int hh = 0; hh < 2; ++hh) {
+                                    A[rr][hh] = pc_ld4(a0 + rr * a_rs + 4 * hh);
+                                    O[rr][hh] = pc_ld4(o0 + rr * o_rs + 4 * hh);
+                                }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int hh = e >> 1, c = (e & 1) * 2;
+                                const float w00 = A[0][hh][c], w01 = A[0][hh][c + 1], w10 = A[1][hh][c], w11 = A[1][hh][c + 1];
+                                int am = 0;
+                                float m = w00;
+                                if (w01 > m) { m = w01; am = 1; }
+                                if (w10 > m) { m = w10; am = 2; }
+                                if (w11 > m) { m = w11; am = 3; }
+                                const float g = m > 0.f ? v[e] * sc : 0.f;
+                                O[0][hh][c] += am == 0 ? g : 0.f;
+                                O[0][hh][c + 1] += am == 1 ? g : 0.f;
+                                O[1][hh][c] += am == 2 ? g : 0.f;
+                                O[1][hh][c + 1] += am == 3 ? g : 0.f;
+                            }
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                                for (int hh = 0; hh < 2; ++hh) pc_st4(o0 + rr * o_rs + 4 * hh, O[rr][hh]);
+                        } else {
+                            const act_t* a1 = a0 + a_rs;
+                            act_t* o1 = o0 + o_rs;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (x + e >= p.W) continue;
+                                const float w00 = pc_ld1(a0 + 2 * e), w01 = pc_ld1(a0 + 2 * e + 1), w10 = pc_ld1(a1 + 2 * e), w11 = pc_ld1(a1 + 2 * e + 1);
+                                int am = 0;
+                                float m = w00;
+                                if (w01 > m) { m = w01; am = 1; }
+                                if (w10 > m) { m = w10; am = 2; }
+                                if (w11 > m) { m = w11; am = 3; }
+                                const float g = m > 0.f ? v[e] * sc : 0.f;
+                                pc_st1(o0 + 2 * e, pc_ld1(o0 + 2 * e) + (am == 0 ? g : 0.f));
+                                pc_st1(o0 + 2 * e + 1, pc_ld1(o0 + 2 * e + 1) + (am == 1 ? g : 0.f));
+                                pc_st1(o1 + 2 * e, pc_ld1(o1 + 2 * e) + (am == 2 ? g : 0.f));
+                                pc_st1(o1 + 2 * e + 1, pc_ld1(o1 + 2 * e + 1) + (am == 3 ? g : 0.f));
+                            }
+                        }
+                    }
+                return;
+            }
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 vv[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int r = 2 * rp + s, y = ey0 + r, x = ex0 + h * 16 + 4 * lk;
+                        f32x4 v = pacc[r][h];
+                        vv[s] = v;
+                        if (y >= p.H || x >= p.W) continue;
+                        act_t* op = outp + eb * o_bs + li * o_cs + (int64_t)y * o_rs + x;
+                        const act_t* ap = act ? act + eb * a_bs + li * a_cs + (int64_t)y * a_rs + x : nullptr;
+                        if (vec) {
+                            if (MODE == MODE_FWD) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float o = v[e] * sc + sh;
+                                    v[e] = p.relu ? fmaxf(o, 0.f) : o;
+                                }
+                            } else {
+                                if (ap) {
+                                    const f32x4 a4 = pc_ld4(ap);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = a4[e] > 0.f ? v[e] * sc : 0.f;
+                                }
+                                if (p.accumulate) {
+                                    const f32x4 o4 = pc_ld4(op);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] += o4[e];
+                                }
+                            }
+                            pc_st4(op, v);
+                            vv[s] = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (x + e >= p.W) continue;
+                                float o = v[e];
+                                if (MODE == MODE_FWD) {
+                                    o = o * sc + sh;
+                                    o = p.relu ? fmaxf(o, 0.f) : o;
+                                } else {
+                                    if (ap) o = pc_ld1(ap + e) > 0.f ? o * sc : 0.f;
+                                    if (p.accumulate) o += pc_ld1(op + e);
+                                }
+                                pc_st1(op + e, o);
+                            }
+                        }
+                    }
+                    if (EPI == EPI_POOL && MODE == MODE_FWD && q.pool_out.ptr && vec) {
+                        // MaxPool2d(2): both rows of the pair and both x of a pair are in the lane
+                        act_t* pp = reinterpret_cast<act_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride + li * q.pool_out.cstride +
+                                    (int64_t)((ey0 >> 1) + rp) * q.pool_out.rstride + (ex0 >> 1) + h * 8 + 2 * lk;
+                        pc_st2(pp, fmaxf(fmaxf(vv[0][0], vv[0][1]), fmaxf(vv[1][0], vv[1][1])),
+                               fmaxf(fmaxf(vv[0][2], vv[0][3]), fmaxf(vv[1][2], vv[1][3])));
+                    }
+                }
+            return;
+        }
         if (POOLB && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W)) {
             // MaxPool2d(2) backward on an interior strip of aligned tensors: the lane's four pooled pixels cover 8 x 2
             // full-resolution pixels = two 16-byte pieces per row of `act` and of the accumulated output (the scalar path
@@ -499,6 +641,19 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         if (!(p.dbg & 2)) {
             load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
             const float* lrow = wl + lk * RS + (COL0 - 1) + li;
+            if constexpr (N16) {
+                // acc[r][h]: output row y0 + r, x half h, channel li
+                const float* l16 = wl + (COL0 - 1) + li;
+#pragma unroll
+                for (int m = 0; m < 18; ++m) {
+                    float av[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) av[u] = l16[aoff16[m] + (u >> 1) * RS + (u & 1) * 16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        acc[u >> 1][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[m / 6][(m % 6) / 2][m % 2], acc[u >> 1][u & 1], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int ci = 0; ci < CHUNK; ++ci) {
 #pragma unroll
@@ -531,7 +686,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 template <int CIN, int COUT, int MODE, int LD, int EPI>
 int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
-    const size_t lds = ((size_t)4 * CHUNK * CSW + 4 * (COUT * (CIN * 3 + 4) + 16)) * sizeof(float);   // wave strips + weight image
+    constexpr bool N16 = COUT == 16 && CHUNK == 8;
+    const size_t lds = ((size_t)4 * CHUNK * CSW + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16))) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);

@@ -487,7 +487,8 @@ def main():
                                    "clip 0.01, Adam, rwa flags), every pixel of every tile selected",
                        "global_batch": B * world, "tile": "15x100x100 -> 6x100x100 (128x128 internal)",
                        "parallelism": f"dp{world}", "graph": not args.no_graph,
-                       "backend": (dist.get_backend() if world > 1 else None)},
+                       "backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "collectives": bool(trainer.reducer.active)},
             "timing": f"median of {len(blocks)} blocks of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
             "ms_per_step_blocks": [round(b / args.steps * 1e3, 4) for b in blocks],
             "final_loss": round(loss_val, 6),
@@ -504,10 +505,21 @@ def main():
             res["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
-    if world > 1:
+    else:
+        res = None
+    # RCCL writes its version banner through C stdio, which (stdout not being a terminal) would otherwise be flushed at exit,
+    # i.e. BEHIND the result: every rank drains it before the last barrier, so that the JSON line is the last line of the stream
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    if dist.is_initialized():               # world > 1, or the forced single-rank collectives (POPCORN_DIST_FORCE=1)
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+        if world > 1:
+            time.sleep(0.5 if rank == 0 else 0.0)        # the other ranks' last flush
+    if res is not None:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

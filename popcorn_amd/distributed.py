@@ -26,12 +26,19 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def force_collectives():
+    """POPCORN_DIST_FORCE=1: take the multi-rank code path (process group, split graphs, both all-reduces) also with ONE rank --
+    the RCCL calls of the data-parallel step on a single-GPU box (tests/test_gpu_dp.py)."""
+    return os.environ.get("POPCORN_DIST_FORCE") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (as set by torch.distributed.run).
-    Returns (rank, local_rank, world).  No-op for world == 1."""
+    Returns (rank, local_rank, world).  No-op for world == 1 (unless POPCORN_DIST_FORCE=1)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # POPCORN_DIST_BACKEND=gloo: functional runs of the multi-rank paths on a box with fewer GPUs than ranks
@@ -48,16 +55,17 @@ class FlatReducer:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and force_collectives())      # collectives are issued
 
     def reduce_stats(self, stats: torch.Tensor):
         """stats: float64[2] {Nsel, sum(scale)} -> global sums (in place)."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         return stats
 
     def reduce_grads(self, flat: torch.Tensor):
         """flat fp32 gradient buffer -> sum over ranks (in place).  One collective per step."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 

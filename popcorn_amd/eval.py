@@ -72,7 +72,7 @@ class Stitcher:
     def all_reduce(self, reducer: FlatReducer):
         """Multi-GPU: windows were sharded over ranks; sum the accumulators (interiors of regular windows are disjoint,
         the bottom/right catch-up windows overlap them -- the count map handles both)."""
-        if reducer.world > 1:
+        if reducer.active:
             import torch.distributed as dist
             dist.all_reduce(self.acc, group=reducer.group)            # all fp32 planes in one ring pass
             c = self.count.to(torch.int32)                            # RCCL has no 16-bit integer sum

@@ -290,7 +290,7 @@ class FusedTrainStep:
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
                 st[k].copy_(sample[k], non_blocking=True)
         sel.copy_(sel_host, non_blocking=True)
-        if self.reducer.world == 1:
+        if not self.reducer.active:
             graphs[0].replay()
         else:
             graphs[0].replay()
@@ -331,7 +331,7 @@ class FusedTrainStep:
         torch.cuda.synchronize()
         self.flat_p.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
         graphs = []
-        if self.reducer.world == 1:
+        if not self.reducer.active:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._forward(st, sel, enc_ng, unet_ng)

@@ -33,7 +33,13 @@ def _run(rank, world, port, use_graph, q):
     from popcorn_amd.model import POPCORN
     from popcorn_amd.train import FusedTrainStep
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    if world > 1:
+    rccl1 = world == "rccl1"             # ONE rank on the real backend, the multi-rank code path forced (POPCORN_DIST_FORCE)
+    if rccl1:
+        world = 1
+        os.environ.update(POPCORN_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     torch.manual_seed(1600)
@@ -48,9 +54,13 @@ def _run(rank, world, port, use_graph, q):
         l = tr.step(s)
         losses.append(l[0].item())
     torch.cuda.synchronize()
+    if rccl1:
+        assert tr.reducer.active and dist.get_backend() == "nccl"
+        if use_graph:
+            assert len(tr._graphs[3]) == 3          # forward | stats all-reduce | backward | gradient all-reduce | update
     if rank == 0:
         q.put((tr.flat_p.cpu().numpy().tolist(), losses))    # plain lists: no shared-memory handles that die with the child
-    if world > 1:
+    if world > 1 or rccl1:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -74,7 +84,7 @@ def _launch(world, use_graph):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(1 if world == "rccl1" else world)]
     for p in procs:
         p.start()
     out = _get(q, procs)
@@ -93,3 +103,13 @@ def test_two_rank_fused_step_equals_single_process(use_graph):
     scale = p1.abs().max().item()
     assert (p1 - p2).abs().max().item() <= 2e-5 * scale, (p1 - p2).abs().max().item()
     assert all(abs(a) < 1e6 for a in l2)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rccl_collectives_in_the_split_graph_step(use_graph):
+    """The data-parallel step with its REAL backend: one rank on nccl (= RCCL; a second rank would need a second GPU), the
+    multi-rank code path forced -- process group, float64 stats all-reduce, flat-gradient all-reduce between the three replayed
+    graphs.  With one rank the sums are identities: parameters and losses must equal the plain single-process step exactly."""
+    p1, l1 = _launch(1, use_graph)
+    pr, lr = _launch("rccl1", use_graph)
+    assert pr == p1 and lr == l1

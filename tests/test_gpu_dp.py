@@ -56,6 +56,15 @@ def _run(rank, world, port, use_graph, q):
     torch.cuda.synchronize()
     if rccl1:
         assert tr.reducer.active and dist.get_backend() == "nccl"
+        # the sharded-inference collectives (eval.Stitcher.all_reduce: fp32 planes + the int16 count map through int32) on RCCL
+        from popcorn_amd.eval import Stitcher
+        st = Stitcher(40, 56, "cuda")
+        st.acc.copy_(torch.rand(4, 40, 56))
+        st.count.copy_(torch.randint(0, 9, (40, 56), dtype=torch.int16))
+        a0, c0 = st.acc.clone(), st.count.clone()
+        st.all_reduce(tr.reducer)
+        torch.cuda.synchronize()
+        assert torch.equal(st.acc, a0) and torch.equal(st.count, c0) and st.count.dtype == torch.int16
         if use_graph:
             assert len(tr._graphs[3]) == 3          # forward | stats all-reduce | backward | gradient all-reduce | update
     if rank == 0:

@@ -1021,6 +1021,21 @@ __device__ __forceinline__ hs16x4 hb_pack4(float a, float b, float c, float d) {
     const uint2 q = make_uint2(pc_pack_bf16(a, b), pc_pack_bf16(c, d));
     return __builtin_bit_cast(hs16x4, q);
 }
+// per 16-bit half: 0xffff where the bf16 is non-zero (packed min with 1, then 0 - x), and the AND of a packed vector with such a mask
+// (two VOP3P instructions per dword; written as asm because hipcc lowers the vector form to 16-bit compares + selects + perms)
+__device__ __forceinline__ unsigned hb_nz32(unsigned x) {
+    unsigned nz, r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(nz) : "v"(x));
+    asm("v_pk_sub_u16 %0, 0, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(nz));
+    return r;
+}
+__device__ __forceinline__ hu32x4 hb_nzmask(const hbf16x8& v) {
+    const hu32x4 q = __builtin_bit_cast(hu32x4, v);
+    return hu32x4{hb_nz32(q[0]), hb_nz32(q[1]), hb_nz32(q[2]), hb_nz32(q[3])};
+}
+__device__ __forceinline__ hbf16x8 hb_and(const hbf16x8& v, const hu32x4& m) {
+    return __builtin_bit_cast(hbf16x8, __builtin_bit_cast(hu32x4, v) & m);
+}
 // `lane` may carry an opaque zero (see the group loops): the fragment reads must stay INSIDE the loop -- hoisted, the 36 KB
 // of loop-invariant weight fragments would occupy ~150 registers per lane and spill the accumulators
 __device__ __forceinline__ hbf16x8 hb_frag8(const unsigned char* lds, int off, int blk, int t, int lane) {
@@ -1165,10 +1180,6 @@ __device__ __forceinline__ hs16x4 hc_tr(const unsigned char* p) {
 __device__ __forceinline__ hbf16x8 hc_pair(hs16x4 a, hs16x4 b) {
     return __builtin_bit_cast(hbf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-__device__ __forceinline__ float hc_sum4(hs16x4 v) {
-    const uint2 q = __builtin_bit_cast(uint2, v);
-    return (__uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xffff0000u)) + (__uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xffff0000u));
-}
 
 __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -1212,7 +1223,10 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
     const int my_mb = wave >> 1, my_nb0 = 2 * (wave & 1);
     f32x4 dW4[2], dW2[2], dW0 = f32x4{0.f, 0.f, 0.f, 0.f};
     dW4[0] = dW4[1] = dW2[0] = dW2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float db4 = 0.f, db2 = 0.f, db0 = 0.f;         // row sums of G3 / G2 / G1 for hidden unit 16 * mb + li (even waves / waves 0..3)
+    // bias gradients = row sums of G3 / G2 / G1 over the pixels: one more MFMA against an all-ones operand (every column of the block
+    // then holds the row sums) instead of 7 VALU per transposed read -- the matrix pipe is 13 % busy, the VALU is the limiter
+    f32x4 dB4 = f32x4{0.f, 0.f, 0.f, 0.f}, dB2 = dB4, dB0 = dB4;      // even waves / even waves / waves 0..3
+    const hbf16x8 ones8 = __builtin_bit_cast(hbf16x8, hu32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     f32x4 dw6[4];
     float db6 = 0.f;
 #pragma unroll
@@ -1288,6 +1302,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));              // opaque: keeps the weight-fragment reads inside the loop
             hbf16x8 hb1[2], hb2[2];
+            hu32x4 m1[2], m2[2];                          // 0xffff per bf16 half of hb1 / hb2 that is non-zero (= passed its ReLU)
             f32x4 h3[4];
             float gout = 0.f;
             if (active) {
@@ -1303,6 +1318,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                         for (int r = 0; r < 4; ++r) h1[mb][r] = fmaxf(h1[mb][r], 0.f);
                     }
                     hb1[0] = hb_pack8(h1[0], h1[1]); hb1[1] = hb_pack8(h1[2], h1[3]);            // the pack rounds to bf16
+                    m1[0] = hb_nzmask(hb1[0]); m1[1] = hb_nzmask(hb1[1]);
                 }
                 {
                     f32x4 h2[4];
@@ -1312,6 +1328,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h2[mb][r] = fmaxf(h2[mb][r], 0.f);
                     hb2[0] = hb_pack8(h2[0], h2[1]); hb2[1] = hb_pack8(h2[2], h2[3]);
+                    m2[0] = hb_nzmask(hb2[0]); m2[1] = hb_nzmask(hb2[1]);
                     hb_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb2, h3);
                     hb_relu_round(h3);
                 }
@@ -1329,7 +1346,6 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                 active = __any(gout != 0.f);
             }
             if (active) {
-                auto nz8 = [](const hbf16x8& v, int e) { return ((__builtin_bit_cast(hu32x4, v)[e >> 1] >> (16 * (e & 1))) & 0xffffu) != 0u; };
                 if (lk == 0) db6 += gout;
                 // ---- backward chain: G3 = relu'(h3) . w6 . gout;  G2 = relu'(h2) . (W4^T G3);  G1 = relu'(h1) . (W2^T G2);  g_x = W0^T G1
                 hbf16x8 gb3[2], gb2[2], gb1[2];
@@ -1354,10 +1370,9 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             g2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T3, mi, t, lane_o), gb3[t], g2[mi], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) g2[mi][r] = nz8(hb2[mi >> 1], 4 * (mi & 1) + r) ? g2[mi][r] : 0.f;
                     }
-                    gb2[0] = hb_pack8(g2[0], g2[1]); gb2[1] = hb_pack8(g2[2], g2[3]);
+                    // the ReLU mask on the PACKED gradient: one AND per two elements
+                    gb2[0] = hb_and(hb_pack8(g2[0], g2[1]), m2[0]); gb2[1] = hb_and(hb_pack8(g2[2], g2[3]), m2[1]);
                 }
                 {
                     f32x4 g1[4];
@@ -1367,10 +1382,8 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             g1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb_frag8(ldsb, HB_T2, mi, t, lane_o), gb2[t], g1[mi], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) g1[mi][r] = nz8(hb1[mi >> 1], 4 * (mi & 1) + r) ? g1[mi][r] : 0.f;
                     }
-                    gb1[0] = hb_pack8(g1[0], g1[1]); gb1[1] = hb_pack8(g1[2], g1[3]);
+                    gb1[0] = hb_and(hb_pack8(g1[0], g1[1]), m1[0]); gb1[1] = hb_and(hb_pack8(g1[2], g1[3]), m1[1]);
                 }
                 f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1424,7 +1437,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                 const unsigned char* ap = base + HC_G3 + t_off + 32 * my_mb;
                 const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
                 const hbf16x8 av = hc_pair(lo, hi);
-                if ((wave & 1) == 0) db4 += hc_sum4(lo) + hc_sum4(hi);
+                if ((wave & 1) == 0) dB4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB4, 0, 0, 0);
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
                     const unsigned char* bp = base + HC_H2 + t_off + 32 * (my_nb0 + n2);
@@ -1435,7 +1448,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                 const unsigned char* ap = base + HC_G2 + t_off + 32 * my_mb;
                 const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
                 const hbf16x8 av = hc_pair(lo, hi);
-                if ((wave & 1) == 0) db2 += hc_sum4(lo) + hc_sum4(hi);
+                if ((wave & 1) == 0) dB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB2, 0, 0, 0);
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
                     const unsigned char* bp = base + HC_H1 + t_off + 32 * (my_nb0 + n2);
@@ -1445,9 +1458,10 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
             if (wave < 4) {
                 const unsigned char* ap = base + HC_G1 + t_off + 32 * wave;
                 const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
-                db0 += hc_sum4(lo) + hc_sum4(hi);
+                const hbf16x8 av = hc_pair(lo, hi);
+                dB0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB0, 0, 0, 0);
                 const unsigned char* bp = base + t_offx;
-                dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hc_pair(lo, hi), hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_XROW)), dW0, 0, 0, 0);
+                dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_XROW)), dW0, 0, 0, 0);
             }
         }
         __syncthreads();
@@ -1461,13 +1475,13 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         *reinterpret_cast<f32x4*>(&part[PE_W2 + ((my_mb * 4 + my_nb0 + n2) * 64 + lane) * 4]) = dW2[n2];
     }
     if (wave < 4) *reinterpret_cast<f32x4*>(&part[PE_W0 + (wave * 64 + lane) * 4]) = dW0;
-    // bias gradients: lane (m = li, k-group lk) holds a partial row sum -> sum over the 4 k-groups
-    db4 += __shfl_xor(db4, 16); db4 += __shfl_xor(db4, 32);
-    db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
-    db0 += __shfl_xor(db0, 16); db0 += __shfl_xor(db0, 32);
-    if (lk == 0) {
-        if ((wave & 1) == 0) { part[PE_B4 + 16 * my_mb + li] = db4; part[PE_B2 + 16 * my_mb + li] = db2; }
-        if (wave < 4) part[PE_B0 + 16 * wave + li] = db0;
+    // bias gradients: every column of the ones-block holds the row sums; column 0 = lanes li == 0, row m = 4 * lk + register
+    if (li == 0) {
+        if ((wave & 1) == 0) {
+            *reinterpret_cast<f32x4*>(&part[PE_B4 + 16 * my_mb + 4 * lk]) = dB4;
+            *reinterpret_cast<f32x4*>(&part[PE_B2 + 16 * my_mb + 4 * lk]) = dB2;
+        }
+        if (wave < 4) *reinterpret_cast<f32x4*>(&part[PE_B0 + 16 * wave + 4 * lk]) = dB0;
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)

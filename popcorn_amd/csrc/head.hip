@@ -1058,11 +1058,26 @@ __device__ __forceinline__ void hb_layer64(const unsigned char* lds, int a_off, 
     }
 }
 
+// ReLU of an MFMA result in ONE instruction: fmaxf() on a value the compiler cannot prove canonical costs a second v_max (x, x)
+// in front; v_med3_f32(x, 0, +inf) needs none.  (Not inline asm: the compiler does not place the MFMA-result hazard wait in front
+// of an asm statement -- measured: non-deterministic losses.)
+__device__ __forceinline__ float hb_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+__device__ __forceinline__ void hb_relu4(f32x4 (&h)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mb][r] = hb_relu(h[mb][r]);
+}
+// ReLU + round to bf16, kept as fp32 values: one pack per PAIR and two unpacks (instead of a pack and a shift per element)
 __device__ __forceinline__ void hb_relu_round(f32x4 (&h)[4]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[mb][r] = pc_bf16r(fmaxf(h[mb][r], 0.f));
+        for (int r = 0; r < 4; r += 2) {
+            const unsigned q = pc_pack_bf16(hb_relu(h[mb][r]), hb_relu(h[mb][r + 1]));
+            h[mb][r] = __uint_as_float(q << 16);
+            h[mb][r + 1] = __uint_as_float(q & 0xffff0000u);
+        }
 }
 
 __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
@@ -1114,10 +1129,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
                 h[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
                 h[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb_frag4(ldsb, HB_A1, mb, lane_o), xb, h[mb], 0, 0, 0);
             }
-            hb_relu_round(h);
+            hb_relu4(h);                                   // the pack rounds to bf16
             hbf16x8 hb[2] = {hb_pack8(h[0], h[1]), hb_pack8(h[2], h[3])};
             hb_layer64(ldsb, HB_A2, lf + 64, lane_o, lk, hb, acc);
-            hb_relu_round(acc);
+            hb_relu4(acc);
             hb[0] = hb_pack8(acc[0], acc[1]); hb[1] = hb_pack8(acc[2], acc[3]);
             hb_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb, h);
             hb_relu_round(h);
@@ -1314,19 +1329,15 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                     for (int mb = 0; mb < 4; ++mb) {
                         h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
                         h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb_frag4(ldsb, HB_A1, mb, lane_o), xb, h1[mb], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h1[mb][r] = fmaxf(h1[mb][r], 0.f);
                     }
+                    hb_relu4(h1);
                     hb1[0] = hb_pack8(h1[0], h1[1]); hb1[1] = hb_pack8(h1[2], h1[3]);            // the pack rounds to bf16
                     m1[0] = hb_nzmask(hb1[0]); m1[1] = hb_nzmask(hb1[1]);
                 }
                 {
                     f32x4 h2[4];
                     hb_layer64(ldsb, HB_A2, lf + 64, lane_o, lk, hb1, h2);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h2[mb][r] = fmaxf(h2[mb][r], 0.f);
+                    hb_relu4(h2);
                     hb2[0] = hb_pack8(h2[0], h2[1]); hb2[1] = hb_pack8(h2[2], h2[3]);
                     m2[0] = hb_nzmask(hb2[0]); m2[1] = hb_nzmask(hb2[1]);
                     hb_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb2, h3);

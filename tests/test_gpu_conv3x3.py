@@ -98,10 +98,11 @@ def test_conv_fwd_reflect_reorder():
 
 @pytest.mark.parametrize("cin_total,c0,cn,cg", [(8, 0, 8, 8), (16, 8, 8, 8), (32, 0, 16, 8), (32, 16, 16, 8),
                                                 (8, 0, 8, 16), (16, 0, 16, 16)])
-def test_conv_dgrad_plain_and_masked(cin_total, c0, cn, cg):
+@pytest.mark.parametrize("shape", [(2, 29, 47), (2, 32, 64)])            # ragged: scalar epilogues; aligned: the 16-byte ones
+def test_conv_dgrad_plain_and_masked(cin_total, c0, cn, cg, shape):
     from popcorn_amd import ops
     from popcorn_amd import _lib as L
-    B, H, W = 2, 29, 47
+    B, H, W = shape
     x = _mk(B, cin_total, H, W, seed=20).requires_grad_(True)
     w = _mk(cg, cin_total, 3, 3, seed=21, scale=0.2)
     g = _mk(B, cg, H, W, seed=22)
@@ -126,25 +127,26 @@ def test_conv_dgrad_plain_and_masked(cin_total, c0, cn, cg):
 
 
 @pytest.mark.parametrize("shape", [(2, 38, 53), (2, 64, 128), (3, 16, 64)])
-def test_conv_dgrad_pool_scatter_matches_autograd(shape):
+@pytest.mark.parametrize("cn", [8, 16])                                   # d1a (8-channel input) / d2a (16: the im2col mapping)
+def test_conv_dgrad_pool_scatter_matches_autograd(shape, cn):
     """d1a-style: y = conv(maxpool(relu_bn_out)); gradient w.r.t. the pre-pool activation's conv output.  The aligned
     shapes take the 16-byte epilogue, the ragged one the scalar path."""
     from popcorn_amd import ops
     from popcorn_amd import _lib as L
     B, Hs, Ws = shape
-    pre = _mk(B, 8, Hs, Ws, seed=30).requires_grad_(True)         # conv output of the producing layer (pre-BN)
-    gamma, beta, mean, var = _bn_params(8, 31)
+    pre = _mk(B, cn, Hs, Ws, seed=30).requires_grad_(True)        # conv output of the producing layer (pre-BN)
+    gamma, beta, mean, var = _bn_params(cn, 31)
     act = F.relu(F.batch_norm(pre, mean, var, gamma, beta, training=False, eps=1e-5))
-    w = _mk(16, 8, 3, 3, seed=32, scale=0.2)
+    w = _mk(16, cn, 3, 3, seed=32, scale=0.2)
     y = F.conv2d(F.max_pool2d(act, 2), w, None, padding=1)
     g = _mk(*y.shape, seed=33)
     y.backward(g)
-    base = _mk(B, 8, Hs, Ws, seed=34)
+    base = _mk(B, cn, Hs, Ws, seed=34)
     ref = base + pre.grad
     out = base.clone().cuda()
     g_, b_, m_, v_ = (t.cuda() for t in (gamma, beta, mean, var))
     bnd = L.bn(None, g_, b_, m_, v_)
-    ops.conv3x3_dgrad(g.cuda(), w.cuda(), 0, 8, out, act=act.detach().cuda(), act_bn=bnd, pool=True, accumulate=True)
+    ops.conv3x3_dgrad(g.cuda(), w.cuda(), 0, cn, out, act=act.detach().cuda(), act_bn=bnd, pool=True, accumulate=True)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
 
 

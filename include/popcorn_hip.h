@@ -301,6 +301,12 @@ int pc_scatter_masked(const float* src, const uint8_t* mask, float* out, void* w
  * convolution's loader); it backs the POPCORN.add_padding API method. */
 int pc_reflect_pad(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
                    void* stream);
+/* The same with the channel gather of popcorn.py:130-134 (S1 / S2 band selection and order): out[b][j] = pad(in[b][sel[j]]) for
+ * in (B, Cin, H, W) -> out (B, nsel, Hp, Wp), nsel <= 8, sel = HOST array.  The fp32 path materialises the padded input once per
+ * forward pass with it: the first convolutions of all (network, stream) pairs and their weight gradients then take the aligned
+ * DIRECT loader instead of running the reflect loader once per consumer. */
+int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, int H, int W, int top, int bottom,
+                          int left, int right, void* stream);
 
 /* ---- training-step scalars ------------------------------------------------------------------------- */
 

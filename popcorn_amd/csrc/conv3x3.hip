@@ -1187,7 +1187,7 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     p.ts = g_conv_ts;
     if (g_pc_precision == PC_PREC_BF16) return launch_conv_bf16<CIN, COUT, MODE>(p, nprob, stream);
     // loader choice: all problems of the group must qualify for a staged loader
-    bool direct = CHUNK >= 8, pool = CHUNK >= 8, reflect = true;
+    bool direct = true, pool = CHUNK >= 8, reflect = true;      // DIRECT also for the 2 / 4-channel first layers (pre-padded input)
     bool vec = (p.W % 4) == 0;
     // fp32 mode: planar fp32 tensors everywhere
     const uintptr_t amask = 15;                        // a 4-pixel vector access: 16 bytes
@@ -1210,11 +1210,9 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
         reflect = reflect && q.a.mode == PC_SRC_REFLECT && q.b.C == 0;
     }
     p.vec_ok = vec ? 1 : 0;
-    if constexpr (CHUNK >= 8) {
-        if (direct) return launch_conv_ld<CIN, COUT, MODE, LD_DIRECT>(p, nprob, stream);
-        if constexpr (CIN <= 16) {
-            if (pool) return launch_conv_ld<CIN, COUT, MODE, LD_POOL>(p, nprob, stream);
-        }
+    if (direct) return launch_conv_ld<CIN, COUT, MODE, LD_DIRECT>(p, nprob, stream);
+    if constexpr (CHUNK >= 8 && CIN <= 16) {
+        if (pool) return launch_conv_ld<CIN, COUT, MODE, LD_POOL>(p, nprob, stream);
     }
     if constexpr (CIN <= 4) {
         if (reflect) return launch_conv_ld<CIN, COUT, MODE, LD_REFLECT>(p, nprob, stream);

@@ -1912,7 +1912,58 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* in, float
     }
 }
 
+// the same with a channel gather: out[b][j] = pad(in[b][sel[j]]); one thread = 4 consecutive x of one output row
+struct PadSel { int sel[8]; };
+__global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in, float* out, PadSel ps, int Cin, int nsel, int H, int W,
+                                                                 int Hp, int Wp, int top, int left, int nrows, int wq, int rows_per_block) {
+    // a block = rows_per_block output rows x wq 4-pixel pieces (wq * rows_per_block <= 256)
+    const int tr = threadIdx.x / wq, piece = threadIdx.x - tr * wq;
+    const int row = blockIdx.x * rows_per_block + tr;
+    if (tr >= rows_per_block || row >= nrows) return;
+    const int pl = row / Hp, y = row - pl * Hp;             // pl = b * nsel + j
+    const int b = pl / nsel, j = pl - b * nsel;
+    const float* src = in + ((int64_t)(b * Cin + ps.sel[j]) * H + pc_reflect(y - top, H)) * W;
+    float* dst = out + (int64_t)row * Wp + 4 * piece;
+    const int x0 = 4 * piece, xs = x0 - left;
+    f32x4 v;
+    if (xs >= 0 && xs + 3 < W) {
+        const f32x4u t = *reinterpret_cast<const f32x4u*>(src + xs);       // interior: one (unaligned) 16-byte load
+        v = f32x4{t[0], t[1], t[2], t[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wp ? src[pc_reflect(xs + e, W)] : 0.f;
+    }
+    if ((Wp & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < Wp) dst[e] = v[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, int H, int W, int top,
+                                     int bottom, int left, int right, void* stream) {
+    if (!in || !out || !sel || B < 1 || nsel < 1 || nsel > 8 || top >= H || bottom >= H || left >= W || right >= W || top < 0 ||
+        bottom < 0 || left < 0 || right < 0)
+        return PC_EINVAL;
+    PadSel ps{};
+    for (int j = 0; j < nsel; ++j) {
+        if (sel[j] < 0 || sel[j] >= Cin) return PC_EINVAL;
+        ps.sel[j] = sel[j];
+    }
+    const int Hp = H + top + bottom, Wp = W + left + right;
+    const int64_t nrows = (int64_t)B * nsel * Hp;
+    const int wq = (Wp + 3) >> 2;
+    if (wq > 256 || nrows > 0x7fffffff) return PC_EINVAL;          // rows of up to 1024 pixels (the training tiles; windows are not padded)
+    const int rpb = 256 / wq;
+    hipLaunchKernelGGL(reflect_pad_select_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, in, out, ps,
+                       Cin, nsel, H, W, Hp, Wp, top, left, (int)nrows, wq, rpb);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pc_sparsity_mask_unet(const float* building, const float* admin_mask, const int64_t* census_idx,
                                      const uint8_t* rowsel, const uint8_t* colsel, float threshold, uint8_t* mask, float* ratio,

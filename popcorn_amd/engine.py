@@ -66,6 +66,8 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
 # data gradient + weight gradient of a conv layer in one launch (bf16 mode: every layer; fp32 mode: the 8 -> 8 layers);
 # POPCORN_FUSED_CONV_BWD=0: separate launches (A/B switch)
 FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
+# fp32: padded + channel-gathered input materialised once per forward pass (POPCORN_PADDED_INPUT=0: reflect loaders; A/B switch)
+PADDED_INPUT = os.environ.get("POPCORN_PADDED_INPUT", "1") != "0"
 
 
 class _Layer:
@@ -341,7 +343,10 @@ class UNetEngine:
             wgs("inc2", "a1", G_a2)
             G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
         for s, chmap, cin, f0 in self.streams:
-            wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
+            if saved.get("Xp") is not None:
+                wg(s, "inc1", saved["Xp"][s], G_a1[s])
+            else:
+                wg(s, "inc1", X, G_a1[s], a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), chmap=chmap, a_channels=cin)
         finish()
 
 
@@ -409,15 +414,32 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
             return conv(tag, pooled, c, h, w)
         return conv(tag, full, c, h, w, a_mode=L.PC_SRC_POOL2)
 
-    # first layer: reflect padding + channel gather fused; Cin differs per stream -> one launch per stream kind
+    # first layer: Cin differs per stream -> one launch per stream kind.  fp32 with real padding and 16-byte rows: the padded,
+    # channel-gathered input is written ONCE (pc_reflect_pad_select) and every consumer -- the first conv of each (network,
+    # stream) pair and, in training, its weight gradient -- takes the aligned DIRECT loader; otherwise the reflect padding + channel
+    # gather stay fused in the loaders (bf16 mode rounds the planar fp32 input there; unpadded inference windows need no copy).
     a1 = {}
+    Xp = None
+    if PADDED_INPUT and L.act_dtype() == torch.float32 and Wp % 4 == 0 and Wp <= 1024 and (Hp, Wp) != tuple(X.shape[2:]) and X.dtype == torch.float32:
+        sel = [c for _, chmap, cin, _ in streams for c in chmap[:cin]]
+        Xp_all = ops.reflect_pad_select(X, sel, pad_top, Hp - X.shape[2] - pad_top, pad_left, Wp - X.shape[3] - pad_left)
+        Xp, off = {}, 0
+        for s, chmap, cin, f0 in streams:
+            Xp[s] = Xp_all[:, off:off + cin]
+            off += cin
     for s, chmap, cin, f0 in streams:
         ks = [k for k in keys if k[1] == s]
         probs = []
         for k in ks:
             a1[k] = E(8, Hp, Wp)
-            probs.append({"a": X, "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k], "chmap": chmap})
-        ops.conv3x3_fwd_group(probs, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), out_hw=(Hp, Wp), a_channels=cin)
+            if Xp is not None:
+                probs.append({"a": Xp[s], "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k]})
+            else:
+                probs.append({"a": X, "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k], "chmap": chmap})
+        if Xp is not None:
+            ops.conv3x3_fwd_group(probs)
+        else:
+            ops.conv3x3_fwd_group(probs, a_mode=L.PC_SRC_REFLECT, a_pad=(pad_top, pad_left), out_hw=(Hp, Wp), a_channels=cin)
     pa2, pb2 = {}, {}
     a2 = conv("inc2", a1, 8, Hp, Wp, pooled=pa2)
     b1 = down("d1a", a2, pa2, 16, H1, W1)
@@ -460,6 +482,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
             sv[s] = dict(a1=a1[k], a2=a2[k], b1=b1[k], b2=b2[k], c1=c1[k], c2=c2[k], u2=u2[k], e1=e1[k], e2=e2[k],
                          u1=u1[k], f1=f1[k], o1=o1, o2=o2, pa2=pa2.get(k), pb2=pb2.get(k))
         sv["X"] = X
+        sv["Xp"] = Xp                       # per stream: the padded, gathered input (fp32 path) or None
         sv["geom"] = (pad_top, pad_left, Hp, Wp)
         sv["feats"] = feats[e]
         saved.append(sv)

@@ -349,6 +349,18 @@ def reflect_pad(x, top, bottom, left, right):
     return out
 
 
+def reflect_pad_select(x, sel, top, bottom, left, right):
+    """out[b][j] = F.pad(x[b][sel[j]], reflect): the padded, channel-gathered copy of a (B, C, H, W) fp32 input."""
+    L.require_device(x)
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    out = torch.empty(B, len(sel), H + top + bottom, W + left + right, device=x.device, dtype=torch.float32)
+    arr = (C.c_int * len(sel))(*[int(v) for v in sel])
+    L.check(L.lib().pc_reflect_pad_select(L.ptr(x), L.ptr(out), B, Cin, len(sel), arr, H, W, top, bottom, left, right, L.stream_ptr()),
+            "pc_reflect_pad_select")
+    return out
+
+
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
              g_feat=None, feat_bn=None):

@@ -296,3 +296,15 @@ def test_conv_backward_fused_op_fp32_refuses_unaligned():
     with pytest.raises(L.PopcornHipError):
         wb.conv3x3_bwd_group([{"g": x, "x": x, "w": torch.zeros(8, 8, 3, 3, device="cuda"), "out": torch.empty_like(x),
                                "dw": torch.empty(8, 8, 3, 3, device="cuda"), "db": torch.empty(8, device="cuda")}], 8, 0)
+
+
+@pytest.mark.parametrize("geom", [(2, 6, 20, 31, 3, 5, 2, 4), (1, 6, 100, 100, 14, 14, 14, 14), (3, 6, 9, 12, 0, 3, 4, 0)])
+def test_reflect_pad_select_matches_torch(geom):
+    """pc_reflect_pad_select: reflect padding + channel gather of the model input (popcorn.py:231-258,130-134) in one pass."""
+    from popcorn_amd import ops
+    B, Cc, H, W, t, b, l, r = geom
+    x = _mk(B, Cc, H, W, seed=95)
+    sel = [4, 5, 2, 1, 0, 3]
+    ref = F.pad(x[:, sel], (l, r, t, b), mode="reflect")
+    out = ops.reflect_pad_select(x.cuda(), sel, t, b, l, r)
+    assert torch.equal(out.cpu(), ref)

@@ -198,6 +198,14 @@ int pc_convt2x2_wgrad_partial(const pc_src* x, const pc_src* g, void* ws, int B,
 typedef struct pc_convt_wgrad_desc { const pc_src* x; const pc_src* g; void* ws; } pc_convt_wgrad_desc;
 int pc_convt2x2_wgrad_partial_group(int n, const pc_convt_wgrad_desc* d, int B, int H, int W, int C, int* nwg_out,
                                     void* stream);
+/* Whole backward of a transposed conv in ONE launch: the weight / bias gradient partials of pc_convt2x2_wgrad_partial_group AND the
+ * data gradient of pc_convt2x2_dgrad_group (out = relu'(x) * bn_scale(x_bn) * W^T g; x_bn NULL: no factor) -- both read the 2x
+ * resolution gradient g, which passes through the kernel once.  fp32: aligned tensors with W % 16 == 0 only (PC_EINVAL otherwise:
+ * the callers keep the two launches); PC_PREC_BF16: any geometry. */
+typedef struct pc_convt_bwd_desc {
+    const pc_src* x; const pc_src* g; const float* w; const pc_bn* x_bn; const pc_dst* out; void* ws;
+} pc_convt_bwd_desc;
+int pc_convt2x2_bwd_group(int n, const pc_convt_bwd_desc* d, int B, int H, int W, int C, int* nwg_out, void* stream);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */

@@ -59,6 +59,11 @@ class PcConvtWgradDesc(C.Structure):
     _fields_ = [("x", C.POINTER(PcSrc)), ("g", C.POINTER(PcSrc)), ("ws", C.c_void_p)]
 
 
+class PcConvtBwdDesc(C.Structure):
+    _fields_ = [("x", C.POINTER(PcSrc)), ("g", C.POINTER(PcSrc)), ("w", C.c_void_p), ("x_bn", C.POINTER(PcBn)),
+                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p)]
+
+
 class PcWgradReduceDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
                 ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("dw_co_stride", C.c_int32)]

@@ -294,7 +294,9 @@ __device__ __forceinline__ ct_s4 ct_tr(const unsigned char* p) {
 }
 
 // group = 32 consecutive input pixels of one row.  LDS per wave: x [32 px][C] and g [2 rows][64 px][C] (bf16), plain copies.
-template <int C>
+// DG: the data gradient of the same 32 pixels from the same two images (pc_convt2x2_bwd_group): convt2x2_dgrad_cl_kernel's MFMA with
+// the pixel operand = one 16-byte slot of the g image, the ReLU mask of x's producer from the x image.
+template <int C, bool DG>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_cl_kernel(const CtGroup grp_) {
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int NBK = C / 4, NT = C / 4;    // N tiles: C = 8: tile = a, n = b*8 + co;  C = 16: tile = (a, b), n = co
@@ -316,6 +318,23 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_cl_kernel(const CtGroup gr
     float bsum[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[t] = 0.f; }
+    constexpr int NH = C / 8;
+    ct_bf8 aw[DG ? NH : 1];
+    float e_scale[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (DG) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            ct_s8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = li < C ? ct_bf(p.w[(li * C + 8 * h + e) * 4 + lk]) : (short)0;
+            aw[h] = __builtin_bit_cast(ct_bf8, t);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sh;
+            if (p.act && 4 * lk + r < C) pc_bn_fold(p.bn, 4 * lk + r, e_scale[r], sh);
+        }
+    }
     constexpr int NXP = XB / 16 / 64 > 0 ? XB / 16 / 64 : 1;       // 16-byte pieces per lane: x (32 or 64 pieces), g (128 or 256)
     constexpr int NGP = GB / 16 / 64;
     ct_u4 RX[NXP], RG[NGP];
@@ -357,6 +376,30 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_cl_kernel(const CtGroup gr
     for (; grp < ngroups; grp += nwaves) {
         commit();
         if (grp + nwaves < ngroups) issue(grp + nwaves);
+        if constexpr (DG) {
+            const int b = grp / (p.H * groups32);
+            const int rem = grp - b * p.H * groups32;
+            const int i = rem / groups32, j0 = (rem - i * groups32) * 32;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int px = 16 * t2 + li;
+                f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const ct_u4 gv = *reinterpret_cast<const ct_u4*>(wg + ((lk >> 1) * 64 + 2 * px + (lk & 1)) * PB + 16 * h);
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[h], __builtin_bit_cast(ct_bf8, gv), dacc, 0, 0, 0);
+                }
+                if (j0 + px < p.W && 4 * lk < C) {
+                    if (p.act) {
+                        const f32x4 a4 = pc_ld4(reinterpret_cast<const pc_bf16_t*>(wx + px * PB) + 4 * lk);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dacc[r] = a4[r] > 0.f ? dacc[r] * e_scale[r] : 0.f;
+                    }
+                    pc_st4(reinterpret_cast<pc_bf16_t*>(p.out.ptr) + b * p.out.bstride + (int64_t)i * p.out.rstride +
+                               (int64_t)(j0 + px) * p.out.xstride + 4 * lk, dacc);
+                }
+            }
+        }
         // A (M = ci): columns 4q .. 4q+3 of pixel j; for C = 8 the quads 2, 3 repeat 0, 1 (rows 8..15 of D are not used)
         const unsigned char* xa = wx + (8 * lk + t_j) * PB + 8 * (C == 8 ? (t_q & 1) : t_q);
         const ct_s4 alo = ct_tr(xa), ahi = ct_tr(xa + 4 * PB);
@@ -415,13 +458,19 @@ bool ct_cl_ok(const CtArgs& p, bool with_g) {
 // both operands use it: lane (., lk) takes pixels 4*lk .. 4*lk+3 of the 16-pixel group, so k-step ks holds pixel 4*lk + ks
 // and a lane's four A values are ONE 16-byte load of x, its four B values the even or odd floats of TWO 16-byte loads of
 // the g row (4 + 4*C/4 scalar gathers before: 12 / 20 four-byte loads per group and lane).
-template <int C, bool VEC>
+// DG (with VEC): the data gradient of the same 16 pixels in the same pass (pc_convt2x2_bwd_group).  It contracts the gradient rows
+// the weight gradient has just loaded over (co, a, b): they go through a wave-private LDS image [co][a][32 floats] (row pitch 36)
+// to become the A operand lane (pixel li, k = (a, b)); the ReLU mask of x's producer is the lane's own x values (D hands lane
+// (ci = li, k-group lk) the pixels 4*lk .. +3 -- exactly its A operand of the weight gradient).
+constexpr int CT_GLRS = 36;
+template <int C, bool VEC, bool DG>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_) {
     using act_t = float;
     const CtArgs& p = grp_.pr[blockIdx.y];
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
-    __shared__ __attribute__((aligned(16))) float lds[4 * NBK * 256];
+    constexpr int GLW = C * 2 * CT_GLRS;                   // floats of a wave's gradient image (DG)
+    __shared__ __attribute__((aligned(16))) float lds[(DG && 4 * GLW > 4 * NBK * 256) ? 4 * GLW : 4 * NBK * 256];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -432,6 +481,16 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_)
     float bsum[NBK];
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) { acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[nb] = 0.f; }
+    // DG: B fragments of the data gradient, lane (k = (a, b) = lk, n = ci = li), one per co; BN scale of x's producer
+    float bwd[DG ? C : 1];
+    float e_scale = 1.f;
+    float* const gl = lds + wave * GLW;
+    if constexpr (DG) {
+#pragma unroll
+        for (int co = 0; co < C; ++co) bwd[co] = li < C ? p.w[(li * C + co) * 4 + lk] : 0.f;
+        float e_shift;
+        if (p.act && li < C) pc_bn_fold(p.bn, li, e_scale, e_shift);
+    }
 
     // group = 16 consecutive input x of one row; 4 k-steps of 4 pixels each
     for (int grp = gwave; grp < p.ngroups; grp += nwaves) {
@@ -453,6 +512,13 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_)
                 const int co = ng >> 2, a = (ng >> 1) & 1, bb = ng & 1;
                 const act_t* gp = gbase + b * p.g.bstride + co * p.g.cstride + (int64_t)(2 * i + a) * p.g.rstride + 2 * j0 + 8 * lk;
                 const f32x4 g0 = pc_ld4(gp), g1 = pc_ld4(gp + 4);
+                if constexpr (DG) {
+                    if (bb == 0) {                          // the b = 1 lane of the pair holds the same eight floats
+                        float* d = gl + (co * 2 + a) * CT_GLRS + 8 * lk;
+                        *reinterpret_cast<f32x4*>(d) = g0;
+                        *reinterpret_cast<f32x4*>(d + 4) = g1;
+                    }
+                }
                 bv[0][nb] = bb ? g0[1] : g0[0];
                 bv[1][nb] = bb ? g0[3] : g0[2];
                 bv[2][nb] = bb ? g1[1] : g1[0];
@@ -479,9 +545,24 @@ __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_)
                 bsum[nb] += bv[ks][nb];
                 acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][nb], acc[nb], 0, 0, 0);
             }
+        if constexpr (DG && VEC) {
+            // gx[ci][i][j] = sum_{co,a,b} w[ci][co][a][b] * g[co][2i+a][2j+b]   (DS operations of a wave execute in order: no barrier)
+            f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* ga = gl + (lk >> 1) * CT_GLRS + 2 * li + (lk & 1);
+#pragma unroll
+            for (int co = 0; co < C; ++co) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[co * 2 * CT_GLRS], bwd[co], dacc, 0, 0, 0);
+            if (li < C) {
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dacc[r] = av[r] > 0.f ? dacc[r] * e_scale : 0.f;
+                }
+                pc_st4(reinterpret_cast<float*>(p.out.ptr) + b * p.out.bstride + li * p.out.cstride + (int64_t)i * p.out.rstride + j0 + 4 * lk, dacc);
+            }
+        }
     }
 
     float* part = p.partial + (int64_t)blockIdx.x * Cfg::E;
+    if constexpr (DG) __syncthreads();         // the reduction slices overlap the other waves' gradient images
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * NBK + nb) * 64 + lane) * 4]) = acc[nb];
     __syncthreads();
@@ -643,7 +724,7 @@ bool ct_wgrad_vec_ok(const CtArgs& p) {
     };
     return p.W % 16 == 0 && al(p.x) && al(p.g);
 }
-int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t st) {
+int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t st, bool dg = false) {
     bool vec = true;
     const bool bf = g_pc_precision == PC_PREC_BF16;
     for (int i = 0; i < n; ++i) {
@@ -652,17 +733,20 @@ int launch_ct_wgrad_group(const CtGroup& g, int n, int C, int nwg, hipStream_t s
         if (bf ? !ct_cl_ok(g.pr[i], true) : !(pc_planar(g.pr[i].x) && pc_planar(g.pr[i].g))) return PC_EINVAL;
     }
     if (bf) {
-        if (C == 16) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<16>), dim3(nwg, n), dim3(256), 0, st, g);
-        else if (C == 8) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<8>), dim3(nwg, n), dim3(256), 0, st, g);
+        if (C == 16 && dg) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<16, true>), dim3(nwg, n), dim3(256), 0, st, g);
+        else if (C == 8 && dg) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<8, true>), dim3(nwg, n), dim3(256), 0, st, g);
+        else if (C == 16) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<16, false>), dim3(nwg, n), dim3(256), 0, st, g);
+        else if (C == 8) hipLaunchKernelGGL((convt2x2_wgrad_cl_kernel<8, false>), dim3(nwg, n), dim3(256), 0, st, g);
         else return PC_EINVAL;
         PC_CHECK_LAUNCH();
         return 0;
     }
-#define PC_CTW(CC, VV) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV>), dim3(nwg, n), dim3(256), 0, st, g)
+    if (dg && !vec) return PC_EINVAL;          // the fused form exists for aligned tensors with W % 16 == 0 only
+#define PC_CTW(CC, VV, DD) hipLaunchKernelGGL((convt2x2_wgrad_kernel<CC, VV, DD>), dim3(nwg, n), dim3(256), 0, st, g)
     if (C == 16) {
-        if (vec) PC_CTW(16, true); else PC_CTW(16, false);
+        if (dg) PC_CTW(16, true, true); else if (vec) PC_CTW(16, true, false); else PC_CTW(16, false, false);
     } else if (C == 8) {
-        if (vec) PC_CTW(8, true); else PC_CTW(8, false);
+        if (dg) PC_CTW(8, true, true); else if (vec) PC_CTW(8, true, false); else PC_CTW(8, false, false);
     } else return PC_EINVAL;
 #undef PC_CTW
     PC_CHECK_LAUNCH();
@@ -704,6 +788,37 @@ extern "C" int pc_convt2x2_wgrad_partial_group(int n, const pc_convt_wgrad_desc*
     if (nwg > CT_MAX_WG / n) nwg = CT_MAX_WG / n;      // the same total number of workgroups as a single-problem launch
     if (nwg < 1) nwg = 1;
     const int rc = launch_ct_wgrad_group(g, n, C, nwg, (hipStream_t)stream);
+    if (rc) return rc;
+    *nwg_out = nwg;
+    return 0;
+}
+
+extern "C" int pc_convt2x2_bwd_group(int n, const pc_convt_bwd_desc* d, int B, int H, int W, int C, int* nwg_out, void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || !d || !nwg_out) return PC_EINVAL;
+    const bool bf = g_pc_precision == PC_PREC_BF16;
+    CtGroup g{};
+    int nwg = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].x || !d[i].g || !d[i].w || !d[i].out || !d[i].ws) return PC_EINVAL;
+        CtArgs& p = g.pr[i];
+        p.x = *d[i].x; p.g = *d[i].g; p.w = d[i].w; p.out = *d[i].out; p.B = B; p.H = H; p.W = W; p.bf = bf;
+        p.partial = reinterpret_cast<float*>(d[i].ws);
+        if (d[i].x_bn) {                       // the mask is x itself (post-ReLU output of the layer x_bn belongs to)
+            p.act = p.x.ptr;
+            p.bn = *d[i].x_bn;
+        }
+        if (p.out.dtype != (bf ? PC_BF16 : PC_F32)) return PC_EINVAL;
+        if (bf) {
+            if (!pc_cl_ok(p.out)) return PC_EINVAL;
+        } else if (!pc_planar(p.out) || (reinterpret_cast<uintptr_t>(p.out.ptr) & 15) || p.out.rstride % 4 || p.out.cstride % 4 ||
+                   p.out.bstride % 4) {
+            return PC_EINVAL;
+        }
+        nwg = fill_groups(p);
+    }
+    if (nwg > CT_MAX_WG / n) nwg = CT_MAX_WG / n;
+    if (nwg < 1) nwg = 1;
+    const int rc = launch_ct_wgrad_group(g, n, C, nwg, (hipStream_t)stream, true);
     if (rc) return rc;
     *nwg_out = nwg;
     return 0;

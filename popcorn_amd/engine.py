@@ -260,6 +260,25 @@ class UNetEngine:
             wb.conv3x3_bwd_group(probs, cin_total, c0)
             return outs
 
+        def ct_bwd(tag, x_key, act_tag, gviews, outs, probs):
+            """transposed conv `tag`: weight gradient + data gradient (masked by x's producer `act_tag`) -- one launch when the
+            fused form applies (bf16: always; fp32: aligned tensors, W % 16 == 0), else the two grouped launches"""
+            xs = {s: A[s][x_key] for s in S}
+            ok = FUSED_CONV_BWD
+            if ok and not bf:
+                for s in S:
+                    if xs[s].shape[3] % 16:
+                        ok = False
+                    for t in (xs[s], gviews[s], outs[s]):
+                        if t.stride(3) != 1 or t.stride(2) % 4 or t.stride(1) % 4 or t.stride(0) % 4 or t.data_ptr() % 16:
+                            ok = False
+            if ok:
+                wb.convt2x2_bwd_group([{"x": xs[s], "g": gviews[s], "w": ly(s, tag).w, "out": outs[s], "x_bn": ly(s, act_tag).bn_nobias,
+                                        "dw": grads[prefix + ly(s, tag).wname], "db": grads[prefix + ly(s, tag).bname]} for s in S])
+            else:
+                wgts(tag, xs, gviews)
+                ops.convt2x2_dgrad_group(probs)
+
         G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
         if fuse8(G_f2, "f1"):
             G_f1 = bwd8("up1b", G_f2, "f1", "up1a", {s: E(8, Hp, Wp) for s in S})
@@ -281,8 +300,7 @@ class UNetEngine:
             g_u1v = g_u1vs[s] = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
             G_e2[s] = E(8, H1, W1)
             probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
-        wgts("up1t", {s: A[s]["e2"] for s in S}, g_u1vs)
-        ops.convt2x2_dgrad_group(probs)
+        ct_bwd("up1t", "e2", "up2b", g_u1vs, G_e2, probs)
         if fuse8(G_e2, "e1"):
             G_e1 = bwd8("up2b", G_e2, "e1", "up2a", {s: E(8, H1, W1) for s in S})
         else:
@@ -304,9 +322,10 @@ class UNetEngine:
             if not encoder_no_grad:
                 G_c2[s] = E(16, H2, W2)
                 probs.append({"g": g_u2v, "w": ly(s, "up2t").w, "out": G_c2[s], "act": A[s]["c2"], "act_bn": ly(s, "d2b").bn_nobias})
-        wgts("up2t", {s: A[s]["c2"] for s in S}, g_u2vs)
         if probs:
-            ops.convt2x2_dgrad_group(probs)
+            ct_bwd("up2t", "c2", "d2b", g_u2vs, G_c2, probs)
+        else:
+            wgts("up2t", {s: A[s]["c2"] for s in S}, g_u2vs)
         if encoder_no_grad:
             finish()
             return

@@ -569,6 +569,25 @@ class WgradBatch:
         for ws, pr in zip(slices, problems):
             self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Cc, Cc, 1))
 
+    def convt2x2_bwd_group(self, problems):
+        """Whole backward of a transposed conv in one launch: problems = list of {x, g, w, out, dw, db, x_bn (opt: ReLU / BN factor
+        of x's producer)}; writes the data gradient into out and queues the weight / bias gradient partials."""
+        n = len(problems)
+        B, Cc, H, W = problems[0]["x"].shape
+        descs = (L.PcConvtBwdDesc * n)()
+        keep, slices = [], []
+        for i, pr in enumerate(problems):
+            sx, sg, d = L.src(pr["x"]), L.src(pr["g"]), L.dst(pr["out"])
+            ws = self._slice()
+            keep += [sx, sg, d]
+            slices.append(ws)
+            descs[i].x, descs[i].g, descs[i].w, descs[i].out, descs[i].ws = C.pointer(sx), C.pointer(sg), pr["w"].data_ptr(), C.pointer(d), ws
+            descs[i].x_bn = C.pointer(pr["x_bn"]) if pr.get("x_bn") is not None else None
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_convt2x2_bwd_group(n, descs, B, H, W, Cc, C.byref(nwg), L.stream_ptr()), "pc_convt2x2_bwd_group")
+        for ws, pr in zip(slices, problems):
+            self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Cc, Cc, 1))
+
     def finish(self):
         n = len(self.entries)
         if n == 0:

@@ -657,3 +657,33 @@ def test_bf16_conv_backward_fused_pool_op(shape, xc):
     _close_bf16(out, (ref + prev.double()).float())
     assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
     assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("C_", [8, 16])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 9, 21), (1, 40, 16)])
+def test_bf16_convt_backward_fused_op(C_, shape):
+    """pc_convt2x2_bwd_group in bf16 mode: data gradient (masked by x's producer) and weight / bias gradient of a transposed conv
+    from one pass over x and g, against torch on the same rounded operands (any geometry: ragged rows included)."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    B, H, W = shape
+    x = _bf(F.relu(_mk(B, C_, H, W, seed=71)))
+    w = _mk(C_, C_, 2, 2, seed=72, scale=0.3)
+    g = _bf(_mk(B, C_, 2 * H, 2 * W, seed=73))
+    gamma, beta, mean, var = _bn(C_, 74)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    xd = x.double().requires_grad_(True)
+    wd = _bf(w).double().requires_grad_(True)
+    bias = torch.zeros(C_, dtype=torch.double, requires_grad=True)
+    F.conv_transpose2d(xd, wd, bias, stride=2).backward(g.double())
+    ref = xd.grad * (x > 0) * scale.view(1, C_, 1, 1).double()
+    with L.precision("bf16"):
+        out = L.empty_act(B, C_, H, W, "cuda")
+        dw, db = torch.empty(C_, C_, 2, 2, device="cuda"), torch.empty(C_, device="cuda")
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.convt2x2_bwd_group([{"x": _dev(x), "g": _dev(g), "w": w.cuda(), "out": out, "dw": dw, "db": db,
+                                "x_bn": L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())}])
+        wb.finish()
+    _close_bf16(out, ref.float())
+    assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()

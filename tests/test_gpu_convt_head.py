@@ -51,6 +51,46 @@ def test_convt_fwd_dgrad_wgrad(C_, shape):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("C_", [8, 16])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 16, 64), (1, 40, 16)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_convt_backward_fused_fp32(C_, shape, masked):
+    """pc_convt2x2_bwd_group (fp32): weight / bias gradient AND data gradient (+ ReLU / BN factor of x's producer) of a transposed
+    conv in one launch, against autograd; the fused form is for aligned tensors with W % 16 == 0 and refuses others."""
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    B, H, W = shape
+    x = F.relu(_mk(B, C_, H, W, seed=11)).requires_grad_(True)
+    w = _mk(C_, C_, 2, 2, seed=12, scale=0.3).requires_grad_(True)
+    bias = _mk(C_, seed=13, scale=0.1).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, bias, stride=2)
+    g = _mk(*y.shape, seed=14)
+    y.backward(g)
+    gen = torch.Generator().manual_seed(16)
+    gamma, var = torch.rand(C_, generator=gen) + 0.5, torch.rand(C_, generator=gen) + 0.3
+    keep = [t.cuda() for t in (gamma, torch.zeros(C_), torch.zeros(C_), var)]
+    gx = torch.full((B, C_, H, W), 7.0, device="cuda")
+    dw, db = torch.empty(C_, C_, 2, 2, device="cuda"), torch.empty(C_, device="cuda")
+    wb = ops.WgradBatch(torch.device("cuda"))
+    wb.convt2x2_bwd_group([{"x": x.detach().cuda(), "g": g.cuda(), "w": w.detach().cuda(), "out": gx, "dw": dw, "db": db,
+                            "x_bn": L.bn(None, *keep) if masked else None}])
+    wb.finish()
+    ref = x.grad * (x > 0) * (gamma / torch.sqrt(var + 1e-5)).view(1, -1, 1, 1) if masked else x.grad
+    torch.testing.assert_close(gx.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-5, atol=2e-6 * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=1e-5, atol=2e-6 * max(1.0, bias.grad.abs().max().item()))
+
+
+def test_convt_backward_fused_fp32_refuses_ragged_rows():
+    from popcorn_amd import ops
+    from popcorn_amd import _lib as L
+    x, g = torch.zeros(1, 8, 9, 21, device="cuda"), torch.zeros(1, 8, 18, 42, device="cuda")
+    wb = ops.WgradBatch(torch.device("cuda"))
+    with pytest.raises(L.PopcornHipError):
+        wb.convt2x2_bwd_group([{"x": x, "g": g, "w": torch.zeros(8, 8, 2, 2, device="cuda"), "out": torch.empty_like(x),
+                                "dw": torch.empty(8, 8, 2, 2, device="cuda"), "db": torch.empty(8, device="cuda")}])
+
+
 def test_outconv_sigmoid_crop():
     from popcorn_amd import ops
     feat = _mk(2, 16, 58, 69, seed=7)

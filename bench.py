@@ -125,7 +125,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     achieved = flops / dur / 1e12
     pmc = _pmc("r2_pmc_head_bwd.json") or _pmc("r1_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    kname = ("head_bwd_bf16_coop_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, 8 waves share the weight gradients through an LDS exchange + transposing reads)" if bf else
+    kname = ("head_bwd_bf16_coop4_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, the 4 waves of a workgroup share the weight gradients through an LDS exchange + transposing reads, 2 workgroups per CU)" if bf else
              "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
     if bf:
         pmc = _pmc("r2_pmc_head_bwd_bf16.json")

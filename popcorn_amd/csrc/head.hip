@@ -124,7 +124,7 @@ __device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
         for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
 }
 
-// fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop_kernel below, channels-last bf16 feature map)
+// fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop4_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     head_copy_image(lds, p.wimage, L_END * (int)sizeof(float));
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 // The 64-wide contractions take 2 instructions of K = 32 instead of 16 fp32 ones, so the matrix pipe stops being the limit.
 // A layer computed as D = mfma(A = W fragment, B = packed activations) leaves lane = pixel, registers = hidden units -- the
 // operand layout of the NEXT layer, so the forward and backward chains stay in registers; the weight gradients (contraction
-// over pixels) take their operands through an LDS exchange and transposing reads (head_bwd_bf16_coop_kernel).
+// over pixels) take their operands through an LDS exchange and transposing reads (head_bwd_bf16_coop4_kernel).
 // K-slot conventions (identical for both operands, so the hardware's internal K order is irrelevant):
 //   64-wide contraction, instruction t of 2:  slot (lk, j) -> hidden unit 16*(2t + (j >> 2)) + 4*lk + (j & 3)
 //       (= D-layout registers h[2t][0..3], h[2t+1][0..3] of the lane, packed in order)
@@ -1171,23 +1171,20 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
 // ---- bf16 backward, cooperative form -------------------------------------------------------------------------------------
 // The first bf16 kernel kept all 160 weight-gradient accumulator registers in every wave and computed every chain twice (a
 // second, transposed orientation: mfma with swapped operands) to get their operands: one wave per SIMD, 116 MFMAs and two sets
-// of bias / ReLU / pack epilogues per 16 pixels, nothing to overlap with (198 us per launch at B = 64; this one 118 us).
-// Here the 8 waves of a workgroup SHARE the weight gradients: every wave runs the
-// forward + backward chain of its own 16-pixel group in the first orientation only (lane = pixel), writes the packed
-// operands H1, H2, G3, G2, G1, X as [pixel][channel] rows into its slot of an LDS exchange area, and after a barrier
-// accumulates only ITS blocks of dW4 / dW2 / dW0 (2 + 2 + at most 1 of the 36 16x16 blocks) over all 8 groups = 128 pixels:
-// the contraction over pixels takes both operands through ds_read_b64_tr_b16 ([4 pixels][16 channels] -> lane = channel,
-// 4 pixels), K = 32 pixels per v_mfma_f32_16x16x32_bf16.  Per wave and group: 38 chain + 18 weight-gradient MFMAs, 36
-// accumulator registers, two waves per SIMD.  Bias gradients are row sums of the same A operands.
-constexpr int HC_ROW = 136;                       // bytes per pixel row of a 64-channel exchange tensor (128 + 8: the 16 pixel rows of a
-                                                  // lane group hit 16 different bank pairs when written)
-constexpr int HC_T = 16 * HC_ROW;                 // one tensor of one group
-constexpr int HC_H1 = 0, HC_H2 = HC_T, HC_G3 = 2 * HC_T, HC_G2 = 3 * HC_T, HC_G1 = 4 * HC_T, HC_X = 5 * HC_T;
-constexpr int HC_XROW = 40;                       // bytes per pixel row of the 16 feature channels
-constexpr int HC_SLOT = HC_X + 16 * HC_XROW;      // 11520 bytes per group
-constexpr int HC_WAVES = 8;
+// of bias / ReLU / pack epilogues per 16 pixels, nothing to overlap with (198 us per launch at B = 64).
+// Here the waves of a workgroup SHARE the weight gradients: every wave runs the forward + backward chain of its own 16-pixel
+// group in the first orientation only (lane = pixel), writes the packed operands H1, H2, G3, G2, G1, X as [pixel][channel] rows
+// into its slot of an LDS exchange area, and after a barrier accumulates only ITS blocks of dW4 / dW2 / dW0 over all the
+// workgroup's groups: the contraction over pixels takes both operands through ds_read_b64_tr_b16 ([4 pixels][16 channels] ->
+// lane = channel, 4 pixels), K = 32 pixels per v_mfma_f32_16x16x32_bf16.  Bias gradients are one more MFMA against an all-ones
+// operand (every column of the block holds the row sums).
+// Workgroup shape: FOUR waves, TWO workgroups per CU (round 2 went 8 waves x 1 workgroup, 118 us -> this, 101 us: the 8-wave form
+// waited 53 % of its wave cycles at the two barriers of an iteration with nothing else resident on the CU).  To fit twice into
+// 160 KiB the exchange rows have no padding (128 bytes per pixel; 32 for the features); the 8-byte pieces of a row are
+// XOR-swizzled with the row index instead -- on the writes and on the transposing reads alike -- so that the 16 pixel rows of a
+// lane group still hit 16 different bank pairs.  A wave owns the row block mb = wave of dW4 / dW2 (4 column blocks each) and of
+// dW0: 38 chain + 15 weight-gradient MFMAs per wave and group, 48 accumulator registers.
 constexpr int HC_EX = (HB_END + 15) & ~15;        // exchange area behind the weight images
-constexpr int HC_END = HC_EX + HC_WAVES * HC_SLOT;
 
 __device__ __forceinline__ hs16x4 hc_tr(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(p));
@@ -1196,14 +1193,21 @@ __device__ __forceinline__ hbf16x8 hc_pair(hs16x4 a, hs16x4 b) {
     return __builtin_bit_cast(hbf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-__global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBwdArgs a) {
+constexpr int H4_ROW = 128, H4_T = 16 * H4_ROW;
+constexpr int H4_H1 = 0, H4_H2 = H4_T, H4_G3 = 2 * H4_T, H4_G2 = 3 * H4_T, H4_G1 = 4 * H4_T, H4_X = 5 * H4_T;
+constexpr int H4_XROW = 32;
+constexpr int H4_SLOT = H4_X + 16 * H4_XROW;      // 10752 bytes per group
+constexpr int H4_WAVES = 4;
+constexpr int H4_END = HC_EX + H4_WAVES * H4_SLOT;
+static_assert(2 * H4_END <= 160 * 1024, "two workgroups per CU");
+__global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const HeadArgs& p = a.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     head_copy_image(ldsb, p.wimage, HB_END);
     // the exchange area starts as zeros: a slot that was never written must not feed NaN bit patterns into 0 * x
-    for (int e = tid; e < HC_WAVES * HC_SLOT / 16; e += 512) reinterpret_cast<uint4*>(ldsb + HC_EX)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = tid; e < H4_WAVES * H4_SLOT / 16; e += 256) reinterpret_cast<uint4*>(ldsb + HC_EX)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
     float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
@@ -1213,7 +1217,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         // padding frame of the channels-last gradient map (the crop is written below, zeros included): one (b, row) job per half-wave
         const int Hp = a.Hp, Wp = a.Wp;
         const int l32 = tid & 31;
-        const int nhw = gridDim.x * 16, hw = blockIdx.x * 16 + (tid >> 5);
+        const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + (tid >> 5);
         const int njobs = p.B * Hp;
         const int right0 = p.px + p.W;
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
@@ -1234,13 +1238,14 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         }
     }
 
-    // ---- this wave's blocks: dW4 / dW2 blocks (mb = wave >> 1, nb = 2 * (wave & 1) + {0, 1}); dW0 block mb = wave for waves 0..3
-    const int my_mb = wave >> 1, my_nb0 = 2 * (wave & 1);
-    f32x4 dW4[2], dW2[2], dW0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    dW4[0] = dW4[1] = dW2[0] = dW2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- this wave's blocks: row block mb = wave of dW4 / dW2 (column blocks 0..3) and of dW0
+    const int my_mb = wave;
+    f32x4 dW4[4], dW2[4], dW0 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dW4[i] = dW2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradients = row sums of G3 / G2 / G1 over the pixels: one more MFMA against an all-ones operand (every column of the block
     // then holds the row sums) instead of 7 VALU per transposed read -- the matrix pipe is 13 % busy, the VALU is the limiter
-    f32x4 dB4 = f32x4{0.f, 0.f, 0.f, 0.f}, dB2 = dB4, dB0 = dB4;      // even waves / even waves / waves 0..3
+    f32x4 dB4 = f32x4{0.f, 0.f, 0.f, 0.f}, dB2 = dB4, dB0 = dB4;
     const hbf16x8 ones8 = __builtin_bit_cast(hbf16x8, hu32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     f32x4 dw6[4];
     float db6 = 0.f;
@@ -1258,11 +1263,16 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         }
     }
     unsigned char* const ex = ldsb + HC_EX;
-    unsigned char* const my = ex + wave * HC_SLOT;
-    // transposing reads: lane supplies pixel row j = li >> 2 and column quad q = li & 3 of a [4 pixels][16 channels] block;
-    // k-group lk = pixels 8 * lk .. + 7 of a 32-pixel pair of groups
-    const int t_off = (lk >> 1) * HC_SLOT + (8 * (lk & 1) + (li >> 2)) * HC_ROW + 8 * (li & 3);
-    const int t_offx = (lk >> 1) * HC_SLOT + HC_X + (8 * (lk & 1) + (li >> 2)) * HC_XROW + 8 * (li & 3);
+    unsigned char* const my = ex + wave * H4_SLOT;
+    // transposing reads: lane supplies pixel row r0 = 8 * (lk & 1) + (li >> 2) (second read: r0 + 4) and column quad q = li & 3 of a
+    // [4 pixels][16 channels] block; k-group lk = pixels 8 * lk .. + 7 of a 32-pixel pair of groups.  Physical 8-byte piece of
+    // (row r, piece p) = p ^ (r & 15): for p = 4 * mb + q the low two bits are q ^ (r & 3), the block index mb ^ (r >> 2).
+    const int t_r0 = 8 * (lk & 1) + (li >> 2);
+    const int t_off = (lk >> 1) * H4_SLOT + t_r0 * H4_ROW + 8 * ((li & 3) ^ (t_r0 & 3));
+    const int t_sel = 32 * (t_r0 >> 2);                       // XOR on the 32-byte block offset: first read; second read: ^ 32
+    // features: 4 pieces per row, physical piece = p ^ ((r ^ (r >> 2)) & 3)
+    const int t_offx = (lk >> 1) * H4_SLOT + H4_X + t_r0 * H4_XROW + 8 * ((li & 3) ^ ((t_r0 ^ (t_r0 >> 2)) & 3));
+    const int t_offx2 = (lk >> 1) * H4_SLOT + H4_X + (t_r0 + 4) * H4_XROW + 8 * ((li & 3) ^ (((t_r0 + 4) ^ ((t_r0 + 4) >> 2)) & 3));
 
     // per-group inputs, fetched one group ahead
     float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
@@ -1285,9 +1295,9 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
         if (a.g_popdense) n_gpd = a.g_popdense[pix];
         if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
     };
-    const int gstep = gridDim.x * HC_WAVES;
+    const int gstep = gridDim.x * H4_WAVES;
     const int niter = (a.total_groups + gstep - 1) / gstep;
-    int gg = blockIdx.x * HC_WAVES + wave;
+    int gg = blockIdx.x * H4_WAVES + wave;
     if (gg < a.total_groups) fetch(gg);
     for (int it = 0; it < niter; ++it, gg += gstep) {
         const bool live = gg < a.total_groups;
@@ -1413,17 +1423,19 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
                 }
                 // ---- operands of the weight gradients into this wave's slot: rows = pixels, 8-byte pieces of 4 channels
                 // (pack t holds hidden 16*(2t) + 4*lk .. +3 and 16*(2t+1) + 4*lk .. +3)
+                // piece p = lk + 4 * k of row li goes to physical piece p ^ li: low bits lk ^ (li & 3), block k ^ (li >> 2)
                 auto put = [&](int tensor, const hbf16x8 (&v)[2]) {
-                    unsigned char* d = my + tensor + li * HC_ROW + 8 * lk;
+                    unsigned char* d = my + tensor + li * H4_ROW + 8 * (lk ^ (li & 3));
+                    const int bs = 32 * (li >> 2);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const hu32x4 q4 = __builtin_bit_cast(hu32x4, v[t]);
-                        *reinterpret_cast<uint2*>(d + 32 * (2 * t)) = make_uint2(q4[0], q4[1]);
-                        *reinterpret_cast<uint2*>(d + 32 * (2 * t + 1)) = make_uint2(q4[2], q4[3]);
+                        *reinterpret_cast<uint2*>(d + ((32 * (2 * t)) ^ bs)) = make_uint2(q4[0], q4[1]);
+                        *reinterpret_cast<uint2*>(d + ((32 * (2 * t + 1)) ^ bs)) = make_uint2(q4[2], q4[3]);
                     }
                 };
-                put(HC_H1, hb1); put(HC_H2, hb2); put(HC_G3, gb3); put(HC_G2, gb2); put(HC_G1, gb1);
-                *reinterpret_cast<uint2*>(my + HC_X + li * HC_XROW + 8 * lk) = f4;
+                put(H4_H1, hb1); put(H4_H2, hb2); put(H4_G3, gb3); put(H4_G2, gb2); put(H4_G1, gb1);
+                *reinterpret_cast<uint2*>(my + H4_X + li * H4_XROW + 8 * (lk ^ ((li ^ (li >> 2)) & 3))) = f4;
                 wrote = true;
             } else if (a.zero_in_kernel && valid) {
                 *reinterpret_cast<uint2*>(gxp) = make_uint2(0u, 0u);
@@ -1434,45 +1446,37 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
             const uint2 z2 = make_uint2(0u, 0u);
 #pragma unroll
             for (int tz = 0; tz < 3; ++tz) {
-                unsigned char* d = my + HC_G3 + tz * HC_T + li * HC_ROW + 8 * lk;
+                unsigned char* d = my + H4_G3 + tz * H4_T + li * H4_ROW + 8 * lk;      // all 16 pieces of the row: no swizzle needed
 #pragma unroll
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(d + 32 * k) = z2;
             }
         }
         __syncthreads();
-        // ---- weight gradients over the 8 groups: 4 K-steps of 32 pixels (slots 2*ks, 2*ks + 1)
+        // ---- weight gradients over the 4 groups: 2 K-steps of 32 pixels (slots 2*ks, 2*ks + 1)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const unsigned char* base = ex + 2 * ks * HC_SLOT;
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned char* base = ex + 2 * ks * H4_SLOT + t_off;
+            auto frag = [&](int tensor, int blk) {           // operand block `blk` (16 channels) of a tensor: two transposed reads
+                const int o = (32 * blk) ^ t_sel;
+                return hc_pair(hc_tr(base + tensor + o), hc_tr(base + tensor + 4 * H4_ROW + (o ^ 32)));
+            };
             {
-                const unsigned char* ap = base + HC_G3 + t_off + 32 * my_mb;
-                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
-                const hbf16x8 av = hc_pair(lo, hi);
-                if ((wave & 1) == 0) dB4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB4, 0, 0, 0);
+                const hbf16x8 av = frag(H4_G3, my_mb);
+                dB4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB4, 0, 0, 0);
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
-                    const unsigned char* bp = base + HC_H2 + t_off + 32 * (my_nb0 + n2);
-                    dW4[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_ROW)), dW4[n2], 0, 0, 0);
-                }
+                for (int nb = 0; nb < 4; ++nb) dW4[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, frag(H4_H2, nb), dW4[nb], 0, 0, 0);
             }
             {
-                const unsigned char* ap = base + HC_G2 + t_off + 32 * my_mb;
-                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
-                const hbf16x8 av = hc_pair(lo, hi);
-                if ((wave & 1) == 0) dB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB2, 0, 0, 0);
+                const hbf16x8 av = frag(H4_G2, my_mb);
+                dB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB2, 0, 0, 0);
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
-                    const unsigned char* bp = base + HC_H1 + t_off + 32 * (my_nb0 + n2);
-                    dW2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_ROW)), dW2[n2], 0, 0, 0);
-                }
+                for (int nb = 0; nb < 4; ++nb) dW2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, frag(H4_H1, nb), dW2[nb], 0, 0, 0);
             }
-            if (wave < 4) {
-                const unsigned char* ap = base + HC_G1 + t_off + 32 * wave;
-                const hs16x4 lo = hc_tr(ap), hi = hc_tr(ap + 4 * HC_ROW);
-                const hbf16x8 av = hc_pair(lo, hi);
+            {
+                const hbf16x8 av = frag(H4_G1, my_mb);
                 dB0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones8, dB0, 0, 0, 0);
-                const unsigned char* bp = base + t_offx;
-                dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(bp), hc_tr(bp + 4 * HC_XROW)), dW0, 0, 0, 0);
+                const unsigned char* xb = ex + 2 * ks * H4_SLOT;
+                dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(xb + t_offx), hc_tr(xb + t_offx2)), dW0, 0, 0, 0);
             }
         }
         __syncthreads();
@@ -1481,18 +1485,16 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
     // ---- workgroup partial (layout of head_bwd_pc_kernel): every 16x16 block has ONE owner; dw6 / db6 are summed over the waves
     // D layout of a block: lane = (m >> 2) * 16 + n, register = m & 3  (m = row = gradient's hidden unit, n = column)
 #pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2) {
-        *reinterpret_cast<f32x4*>(&part[PE_W4 + ((my_mb * 4 + my_nb0 + n2) * 64 + lane) * 4]) = dW4[n2];
-        *reinterpret_cast<f32x4*>(&part[PE_W2 + ((my_mb * 4 + my_nb0 + n2) * 64 + lane) * 4]) = dW2[n2];
+    for (int nb = 0; nb < 4; ++nb) {
+        *reinterpret_cast<f32x4*>(&part[PE_W4 + ((my_mb * 4 + nb) * 64 + lane) * 4]) = dW4[nb];
+        *reinterpret_cast<f32x4*>(&part[PE_W2 + ((my_mb * 4 + nb) * 64 + lane) * 4]) = dW2[nb];
     }
-    if (wave < 4) *reinterpret_cast<f32x4*>(&part[PE_W0 + (wave * 64 + lane) * 4]) = dW0;
+    *reinterpret_cast<f32x4*>(&part[PE_W0 + (wave * 64 + lane) * 4]) = dW0;
     // bias gradients: every column of the ones-block holds the row sums; column 0 = lanes li == 0, row m = 4 * lk + register
     if (li == 0) {
-        if ((wave & 1) == 0) {
-            *reinterpret_cast<f32x4*>(&part[PE_B4 + 16 * my_mb + 4 * lk]) = dB4;
-            *reinterpret_cast<f32x4*>(&part[PE_B2 + 16 * my_mb + 4 * lk]) = dB2;
-        }
-        if (wave < 4) *reinterpret_cast<f32x4*>(&part[PE_B0 + 16 * wave + 4 * lk]) = dB0;
+        *reinterpret_cast<f32x4*>(&part[PE_B4 + 16 * my_mb + 4 * lk]) = dB4;
+        *reinterpret_cast<f32x4*>(&part[PE_B2 + 16 * my_mb + 4 * lk]) = dB2;
+        *reinterpret_cast<f32x4*>(&part[PE_B0 + 16 * my_mb + 4 * lk]) = dB0;
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -1512,7 +1514,7 @@ __global__ __launch_bounds__(512, 1) void head_bwd_bf16_coop_kernel(const HeadBw
     if (tid < 65) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < HC_WAVES; ++w) t += red[w * 65 + tid];
+        for (int w = 0; w < H4_WAVES; ++w) t += red[w * 65 + tid];
         part[(tid < 64 ? PE_W6 + tid : PE_B6)] = t;
     }
 }
@@ -1528,11 +1530,11 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* 
 constexpr int HEAD_IMG_BYTES = 96 * 1024;      // room for the largest image (fp32 backward: LB_SCR floats = 72 KB)
 static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES, "weight image slot");
 // the images live in the unused tail of the backward partial area of the workspace (pc_head_ws_bytes reserves 512 x 12288
-// floats, the backward uses at most 256 x PE_TOTAL): slot 0 forward, slot 1 backward
+// floats, the backward uses at most 512 x PE_TOTAL = 395 x 12288): slot 0 forward, slot 1 backward
 __host__ inline void* head_image_slot(void* ws, int B, int H, int W, int slot) {
     const int groups = (H * W + 15) / 16;
     const int64_t nchunk = (groups + 31) / 32 + 1;
-    return reinterpret_cast<char*>(ws) + (int64_t)B * nchunk * 2 * sizeof(float) + (int64_t)300 * 12288 * sizeof(float) + (int64_t)slot * HEAD_IMG_BYTES;
+    return reinterpret_cast<char*>(ws) + (int64_t)B * nchunk * 2 * sizeof(float) + (int64_t)490 * 12288 * sizeof(float) + (int64_t)slot * HEAD_IMG_BYTES;
 }
 
 struct HeadReduceArgs {
@@ -1544,24 +1546,29 @@ struct HeadReduceArgs {
 
 // outputs: w0 (1024) b0 (64) w2 (4096) b2 (64) w4 (4096) b4 (64) w6 (128) b6 (2)  = 9538
 __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceArgs p) {
-    // 32 outputs x 8 slices of the partial list per workgroup (299 workgroups): the sums are short dependent-latency
-    // chains, so the launch is sized for memory-level parallelism, not for arithmetic
+    // 32 CONSECUTIVE partial elements x 8 slices of the partial list per workgroup: the loads of a lane group are one 128-byte
+    // line per partial (indexing by output element instead scattered them over the MFMA fragment layout: 16x the sectors); the
+    // output index is the inverse of the fragment layout.  The sums are short dependent-latency chains: sized for memory-level
+    // parallelism.
     __shared__ float red[256];
     const int tid = threadIdx.x, slice = tid >> 5;
-    const int o = blockIdx.x * 32 + (tid & 31);
-    int t = -1, idx = 0, e = -1;      // tensor id, index within tensor, partial element (-1 = structural zero)
-    if (o < 1024) { t = 0; idx = o; const int r = o >> 4, c = o & 15; e = PE_W0 + (((r >> 4) * 64) + ((r & 15) >> 2) * 16 + c) * 4 + (r & 3); }
-    else if (o < 1088) { t = 1; idx = o - 1024; e = PE_B0 + idx; }
-    else if (o < 5184) { t = 2; idx = o - 1088; const int r = idx >> 6, c = idx & 63;
-                         e = PE_W2 + ((((r >> 4) * 4 + (c >> 4)) * 64) + ((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3); }
-    else if (o < 5248) { t = 3; idx = o - 5184; e = PE_B2 + idx; }
-    else if (o < 9344) { t = 4; idx = o - 5248; const int r = idx >> 6, c = idx & 63;
-                         e = PE_W4 + ((((r >> 4) * 4 + (c >> 4)) * 64) + ((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3); }
-    else if (o < 9408) { t = 5; idx = o - 9344; e = PE_B4 + idx; }
-    else if (o < 9536) { t = 6; idx = o - 9408; e = idx < 64 ? PE_W6 + idx : -1; }
-    else if (o < 9538) { t = 7; idx = o - 9536; e = idx == 0 ? PE_B6 : -1; }
+    const int e = blockIdx.x * 32 + (tid & 31);
+    int t = -1, idx = 0;               // tensor id, index within the tensor
+    if (e < PE_W0) {                   // dW4 / dW2: D[(mb, nb) block][lane = (m >> 2) * 16 + n][reg = m & 3]
+        const int e2 = e & 4095, l = e2 >> 2, blk = l >> 6, lane = l & 63;
+        t = e < PE_W2 ? 4 : 2;
+        idx = (16 * (blk >> 2) + 4 * (lane >> 4) + (e2 & 3)) * 64 + 16 * (blk & 3) + (lane & 15);
+    } else if (e < PE_W6) {            // dW0: block mb, 16 feature columns
+        const int e2 = e - PE_W0, l = e2 >> 2, lane = l & 63;
+        t = 0;
+        idx = (16 * (l >> 6) + 4 * (lane >> 4) + (e2 & 3)) * 16 + (lane & 15);
+    } else if (e < PE_B0) { t = 6; idx = e - PE_W6; }
+    else if (e < PE_B2) { t = 1; idx = e - PE_B0; }
+    else if (e < PE_B4) { t = 3; idx = e - PE_B2; }
+    else if (e < PE_B6) { t = 5; idx = e - PE_B4; }
+    else if (e == PE_B6) { t = 7; idx = 0; }
     float s = 0.f;
-    if (t >= 0 && e >= 0) {
+    if (t >= 0) {
 #pragma unroll 8
         for (int w = slice; w < p.nwg; w += 8) s += p.partial[(int64_t)w * PE_TOTAL + e];
     }
@@ -1572,6 +1579,11 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceAr
                            ((red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid])));
         float* d = p.dhw[t] + idx;
         *d = p.accumulate ? *d + tot : tot;
+    }
+    // structural zeros: the second (unused) output row of the last layer -- weight elements 64..127 and bias element 1
+    if (blockIdx.x == 0 && !p.accumulate) {
+        if (tid < 64 && p.dhw[6]) p.dhw[6][64 + tid] = 0.f;
+        if (tid == 64 && p.dhw[7]) p.dhw[7][1] = 0.f;
     }
 }
 
@@ -2207,13 +2219,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    static bool coop_attr = false;
-    if (!coop_attr) {
-        hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_coop_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, HC_END);
-        if (e4 != hipSuccess) return (int)e4;
-        coop_attr = true;
-    }
     {
         void* img = head_image_slot(ws, B, H, W, 1);
         p.wimage = img;
@@ -2221,10 +2226,22 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         PC_CHECK_LAUNCH();
     }
     if (p.bf) {
-        nwg = (a.total_groups + HC_WAVES - 1) / HC_WAVES;       // one 8-wave workgroup per CU at most (130 KB of LDS)
-        if (nwg > 256) nwg = 256;
+        static bool a4 = false;
+        if (!a4) {
+            hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_coop4_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, H4_END);
+            if (e5 != hipSuccess) return (int)e5;
+            if (getenv("POPCORN_CONV_DBG")) {
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, head_bwd_bf16_coop4_kernel, 256, H4_END);
+                fprintf(stderr, "head_bwd_bf16_coop4: %d bytes of LDS -> %d workgroups per CU\n", H4_END, nb);
+            }
+            a4 = true;
+        }
+        nwg = (a.total_groups + H4_WAVES - 1) / H4_WAVES;       // two 4-wave workgroups per CU (2 x 79 KB of LDS)
+        if (nwg > 512) nwg = 512;
         if (nwg < 1) nwg = 1;
-        hipLaunchKernelGGL(head_bwd_bf16_coop_kernel, dim3(nwg), dim3(512), HC_END, st, a);
+        hipLaunchKernelGGL(head_bwd_bf16_coop4_kernel, dim3(nwg), dim3(256), H4_END, st, a);
     }
     else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
@@ -2232,7 +2249,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     HeadReduceArgs r{};
     r.partial = a.partial; r.nwg = nwg; r.accumulate = accumulate;
     for (int i = 0; i < 8; ++i) r.dhw[i] = dhw[i];
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((9538 + 31) / 32), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((PE_TOTAL + 31) / 32), dim3(256), 0, st, r);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -25,7 +25,7 @@ def mean(v):
 
 
 for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kernel", "conv3x3_mfma_kernel", 4),
-                                                 ("bf16", "_bf16", "head_bwd_bf16_coop_kernel", "conv3x3_cl_kernel", 2)):
+                                                 ("bf16", "_bf16", "head_bwd_bf16_coop4_kernel", "conv3x3_cl_kernel", 2)):
     step = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for n, cs in per_kernel(f"{OUT}/pmc_{prec}_{c}/**/*counter_collection.csv").items():

@@ -46,10 +46,6 @@ __device__ __forceinline__ s16x4 bw_tr(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 __device__ __forceinline__ bf16x8 bw_pair(s16x4 a, s16x4 b) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7)); }
-__device__ __forceinline__ float bw_sum4(s16x4 v) {
-    const uint2 q = __builtin_bit_cast(uint2, v);
-    return (__uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xffff0000u)) + (__uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xffff0000u));
-}
 
 // GC = channels of g (the layer's output channels), XC = channels of x (this block of the layer's input channels): 8 or 16
 template <int GC, int XC>
@@ -182,10 +178,13 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     // B (N = (v, ci4)): quad = input row v = tq (image row 2*rpi + v), pixel index 8*lk + 4*e + j + dx, channel half nb
     const int b_off = (t_q * BSLOTS + (COL0 - 1) + 8 * lk + t_j) * 16;
     f32x4 wacc[NG][NBLK];
-    float bsum[NG];
+    // bias gradient = row sums of the A operand over the pixels: one more MFMA against an all-ones operand (every column of the
+    // block then holds the row sums) instead of ~14 VALU per transposed read pair
+    f32x4 bacc[NG];
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 #pragma unroll
     for (int mb = 0; mb < NG; ++mb) {
-        bsum[mb] = 0.f;
+        bacc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) wacc[mb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
                 const unsigned char* ga = igb + mb * IMG_B + 2 * rpi * BSLOTS * 16 + a_off;
                 const s16x4 lo = bw_tr(ga), hi = bw_tr(ga + 4 * 16);
                 av[mb] = bw_pair(lo, hi);
-                bsum[mb] += bw_sum4(lo) + bw_sum4(hi);
+                bacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb], ones8, bacc[mb], 0, 0, 0);
             }
 #pragma unroll
             for (int nb = 0; nb < NBP; ++nb)
@@ -321,20 +320,18 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
         }
     }
     __syncthreads();
+    // column 0 of the ones-block = lanes li == 0: row m = 4 * lk + register, m = s * 8 + c8
+    if (li == 0) {
 #pragma unroll
-    for (int mb = 0; mb < NG; ++mb) lds[(wave * NG + mb) * 64 + lane] = bsum[mb];
+        for (int mb = 0; mb < NG; ++mb) *reinterpret_cast<f32x4*>(&lds[(wave * NG + mb) * 16 + 4 * lk]) = bacc[mb];
+    }
     __syncthreads();
     if (tid < GC) {
         const int mb = tid >> 3, c8 = tid & 7;
-        float t = 0.f;
-#pragma unroll
-        for (int lk2 = 0; lk2 < 4; ++lk2) {
-            const int ea = mb * 64 + lk2 * 16 + c8, eb = ea + 8;
-            const float sa = ((lds[ea] + lds[NG * 64 + ea]) + lds[2 * NG * 64 + ea]) + lds[3 * NG * 64 + ea];
-            const float sb = ((lds[eb] + lds[NG * 64 + eb]) + lds[2 * NG * 64 + eb]) + lds[3 * NG * 64 + eb];
-            t += sa + sb;
-        }
-        part[GC * XC * 9 + tid] = t;
+        const int ea = mb * 16 + c8, eb = ea + 8;
+        const float sa = ((lds[ea] + lds[NG * 16 + ea]) + lds[2 * NG * 16 + ea]) + lds[3 * NG * 16 + ea];
+        const float sb = ((lds[eb] + lds[NG * 16 + eb]) + lds[2 * NG * 16 + eb]) + lds[3 * NG * 16 + eb];
+        part[GC * XC * 9 + tid] = sa + sb;
     }
 }
 

@@ -170,6 +170,8 @@ typedef struct pc_conv_bwd_desc {
     /* optional (Down blocks): x is the 2x2-max-pooled copy of this full-resolution activation; the data gradient is then
      * scattered (+=) to the first arg-max of every window of `out` (twice the resolution), times relu'(pool_act) * bn_scale(x_bn) */
     const pc_src* pool_act;
+    /* added to the call's c0 for THIS problem: the column blocks of a concat layer (same g, different x) can share one launch */
+    int32_t c0_add; int32_t _pad;
 } pc_conv_bwd_desc;
 int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                          int* nwg_out, void* stream);

@@ -71,7 +71,8 @@ class PcWgradReduceDesc(C.Structure):
 
 class PcConvBwdDesc(C.Structure):
     _fields_ = [("g", C.POINTER(PcSrc)), ("x", C.POINTER(PcSrc)), ("w", C.c_void_p), ("x_bn", C.POINTER(PcBn)),
-                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p), ("pool_act", C.POINTER(PcSrc))]
+                ("out", C.POINTER(PcDst)), ("ws", C.c_void_p), ("pool_act", C.POINTER(PcSrc)), ("c0_add", C.c_int32),
+                ("_pad", C.c_int32)]
 
 
 PC_MAX_GROUP = 4
@@ -206,4 +207,5 @@ def bn(conv_bias=None, gamma=None, beta=None, mean=None, var=None, eps=1e-5) -> 
     b.mean = 0 if mean is None else mean.data_ptr()
     b.var = 0 if var is None else var.data_ptr()
     b.eps = eps
+    b._keep = (conv_bias, gamma, beta, mean, var)      # the descriptor holds raw pointers: keep the tensors alive with it
     return b

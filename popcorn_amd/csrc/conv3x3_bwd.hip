@@ -608,7 +608,8 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         BwdProb& q = p.pr[i];
         q.g = *d[i].g; q.x = *d[i].x;
         if (i == 0) { GC = q.g.C; XC = q.x.C; }
-        if (q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT || q.g.mode != PC_SRC_DIRECT || c0 < 0 || c0 + XC > Cin_total)
+        const int c0i = c0 + d[i].c0_add;
+        if (q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT || q.g.mode != PC_SRC_DIRECT || c0i < 0 || c0i + XC > Cin_total)
             return PC_EINVAL;
         if (f32) {
             // planar fp32, 8 -> 8 channels, 16-byte aligned rows, x placed at (0, 0) with the extent of g
@@ -624,7 +625,7 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         } else if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out)) {
             return PC_EINVAL;
         }
-        q.w = d[i].w + (int64_t)c0 * 9;
+        q.w = d[i].w + (int64_t)c0i * 9;
         q.w_ci_stride = Cin_total * 9;
         q.mask = d[i].x_bn != nullptr;
         if (d[i].x_bn) q.bn = *d[i].x_bn;

@@ -244,6 +244,26 @@ class UNetEngine:
                         return False
             return True
 
+        def bwd_cat(tag, gs, skip_key, skip_act, up_key, off_key, C_, cin_total, h, w):
+            """both column blocks of a concat layer (networks.py:318: [skip | up]) in ONE launch: same g, the skip block masked by
+            its producer, the up-sampled block placed at its offset, unmasked and without a second bias gradient"""
+            g_skip, g_up = {s: E(C_, h, w) for s in S}, {s: E(C_, h, w) for s in S}
+            probs = []
+            for s in S:
+                lay = ly(s, tag)
+                probs.append({"g": gs[s], "x": A[s][skip_key], "w": lay.w, "out": g_skip[s], "dw": grads[prefix + lay.wname],
+                              "db": grads[prefix + lay.bname], "x_bn": ly(s, skip_act).bn_nobias})
+            for s in S:
+                lay = ly(s, tag)
+                probs.append({"g": gs[s], "x": A[s][up_key], "w": lay.w, "out": g_up[s], "dw": grads[prefix + lay.wname], "db": None,
+                              "x_offset": A[s][off_key], "c0_add": C_})
+            if len(probs) <= L.PC_MAX_GROUP:
+                wb.conv3x3_bwd_group(probs, cin_total, 0)
+            else:
+                wb.conv3x3_bwd_group(probs[:len(S)], cin_total, 0)
+                wb.conv3x3_bwd_group(probs[len(S):], cin_total, 0)
+            return g_skip, g_up
+
         def bwd8(tag, gs, x_key, act_tag, outs, c0=0, cin_total=8, off_key=None, with_db=True, pool_key=None):
             probs = []
             for s in S:
@@ -286,8 +306,7 @@ class UNetEngine:
             wgs("up1b", "f1", G_f2)
             G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
         if not encoder_no_grad and fuse8(G_f1, "a2") and fuse8(G_f1, "u1", "o1"):
-            G_a2 = bwd8("up1a", G_f1, "a2", "inc2", {s: E(8, Hp, Wp) for s in S}, c0=0, cin_total=16)
-            g_u1 = bwd8("up1a", G_f1, "u1", None, {s: E(8, Hp, Wp) for s in S}, c0=8, cin_total=16, off_key="o1", with_db=False)
+            G_a2, g_u1 = bwd_cat("up1a", G_f1, "a2", "inc2", "u1", "o1", 8, 16, Hp, Wp)
         else:
             wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
             if not encoder_no_grad:
@@ -307,8 +326,7 @@ class UNetEngine:
             wgs("up2b", "e1", G_e2)
             G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
         if fuse and not encoder_no_grad:
-            G_b2 = bwd8("up2a", G_e1, "b2", "d1b", {s: E(16, H1, W1) for s in S}, c0=0, cin_total=32)
-            g_u2 = bwd8("up2a", G_e1, "u2", None, {s: E(16, H1, W1) for s in S}, c0=16, cin_total=32, off_key="o2", with_db=False)
+            G_b2, g_u2 = bwd_cat("up2a", G_e1, "b2", "d1b", "u2", "o2", 16, 32, H1, W1)
         else:
             wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
             if not encoder_no_grad:

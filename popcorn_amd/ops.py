@@ -517,8 +517,9 @@ class WgradBatch:
     def conv3x3_bwd_group(self, problems, cin_total, c0, accumulate=False):
         """bf16 mode: data gradient + weight-gradient partials of a conv layer (g: 8 / 16 channels, x: an 8- or 16-channel column
         block of the layer's input) in ONE launch.  problems: list of dicts {g, x, w, out, dw (the full [Cg][cin_total][3][3]
-        gradient), db (or None), x_bn (opt: ReLU / BN factor of x's producer), x_offset (opt)}; the partials cover the columns
-        [c0, c0 + x.shape[1]) of dw."""
+        gradient), db (or None), x_bn (opt: ReLU / BN factor of x's producer), x_offset (opt), c0_add (opt: this problem's column
+        block starts at c0 + c0_add -- the blocks of a concat layer in one launch)}; the partials cover the columns
+        [c0 + c0_add, c0 + c0_add + x.shape[1]) of dw."""
         n = len(problems)
         g0 = problems[0]["g"]
         B, Cg, H, W = g0.shape
@@ -531,6 +532,7 @@ class WgradBatch:
             slots.append(ws)
             descs[i].g, descs[i].x, descs[i].w, descs[i].out, descs[i].ws = C.pointer(sg), C.pointer(sx), pr["w"].data_ptr(), C.pointer(d), ws
             descs[i].x_bn = C.pointer(pr["x_bn"]) if pr.get("x_bn") is not None else None
+            descs[i].c0_add = int(pr.get("c0_add", 0))
             if pr.get("pool_act") is not None:        # Down blocks: x is the pooled copy of pool_act; out is at twice the resolution (+=)
                 spa = L.src(pr["pool_act"])
                 keep.append(spa)
@@ -539,7 +541,8 @@ class WgradBatch:
         L.check(L.lib().pc_conv3x3_bwd_group(n, descs, cin_total, c0, int(accumulate), B, H, W, C.byref(nwg), L.stream_ptr()),
                 "pc_conv3x3_bwd_group")
         for ws, pr in zip(slots, problems):
-            self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, pr["x"].shape[1], Cg, 0, cin_total * 9, c0 * 9))
+            self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, pr["x"].shape[1], Cg, 0, cin_total * 9,
+                                 (c0 + int(pr.get("c0_add", 0))) * 9))
 
     def convt2x2(self, x, g, dw, db):
         B, Cc, H, W = x.shape

@@ -308,3 +308,31 @@ def test_reflect_pad_select_matches_torch(geom):
     ref = F.pad(x[:, sel], (l, r, t, b), mode="reflect")
     out = ops.reflect_pad_select(x.cuda(), sel, t, b, l, r)
     assert torch.equal(out.cpu(), ref)
+
+
+def test_conv_backward_fused_both_concat_blocks_in_one_launch():
+    """c0_add: the skip block (masked) and the up-sampled block (unmasked, no second bias gradient) of a concat layer as two
+    problems of ONE pc_conv3x3_bwd_group launch, against autograd through torch.cat."""
+    from popcorn_amd import ops, _lib as L
+    B, H, W = 2, 64, 64
+    skip, up = F.relu(_mk(B, 8, H, W, seed=60)), _mk(B, 8, H, W, seed=61)
+    w = _mk(8, 16, 3, 3, seed=62, scale=0.2)
+    g = _mk(B, 8, H, W, seed=63)
+    gamma, beta, mean, var = _bn_params(8, 64)
+    xd = torch.cat([skip, up], 1).double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    bias = torch.zeros(8, dtype=torch.double, requires_grad=True)
+    F.conv2d(xd, wd, bias, padding=1).backward(g.double())
+    scale = (gamma / torch.sqrt(var + 1e-5)).view(1, 8, 1, 1).double()
+    o_skip, o_up = torch.empty(B, 8, H, W, device="cuda"), torch.empty(B, 8, H, W, device="cuda")
+    dw, db = torch.empty(8, 16, 3, 3, device="cuda"), torch.empty(8, device="cuda")
+    wb = ops.WgradBatch(torch.device("cuda"))
+    gd = g.cuda()
+    wb.conv3x3_bwd_group([{"g": gd, "x": skip.cuda(), "w": w.cuda(), "out": o_skip, "dw": dw, "db": db,
+                           "x_bn": L.bn(None, gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda())},
+                          {"g": gd, "x": up.cuda(), "w": w.cuda(), "out": o_up, "dw": dw, "db": None, "c0_add": 8}], 16, 0)
+    wb.finish()
+    torch.testing.assert_close(o_skip.cpu().double(), xd.grad[:, :8] * (skip > 0) * scale, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(o_up.cpu().double(), xd.grad[:, 8:], rtol=1e-5, atol=2e-5)
+    assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()

@@ -1340,8 +1340,7 @@ extern "C" int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Ci
     ConvArgs p{};
     for (int i = 0; i < n; ++i) {
         const int rc = fill_dgrad(p.pr[i], d[i].g, d[i].w, c0, d[i].act, d[i].act_bn, pool, d[i].out, Cg);
-        if (rc) return rc;
-        if ((d[i].act != nullptr) != (d[0].act != nullptr)) return PC_EINVAL;
+        if (rc) return rc;         // (act is a per-problem property: the masked skip block and the plain up block of a concat layer mix)
     }
     p.w_co_stride = 9;
     p.w_ci_stride = Cin_total * 9;

@@ -329,9 +329,16 @@ class UNetEngine:
             G_b2, g_u2 = bwd_cat("up2a", G_e1, "b2", "d1b", "u2", "o2", 16, 32, H1, W1)
         else:
             wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
-            if not encoder_no_grad:
-                G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
-            g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
+            if not encoder_no_grad and 2 * len(S) <= L.PC_MAX_GROUP:
+                # both column blocks in one launch: the four problems read the same gradient
+                G_b2, g_u2 = {s: E(16, H1, W1) for s in S}, {s: E(16, H1, W1) for s in S}
+                ops.conv3x3_dgrad_group(
+                    [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": G_b2[s], "act": A[s]["b2"], "act_bn": ly(s, "d1b").bn_nobias} for s in S] +
+                    [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": g_u2[s], "c0_add": 16} for s in S], 0, 16)
+            else:
+                if not encoder_no_grad:
+                    G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+                g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
         G_c2, probs = {}, []
         g_u2vs = {}
         for s in S:

@@ -96,7 +96,8 @@ def pool_out_like(out):
 
 
 def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):
-    """Grouped conv3x3_dgrad: problems = list of dicts {g, w, out, act (optional), act_bn (optional)}."""
+    """Grouped conv3x3_dgrad: problems = list of dicts {g, w, out, act (optional), act_bn (optional), c0_add (optional: this
+    problem's input-channel block starts at c0 + c0_add -- both column blocks of a concat layer in one launch)}."""
     n = len(problems)
     assert 1 <= n <= L.PC_MAX_GROUP
     g0, w0 = problems[0]["g"], problems[0]["w"]
@@ -109,7 +110,9 @@ def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):
         sa = L.src(pr["act"]) if pr.get("act") is not None else None
         keep += [sg, d, sa]
         descs[i].g = C.pointer(sg)
-        descs[i].w = pr["w"].data_ptr()
+        ca = int(pr.get("c0_add", 0))
+        assert 0 <= c0 + ca and c0 + ca + cn <= pr["w"].shape[1]
+        descs[i].w = pr["w"].data_ptr() + 4 * 9 * ca
         descs[i].act = C.pointer(sa) if sa is not None else None
         descs[i].act_bn = C.pointer(pr["act_bn"]) if pr.get("act_bn") is not None else None
         descs[i].out = C.pointer(d)

@@ -542,12 +542,181 @@ def g10_transform():
     np.savez_compressed(os.path.join(OUT, "g10_transform.npz"), **out)
 
 
+def g12_stitch():
+    """The REAL ``Trainer.test_target`` of run_eval.py (:71-203): window loop, ensemble sums, interior write-back into the
+    raster accumulators, averaging / std where count > 1, census conversion, metrics, dasymetric adjustment -- called UNBOUND
+    on a namespace.  What is stubbed is only what the image lacks or what touches a GPU / the disk:
+      * ``configargparse`` (arguments/eval.py parses ``sys.argv`` at import: an argparse subclass that swallows
+        ``is_config_file``), ``wandb`` (``log`` is a no-op), ``rasterio`` / ``torchvision`` (as for g9 / g10);
+      * ``Tensor.cuda`` = identity and a ``torch`` proxy in the module's namespace whose ``zeros`` drops ``device="cuda"``
+        (run_eval.py:103-106) and records the int16 visit-count map (never saved by the reference);
+      * ``inference_patch_size`` (module global ``ips``) = 40 instead of 2048 so that the fixture stays small;
+      * the dataloader: the reference's own ``get_patch_indices`` / ``_create_mask`` produce the windows of a seeded raster;
+        the dataset stub binds the reference's ``convert_popmap_to_census`` / ``adjust_map_to_census`` behind the fake
+        ``rasterio.open`` of g9; the ensemble members are fixed functions of the NORMALISED input (so that
+        ``apply_transformations_and_normalize`` is on the pinned path)."""
+    import argparse
+    import json
+    import tempfile
+    import pandas as pd
+    _stub_rasterio()
+    _stub_torchvision()
+    cap = types.ModuleType("configargparse")
+
+    class AP(argparse.ArgumentParser):
+        def add_argument(self, *a, **k):
+            k.pop("is_config_file", None)
+            return super().add_argument(*a, **k)
+
+    cap.ArgumentParser = AP
+    sys.modules["configargparse"] = cap
+    wb = types.ModuleType("wandb")
+    wb.log = lambda *a, **k: None
+    wb.init = lambda *a, **k: None
+    sys.modules["wandb"] = wb
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    argv, sys.argv = sys.argv, ["run_eval.py"]
+    import run_eval as RE
+    sys.argv = argv
+    import data.PopulationDataset as PD
+
+    counts = []
+
+    class TorchProxy:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def zeros(*a, **k):
+            k.pop("device", None)
+            t = torch.zeros(*a, **k)
+            if t.dtype == torch.int16:
+                counts.append(t)
+            return t
+
+    RE.torch = TorchProxy()
+    with open(os.path.join(REF, "data/config/dataset_stats.json")) as fh:
+        stats = json.load(fh)
+    for mkey in stats:
+        if isinstance(stats[mkey], dict):
+            for key, val in stats[mkey].items():
+                stats[mkey][key] = torch.tensor(val)
+
+    class Member:
+        """ensemble member i: fixed per-pixel functions of the normalised 6-channel input"""
+
+        def __init__(self, i):
+            self.i = i
+
+        def eval(self):
+            return self
+
+        def __call__(self, sample, padding=False):
+            assert padding is False
+            x = sample["input"]
+            i = self.i
+            pd_ = torch.relu(x[:, i % 6] * (0.5 + 0.25 * i) + x[:, (i + 3) % 6] * 0.125 + 0.75)
+            sc = (x[:, (i + 1) % 6] * 0.5).abs() + 0.0625 * i
+            return {"popdensemap": pd_, "scale": sc}
+
+    out = {}
+    ips, ov = 40, 4
+    RE.ips = ips
+    RE.testlevels_eval = {"uga": ["coarse"]}
+    for name, seed, h, w, fs, M in [("a", 121, 84, 95, True, 3), ("b", 122, 70, 61, False, 1), ("c", 123, 61, 97, False, 2)]:
+        g = torch.Generator().manual_seed(seed)
+        S = 4 if fs else 1
+        s2 = torch.randint(0, 10000, (S, 4, h, w), generator=g).float()
+        s1 = (torch.randn(S, 2, h, w, generator=g) * 5.0 - 12.0).half().float()
+        nreg = 11
+        gy, gx = max(1, h // 6), max(1, w // 5)
+        coarse = torch.randint(0, nreg + 1, ((h + gy - 1) // gy, (w + gx - 1) // gx), generator=g)
+        boundary = coarse.repeat_interleave(gy, 0).repeat_interleave(gx, 1)[:h, :w].contiguous().to(torch.int32)
+        ids, bbox, pop = [], [], []
+        for cid in range(1, nreg + 1):
+            m = boundary == cid
+            if not m.any():
+                continue
+            xs, ys = torch.where(m)
+            ids.append(cid)
+            bbox.append(str((int(xs.min()), int(xs.max()) + 1, int(ys.min()), int(ys.max()) + 1)))
+            pop.append(float(torch.rand(1, generator=g).item() * 900.0 + 1.0))
+        tmp = tempfile.mkdtemp()
+        csv = os.path.join(tmp, "census.csv")
+        pd.DataFrame({"idx": ids, "bbox": bbox, "POP20": pop}).to_csv(csv, index=False)
+
+        class FakeSrc:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+            def read(self, band):
+                return boundary.numpy().copy()
+
+        PD.rasterio.open = lambda path, mode="r": FakeSrc()
+        saved = {}
+
+        class DS:
+            region = "uga"
+            file_paths = {"coarse": {"boundary": "boundary.tif", "census": csv}}
+            train_level = "coarse"
+            img_shape = (h, w)
+            fourseasons = fs
+
+            def shape(self):
+                return self.img_shape
+
+            def save(self, m, folder, tag=""):
+                saved[tag] = m.clone()
+
+            convert_popmap_to_census = PD.Population_Dataset.convert_popmap_to_census
+            adjust_map_to_census = PD.Population_Dataset.adjust_map_to_census
+
+        ds = DS()
+        idx = PD.Population_Dataset.get_patch_indices(ds, ips, ov)
+        mask = torch.from_numpy(PD.Population_Dataset._create_mask(ds, ips, ips, ov).copy())
+
+        class Loader:
+            dataset = ds
+
+            def __iter__(self):
+                for x, y, s in idx.tolist():
+                    # what DataLoader(batch_size=1) hands over for the test item (PopulationDataset.py:462-520)
+                    yield {"S2": s2[s:s + 1, :, x:x + ips, y:y + ips].clone(), "S1": s1[s:s + 1, :, x:x + ips, y:y + ips].clone(),
+                           "img_coords": [torch.tensor([x]), torch.tensor([y])], "mask": mask[None].clone()}
+
+            def __len__(self):
+                return idx.shape[0]
+
+        ns = types.SimpleNamespace(model=[Member(i) for i in range(M)], dataloaders={"test_target": [Loader()]},
+                                   dataset_stats=stats, args=types.SimpleNamespace(buildinginput=False, segmentationinput=False),
+                                   experiment_folder=tmp, info={"epoch": 0, "iter": 0, "sampleitr": 0})
+        counts.clear()
+        RE.Trainer.test_target(ns, save=True, full=False)
+        out[f"{name}/s2"], out[f"{name}/s1"] = s2.numpy().astype(np.int16), s1.numpy().astype(np.float16)
+        out[f"{name}/boundary"] = np_(boundary)
+        out[f"{name}/windows"] = idx.numpy().copy()
+        out[f"{name}/meta"] = np.array([h, w, ips, ov, M, int(fs)], dtype=np.int64)
+        out[f"{name}/census_idx"] = np.array(ids, dtype=np.int64)
+        out[f"{name}/census_pop"] = np.array(pop, dtype=np.float64)
+        out[f"{name}/map"], out[f"{name}/std"] = np_(saved[""]), np_(saved["STD"])
+        out[f"{name}/scale"], out[f"{name}/scale_std"] = np_(saved["SCALE_uga"]), np_(saved["SCALE_STD"])
+        out[f"{name}/adjusted"] = np_(saved["ADJ_uga"])
+        out[f"{name}/count"] = np_(counts[0])
+        keys = sorted(ns.target_test_stats)
+        out[f"{name}/metric_keys"] = np.array(keys)
+        out[f"{name}/metric_vals"] = np.array([float(ns.target_test_stats[k]) for k in keys], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g12_stitch.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     popcorn, networks, get_model, losses, metrics = import_reference()
     only = set(sys.argv[1:])                    # e.g. `make_golden.py g9 g10`: regenerate just those fixture files
     if only:
-        for tag, fn in (("g9", g9_census), ("g10", g10_transform)):
+        for tag, fn in (("g9", g9_census), ("g10", g10_transform), ("g12", g12_stitch)):
             if tag in only:
                 fn()
         if "g11" in only:
@@ -564,6 +733,7 @@ def main():
     g9_census()
     g10_transform()
     g11_sparse_unet_mask(popcorn, m)
+    g12_stitch()
     args = get_model.Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True,
                           pretrained=True, biasinit=0.9407, sentinelbuildings=True)
     kw = get_model.get_model_kwargs(args, "POPCORN")

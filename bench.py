@@ -23,6 +23,12 @@ times are in `ms_per_step_blocks`).  Rank 0 prints ONE JSON line with
   roofline_conv_class every conv / transposed-conv launch of one step timed live (events between the eager launches):
                       per-layer us, algorithmic flops and compulsory bytes, and the class totals against both peaks
   cpu_baseline        the CPU oracle ("port") timed on the host cores, several bounded legs (N = 1 only)
+  per_rank_ms_per_step  every rank's own median block (a straggler shows here; `ms_per_step` is the max over ranks)
+  bf16                BASELINE config 4's mixed precision on the same workload in the same process (value, ms_per_step, HBM view
+                      of its conv class, final loss) -- a second figure, never the headline
+  soak                N = 1: ONE block of 1500 replayed steps (thermal / power steady state next to the 30-step blocks)
+  h2d                 the same step with every batch coming from PINNED HOST memory through a copy stream, double-buffered
+                      (6 pre-selected bands and the full 15-band tile): tiles/s with feeding (the headline keeps its inputs resident)
 """
 import argparse
 import json
@@ -56,6 +62,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=7.0, help="CPU work per cpu_baseline leg")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: BASELINE config 4's mixed precision (PC_PREC_BF16) as a SECOND line; the headline stays fp32")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra objects of the line: `bf16` (config 4's precision, same process), `soak` (N = 1: one "
+                         "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
+    ap.add_argument("--soak-steps", type=int, default=1500)
     return ap.parse_args()
 
 
@@ -282,9 +292,18 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
     def c_finish(self):
         return 0.0, 0, "wgrad second stage (batched reduce)"
 
+    def c_level2(problems):
+        # DoubleConv(16,16) @32x32 + ConvTranspose2d(16,16,2,2) in one launch: x read, u2 (and c1, c2 where kept) written
+        p0 = problems[0]
+        Bn = p0["x"].shape[0]
+        n = len(problems)
+        by = sum(nb(p["x"]) + nb(p["u2"]) + nb(p.get("c1")) + nb(p.get("c2")) for p in problems)
+        return (2.0 * 2 * 9 * 16 * 16 + 2.0 * 4 * 16 * 16) * Bn * 32 * 32 * n, by, f"level2 fwd (2 x conv 16->16 + convT 16) @32x32 x{n}"
+
     saved_graph = trainer.use_graph
     trainer.use_graph = False
     patches = [wrap(ops, "conv3x3_fwd_group", "conv_fwd", c_fwd), wrap(ops, "conv3x3_dgrad_group", "conv_dgrad", c_dgrad),
+               wrap(ops, "level2_fwd_group", "level2_fused", c_level2),
                wrap(ops.WgradBatch, "conv3x3_group", "conv_wgrad", c_wgrad_g), wrap(ops.WgradBatch, "conv3x3", "conv_wgrad", c_wgrad_1),
                wrap(ops.WgradBatch, "conv3x3_bwd_group", "conv_bwd_fused", c_bwd),
                wrap(ops, "convt2x2_group", "convt", c_convt), wrap(ops, "convt2x2_dgrad_group", "convt", c_convt_d),
@@ -388,6 +407,124 @@ def cpu_baseline(torch, sd, seconds):
             "legs": legs}
 
 
+def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
+    """The train step with every batch coming from PINNED HOST memory: a copy stream moves batch i+1 (raw bands, region ids,
+    census ids, targets) into one of two device staging sets while step i computes; the compute stream waits for the copy
+    event, selects + normalises into the graph's static input and frees the staging set.  The reference's loop does the same
+    H2D every step (run_train.py:186, utils/utils.py:22-27), synchronously."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    dev = batch["raw"].device
+    raw = batch["raw"] if band_sel is None else batch["raw"][:, list(band_sel)].contiguous()
+    sel = stats.BAND6 if band_sel is None else tuple(range(6))
+    host = {"raw": raw.cpu().pin_memory(), "admin_mask": batch["admin_mask"].float().cpu().pin_memory(),
+            "census_idx": batch["census_idx"].cpu().pin_memory(), "y": batch["y"].cpu().pin_memory()}
+    stage = [{k: torch.empty_like(v, device=dev) for k, v in host.items()} for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    cstream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    for e in consumed:
+        e.record(cur)
+
+    def feed(i):
+        slot = i & 1
+        with torch.cuda.stream(cstream):
+            cstream.wait_event(consumed[slot])
+            for k, v in host.items():
+                stage[slot][k].copy_(v, non_blocking=True)
+            copied[slot].record(cstream)
+
+    def run(n):
+        feed(0)
+        for i in range(n):
+            if i + 1 < n:
+                feed(i + 1)
+            slot = i & 1
+            cur.wait_event(copied[slot])
+            ops.select_normalize(stage[slot]["raw"], sel, stats.MEAN6, stats.STD6, out=sample["input"])
+            for k in ("admin_mask", "census_idx", "y"):
+                sample[k].copy_(stage[slot][k], non_blocking=True)
+            consumed[slot].record(cur)
+            trainer.step(sample)
+    run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(nsteps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = sum(v.numel() * v.element_size() for v in host.values())
+    return {"feed": label, "steps": nsteps, "ms_per_step": round(dt / nsteps * 1e3, 4), "host_bytes_per_step": nbytes,
+            "h2d_gbps_sustained": round(nbytes * nsteps / dt / 1e9, 2)}, dt
+
+
+def extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, build, run_blocks, timed_block):
+    """`soak`, `h2d`, `bf16` (see the module docstring).  Every leg runs the same code on every rank (barrier-bracketed
+    like the headline), so the multi-GPU line carries them too; `soak` only at N = 1."""
+    out = {}
+    sel6 = None
+
+    def agg(dt):            # max over ranks of a wall time
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item()
+        return dt
+
+    # ---- h2d: the headline precision, fed from pinned host memory
+    from popcorn_amd.data import stats
+    legs = []
+    for band_sel, label in ((stats.BAND6, "6 pre-selected bands (240 KB / tile)"), (None, "15-band tile (600 KB / tile), band select on the device")):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        leg, dt = h2d_leg(torch, trainer, sample, batch, band_sel, args.steps * 2, label)
+        dt = agg(dt)
+        leg["ms_per_step"] = round(dt / (args.steps * 2) * 1e3, 4)
+        leg["value"] = round(B * world * args.steps * 2 / dt, 1)
+        legs.append(leg)
+    out["h2d"] = {"unit": "patches/s", "precision": args.precision, "legs": legs,
+                  "note": "whole job, max over ranks; pinned host -> device staging (double-buffered) on a copy stream, "
+                          "compute waits on the copy event; the headline `value` keeps its inputs resident in HBM"}
+    # restore the resident inputs of the static sample
+    sample["admin_mask"].copy_(batch["admin_mask"]); sample["census_idx"].copy_(batch["census_idx"]); sample["y"].copy_(batch["y"])
+
+    # ---- soak: one long block (N = 1)
+    if world == 1 and args.soak_steps > 0:
+        from popcorn_amd import ops
+
+        def step():
+            ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6, out=sample["input"])
+            return trainer.step(sample)
+        dt, _, _ = timed_block(step, args.soak_steps)
+        out["soak"] = {"steps": args.soak_steps, "ms_per_step": round(dt / args.soak_steps * 1e3, 4),
+                       "value": round(B * args.soak_steps / dt, 1), "unit": "patches/s", "precision": args.precision}
+
+    # ---- bf16 (BASELINE config 4's precision) in the same process; skipped when the headline itself was asked in bf16
+    if args.precision == "fp32":
+        model16, tr16, smp16, step16, _ = build("bf16")
+        torch.manual_seed(1600 + rank)
+        for _ in range(max(args.warmup, 1)):
+            step16()
+        blocks, _, loss16 = run_blocks(step16, args.steps, args.repeats)
+        dt = statistics.median(blocks)
+        v16 = B * world * args.steps / dt
+        o = {"value": round(v16, 1), "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+             "ms_per_step_blocks": [round(b / args.steps * 1e3, 4) for b in blocks], "final_loss": round(loss16, 6),
+             "dtype": "bf16 (MFMA operands + stored activations; fp32 accumulate, master weights, Adam)",
+             "step_frac_of_bf16_mfma_peak": round(v16 * FLOP_TRAIN_PER_TILE / (BF16_MATRIX_PEAK * world), 4)}
+        if world == 1 and rank == 0 and not args.no_class_sweep:
+            from popcorn_amd import _lib as L
+            with L.precision("bf16"):
+                sw = conv_class_sweep(torch, tr16, smp16)
+            o["roofline"] = {"bound": "hbm", "kernel": "conv class of the bf16 step (every conv / transposed-conv launch, channels-last bf16)",
+                             "achieved": sw["hbm_view"]["achieved_gbps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": sw["hbm_view"]["frac"], "launches": sw["launches"], "us": sw["us"],
+                             "alg_mbytes": sw["alg_mbytes"], "mfma_view": sw["mfma_view"], "by_kind": sw["by_kind"]}
+        out["bf16"] = o
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -421,39 +558,45 @@ def main():
     # rwa recipe (README.md:187): -S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407
     margs = Args(Sentinel1=True, NIR=True, Sentinel2=True, feature_extractor="DDA", occupancymodel=True, pretrained=True,
                  biasinit=0.9407, sentinelbuildings=True)
-    torch.manual_seed(1600)
-    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
-    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    model.set_precision(args.precision)
-    trainer = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,),
-                             scale_regularization=0.01, lam_weak=100.0, reducer=FlatReducer(),
-                             use_graph=not args.no_graph)
     batch = make_raw_batch(B, 100, 100, seed=1600 + rank, device=dev)           # resident in HBM before timing
-    # the loader side of the step writes into the tensors the captured graph reads (no per-step input copies)
-    sample = trainer.static_buffers(B, 100, 100) if not args.no_graph else \
-        {"input": torch.empty(B, 6, 100, 100, device=dev), "admin_mask": torch.empty(B, 100, 100, device=dev),
-         "census_idx": torch.empty(B, dtype=torch.int64, device=dev), "y": torch.empty(B, device=dev)}
-    sample["admin_mask"].copy_(batch["admin_mask"])
-    sample["census_idx"].copy_(batch["census_idx"])
-    sample["y"].copy_(batch["y"])
 
-    def step():
-        ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6, out=sample["input"])
-        return trainer.step(sample)
+    def build(precision):
+        """model + fused trainer + the static sample the captured graph reads + the step closure, for one precision"""
+        torch.manual_seed(1600)
+        model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        model.set_precision(precision)
+        tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,),
+                            scale_regularization=0.01, lam_weak=100.0, reducer=FlatReducer(), use_graph=not args.no_graph)
+        # the loader side of the step writes into the tensors the captured graph reads (no per-step input copies)
+        smp = tr.static_buffers(B, 100, 100) if not args.no_graph else \
+            {"input": torch.empty(B, 6, 100, 100, device=dev), "admin_mask": torch.empty(B, 100, 100, device=dev),
+             "census_idx": torch.empty(B, dtype=torch.int64, device=dev), "y": torch.empty(B, device=dev)}
+        smp["admin_mask"].copy_(batch["admin_mask"])
+        smp["census_idx"].copy_(batch["census_idx"])
+        smp["y"].copy_(batch["y"])
+
+        def one_step():
+            ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6, out=smp["input"])
+            return tr.step(smp)
+        return model, tr, smp, one_step, sd
+
+    model, trainer, sample, step, sd_cpu = build(args.precision)
 
     torch.manual_seed(1600 + rank)
     for _ in range(max(args.warmup, 1)):
         step()
 
-    def timed_block():
+    def timed_block(step, nsteps):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(nsteps):
             loss = step()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0              # this rank's own time (before the closing barrier)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -462,16 +605,33 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        return dt, loss
+        return dt, loss, own
 
-    blocks = []
-    for _ in range(max(1, args.repeats)):
-        dt, loss = timed_block()
-        blocks.append(dt)
+    def run_blocks(step, nsteps, repeats):
+        blocks, owns, loss = [], [], None
+        for _ in range(max(1, repeats)):
+            dt, loss, own = timed_block(step, nsteps)
+            blocks.append(dt)
+            owns.append(own)
+        loss_val = float(loss[0].item())
+        if not (loss_val == loss_val) or abs(loss_val) == float("inf"):
+            raise SystemExit(f"non-finite loss {loss_val}")
+        return blocks, owns, loss_val
+
+    blocks, owns, loss_val = run_blocks(step, args.steps, args.repeats)
     dt = statistics.median(blocks)
-    loss_val = float(loss[0].item())
-    if not (loss_val == loss_val) or abs(loss_val) == float("inf"):
-        raise SystemExit(f"non-finite loss {loss_val}")
+    own_ms = statistics.median(owns) / args.steps * 1e3
+    if world > 1:
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = own_ms
+        dist.all_reduce(t)
+        per_rank = [round(v, 4) for v in t.tolist()]
+    else:
+        per_rank = [round(own_ms, 4)]
+
+    extras = {}
+    if not args.no_extras:
+        extras = extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, build, run_blocks, timed_block)
 
     if rank == 0:
         tiles = B * world * args.steps
@@ -491,6 +651,7 @@ def main():
                        "collectives": bool(trainer.reducer.active)},
             "timing": f"median of {len(blocks)} blocks of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
             "ms_per_step_blocks": [round(b / args.steps * 1e3, 4) for b in blocks],
+            "per_rank_ms_per_step": per_rank,
             "final_loss": round(loss_val, 6),
             "step_tflops": round(value * FLOP_TRAIN_PER_TILE / 1e12, 3),
             "step_frac_of_fp32_mfma_peak": round(value * FLOP_TRAIN_PER_TILE / (FP32_MATRIX_PEAK * world), 4),
@@ -505,6 +666,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None
+        res.update(extras)
     else:
         res = None
     # RCCL writes its version banner through C stdio, which (stdout not being a terminal) would otherwise be flushed at exit,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 3
+#define PC_ABI_VERSION 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -83,14 +83,14 @@ int pc_abi_version(void);
 /* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
 int pc_device_count(void);
 const char* pc_error_string(int code);
-/* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn, 3 = pc_conv_fwd_desc, 4 = pc_adam_groups
-   (lets a binding verify its struct layout) */
+/* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn, 3 = pc_conv_fwd_desc, 4 = pc_adam_groups,
+   5 = pc_level2_fwd_desc (lets a binding verify its struct layout) */
 int pc_sizeof(int which);
 
 /* ---- arithmetic mode -----------------------------------------------------------------------------------
  * PC_PREC_FP32 (default): fp32 operands on the fp32 MFMA (v_mfma_f32_16x16x4_f32), the reference's arithmetic.
  * PC_PREC_BF16: bf16 mixed precision (BASELINE config 4; the reference has no such mode -- its only hook is the unused
- *   `half` flag of to_cuda_inplace, utils/utils.py:22-27).  Rounding points, restated by oracle/popcorn_oracle_bf16.py:
+ *   `half` flag of to_cuda_inplace, utils/utils.py:22-27).  Rounding points, restated by oracle/popcorn_oracle.py (bf16_mode):
  *     - every operand of a matrix product (conv / transposed conv / 1x1 head layer: activations, gradients, weights) is a
  *       bf16 value (round-to-nearest-even); products accumulate in fp32;
  *     - every activation / activation-gradient tensor a kernel writes (conv + BN + ReLU outputs, pooled copies, transposed-
@@ -208,6 +208,21 @@ typedef struct pc_convt_bwd_desc {
     const pc_src* x; const pc_src* g; const float* w; const pc_bn* x_bn; const pc_dst* out; void* ws;
 } pc_convt_bwd_desc;
 int pc_convt2x2_bwd_group(int n, const pc_convt_bwd_desc* d, int B, int H, int W, int C, int* nwg_out, void* stream);
+
+/* ---- the whole 32 x 32 level of a U-Net stream in ONE launch (PC_PREC_FP32): Down.mpconv[1] = DoubleConv(16, 16)
+ * (networks.py:253-271,284-295) on an already pooled 16-channel 32 x 32 map, followed by Up.up = ConvTranspose2d(16, 16, 2, 2)
+ * (networks.py:302,306):   c1 = relu(bn1(conv3x3(x, w1)));  c2 = relu(bn2(conv3x3(c1, w2)));  u2 = convT(c2, wt) + bt.
+ * One workgroup per (tile, problem) keeps x, c1 and c2 in LDS (a whole map is 64 KB: no halo exists at whole-tile residency);
+ * only u2 (B x 16 x 64 x 64) and, when c1 / c2 are given (networks whose backward pass needs them), those two maps go to HBM.
+ * Replaces two pc_conv3x3_bn_relu_fwd_group launches and one pc_convt2x2_fwd_group launch.  Geometry: x 16 channels, 32 x 32,
+ * planar fp32, 16-byte aligned rows (pc_level2_fwd_ok); anything else returns PC_EINVAL and the callers keep the three launches. */
+typedef struct pc_level2_fwd_desc {
+    const pc_src* x; const float* w1; const pc_bn* bn1; const float* w2; const pc_bn* bn2; const float* wt; const float* bt;
+    const pc_dst* c1; const pc_dst* c2;   /* optional (NULL: not written) */
+    const pc_dst* u2;
+} pc_level2_fwd_desc;
+int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2);
+int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */

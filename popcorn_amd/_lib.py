@@ -75,6 +75,12 @@ class PcConvBwdDesc(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class PcLevel2FwdDesc(C.Structure):
+    _fields_ = [("x", C.POINTER(PcSrc)), ("w1", C.c_void_p), ("bn1", C.POINTER(PcBn)), ("w2", C.c_void_p), ("bn2", C.POINTER(PcBn)),
+                ("wt", C.c_void_p), ("bt", C.c_void_p), ("c1", C.POINTER(PcDst)), ("c2", C.POINTER(PcDst)), ("u2", C.POINTER(PcDst))]
+
+
+PC_ABI_VERSION = 4
 PC_MAX_GROUP = 4
 PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
 
@@ -99,7 +105,15 @@ def lib():
             raise PopcornHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C popcorn_amd/csrc`).  popcorn_amd has no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
+        cand = C.CDLL(LIB_PATH)
+        # the .so is a build artefact (git-ignored): refuse a stale one instead of handing it descriptors of another layout
+        ver = cand.pc_abi_version() if hasattr(cand, "pc_abi_version") else -1
+        sizes = [cand.pc_sizeof(i) for i in range(6)] if hasattr(cand, "pc_sizeof") else []
+        want = [C.sizeof(t) for t in (PcSrc, PcDst, PcBn, PcConvFwdDesc, PcAdamGroups, PcLevel2FwdDesc)]
+        if ver != PC_ABI_VERSION or sizes != want:
+            raise PopcornHipError(f"{LIB_PATH} is stale: ABI version {ver} (binding: {PC_ABI_VERSION}), struct sizes {sizes} "
+                                  f"(binding: {want}); rebuild it with `make -C popcorn_amd/csrc`")
+        _lib = cand
         _lib.pc_error_string.restype = C.c_char_p
         for name in ("pc_conv3x3_wgrad_ws_bytes", "pc_convt2x2_wgrad_ws_bytes", "pc_head_ws_bytes",
                      "pc_compact_ws_bytes", "pc_unet_ws_bytes"):

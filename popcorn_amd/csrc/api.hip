@@ -30,7 +30,7 @@ extern "C" const char* pc_error_string(int code) {
 }
 
 // sizeof() of the ABI structs as the compiler laid them out: 0 = pc_src, 1 = pc_dst, 2 = pc_bn,
-// 3 = pc_conv_fwd_desc, 4 = pc_adam_groups (binding self-check)
+// 3 = pc_conv_fwd_desc, 4 = pc_adam_groups, 5 = pc_level2_fwd_desc (binding self-check)
 extern "C" int pc_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(pc_src);
@@ -38,6 +38,7 @@ extern "C" int pc_sizeof(int which) {
         case 2: return (int)sizeof(pc_bn);
         case 3: return (int)sizeof(pc_conv_fwd_desc);
         case 4: return (int)sizeof(pc_adam_groups);
+        case 5: return (int)sizeof(pc_level2_fwd_desc);
         default: return -1;
     }
 }

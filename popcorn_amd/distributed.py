@@ -56,6 +56,21 @@ class FlatReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (dist.is_initialized() and force_collectives())      # collectives are issued
+        self.capture_failed = False
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        if self.active and self.backend == "nccl" and torch.cuda.is_available():
+            # communicator set-up (and RCCL's lazy channel allocation) happens on the first collective: do it here, on every
+            # rank alike, so that the first captured step records plain collective nodes
+            t = torch.zeros(2, device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, group=group)
+            t32 = torch.zeros(64, device="cuda", dtype=torch.float32)
+            dist.all_reduce(t32, group=group)
+            torch.cuda.synchronize()
+
+    def capturable(self):
+        """Collectives of this group can be recorded into a HIP graph (torch's NCCL / RCCL backend supports stream capture;
+        gloo works through the host and cannot)."""
+        return self.active and self.backend == "nccl" and not self.capture_failed and os.environ.get("POPCORN_DP_ONE_GRAPH", "1") != "0"
 
     def reduce_stats(self, stats: torch.Tensor):
         """stats: float64[2] {Nsel, sum(scale)} -> global sums (in place)."""

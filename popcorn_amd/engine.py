@@ -66,6 +66,8 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
 # data gradient + weight gradient of a conv layer in one launch (bf16 mode: every layer; fp32 mode: the 8 -> 8 layers);
 # POPCORN_FUSED_CONV_BWD=0: separate launches (A/B switch)
 FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
+# fp32: the whole 32 x 32 level (down2's DoubleConv + up2's transposed conv) in one launch (POPCORN_FUSED_LEVEL2=0: three launches)
+FUSED_LEVEL2 = os.environ.get("POPCORN_FUSED_LEVEL2", "1") != "0"
 # fp32: padded + channel-gathered input materialised once per forward pass (POPCORN_PADDED_INPUT=0: reflect loaders; A/B switch)
 PADDED_INPUT = os.environ.get("POPCORN_PADDED_INPUT", "1") != "0"
 
@@ -488,14 +490,28 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     a2 = conv("inc2", a1, 8, Hp, Wp, pooled=pa2)
     b1 = down("d1a", a2, pa2, 16, H1, W1)
     b2 = conv("d1b", b1, 16, H1, W1, pooled=pb2)
-    c1 = down("d2a", b2, pb2, 16, H2, W2)
-    c2 = conv("d2b", c1, 16, H2, W2)
     def convt(tag, ins, c, h, w):
         outs = {k: E(c, h, w) for k in keys}
         ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in keys])
         return outs
 
-    u2 = convt("up2t", c2, 16, 2 * H2, 2 * W2)
+    u2 = None
+    if FUSED_LEVEL2 and L.act_dtype() == torch.float32 and pb2 and (H2, W2) == (32, 32):
+        # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with
+        # the 16 x 32 x 32 maps in LDS; c1 / c2 go to HBM only for the networks whose backward pass reads them
+        u2 = {k: E(16, 2 * H2, 2 * W2) for k in keys}
+        if all(ops.level2_fwd_ok(pb2[k], u2[k]) for k in keys):
+            c1 = {k: (E(16, H2, W2) if saves[k[0]] else None) for k in keys}
+            c2 = {k: (E(16, H2, W2) if saves[k[0]] else None) for k in keys}
+            ops.level2_fwd_group([{"x": pb2[k], "w1": ly(k, "d2a").w, "bn1": ly(k, "d2a").bn, "w2": ly(k, "d2b").w,
+                                   "bn2": ly(k, "d2b").bn, "wt": ly(k, "up2t").w, "bt": ly(k, "up2t").b, "c1": c1[k], "c2": c2[k],
+                                   "u2": u2[k]} for k in keys])
+        else:
+            u2 = None
+    if u2 is None:
+        c1 = down("d2a", b2, pb2, 16, H2, W2)
+        c2 = conv("d2b", c1, 16, H2, W2)
+        u2 = convt("up2t", c2, 16, 2 * H2, 2 * W2)
     o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
     e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
     e2 = conv("up2b", e1, 8, H1, W1)

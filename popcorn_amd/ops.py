@@ -201,6 +201,40 @@ def convt2x2_group(problems):
     L.check(L.lib().pc_convt2x2_fwd_group(n, descs, B, H, W, Cc, L.stream_ptr()), "pc_convt2x2_fwd_group")
 
 
+def level2_fwd_ok(x, u2):
+    """Does the one-launch 32 x 32 level (pc_level2_fwd_group) take these tensors?  x: (B,16,32,32) pooled map, u2: (B,16,64,64)."""
+    if x is None or x.dim() != 4 or tuple(x.shape[1:]) != (16, 32, 32) or tuple(u2.shape[1:]) != (16, 64, 64):
+        return False
+    if x.dtype != torch.float32 or u2.dtype != torch.float32 or x.stride(3) != 1 or u2.stride(3) != 1:
+        return False
+    sx, du = L.src(x), L.dst(u2)
+    return bool(L.lib().pc_level2_fwd_ok(C.byref(sx), C.byref(du)))
+
+
+def level2_fwd_group(problems):
+    """DoubleConv(16,16) + ConvTranspose2d(16,16,2,2) of the 32 x 32 level in ONE launch (networks.py:253-271,302): problems =
+    list (<= 4) of dicts {x (pooled input), w1, bn1, w2, bn2, wt, bt, u2 (out), c1 / c2 (optional outs: saved activations)}."""
+    n = len(problems)
+    assert 1 <= n <= L.PC_MAX_GROUP
+    L.require_device(problems[0]["x"], problems[0]["u2"])
+    B = problems[0]["x"].shape[0]
+    keep = []
+    descs = (L.PcLevel2FwdDesc * n)()
+    for i, pr in enumerate(problems):
+        sx, du = L.src(pr["x"]), L.dst(pr["u2"])
+        d1 = L.dst(pr["c1"]) if pr.get("c1") is not None else None
+        d2 = L.dst(pr["c2"]) if pr.get("c2") is not None else None
+        keep += [sx, du, d1, d2]
+        descs[i].x = C.pointer(sx)
+        descs[i].w1, descs[i].w2, descs[i].wt = pr["w1"].data_ptr(), pr["w2"].data_ptr(), pr["wt"].data_ptr()
+        descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
+        descs[i].bn1, descs[i].bn2 = C.pointer(pr["bn1"]), C.pointer(pr["bn2"])
+        descs[i].c1 = C.pointer(d1) if d1 is not None else None
+        descs[i].c2 = C.pointer(d2) if d2 is not None else None
+        descs[i].u2 = C.pointer(du)
+    L.check(L.lib().pc_level2_fwd_group(n, descs, B, L.stream_ptr()), "pc_level2_fwd_group")
+
+
 def convt2x2_dgrad_group(problems):
     """Grouped convT data gradient: problems = list of {g, w, out, act, act_bn}."""
     n = len(problems)

@@ -85,7 +85,7 @@ class FusedTrainStep:
         self._graph_cache = {}          # key -> captured step; a few recurring shapes (e.g. the smaller last batch of an epoch,
         self._graph_cache_max = 6       # alternating truncation regimes) replay instead of being captured over and over
         self._static = None
-        self._static = None
+        self._sel_ring, self._sel_next = [], 0          # pinned host slots for the per-step selection grid (H2D without a host sync)
         self.last = {}
 
     # ------------------------------------------------------------------------------------------------------------
@@ -256,6 +256,26 @@ class FusedTrainStep:
         sel[H + yi] = 1
         return sel
 
+    def _sel_to_device(self, sel_host, dst=None):
+        """The per-step row / column selection (H + W bytes drawn on the CPU generator, like the reference) goes to the device
+        through a ring of PINNED host slots: a ``copy_`` from pageable memory is a host synchronisation per step on every rank
+        (round-2 review).  A slot is reused only after the copy that read it has completed (its event)."""
+        n = sel_host.numel()
+        if not self._sel_ring or self._sel_ring[0][0].numel() < n:
+            self._sel_ring = [(torch.empty(max(n, 256), dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._sel_next = 0
+            for _, ev in self._sel_ring:
+                ev.record()
+        buf, ev = self._sel_ring[self._sel_next]
+        self._sel_next = (self._sel_next + 1) % len(self._sel_ring)
+        ev.synchronize()                                  # eight steps back: complete unless the host runs far ahead
+        buf[:n].copy_(sel_host)
+        if dst is None:
+            dst = torch.empty(n, dtype=torch.uint8, device=self.device)
+        dst.copy_(buf[:n], non_blocking=True)
+        ev.record()
+        return dst
+
     def step(self, sample, encoder_no_grad=False, unet_no_grad=False):
         """One optimisation step on ``sample`` = {input (B,6,H,W) normalised, admin_mask, census_idx, y}.  Returns the
         device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
@@ -264,7 +284,7 @@ class FusedTrainStep:
         if not self.use_graph:
             s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
             s["admin_mask"] = s["admin_mask"].float()
-            sel = sel_host.to(self.device, non_blocking=True)
+            sel = self._sel_to_device(sel_host)
             with L.precision(self.model.precision):
                 self._forward(s, sel, encoder_no_grad, unet_no_grad)
                 self.reducer.reduce_stats(self.stats)
@@ -289,8 +309,8 @@ class FusedTrainStep:
         for k in ("input", "admin_mask", "census_idx", "y"):
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
                 st[k].copy_(sample[k], non_blocking=True)
-        sel.copy_(sel_host, non_blocking=True)
-        if not self.reducer.active:
+        self._sel_to_device(sel_host, sel)
+        if len(graphs) == 1:                      # single process, or both collectives captured inside the one graph (RCCL)
             graphs[0].replay()
         else:
             graphs[0].replay()
@@ -331,14 +351,26 @@ class FusedTrainStep:
         torch.cuda.synchronize()
         self.flat_p.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
         graphs = []
-        if not self.reducer.active:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._forward(st, sel, enc_ng, unet_ng)
-                self._backward(st, enc_ng, unet_ng)
-                self._update(enc_ng, unet_ng)
-            graphs = [g]
-        else:
+        if not self.reducer.active or self.reducer.capturable():
+            # ONE graph for the whole step.  Data parallel on RCCL: the two collectives ({Nsel, sum scale}: 16 bytes; the flat
+            # gradient: 157 KB) are captured as nodes of the same graph -- no graph boundary and no eager collective launch
+            # between the three sections (POPCORN_DP_ONE_GRAPH=0 or a backend that cannot be captured: the split form below)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward(st, sel, enc_ng, unet_ng)
+                    self.reducer.reduce_stats(self.stats)
+                    self._backward(st, enc_ng, unet_ng)
+                    self.reducer.reduce_grads(self.flat_g)
+                    self._update(enc_ng, unet_ng)
+                graphs = [g]
+            except Exception:
+                if not self.reducer.active:
+                    raise
+                torch.cuda.synchronize()
+                self.reducer.capture_failed = True
+                graphs = []
+        if not graphs:
             g0, g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g0):
                 self._forward(st, sel, enc_ng, unet_ng)

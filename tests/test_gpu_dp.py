@@ -33,10 +33,12 @@ def _run(rank, world, port, use_graph, q):
     from popcorn_amd.model import POPCORN
     from popcorn_amd.train import FusedTrainStep
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    rccl1 = world == "rccl1"             # ONE rank on the real backend, the multi-rank code path forced (POPCORN_DIST_FORCE)
+    rccl1 = world in ("rccl1", "rccl1split")   # ONE rank on the real backend, the multi-rank code path forced (POPCORN_DIST_FORCE)
     if rccl1:
+        os.environ.update(POPCORN_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                          POPCORN_DP_ONE_GRAPH="0" if world == "rccl1split" else "1")
+        split = world == "rccl1split"
         world = 1
-        os.environ.update(POPCORN_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1)
     elif world > 1:
@@ -66,7 +68,9 @@ def _run(rank, world, port, use_graph, q):
         torch.cuda.synchronize()
         assert torch.equal(st.acc, a0) and torch.equal(st.count, c0) and st.count.dtype == torch.int16
         if use_graph:
-            assert len(tr._graphs[3]) == 3          # forward | stats all-reduce | backward | gradient all-reduce | update
+            # one graph with both collectives captured as nodes (default on RCCL), or
+            # forward | stats all-reduce | backward | gradient all-reduce | update as three graphs around two eager collectives
+            assert len(tr._graphs[3]) == (3 if split else 1), (len(tr._graphs[3]), tr.reducer.capture_failed)
     if rank == 0:
         q.put((tr.flat_p.cpu().numpy().tolist(), losses))    # plain lists: no shared-memory handles that die with the child
     if world > 1 or rccl1:
@@ -93,7 +97,7 @@ def _launch(world, use_graph):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(1 if world == "rccl1" else world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, use_graph, q)) for r in range(1 if isinstance(world, str) else world)]
     for p in procs:
         p.start()
     out = _get(q, procs)
@@ -114,11 +118,13 @@ def test_two_rank_fused_step_equals_single_process(use_graph):
     assert all(abs(a) < 1e6 for a in l2)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_rccl_collectives_in_the_split_graph_step(use_graph):
+@pytest.mark.parametrize("use_graph,mode", [(False, "rccl1"), (True, "rccl1"), (True, "rccl1split")])
+def test_rccl_collectives_in_the_graph_step(use_graph, mode):
     """The data-parallel step with its REAL backend: one rank on nccl (= RCCL; a second rank would need a second GPU), the
-    multi-rank code path forced -- process group, float64 stats all-reduce, flat-gradient all-reduce between the three replayed
-    graphs.  With one rank the sums are identities: parameters and losses must equal the plain single-process step exactly."""
+    multi-rank code path forced -- process group, float64 stats all-reduce, flat-gradient all-reduce, both CAPTURED INSIDE the
+    one replayed HIP graph (``rccl1``) or issued eagerly between three replayed graphs (``rccl1split``,
+    POPCORN_DP_ONE_GRAPH=0).  With one rank the sums are identities: parameters and losses must equal the plain
+    single-process step exactly."""
     p1, l1 = _launch(1, use_graph)
-    pr, lr = _launch("rccl1", use_graph)
+    pr, lr = _launch(mode, use_graph)
     assert pr == p1 and lr == l1

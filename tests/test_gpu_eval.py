@@ -161,3 +161,38 @@ def test_evaluate_raster_sharded_equals_unsharded():
     assert (tot.count[ov:h - ov, ov:w - ov] >= 1).all()
     # and the stitched map equals a direct full-raster forward on interior pixels far from window seams is NOT expected
     # (receptive field 20 px < overlap 16 would leak) -- the reference has the same property with 128 px overlap.
+
+
+def test_stitcher_and_census_vs_the_references_own_test_target_g12():
+    """``pc_stitch_accumulate`` / ``pc_stitch_finalize`` + the census kernels against the maps the reference's OWN
+    ``Trainer.test_target`` (run_eval.py:71-203) produced for the same windows (fixture g12: real patch grid, interior mask,
+    ensemble sums, averaging / unbiased std where count > 1, plain sums where a pixel was visited once, census conversion,
+    metrics, dasymetric adjustment).  The window inputs go through the HIP normalisation (``pc_select_normalize``)."""
+    from popcorn_amd import eval as E
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.utils.metrics import get_test_metrics
+    from tests.g12_case import CASES, load_case
+    for name in CASES:
+        c = load_case(name, lambda raw: ops.select_normalize(raw.cuda(), (0, 1, 2, 3, 4, 5), stats.MEAN6, stats.STD6))
+        assert torch.equal(E.get_patch_indices(c["h"], c["w"], c["ips"], c["ov"], c["fourseasons"]),
+                           torch.from_numpy(c["window_list"]))
+        st = E.Stitcher(c["h"], c["w"], "cuda")
+        for x, y, pd, sc in c["windows"]:
+            st.add_window(x, y, pd, sc, c["ov"])
+        out, out_sq, sc_m, sc_sq = st.finalize()
+        r = c["ref"]
+        assert torch.equal(st.count.cpu(), r["count"]), name
+        torch.testing.assert_close(out.cpu(), r["map"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(sc_m.cpu(), r["scale"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out_sq.cpu(), r["std"], rtol=1e-3, atol=3e-3, equal_nan=True)
+        torch.testing.assert_close(sc_sq.cpu(), r["scale_std"], rtol=1e-3, atol=3e-3, equal_nan=True)
+        # census conversion + metrics + adjustment on the reference's stitched map
+        bnd = r["boundary"].cuda()
+        cp, gt = E.convert_popmap_to_census(r["map"].cuda(), bnd, c["census_idx"], c["census_pop"])
+        m = get_test_metrics(cp, gt, tag="MainCensus_uga_coarse")
+        for k, v in m.items():
+            ref = c["metrics"][k]
+            assert abs(float(v) - ref) <= 5e-5 * max(1.0, abs(ref)), (name, k, float(v), ref)
+        adj = E.adjust_map_to_census(r["map"].cuda().clone(), bnd, c["census_idx"], c["census_pop"])
+        torch.testing.assert_close(adj.cpu(), r["adjusted"], rtol=2e-5, atol=1e-6)

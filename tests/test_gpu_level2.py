@@ -1,0 +1,93 @@
+"""The one-launch 32 x 32 level (pc_level2_fwd_group: down2's DoubleConv + up2's ConvTranspose2d with the maps resident in LDS;
+reference model/DDA_model/utils/networks.py:253-271,284-295,302-306) against torch-CPU on the same operands, and the U-Net
+forward with the fused level against the layer-by-layer launches."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(c, g):
+    return (torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1,
+            torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5)          # conv bias, gamma, beta, mean, var
+
+
+def _ref_layer(x, w, p):
+    bias, gamma, beta, mean, var = p
+    y = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    y = (y - mean.double().view(1, -1, 1, 1)) / torch.sqrt(var.double().view(1, -1, 1, 1) + 1e-5) * gamma.double().view(1, -1, 1, 1) \
+        + beta.double().view(1, -1, 1, 1)
+    return torch.relu(y)
+
+
+@pytest.mark.parametrize("nprob,save", [(1, True), (4, True), (2, False)])
+def test_level2_fwd_group_vs_torch(nprob, save):
+    from popcorn_amd import _lib as L
+    from popcorn_amd import ops
+    g = torch.Generator().manual_seed(11 + nprob)
+    B = 3
+    probs, refs, keep = [], [], []
+    for i in range(nprob):
+        # a strided view (channel slice of a wider tensor) for the input: descriptors carry the strides
+        xw = torch.relu(torch.randn(B, 20, 32, 32, generator=g))
+        x = xw[:, 2:18]
+        w1, w2 = torch.randn(16, 16, 3, 3, generator=g) * 0.1, torch.randn(16, 16, 3, 3, generator=g) * 0.1
+        p1, p2 = _bn(16, g), _bn(16, g)
+        wt, bt = torch.randn(16, 16, 2, 2, generator=g) * 0.2, torch.randn(16, generator=g) * 0.1
+        c1 = _ref_layer(x, w1, p1)
+        c2 = _ref_layer(c1, w2, p2)
+        u2 = F.conv_transpose2d(c2, wt.double(), bt.double(), stride=2)
+        refs.append((c1.float(), c2.float(), u2.float()))
+        dv = [t.cuda() for t in (w1, w2, wt, bt)]
+        d1, d2 = [t.cuda() for t in p1], [t.cuda() for t in p2]
+        xd = xw.cuda()[:, 2:18]
+        pr = {"x": xd, "w1": dv[0], "w2": dv[1], "wt": dv[2], "bt": dv[3],
+              "bn1": L.bn(d1[0], d1[1], d1[2], d1[3], d1[4], 1e-5), "bn2": L.bn(d2[0], d2[1], d2[2], d2[3], d2[4], 1e-5),
+              "u2": torch.full((B, 16, 64, 64), float("nan"), device="cuda")}
+        if save:
+            pr["c1"] = torch.full((B, 16, 32, 32), float("nan"), device="cuda")
+            pr["c2"] = torch.full((B, 16, 32, 32), float("nan"), device="cuda")
+        assert ops.level2_fwd_ok(pr["x"], pr["u2"])
+        keep.append((dv, d1, d2))
+        probs.append(pr)
+    ops.level2_fwd_group(probs)
+    torch.cuda.synchronize()
+    for pr, (c1, c2, u2) in zip(probs, refs):
+        names = [("u2", u2)] + ([("c1", c1), ("c2", c2)] if save else [])
+        for name, ref in names:
+            got = pr[name].cpu()
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 2e-5, (name, err)                      # fp32 MFMA accumulation vs float64: a few ulp of the largest value
+
+
+def test_level2_refuses_other_geometries():
+    from popcorn_amd import ops
+    x = torch.zeros(2, 16, 32, 32, device="cuda")
+    assert ops.level2_fwd_ok(x, torch.zeros(2, 16, 64, 64, device="cuda"))
+    assert not ops.level2_fwd_ok(torch.zeros(2, 16, 30, 32, device="cuda"), torch.zeros(2, 16, 60, 64, device="cuda"))
+    assert not ops.level2_fwd_ok(torch.zeros(2, 16, 32, 33, device="cuda")[..., 1:], torch.zeros(2, 16, 64, 64, device="cuda"))   # rows not 16-byte aligned
+    assert not ops.level2_fwd_ok(x.bfloat16(), torch.zeros(2, 16, 64, 64, device="cuda"))
+
+
+def test_unet_forward_fused_level_equals_layerwise(monkeypatch):
+    """forward_multi with the one-launch level against the three launches it replaces: same saved activations (c1, c2, u2) and
+    features to fp32 summation-order accuracy, for the trainable U-Net next to the frozen extractor (4 problems, 2 saved)."""
+    from popcorn_amd import engine as E
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    eng_u, eng_b = m.engines()
+    X = torch.randn(2, 6, 100, 100, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(E, "FUSED_LEVEL2", flag)
+        (f_b, f_u), (_, saved) = E.forward_multi([eng_b, eng_u], X, 14, 14, 128, 128, [False, True], logit_only=[True, False])
+        torch.cuda.synchronize()
+        outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("c1", "c2", "u2", "e1")} for s in ("sar_stream", "optical_stream")})
+    for a, b in ((outs[True][0], outs[False][0]), (outs[True][1], outs[False][1])):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    for s in ("sar_stream", "optical_stream"):
+        for k in ("c1", "c2", "u2", "e1"):
+            a, b = outs[True][2][s][k], outs[False][2][s][k]
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (s, k)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over the grouped conv ablation (tools/ablate_conv_group.py); usage: tools/pmc_conv.sh CIN COUT HW [dbg]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repository copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
 export ABL_ONE=${4:-0}
 i=0
 for pmc in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \

@@ -2,25 +2,27 @@
 # Round profile on the GPU box: rocprofv3 kernel stats of the bench (fp32 and bf16 lines, graph replay) and the FETCH_SIZE /
 # WRITE_SIZE PMC passes (separate runs, --kernel-trace only, eager dispatches) that feed `roofline.traffic`, for both modes.
 #   usage: tools/profile_round.sh r2        -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
-TAG=${1:-r2}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:-r3}
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repository copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
 mkdir -p $OUT
 for prec in fp32 bf16; do
   rm -rf $OUT/prof_$prec
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$prec -o bench -- \
-      python3 bench.py --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-class-sweep --precision $prec > $OUT/${TAG}_${prec}_bench_under_profiler.json 2> $OUT/prof_$prec.err
+      python3 bench.py --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-class-sweep --no-extras --precision $prec > $OUT/${TAG}_${prec}_bench_under_profiler.json 2> $OUT/prof_$prec.err
   f=$(find $OUT/prof_$prec -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_${prec}_graph_kernel_stats.csv
   # PMC: one counter set per run (FETCH_SIZE costs 3 of the 4 TCC slots), eager launches so that every kernel is a dispatch
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_${prec}_$c
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${prec}_$c -o b -- \
-        python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-class-sweep --precision $prec > $OUT/pmc_${prec}_$c.log 2>&1
+        python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-class-sweep --no-extras --precision $prec > $OUT/pmc_${prec}_$c.log 2>&1
   done
 done
-# the standalone grouped conv 8->8 @128x128 x4 launch (roofline_conv): the precision goes through a file, not the environment
-# (the profiled program must be the one after `--`)
+# the standalone grouped conv 8->8 @128x128 x4 launch (roofline_conv): the precision goes through exported variables (ABL_PREC) that
+# the profiled python program reads itself -- the program after `--` is python3, never `env`
 for prec in fp32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
     n=$(echo $c | cut -d' ' -f1)

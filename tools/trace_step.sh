@@ -1,8 +1,10 @@
 #!/bin/bash
 # kernel timeline of one replayed step:  tools/trace_step.sh [bench args]  -> prints the last step's launches (start, duration)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repository copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf gpurun_out/trace_step
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_step -o t -- python3 bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-class-sweep "$@" > gpurun_out/trace_step.json 2> gpurun_out/trace_step.err
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_step -o t -- python3 bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras --no-class-sweep "$@" > gpurun_out/trace_step.json 2> gpurun_out/trace_step.err
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_step/**/*kernel_trace.csv", recursive=True)[0]

@@ -223,6 +223,20 @@ typedef struct pc_level2_fwd_desc {
 } pc_level2_fwd_desc;
 int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2);
 int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream);
+/* Backward of the two convolutions of that level in ONE launch (PC_PREC_FP32), given g2 = dL/d(conv2 output) (already times
+ * relu'(c2) * bn2 scale: pc_convt2x2_bwd_group writes it): weight / bias gradient partials of both layers (ws2: dW2, db2 from
+ * g2 x c1; ws1: dW1, db1 from g1 x x; 8 partials per tile in the layout pc_wgrad_reduce_batch finishes as kind 0, Cin = Cout = 16:
+ * *nwg_out = 8 B, each ws pc_level2_bwd_ws_bytes(B) bytes), the data gradient g1 = relu'(c1) * bn1 scale * conv^T(g2, w2) kept in
+ * LDS, and the MaxPool2d(2) backward of conv^T(g1, w1) accumulated into `out` (B x 16 x 64 x 64: the first arg-max of every 2 x 2
+ * window of `act`, times relu'(act) * act_bn scale).  Replaces two pc_conv3x3_wgrad_partial_group and two
+ * pc_conv3x3_dgrad_group launches; same geometry rule as the forward (pc_level2_bwd_ok). */
+typedef struct pc_level2_bwd_desc {
+    const pc_src* g2; const pc_src* c1; const pc_src* x; const float* w1; const float* w2; const pc_bn* bn1;
+    const pc_src* act; const pc_bn* act_bn; const pc_dst* out; void* ws1; void* ws2;
+} pc_level2_bwd_desc;
+int64_t pc_level2_bwd_ws_bytes(int B);
+int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const pc_src* act, const pc_dst* out);
+int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */
@@ -332,6 +346,11 @@ int pc_reflect_pad(const float* in, float* out, int64_t planes, int H, int W, in
  * DIRECT loader instead of running the reflect loader once per consumer. */
 int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, int H, int W, int top, int bottom,
                           int left, int right, void* stream);
+/* The ingest of a raw tile in ONE pass: band selection (data/PopulationDataset.py:566-568) + apply_normalize (utils/utils.py:105-127)
+ * + the reflect padding / channel order above:  out[b][j] = pad((raw[b][band[j]] - mean[j]) / std[j]),  raw (B, Craw, H, W),
+ * band / mean / std = HOST arrays of nsel <= 8 entries.  Replaces pc_select_normalize followed by pc_reflect_pad_select. */
+int pc_select_normalize_pad(const float* raw, float* out, int B, int Craw, int nsel, const int* band, const float* mean,
+                            const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream);
 
 /* ---- training-step scalars ------------------------------------------------------------------------- */
 

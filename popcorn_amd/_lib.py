@@ -80,6 +80,12 @@ class PcLevel2FwdDesc(C.Structure):
                 ("wt", C.c_void_p), ("bt", C.c_void_p), ("c1", C.POINTER(PcDst)), ("c2", C.POINTER(PcDst)), ("u2", C.POINTER(PcDst))]
 
 
+class PcLevel2BwdDesc(C.Structure):
+    _fields_ = [("g2", C.POINTER(PcSrc)), ("c1", C.POINTER(PcSrc)), ("x", C.POINTER(PcSrc)), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("bn1", C.POINTER(PcBn)), ("act", C.POINTER(PcSrc)), ("act_bn", C.POINTER(PcBn)), ("out", C.POINTER(PcDst)),
+                ("ws1", C.c_void_p), ("ws2", C.c_void_p)]
+
+
 PC_ABI_VERSION = 4
 PC_MAX_GROUP = 4
 PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
@@ -116,7 +122,7 @@ def lib():
         _lib = cand
         _lib.pc_error_string.restype = C.c_char_p
         for name in ("pc_conv3x3_wgrad_ws_bytes", "pc_convt2x2_wgrad_ws_bytes", "pc_head_ws_bytes",
-                     "pc_compact_ws_bytes", "pc_unet_ws_bytes"):
+                     "pc_compact_ws_bytes", "pc_unet_ws_bytes", "pc_level2_bwd_ws_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib

@@ -124,6 +124,14 @@ __global__ __launch_bounds__(256) void stitch_finalize_kernel(float* out_sum, fl
     }
 }
 
+// zero fill as a kernel (memset nodes were unreliable under HIP-graph replay on this stack)
+__global__ __launch_bounds__(256) void census_zero_kernel(double* sums, int32_t* counts, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        sums[i] = 0.0;
+        if (counts) counts[i] = 0;
+    }
+}
+
 int stream_grid(int64_t n, int per_thread = 4) {
     int64_t g = (n / per_thread + 255) / 256;
     if (g > 4096) g = 4096;
@@ -138,12 +146,8 @@ extern "C" int pc_census_sum(const float* pred, const int32_t* boundary, int64_t
     if (!pred || !boundary || !sums || num_ids <= 0) return PC_EINVAL;
     if ((reinterpret_cast<uintptr_t>(pred) & 15) || (reinterpret_cast<uintptr_t>(boundary) & 15)) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)num_ids * sizeof(double), st);
-    if (e != hipSuccess) return (int)e;
-    if (counts) {
-        e = hipMemsetAsync(counts, 0, (size_t)num_ids * sizeof(int32_t), st);
-        if (e != hipSuccess) return (int)e;
-    }
+    hipLaunchKernelGGL(census_zero_kernel, dim3((num_ids + 255) / 256 > 64 ? 64 : (num_ids + 255) / 256), dim3(256), 0, st, sums, counts, num_ids);
+    PC_CHECK_LAUNCH();
     int grid = stream_grid(n, 16);
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(census_sum_kernel, dim3(grid), dim3(256), 0, st, pred, boundary, n, num_ids, sums, counts);

@@ -96,6 +96,10 @@ struct ConvArgs {
 // tile: MFMA pipe 42 % busy with waves parked in issue stalls, total time == sum of the phases; tools/ablate_conv.py.)
 // The price is a 6/4 instead of 18/16 row halo, served by L2.
 constexpr int SROWS = 6;                 // input rows of a 4-row strip
+#ifndef POPCORN_CONV_P2
+#define POPCORN_CONV_P2 0
+#endif
+constexpr bool CONV_P2 = POPCORN_CONV_P2 != 0;   // build-time A/B switch of the paired-pixel operand mapping (see the kernel)
 constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS region
 
 // EPI: extra work of the forward vector epilogue, as separate instantiations so that the other shapes keep their register
@@ -115,6 +119,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // every issued MFMA slot is a tap (the row-pair mapping of the 8-channel blocks spends 12 K-slots on 9 taps)
     constexpr bool N16 = COUT == 16 && CHUNK == 8;
     constexpr int W16_S = CIN * 9 + 1;                   // N16 weight image [co][ci * 9 + tap], odd row stride: 16 channels on 16 banks
+    // P2 ("paired pixels", the 8-output layers with full 8-channel chunks): M index i of an MFMA is pixel x = 2 i + j of the
+    // 32-px strip row (j = 0, 1: two MFMAs), so that ONE aligned ds_read_b64 feeds two pixels = operands of several (j, dx)
+    // MFMAs: 3 LDS reads per 6 MFMAs instead of 6 (tools/mfma_peak.hip: the fp32 matrix pipe sustains 153 TFLOP/s from
+    // registers but 97-107 with one ds_read_b32 per MFMA -- the conv kernels' MFMA phase was LDS-operand-issue bound, not power
+    // bound).  The strip image becomes [row][channel][40] with a row-plane stride == 32 (mod 64) dwords: the two rows a 32-lane
+    // half of a b64 read touches fall on complementary bank halves.
+    constexpr bool P2 = CONV_P2 && !N16 && CHUNK == 8;
+    constexpr int LCH = P2 ? 40 : CSW;                   // floats between channels of the strip image
+    constexpr int LROW = P2 ? 8 * 40 + 32 : RS;          // floats between rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const ConvProb& q = p.pr[blockIdx.y];
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 
-    constexpr int WAVE_F = CHUNK * CSW;                  // floats of one wave's LDS region
+    constexpr int WAVE_F = P2 ? SROWS * LROW : CHUNK * CSW;   // floats of one wave's LDS region
     float* const wl = lds + wave * WAVE_F;               // this wave's LDS region
 
     // ---- staged loader: lane = (row r of the 6-row strip, 16-byte segment seg of the 40-float row)
@@ -185,10 +198,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     };
     auto commit = [&]() {
         if (l_act) {
-            float* d = wl + l_r * RS + 4 * l_seg;
+            float* d = wl + l_r * LROW + 4 * l_seg;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                *reinterpret_cast<f32x4*>(d + it * CSW) = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(d + it * LCH) = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto load_generic = [&](int ch, int b, int y0, int x0) {
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             const int cg = ch * CHUNK + ci;
             const float v = cg < CA ? pc_fetch(q.a, b, cg, y0 - 1 + r, x0 - 1 + c, p.H, p.W)
                                     : pc_fetch(q.b, b, cg - CA, y0 - 1 + r, x0 - 1 + c, p.H, p.W);
-            wl[ci * CSW + r * RS + (COL0 - 1) + c] = v;
+            wl[ci * LCH + r * LROW + (COL0 - 1) + c] = v;
         }
     };
 
@@ -327,8 +340,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     f32x4 pacc[4][NB];
     int eb = 0, ey0 = 0, ex0 = 0;
     bool have_prev = false;
+    // x offset (inside the 32-px strip row) of the four consecutive pixels a lane holds for unit u
+    auto xu = [&](int u) { return P2 ? 8 * lk + 4 * (u & 1) : (u & 1) * 16 + 4 * lk; };
     auto epilogue = [&]() {
-        // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + (u&1)*16 + 4*lk + r), r = 0..3
+        // lane holds (co = nb*8+col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + xu(u) + r), r = 0..3
         if (ey0 >= p.H) return;
         constexpr bool POOLB = MODE == MODE_DGRAD && EPI == EPI_POOLBWD;   // p.pool, as a compile-time property
         if constexpr (N16) {
@@ -461,7 +476,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             // below issues 12 four-byte accesses per pooled pixel; these two launches were 127 us of the step)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int y = ey0 + 2 * (u >> 1) + s_row, x = ex0 + (u & 1) * 16 + 4 * lk;
+                const int y = ey0 + 2 * (u >> 1) + s_row, x = ex0 + xu(u);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int co = nb * 8 + col;
@@ -502,14 +517,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         const bool full = !POOLB && p.vec_ok && (ey0 + 4 <= p.H) && (ex0 + TW <= p.W);
         if (full) {
             // interior strip, aligned tensors: no bounds checks, 16-byte accesses only
-            act_t* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0 + 4 * lk;
-            const act_t* ab = act ? act + eb * a_bs + col * a_cs + (int64_t)(ey0 + s_row) * a_rs + ex0 + 4 * lk : nullptr;
+            act_t* ob = outp + eb * o_bs + col * o_cs + (int64_t)(ey0 + s_row) * o_rs + ex0;
+            const act_t* ab = act ? act + eb * a_bs + col * a_cs + (int64_t)(ey0 + s_row) * a_rs + ex0 : nullptr;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x4 v = pacc[u][nb];
-                    act_t* op = ob + nb * 8 * o_cs + (int64_t)((u >> 1) * 2) * o_rs + (u & 1) * 16;
+                    act_t* op = ob + nb * 8 * o_cs + (int64_t)((u >> 1) * 2) * o_rs + xu(u);
                     if (MODE == MODE_FWD) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         }
                     } else {
                         if (ab) {
-                            const f32x4 a4 = pc_ld4(ab + nb * 8 * a_cs + (int64_t)((u >> 1) * 2) * a_rs + (u & 1) * 16);
+                            const f32x4 a4 = pc_ld4(ab + nb * 8 * a_cs + (int64_t)((u >> 1) * 2) * a_rs + xu(u));
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb] : 0.f;
                         }
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         }
                         if (col == 0)
                             *reinterpret_cast<f32x4*>(q.dot_out.ptr + eb * q.dot_out.bstride +
-                                                      (int64_t)(ey0 + s_row + (u >> 1) * 2) * q.dot_out.rstride + ex0 + (u & 1) * 16 + 4 * lk) = t;
+                                                      (int64_t)(ey0 + s_row + (u >> 1) * 2) * q.dot_out.rstride + ex0 + xu(u)) = t;
                         continue;
                     }
                     pc_st4(op, v);
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         m1 = fmaxf(m1, __shfl_xor(m1, 8));
                         if (s_row == 0) {
                             act_t* pp = reinterpret_cast<act_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride + (nb * 8 + col) * q.pool_out.cstride +
-                                        (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride + (ex0 >> 1) + (u & 1) * 8 + 2 * lk;
+                                        (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride + (ex0 >> 1) + (xu(u) >> 1);
                             pc_st2(pp, m0, m1);
                         }
                     }
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int y = ey0 + 2 * (u >> 1) + s_row;
-            const int x = ex0 + (u & 1) * 16 + 4 * lk;
+            const int x = ex0 + xu(u);
             if (y >= p.H || x >= p.W) continue;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -641,7 +656,28 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         if (!(p.dbg & 2)) {
             load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
             const float* lrow = wl + lk * RS + (COL0 - 1) + li;
-            if constexpr (N16) {
+            if constexpr (P2) {
+                // lane (li, lk): input row 2 rp + lk, columns 2 + 2 li .. 7 + 2 li (three aligned b64) = pixels x0 - 2 + 2 li ..;
+                // operand of (j, dx) = pixel x0 - 1 + 2 li + j + dx = element 1 + j + dx of the six
+                const float* l2 = wl + lk * LROW + 2 + 2 * li;
+#pragma unroll
+                for (int ci = 0; ci < CHUNK; ++ci) {
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        const float* src = l2 + ci * LCH + rp * 2 * LROW;
+                        const float2 q0 = *reinterpret_cast<const float2*>(src), q1 = *reinterpret_cast<const float2*>(src + 2),
+                                     q2 = *reinterpret_cast<const float2*>(src + 4);
+                        const float sv[4] = {q0.y, q1.x, q1.y, q2.x};
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+                                    acc[rp * 2 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j + dx], bw[ci][dx][nb], acc[rp * 2 + j][nb], 0, 0, 0);
+                    }
+                }
+            } else if constexpr (N16) {
                 // acc[r][h]: output row y0 + r, x half h, channel li
                 const float* l16 = wl + (COL0 - 1) + li;
 #pragma unroll
@@ -673,7 +709,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) pacc[u][nb] = acc[u][nb];
+                for (int nb = 0; nb < NB; ++nb) {
+                    if constexpr (P2) {
+                        // acc[rp*2 + j][nb][r] = pixel 2 (4 lk + r) + j  ->  pacc[rp*2 + h][nb][e] = pixel 8 lk + 4 h + e
+                        const int rp = u >> 1, h = u & 1;
+                        const f32x4 a0 = acc[rp * 2][nb], a1 = acc[rp * 2 + 1][nb];
+                        pacc[u][nb] = f32x4{a0[2 * h], a1[2 * h], a0[2 * h + 1], a1[2 * h + 1]};
+                    } else {
+                        pacc[u][nb] = acc[u][nb];
+                    }
+                }
             eb = b; ey0 = y0; ex0 = x0;
             have_prev = true;
         }
@@ -687,7 +732,8 @@ template <int CIN, int COUT, int MODE, int LD, int EPI>
 int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr bool N16 = COUT == 16 && CHUNK == 8;
-    const size_t lds = ((size_t)4 * CHUNK * CSW + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16))) * sizeof(float);   // wave strips + weight image
+    constexpr bool P2 = CONV_P2 && !N16 && CHUNK == 8;
+    const size_t lds = ((size_t)4 * (P2 ? SROWS * (8 * 40 + 32) : CHUNK * CSW) + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16))) * sizeof(float);   // wave strips + weight image
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);

@@ -1925,7 +1925,10 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* in, float
 }
 
 // the same with a channel gather: out[b][j] = pad(in[b][sel[j]]); one thread = 4 consecutive x of one output row
-struct PadSel { int sel[8]; };
+// NORM: also (x - mean[j]) / std[j] per output plane -- band selection + apply_normalize (utils/utils.py:105-127) + add_padding in
+// ONE pass over the raw tile (pc_select_normalize_pad); the division is the one pc_select_normalize performs (same bits)
+struct PadSel { int sel[8]; float mean[8]; float stdv[8]; };
+template <bool NORM>
 __global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in, float* out, PadSel ps, int Cin, int nsel, int H, int W,
                                                                  int Hp, int Wp, int top, int left, int nrows, int wq, int rows_per_block) {
     // a block = rows_per_block output rows x wq 4-pixel pieces (wq * rows_per_block <= 256)
@@ -1945,6 +1948,11 @@ __global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wp ? src[pc_reflect(xs + e, W)] : 0.f;
     }
+    if (NORM) {
+        const float mu = ps.mean[j], sd = ps.stdv[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) / sd;
+    }
     if ((Wp & 3) == 0) {
         *reinterpret_cast<f32x4*>(dst) = v;
     } else {
@@ -1956,8 +1964,8 @@ __global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in
 
 }  // namespace
 
-extern "C" int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, int H, int W, int top,
-                                     int bottom, int left, int right, void* stream) {
+static int launch_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, const float* mean, const float* stdv,
+                             int H, int W, int top, int bottom, int left, int right, void* stream) {
     if (!in || !out || !sel || B < 1 || nsel < 1 || nsel > 8 || top >= H || bottom >= H || left >= W || right >= W || top < 0 ||
         bottom < 0 || left < 0 || right < 0)
         return PC_EINVAL;
@@ -1965,16 +1973,34 @@ extern "C" int pc_reflect_pad_select(const float* in, float* out, int B, int Cin
     for (int j = 0; j < nsel; ++j) {
         if (sel[j] < 0 || sel[j] >= Cin) return PC_EINVAL;
         ps.sel[j] = sel[j];
+        ps.mean[j] = mean ? mean[j] : 0.f;
+        ps.stdv[j] = stdv ? stdv[j] : 1.f;
     }
     const int Hp = H + top + bottom, Wp = W + left + right;
     const int64_t nrows = (int64_t)B * nsel * Hp;
     const int wq = (Wp + 3) >> 2;
     if (wq > 256 || nrows > 0x7fffffff) return PC_EINVAL;          // rows of up to 1024 pixels (the training tiles; windows are not padded)
     const int rpb = 256 / wq;
-    hipLaunchKernelGGL(reflect_pad_select_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, in, out, ps,
-                       Cin, nsel, H, W, Hp, Wp, top, left, (int)nrows, wq, rpb);
+    const dim3 grid((unsigned)((nrows + rpb - 1) / rpb));
+    if (mean)
+        hipLaunchKernelGGL(reflect_pad_select_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, out, ps, Cin, nsel, H, W, Hp, Wp,
+                           top, left, (int)nrows, wq, rpb);
+    else
+        hipLaunchKernelGGL(reflect_pad_select_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, out, ps, Cin, nsel, H, W, Hp, Wp,
+                           top, left, (int)nrows, wq, rpb);
     PC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, int H, int W, int top,
+                                     int bottom, int left, int right, void* stream) {
+    return launch_pad_select(in, out, B, Cin, nsel, sel, nullptr, nullptr, H, W, top, bottom, left, right, stream);
+}
+
+extern "C" int pc_select_normalize_pad(const float* raw, float* out, int B, int Craw, int nsel, const int* band, const float* mean,
+                                       const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream) {
+    if (!mean || !stdv) return PC_EINVAL;
+    return launch_pad_select(raw, out, B, Craw, nsel, band, mean, stdv, H, W, top, bottom, left, right, stream);
 }
 
 extern "C" int pc_sparsity_mask_unet(const float* building, const float* admin_mask, const int64_t* census_idx,

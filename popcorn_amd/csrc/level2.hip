@@ -207,6 +207,227 @@ __global__ __launch_bounds__(512) void level2_fwd_kernel(const L2Args args) {
     }
 }
 
+
+// =====================================================================================================================
+// Backward of the two convolutions of the level (down2's DoubleConv) in ONE launch, same whole-tile residency:
+//     given  G2 = dL/d(conv2 output)  (already multiplied by relu'(c2) * bn2-scale: the transposed-conv backward writes it),
+//     dW2[co][ci][t] = sum_px G2[co][px] c1[ci][px + t]        db2[co] = sum_px G2[co][px]
+//     G1 = relu'(c1) * bn1-scale * conv3x3(G2, w2 transposed / flipped)                  (never leaves LDS)
+//     dW1[co][ci][t] = sum_px G1[co][px] x[ci][px + t]         db1[co] = sum_px G1[co][px]       (x = the pooled input)
+//     Gp = conv3x3(G1, w1 transposed / flipped)                                           (registers only)
+//     MaxPool2d(2) backward: G_b2[c][first arg-max of the 2x2 window of b2] += relu'(b2 max) * bn-scale(d1b) * Gp
+// Replaces two weight-gradient and two data-gradient launches of the layer-by-layer path (the second one with the pooling
+// scatter); G1 and Gp are never written to HBM.  Two LDS images: {G2, later x} and {c1, overwritten in place by G1}.
+// Image channel stride 1252 == 4 (mod 32): the data-gradient reads (lanes = 16 consecutive x, tap pairs = dx 0 / 1 of one
+// (channel, row) or dx 2 of channels ci / ci + 4: 4 * 1252 == 16 mod 32) are conflict-free, the weight-gradient reads
+// (lanes = 16 channels) are 2-way conflicted -- 40 LDS cycles per 9 MFMAs, far below the matrix time.
+// Weight-gradient mapping: M = co, N = ci, K = 4 consecutive pixels of a row; per 4-pixel group ONE A read (G) feeds the 9
+// tap MFMAs, whose B operands are the 9 shifted reads of x.  Every wave writes its own partial (8 per tile) in the layout of
+// pc_wgrad_reduce_batch (kind 0, Cin = Cout = 16): no cross-wave reduction.
+constexpr int B2_CS = 34 * L2_RS + 28;          // 1252 == 4 (mod 32)
+constexpr int B2_BUF = 16 * B2_CS;
+constexpr size_t B2_LDS = (size_t)(2 * B2_BUF) * sizeof(float);
+constexpr int B2_EC = 16 * 16 * 9 + 16;          // floats of one partial (WgradCfg::EC of conv3x3_wgrad.hip)
+
+struct B2Prob {
+    const float* g2; int64_t g2_bs, g2_cs; int g2_rs;
+    const float* c1; int64_t c1_bs, c1_cs; int c1_rs;
+    const float* x;  int64_t x_bs, x_cs; int x_rs;
+    const float* w1; const float* w2;
+    pc_bn bn1;                                   // BN of conv1 (scale of relu'(c1))
+    const float* act; int64_t a_bs, a_cs; int a_rs;     // b2: full-resolution activations that were pooled (B,16,64,64)
+    pc_bn act_bn;                                // BN of the layer that produced b2
+    float* out; int64_t o_bs, o_cs; int o_rs;    // G_b2 (B,16,64,64), accumulated
+    float* ws2; float* ws1;                      // partials: [B * 8][B2_EC]
+};
+struct B2Args { B2Prob pr[PC_MAX_GROUP]; };
+
+// K-slot k = 4 m + lk (m = 0..35) -> tap (input channel ci 0..15, dy, dx) of the data-gradient convolutions
+__device__ __forceinline__ void b2_tap(int k, int& ci, int& dy, int& dx) {
+    const int pi = k >> 1, e = k & 1;
+    if (pi < 48) { ci = pi / 3; dy = pi - 3 * ci; dx = e; }
+    else { const int q = pi - 48, cq = q / 3; dy = q - 3 * cq; ci = (cq >> 2) * 8 + (cq & 3) + 4 * e; dx = 2; }
+}
+
+__global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const B2Prob& q = args.pr[blockIdx.y];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    float* const img0 = lds;                    // G2, later x
+    float* const img1 = lds + B2_BUF;           // c1, later G1
+
+    auto stage = [&](const float* src, int64_t bs, int64_t cs, int rs, float* img) {
+        f32x4 t[8];
+        const float* sp = src + b * bs;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 512 * i, ch = idx >> 8, row = (idx >> 3) & 31, seg = idx & 7;
+            t[i] = *reinterpret_cast<const f32x4*>(sp + ch * cs + (int64_t)row * rs + 4 * seg);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 512 * i, ch = idx >> 8, row = (idx >> 3) & 31, seg = idx & 7;
+            *reinterpret_cast<f32x4*>(img + ch * B2_CS + (row + 1) * L2_RS + 4 + 4 * seg) = t[i];
+        }
+    };
+    // data-gradient weights of layer `w` ([co][ci][3][3]): B[k = tap (input channel co_in, dy, dx)][n = li = output channel ci_out]
+    //   = w[co_in][ci_out][8 - (3 dy + dx)]
+    auto load_wT = [&](const float* w, float (&wv)[36]) {
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+            int ci, dy, dx;
+            b2_tap(4 * m + lk, ci, dy, dx);
+            wv[m] = w[(ci * 16 + li) * 9 + 8 - (3 * dy + dx)];
+        }
+    };
+    float wv[36];
+    load_wT(q.w2, wv);
+    {
+        // halo / pad zeros of both images: per channel row 0 (9 pieces), row 33 + pad (36 + 28 floats = 16 pieces),
+        // cols 0..3 of rows 1..32 (32 pieces) = 57 pieces
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = tid; e < 2 * 16 * 57; e += 512) {
+            const int img = e / (16 * 57), r = e - img * 16 * 57, ch = r / 57, pc = r - ch * 57;
+            float* base = lds + img * B2_BUF + ch * B2_CS;
+            int off;
+            if (pc < 9) off = 4 * pc;
+            else if (pc < 25) off = 33 * L2_RS + 4 * (pc - 9);
+            else off = (pc - 25 + 1) * L2_RS;
+            *reinterpret_cast<f32x4*>(base + off) = z;
+        }
+    }
+    stage(q.g2, q.g2_bs, q.g2_cs, q.g2_rs, img0);
+    stage(q.c1, q.c1_bs, q.c1_cs, q.c1_rs, img1);
+    int aoff[36];
+#pragma unroll
+    for (int m = 0; m < 36; ++m) {
+        int ci, dy, dx;
+        b2_tap(4 * m + lk, ci, dy, dx);
+        aoff[m] = ci * B2_CS + (4 * wave + dy) * L2_RS + dx + 3 + li;
+    }
+    __syncthreads();
+
+    // ---- weight gradient of one layer: G image x X image over this wave's 4 rows -> its own partial in ws
+    auto wgrad = [&](const float* gimg, const float* ximg, float* ws) {
+        f32x4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float dbs = 0.f;
+        const float* gl = gimg + li * B2_CS + (4 * wave + 1) * L2_RS + 4 + lk;        // A: (co = li, px + lk)
+        const float* xl = ximg + li * B2_CS + (4 * wave) * L2_RS + 3 + lk;            // B: (ci = li, row + dy, px + lk + dx)
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const float a = gl[r * L2_RS + 4 * g4];
+                dbs += a;
+                float bx[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bx[t] = xl[(r + t / 3) * L2_RS + 4 * g4 + (t % 3)];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[t], acc[t], 0, 0, 0);
+            }
+        }
+        // D[co = 4 lk + e][ci = li] -> partial[co][ci][tap];  db[co]: lanes (li = co, lk) hold the sums over their pixels
+        float* pw = ws + (int64_t)(b * 8 + wave) * B2_EC;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw[(4 * lk + e) * 144 + li * 9 + t] = acc[t][e];
+        dbs += __shfl_xor(dbs, 16);
+        dbs += __shfl_xor(dbs, 32);
+        if (lk == 0) pw[2304 + li] = dbs;
+    };
+    // ---- data-gradient convolution of an image with the register weights: acc[r][h] = (channel li, row 4 wave + r, x = 16 h + 4 lk + e)
+    auto dgrad = [&](const float* img, f32x4 (&acc)[4][2]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+            float av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = img[aoff[m] + (u >> 1) * L2_RS + (u & 1) * 16];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc[u >> 1][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[m], acc[u >> 1][u & 1], 0, 0, 0);
+        }
+    };
+
+    wgrad(img0, img1, q.ws2);                      // dW2, db2: G2 x c1
+    __syncthreads();                               // every wave has finished reading c1's neighbour rows
+    {
+        f32x4 acc[4][2];
+        dgrad(img0, acc);                          // conv(G2, w2^T)
+        float sc, sh;
+        pc_bn_fold(q.bn1, li, sc, sh);
+        (void)sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float* p1 = img1 + li * B2_CS + (4 * wave + r + 1) * L2_RS + 4 + 16 * h + 4 * lk;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p1);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = c[e] > 0.f ? acc[r][h][e] * sc : 0.f;
+                *reinterpret_cast<f32x4*>(p1) = v;      // G1 over c1, same positions
+            }
+    }
+    load_wT(q.w1, wv);
+    __syncthreads();                               // G1 complete, G2 dead
+    stage(q.x, q.x_bs, q.x_cs, q.x_rs, img0);
+    __syncthreads();
+    wgrad(img1, img0, q.ws1);                      // dW1, db1: G1 x pooled input
+    {
+        f32x4 acc[4][2];
+        dgrad(img1, acc);                          // Gp = conv(G1, w1^T): gradient w.r.t. the pooled map
+        float sc, sh;
+        pc_bn_fold(q.act_bn, li, sc, sh);
+        (void)sh;
+        // MaxPool2d(2) backward: the lane's four pooled pixels cover 2 rows x 8 full-resolution pixels
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int y = 4 * wave + r, x = 16 * h + 4 * lk;
+                const float* a0 = q.act + b * q.a_bs + li * q.a_cs + (int64_t)(2 * y) * q.a_rs + 2 * x;
+                float* o0 = q.out + b * q.o_bs + li * q.o_cs + (int64_t)(2 * y) * q.o_rs + 2 * x;
+                f32x4 A[2][2], O[2][2];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        A[rr][hh] = *reinterpret_cast<const f32x4*>(a0 + rr * q.a_rs + 4 * hh);
+                        O[rr][hh] = *reinterpret_cast<const f32x4*>(o0 + rr * q.o_rs + 4 * hh);
+                    }
+                const f32x4 v = acc[r][h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int hh = e >> 1, c = (e & 1) * 2;
+                    const float w00 = A[0][hh][c], w01 = A[0][hh][c + 1], w10 = A[1][hh][c], w11 = A[1][hh][c + 1];
+                    int am = 0;
+                    float mx = w00;
+                    if (w01 > mx) { mx = w01; am = 1; }
+                    if (w10 > mx) { mx = w10; am = 2; }
+                    if (w11 > mx) { mx = w11; am = 3; }
+                    const float g = mx > 0.f ? v[e] * sc : 0.f;
+                    O[0][hh][c] += am == 0 ? g : 0.f;
+                    O[0][hh][c + 1] += am == 1 ? g : 0.f;
+                    O[1][hh][c] += am == 2 ? g : 0.f;
+                    O[1][hh][c + 1] += am == 3 ? g : 0.f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4*>(o0 + rr * q.o_rs + 4 * hh) = O[rr][hh];
+            }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) {
     return p && dtype == PC_F32 && xs <= 1 && aligned16(p) && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
@@ -249,5 +470,45 @@ extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, vo
     }
     hipLaunchKernelGGL(level2_fwd_kernel, dim3(B, n), dim3(512), L2_LDS, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t pc_level2_bwd_ws_bytes(int B) { return (int64_t)B * 8 * B2_EC * (int64_t)sizeof(float); }
+
+static bool src_ok(const pc_src* s, int Cc, int Hh, int Ww) {
+    return s && s->C == Cc && s->H == Hh && s->W == Ww && s->mode == PC_SRC_DIRECT && !s->oy && !s->ox &&
+           plane_ok(s->ptr, s->bstride, s->cstride, s->rstride, s->xstride, s->dtype);
+}
+
+extern "C" int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const pc_src* act, const pc_dst* out) {
+    if (g_pc_precision != PC_PREC_FP32 || !out) return 0;
+    return src_ok(g2, 16, 32, 32) && src_ok(c1, 16, 32, 32) && src_ok(x, 16, 32, 32) && src_ok(act, 16, 64, 64) &&
+           plane_ok(out->ptr, out->bstride, out->cstride, out->rstride, out->xstride, out->dtype);
+}
+
+extern "C" int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream) {
+    if (n < 1 || n > PC_MAX_GROUP || B < 1 || !d || !nwg_out) return PC_EINVAL;
+    B2Args a;
+    for (int i = 0; i < n; ++i) {
+        const pc_level2_bwd_desc& s = d[i];
+        if (!s.w1 || !s.w2 || !s.bn1 || !s.act_bn || !s.ws1 || !s.ws2 || !pc_level2_bwd_ok(s.g2, s.c1, s.x, s.act, s.out)) return PC_EINVAL;
+        B2Prob& p = a.pr[i];
+        p.g2 = s.g2->ptr; p.g2_bs = s.g2->bstride; p.g2_cs = s.g2->cstride; p.g2_rs = s.g2->rstride;
+        p.c1 = s.c1->ptr; p.c1_bs = s.c1->bstride; p.c1_cs = s.c1->cstride; p.c1_rs = s.c1->rstride;
+        p.x = s.x->ptr; p.x_bs = s.x->bstride; p.x_cs = s.x->cstride; p.x_rs = s.x->rstride;
+        p.w1 = s.w1; p.w2 = s.w2; p.bn1 = *s.bn1; p.act_bn = *s.act_bn;
+        p.act = s.act->ptr; p.a_bs = s.act->bstride; p.a_cs = s.act->cstride; p.a_rs = s.act->rstride;
+        p.out = s.out->ptr; p.o_bs = s.out->bstride; p.o_cs = s.out->cstride; p.o_rs = s.out->rstride;
+        p.ws1 = (float*)s.ws1; p.ws2 = (float*)s.ws2;
+    }
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(level2_bwd_kernel, dim3(B, n), dim3(512), B2_LDS, (hipStream_t)stream, a);
+    PC_CHECK_LAUNCH();
+    *nwg_out = 8 * B;
     return 0;
 }

@@ -172,10 +172,10 @@ class UNetEngine:
         (= or += per ``accumulate``).  encoder_no_grad: networks.py:124-132 semantics.
         Data-gradient launches are grouped over the two streams (same shapes); weight-gradient launches are per
         stream (each owns its partial-sum workspace)."""
-        X = saved["X"]
+        X = saved["X"]                     # None when the forward pass was fed the padded input directly (Xp_all)
         pad_top, pad_left, Hp, Wp = saved["geom"]
-        B = X.shape[0]
-        dev = X.device
+        B = G.shape[0]
+        dev = G.device
         H1, W1 = Hp // 2, Wp // 2
         H2, W2 = H1 // 2, W1 // 2
         E = lambda c, h, w: L.empty_act(B, c, h, w, dev)  # noqa: E731
@@ -396,7 +396,12 @@ class UNetEngine:
         finish()
 
 
-def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None, logit_only=None):
+def stream_channel_order(streams):
+    """Input channels (indices into the model input [R,G,B,NIR,VV,VH]) in the order the padded per-stream input holds them."""
+    return [c for _, chmap, cin, _ in streams for c in chmap[:cin]]
+
+
+def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None, logit_only=None, Xp_all=None):
     """Forward of several DualStreamUNets (e.g. the frozen building extractor and the trainable U-Net) on the same
     input and geometry, layer by layer, with ONE launch per layer for all (network, stream) pairs: 4x fewer
     launches than per-stream execution and 4x more workgroups per launch on the 32x32 layers.
@@ -406,15 +411,24 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     feature map is only ever consumed by its 1x1 ``fusion_out_conv`` (popcorn.py:301), so the last conv of each stream
     writes that layer's partial sum over its own 8 channels instead of the features; ``features[e]`` is then the
     (B, 2, Hp, Wp) tensor of the two partial logits (add them and the bias: ``partial_logit_weights``), or the ordinary
-    16-channel map when the geometry does not qualify."""
-    L.require_device(X)
-    B = X.shape[0]
-    if pad_top >= X.shape[2] or pad_left >= X.shape[3] or Hp - X.shape[2] - pad_top >= X.shape[2] \
-            or Wp - X.shape[3] - pad_left >= X.shape[3]:
-        raise ValueError("reflect padding must be smaller than the input (same restriction as F.pad reflect)")
+    16-channel map when the geometry does not qualify.
+
+    Xp_all (fp32 mode): the already padded, normalised, channel-gathered input (B, sum of stream channels in stream order, Hp, Wp)
+    as ``ops.select_normalize_pad`` writes it from a raw tile -- X may then be None (nothing reads the unpadded input)."""
+    if Xp_all is not None:
+        L.require_device(Xp_all)
+        if L.act_dtype() != torch.float32 or tuple(Xp_all.shape[2:]) != (Hp, Wp) or Wp % 4 or Xp_all.dtype != torch.float32:
+            raise ValueError("Xp_all needs the fp32 mode and a (B, C, Hp, Wp) fp32 tensor with Wp % 4 == 0")
+        B, dev = Xp_all.shape[0], Xp_all.device
+    else:
+        L.require_device(X)
+        B = X.shape[0]
+        if pad_top >= X.shape[2] or pad_left >= X.shape[3] or Hp - X.shape[2] - pad_top >= X.shape[2] \
+                or Wp - X.shape[3] - pad_left >= X.shape[3]:
+            raise ValueError("reflect padding must be smaller than the input (same restriction as F.pad reflect)")
+        dev = X.device
     if Hp < 4 or Wp < 4:
         raise ValueError("input too small for two 2x2 poolings")
-    dev = X.device
     H1, W1 = Hp // 2, Wp // 2
     H2, W2 = H1 // 2, W1 // 2
     nE = len(engines)
@@ -466,9 +480,11 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     # gather stay fused in the loaders (bf16 mode rounds the planar fp32 input there; unpadded inference windows need no copy).
     a1 = {}
     Xp = None
-    if PADDED_INPUT and L.act_dtype() == torch.float32 and Wp % 4 == 0 and Wp <= 1024 and (Hp, Wp) != tuple(X.shape[2:]) and X.dtype == torch.float32:
-        sel = [c for _, chmap, cin, _ in streams for c in chmap[:cin]]
+    if Xp_all is None and PADDED_INPUT and L.act_dtype() == torch.float32 and Wp % 4 == 0 and Wp <= 1024 \
+            and (Hp, Wp) != tuple(X.shape[2:]) and X.dtype == torch.float32:
+        sel = stream_channel_order(streams)
         Xp_all = ops.reflect_pad_select(X, sel, pad_top, Hp - X.shape[2] - pad_top, pad_left, Wp - X.shape[3] - pad_left)
+    if Xp_all is not None:
         Xp, off = {}, 0
         for s, chmap, cin, f0 in streams:
             Xp[s] = Xp_all[:, off:off + cin]

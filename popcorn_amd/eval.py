@@ -46,17 +46,27 @@ def create_mask(patchsize_x, patchsize_y, overlap):
 
 
 class Stitcher:
-    """Device-resident accumulators of run_eval.py:84-90 and the write-back / averaging of :127-154."""
+    """Device-resident accumulators of run_eval.py:84-90 and the write-back / averaging of :127-154.
 
-    def __init__(self, h, w, device, with_scale=True):
+    Multi-GPU (windows sharded over ranks): ``world`` pads the row count to a multiple of the world size so that
+    ``reduce_scatter`` can hand every rank the SUM of one equal row band (one ring pass over the four fp32 planes -- half the
+    bytes of an all-reduce); the visit-count map is not communicated at all: it depends only on the window list, so every
+    rank adds the windows of the OTHER ranks to its own count map (``add_count_only``).  Each rank then finalises its band;
+    ``gather_bands`` assembles the full maps where a caller wants them (the census sums do not: ``census_sums`` on the band
+    plus one tiny all-reduce of the per-region sums)."""
+
+    def __init__(self, h, w, device, with_scale=True, world=1):
         if torch.device(device).type != "cuda":
             raise L.PopcornHipError("Stitcher accumulates on a HIP device only")
-        self.h, self.w = h, w
-        # the fp32 accumulators are planes of ONE allocation: a multi-GPU run sums them with a single collective
-        self.acc = torch.zeros(4 if with_scale else 2, h, w, dtype=torch.float32, device=device)
-        self.out, self.out_sq = self.acc[0], self.acc[1]
-        self.scale, self.scale_sq = (self.acc[2], self.acc[3]) if with_scale else (None, None)
-        self.count = torch.zeros(h, w, dtype=torch.int16, device=device)
+        self.h, self.w, self.world = h, w, max(1, int(world))
+        self.hb = -(-h // self.world)                      # rows per rank band
+        self.hp = self.hb * self.world                     # padded row count (rows >= h are never written)
+        # the fp32 accumulators are planes of ONE allocation
+        self.acc = torch.zeros(4 if with_scale else 2, self.hp, w, dtype=torch.float32, device=device)
+        self.out, self.out_sq = self.acc[0][:h], self.acc[1][:h]
+        self.scale, self.scale_sq = (self.acc[2][:h], self.acc[3][:h]) if with_scale else (None, None)
+        self.count = torch.zeros(self.hp, w, dtype=torch.int16, device=device)[:h]
+        self.band = None                                   # (row0, row1) once the accumulators hold only this rank's band
 
     def add_window(self, xl, yl, popdense, scale=None, overlap=OVERLAP):
         """popdense / scale: (M, ps, ps) member outputs of the window whose origin is row xl, column yl (the reference's
@@ -69,9 +79,16 @@ class Stitcher:
                                              L.ptr(self.out), L.ptr(self.out_sq), L.ptr(self.scale), L.ptr(self.scale_sq),
                                              L.ptr(self.count), self.h, self.w, L.stream_ptr()), "pc_stitch_accumulate")
 
+    def add_count_only(self, xl, yl, M, ps, overlap=OVERLAP):
+        """A window another rank computed: only its visit count (interior += M), no data."""
+        x0, x1 = xl + overlap, min(xl + ps - overlap, self.h)
+        y0, y1 = yl + overlap, min(yl + ps - overlap, self.w)
+        if x1 > x0 and y1 > y0:
+            self.count[x0:x1, y0:y1] += M
+
     def all_reduce(self, reducer: FlatReducer):
-        """Multi-GPU: windows were sharded over ranks; sum the accumulators (interiors of regular windows are disjoint,
-        the bottom/right catch-up windows overlap them -- the count map handles both)."""
+        """Multi-GPU, simple form: sum the full accumulators on every rank (interiors of regular windows are disjoint, the
+        bottom/right catch-up windows overlap them -- the count map handles both)."""
         if reducer.active:
             import torch.distributed as dist
             dist.all_reduce(self.acc, group=reducer.group)            # all fp32 planes in one ring pass
@@ -79,10 +96,50 @@ class Stitcher:
             dist.all_reduce(c, group=reducer.group)
             self.count.copy_(c)
 
+    def reduce_scatter(self, reducer: FlatReducer, rank):
+        """Multi-GPU, band form: this rank ends up with the summed accumulators of rows [rank * hb, (rank + 1) * hb) (clipped
+        to h) in place; the other rows of its planes are stale afterwards.  The count map must already be complete
+        (``add_count_only`` for the other ranks' windows).  Returns (row0, row1)."""
+        r0, r1 = min(rank * self.hb, self.h), min((rank + 1) * self.hb, self.h)
+        if reducer.active:
+            import torch.distributed as dist
+            assert reducer.world == self.world, "Stitcher(world=...) must equal the reducer's world size"
+            if reducer.backend == "nccl":
+                for p in range(self.acc.shape[0]):
+                    plane = self.acc[p]                                # (hp, w) contiguous: chunk r = band r
+                    dist.reduce_scatter_tensor(plane[rank * self.hb:(rank + 1) * self.hb], plane, group=reducer.group)
+            else:                                                      # gloo (functional runs): no reduce-scatter on devices
+                dist.all_reduce(self.acc, group=reducer.group)
+        self.band = (r0, r1)
+        return self.band
+
     def finalize(self):
-        n = self.h * self.w
-        L.check(L.lib().pc_stitch_finalize(L.ptr(self.out), L.ptr(self.out_sq), L.ptr(self.scale), L.ptr(self.scale_sq),
-                                           L.ptr(self.count), C.c_int64(n), L.stream_ptr()), "pc_stitch_finalize")
+        """mean / std where count > 1 (run_eval.py:140-154) over the whole raster, or over this rank's band after
+        ``reduce_scatter``.  Returns the four maps (full-raster views; after a reduce_scatter only the band rows are valid)."""
+        r0, r1 = self.band if self.band is not None else (0, self.h)
+        n = (r1 - r0) * self.w
+        if n > 0:
+            sl = lambda t: None if t is None else t[r0:r1]  # noqa: E731
+            L.check(L.lib().pc_stitch_finalize(L.ptr(sl(self.out)), L.ptr(sl(self.out_sq)), L.ptr(sl(self.scale)),
+                                               L.ptr(sl(self.scale_sq)), L.ptr(sl(self.count)), C.c_int64(n), L.stream_ptr()),
+                    "pc_stitch_finalize")
+        return self.out, self.out_sq, self.scale, self.scale_sq
+
+    def gather_bands(self, reducer: FlatReducer):
+        """After reduce_scatter + finalize: every rank receives every band (the full finalised maps)."""
+        if reducer.active and self.band is not None:
+            import torch.distributed as dist
+            for p in range(self.acc.shape[0]):
+                plane = self.acc[p]
+                if reducer.backend == "nccl":
+                    r = dist.get_rank(reducer.group)
+                    dist.all_gather_into_tensor(plane, plane[r * self.hb:(r + 1) * self.hb].clone(), group=reducer.group)
+                else:
+                    parts = [torch.empty(self.hb, self.w, device=plane.device) for _ in range(self.world)]
+                    r = dist.get_rank(reducer.group)
+                    dist.all_gather(parts, plane[r * self.hb:(r + 1) * self.hb].contiguous(), group=reducer.group)
+                    plane.copy_(torch.cat(parts, 0))
+        self.band = None
         return self.out, self.out_sq, self.scale, self.scale_sq
 
 
@@ -96,6 +153,20 @@ def census_sums(pred, boundary, num_ids, want_counts=False):
     L.check(L.lib().pc_census_sum(L.ptr(pred), L.ptr(boundary), C.c_int64(pred.numel()), num_ids, L.ptr(sums),
                                   L.ptr(counts), L.stream_ptr()), "pc_census_sum")
     return (sums, counts) if want_counts else sums
+
+
+def census_sums_sharded(st: "Stitcher", boundary, num_ids, reducer: FlatReducer):
+    """Region sums of a map that is distributed by row band (``evaluate_raster(..., gather=False)``): each rank sums its own
+    band, then ONE all-reduce of the float64 per-region sums (num_ids * 8 bytes) -- the full map never travels."""
+    r0, r1 = st.band if st.band is not None else (0, st.h)
+    if r1 > r0:
+        sums = census_sums(st.out[r0:r1], boundary[r0:r1].contiguous().to(torch.int32), num_ids)
+    else:
+        sums = torch.zeros(num_ids, dtype=torch.float64, device=st.out.device)
+    if reducer.active:
+        import torch.distributed as dist
+        dist.all_reduce(sums, group=reducer.group)
+    return sums
 
 
 def convert_popmap_to_census(pred, boundary, census_idx, census_pop):
@@ -127,12 +198,17 @@ def adjust_map_to_census(pred, boundary, census_idx, census_pop):
 
 
 def evaluate_raster(models, raster, patchsize=INFERENCE_PATCH_SIZE, overlap=OVERLAP, fourseasons=False,
-                    reducer: FlatReducer | None = None, rank=0):
+                    reducer: FlatReducer | None = None, rank=0, band_reduce=True, gather=True, return_stitcher=False):
     """Ensemble sliding-window inference over ``raster`` = callable (x, y, season, ps) -> normalised model input
     (1,6,ps,ps) on the device (the reference's Population_Dataset(mode="test") item, PopulationDataset.py:336-420), or a
     (S,6,h,w) device tensor of pre-normalised seasons.  Returns the finalised (mean map, std map, scale mean, scale std).
 
-    Windows are assigned round-robin to ranks (no data-path collective); accumulators are summed once at the end."""
+    Windows are assigned round-robin to ranks (no data-path collective).  Multi-GPU: ``band_reduce`` (default) sums the
+    accumulators with one reduce-scatter by row band, every rank finalises its own band, and ``gather`` decides whether the
+    bands are then all-gathered into full maps on every rank (True: the four maps are returned, as in the single-process
+    case) or stay distributed (False: the ``Stitcher`` is returned; ``census_sums_sharded`` works on the band).
+    ``band_reduce=False``: the round-2 form, an all-reduce of the full planes and of the count map.
+    ``return_stitcher``: also return the ``Stitcher`` (its visit-count map)."""
     reducer = reducer or FlatReducer()
     if torch.is_tensor(raster):
         h, w = raster.shape[-2:]
@@ -141,10 +217,15 @@ def evaluate_raster(models, raster, patchsize=INFERENCE_PATCH_SIZE, overlap=OVER
     else:
         h, w = raster.shape
     dev = next(models[0].parameters()).device
-    st = Stitcher(h, w, dev)
+    st = Stitcher(h, w, dev, world=reducer.world)
     idx = get_patch_indices(h, w, patchsize, overlap, fourseasons)
-    for i in shard_indices(idx.shape[0], rank, reducer.world):
+    mine = set(shard_indices(idx.shape[0], rank, reducer.world))
+    for i in range(idx.shape[0]):
         x, y, season = (int(v) for v in idx[i])
+        if i not in mine:
+            if band_reduce and reducer.world > 1:
+                st.add_count_only(x, y, len(models), patchsize, overlap)      # the visit count needs no collective
+            continue
         inp = raster(x, y, season, patchsize).contiguous()
         sample = {"input": inp}
         pds, scs = [], []
@@ -163,5 +244,14 @@ def evaluate_raster(models, raster, patchsize=INFERENCE_PATCH_SIZE, overlap=OVER
                 if o.get("scale") is not None:
                     scs.append(o["scale"][0])
         st.add_window(x, y, torch.stack(pds), torch.stack(scs) if scs else None, overlap)
+    if band_reduce and reducer.world > 1:
+        # one reduce-scatter by row band (half the bytes of an all-reduce, no count collective), every rank finalises its band
+        st.reduce_scatter(reducer, rank)
+        st.finalize()
+        if not gather:
+            return st
+        maps = st.gather_bands(reducer)
+        return (maps, st) if return_stitcher else maps
     st.all_reduce(reducer)
-    return st.finalize()
+    maps = st.finalize()
+    return (maps, st) if return_stitcher else maps

@@ -398,6 +398,20 @@ def reflect_pad_select(x, sel, top, bottom, left, right):
     return out
 
 
+def select_normalize_pad(raw, band, mean, std, top, bottom, left, right, out=None):
+    """Band selection + (x - mean) / std + reflect padding in one pass: out[b][j] = pad((raw[b][band[j]] - mean[j]) / std[j])."""
+    L.require_device(raw)
+    assert raw.is_contiguous() and raw.dtype == torch.float32
+    B, Craw, H, W = raw.shape
+    n = len(band)
+    if out is None:
+        out = torch.empty(B, n, H + top + bottom, W + left + right, device=raw.device, dtype=torch.float32)
+    L.check(L.lib().pc_select_normalize_pad(L.ptr(raw), L.ptr(out), B, Craw, n, (C.c_int * n)(*[int(v) for v in band]),
+                                            (C.c_float * n)(*[float(v) for v in mean]), (C.c_float * n)(*[float(v) for v in std]),
+                                            H, W, top, bottom, left, right, L.stream_ptr()), "pc_select_normalize_pad")
+    return out
+
+
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
              g_feat=None, feat_bn=None):

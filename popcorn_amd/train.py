@@ -27,7 +27,13 @@ HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
 class FusedTrainStep:
     def __init__(self, model, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, gradient_clip=0.01,
                  loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01, lam_weak=100.0,
-                 reducer: FlatReducer | None = None, use_graph=False):
+                 reducer: FlatReducer | None = None, use_graph=False, raw_norm=None):
+        """raw_norm = (band6, mean6, std6): how a RAW tile (sample key "raw" instead of "input": (B, Craw, H, W) reflectances /
+        backscatter) becomes the model input -- band selection (data/PopulationDataset.py:566-568) + apply_normalize
+        (utils/utils.py:105-127); default: the reference's dataset statistics (popcorn_amd.data.stats).  With a raw sample the
+        step's first launch does select + normalise + reflect padding in one pass (pc_select_normalize_pad)."""
+        from .data import stats as _stats
+        self.raw_norm = raw_norm or (_stats.BAND6, _stats.MEAN6, _stats.STD6)
         self.model = model
         self.names, params = model.trainable()
         dev = params[0].device
@@ -192,14 +198,27 @@ class FusedTrainStep:
     # ---- the three stream-ordered sections -------------------------------------------------------------------------
     def _forward(self, s, sel, encoder_no_grad, unet_no_grad):
         m = self.model
-        X = s["input"]
-        B, _, H, W = X.shape
+        raw = s.get("raw") if s.get("input") is None else None
+        B, _, H, W = (raw if raw is not None else s["input"]).shape
         eng_u, eng_b = m.engines()
         pt, pb, pl, pr = pad_geometry(H, W, False)
         fused = (pt, pb, pl, pr) == (m.p, m.p, m.p, m.p)      # e.g. 100x100 tiles: both networks see the same 128x128 domain
+        Xp_all = None
+        if raw is not None:
+            band, mean, std = self.raw_norm
+            if fused and E.PADDED_INPUT and L.act_dtype() == torch.float32 and (W + pl + pr) % 4 == 0 and len(eng_u.streams) == 2:
+                # raw tile -> padded, normalised, stream-ordered input in ONE launch; the unpadded input is never written
+                order = E.stream_channel_order(eng_u.streams)
+                Xp_all = ops.select_normalize_pad(raw, [band[c] for c in order], [mean[c] for c in order], [std[c] for c in order],
+                                                  pt, pb, pl, pr)
+                X = None
+            else:
+                X = ops.select_normalize(raw, band, mean, std)
+        else:
+            X = s["input"]
         if fused:
             (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
-                                                       [False, not unet_no_grad], logit_only=[True, False])
+                                                       [False, not unet_no_grad], logit_only=[True, False], Xp_all=Xp_all)
             building, mask, counts = eng_b.score_and_mask(f_b, H, W, pt, pl, s["admin_mask"], s["census_idx"], sel[:H],
                                                           sel[H:], m.occupancymodel)
         else:
@@ -277,12 +296,13 @@ class FusedTrainStep:
         return dst
 
     def step(self, sample, encoder_no_grad=False, unet_no_grad=False):
-        """One optimisation step on ``sample`` = {input (B,6,H,W) normalised, admin_mask, census_idx, y}.  Returns the
-        device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
-        B, _, H, W = sample["input"].shape
+        """One optimisation step on ``sample`` = {input (B,6,H,W) normalised -- or raw (B,Craw,H,W), see ``raw_norm`` --,
+        admin_mask, census_idx, y}.  Returns the device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
+        dkey = "input" if sample.get("input") is not None else "raw"
+        B, _, H, W = sample[dkey].shape
         sel_host = self._draw_selection(H, W)
         if not self.use_graph:
-            s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
+            s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items() if not k.startswith("_")}
             s["admin_mask"] = s["admin_mask"].float()
             sel = self._sel_to_device(sel_host)
             with L.precision(self.model.precision):
@@ -295,7 +315,8 @@ class FusedTrainStep:
         return self._graph_step(sample, sel_host, encoder_no_grad, unet_no_grad)
 
     def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
-        key = (tuple(sample["input"].shape), encoder_no_grad, unet_no_grad, self.model.precision)
+        dkey = "input" if sample.get("input") is not None else "raw"
+        key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision)
         if self._graphs is None or self._graphs[0] != key:
             if key in self._graph_cache:
                 self._graphs, self.last = self._graph_cache.pop(key)      # (re-inserted below: most recently used last)
@@ -306,7 +327,7 @@ class FusedTrainStep:
             while len(self._graph_cache) > self._graph_cache_max:
                 self._graph_cache.pop(next(iter(self._graph_cache)))
         _, st, sel, graphs = self._graphs
-        for k in ("input", "admin_mask", "census_idx", "y"):
+        for k in (dkey, "admin_mask", "census_idx", "y"):
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
                 st[k].copy_(sample[k], non_blocking=True)
         self._sel_to_device(sel_host, sel)
@@ -320,22 +341,46 @@ class FusedTrainStep:
             graphs[2].replay()
         return self.loss_out
 
-    def static_buffers(self, B, H, W, C=6):
+    def static_buffers(self, B, H, W, C=6, raw_channels=None):
         """The device tensors the captured graph reads {input, admin_mask (float ids), census_idx, y}.  A data pipeline
         that writes its batch straight into them (e.g. ``ops.select_normalize(raw, ..., out=buf["input"])``) and passes
-        this very dict to ``step`` saves the per-step input copies."""
-        if self._static is None or tuple(self._static["input"].shape) != (B, C, H, W):
+        this very dict to ``step`` saves the per-step input copies.  raw_channels: the data tensor is the RAW tile
+        {raw (B, raw_channels, H, W)} instead of the normalised input (the graph then starts with the one-pass ingest)."""
+        dkey = "input" if raw_channels is None else "raw"
+        C = C if raw_channels is None else raw_channels
+        if self._static is None:
+            self._static = {}
+        cur = self._static.get(dkey)
+        if cur is None or tuple(cur[dkey].shape) != (B, C, H, W):
             dev = self.device
-            self._static = {"input": torch.zeros(B, C, H, W, device=dev), "admin_mask": torch.zeros(B, H, W, device=dev),
-                            "census_idx": torch.zeros(B, dtype=torch.int64, device=dev), "y": torch.zeros(B, device=dev)}
-        return self._static
+            # the three small tensors are views of ONE packed byte buffer ("_packed": admin_mask f32 | y f32 | census_idx i64, each
+            # 16-byte aligned): a loader that stages a batch elsewhere moves them with a single device copy
+            n_am, n_y = B * H * W * 4, -(-B * 4 // 16) * 16
+            packed = torch.zeros(n_am + n_y + B * 8, dtype=torch.uint8, device=dev)
+            cur = self._static[dkey] = {dkey: torch.zeros(B, C, H, W, device=dev),
+                                        "admin_mask": packed[:n_am].view(torch.float32).view(B, H, W),
+                                        "y": packed[n_am:n_am + B * 4].view(torch.float32),
+                                        "census_idx": packed[n_am + n_y:].view(torch.int64), "_packed": packed}
+        return cur
+
+    @staticmethod
+    def pack_small(admin_mask, y, census_idx):
+        """Host-side counterpart of the ``_packed`` layout of ``static_buffers`` (one byte tensor)."""
+        B = y.numel()
+        n_am, n_y = admin_mask.numel() * 4, -(-B * 4 // 16) * 16
+        out = torch.zeros(n_am + n_y + B * 8, dtype=torch.uint8)
+        out[:n_am].view(torch.float32).copy_(admin_mask.float().reshape(-1))
+        out[n_am:n_am + B * 4].view(torch.float32).copy_(y.float().reshape(-1))
+        out[n_am + n_y:].view(torch.int64).copy_(census_idx.to(torch.int64).reshape(-1))
+        return out
 
     def _capture(self, sample, sel_host, key):
-        _, enc_ng, unet_ng, _ = key
-        if self._static is not None and all(sample[k] is self._static[k] for k in self._static):
-            st = dict(self._static)
+        dkey, _, enc_ng, unet_ng, _ = key
+        mine = [d for d in (self._static or {}).values() if all(sample.get(k) is d[k] for k in d)]
+        if mine:
+            st = dict(mine[0])
         else:
-            st = {k: sample[k].detach().clone().contiguous() for k in ("input", "admin_mask", "census_idx", "y")}
+            st = {k: sample[k].detach().clone().contiguous() for k in (dkey, "admin_mask", "census_idx", "y")}
             st["admin_mask"] = st["admin_mask"].float()
         sel = sel_host.to(self.device)
         # warm-up on a side stream (first-launch attribute calls, workspace allocation), state restored afterwards

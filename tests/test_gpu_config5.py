@@ -107,7 +107,7 @@ def _free_port():
     return p
 
 
-def _eval_rank(rank, world, port, q):
+def _eval_rank(rank, world, port, q, band=True):
     import torch.distributed as dist
     from popcorn_amd import eval as E
     from popcorn_amd.distributed import FlatReducer
@@ -125,7 +125,8 @@ def _eval_rank(rank, world, port, q):
         ms.append(m)
     g = torch.Generator().manual_seed(9)
     raster = torch.randn(2, 6, 300, 420, generator=g).cuda()       # two "seasons"
-    maps = E.evaluate_raster(ms, raster, patchsize=128, overlap=16, fourseasons=False, reducer=FlatReducer(), rank=rank)
+    maps = E.evaluate_raster(ms, raster, patchsize=128, overlap=16, fourseasons=False, reducer=FlatReducer(), rank=rank,
+                              band_reduce=band)
     torch.cuda.synchronize()
     if rank == 0:
         q.put([t.cpu().numpy() for t in maps])
@@ -134,11 +135,11 @@ def _eval_rank(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _launch(world):
+def _launch(world, band=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_eval_rank, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_eval_rank, args=(r, world, port, q, band)) for r in range(world)]
     for p in procs:
         p.start()
     from tests.test_gpu_dp import _get
@@ -149,11 +150,14 @@ def _launch(world):
     return out
 
 
-def test_two_rank_evaluate_raster_through_all_reduce_equals_single_process():
-    """Two processes (gloo group, both on the one GPU of the test box) shard the window list round-robin, accumulate into
-    their own device stitchers and meet in ``Stitcher.all_reduce``; the finalised maps equal the single-process run."""
+@pytest.mark.parametrize("band", [True, False])
+def test_two_rank_evaluate_raster_equals_single_process(band):
+    """Two processes (gloo group, both on the one GPU of the test box) shard the window list round-robin and accumulate into
+    their own device stitchers.  band=True: the visit count comes from the window list (no count collective), the planes are
+    reduced by row band, every rank finalises its band, the bands are gathered; band=False: the all-reduce form.  Either way the
+    finalised maps equal the single-process run (300 rows over 2 ranks: bands of 150)."""
     one = _launch(1)
-    two = _launch(2)
+    two = _launch(2, band)
     for a, b, name in zip(one, two, ("mean", "std", "scale mean", "scale std")):
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)), name

@@ -67,6 +67,16 @@ def _run(rank, world, port, use_graph, q):
         st.all_reduce(tr.reducer)
         torch.cuda.synchronize()
         assert torch.equal(st.acc, a0) and torch.equal(st.count, c0) and st.count.dtype == torch.int16
+        # the band form on RCCL: reduce_scatter_tensor (in place) + finalise + all_gather_into_tensor == finalise of the whole
+        ref = Stitcher(40, 56, "cuda")
+        ref.acc.copy_(a0); ref.count.copy_(c0)
+        want = [t.clone() for t in ref.finalize()]
+        assert st.reduce_scatter(tr.reducer, 0) == (0, 40)
+        st.finalize()
+        got = st.gather_bands(tr.reducer)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a.nan_to_num(-1.0), b.nan_to_num(-1.0))
         if use_graph:
             # one graph with both collectives captured as nodes (default on RCCL), or
             # forward | stats all-reduce | backward | gradient all-reduce | update as three graphs around two eager collectives

@@ -91,3 +91,43 @@ def test_unet_forward_fused_level_equals_layerwise(monkeypatch):
         for k in ("c1", "c2", "u2", "e1"):
             a, b = outs[True][2][s][k], outs[False][2][s][k]
             assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (s, k)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_graph):
+    """FusedTrainStep fed the RAW 15-band tile (its first launch = pc_select_normalize_pad: band select + normalise + reflect
+    padding in one pass, the unpadded input never exists) against the same step fed ``ops.select_normalize``'s output:
+    identical arithmetic, so losses and parameters agree bit for bit over three steps."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=5, device="cuda", region="disc")
+    x = ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    runs = []
+    for key, data in (("input", x), ("raw", batch["raw"])):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        tr = FusedTrainStep(m, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
+        s = {key: data, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}
+        losses = []
+        for it in range(3):
+            torch.manual_seed(40 + it)
+            losses.append(tr.step(dict(s))[0].item())
+        torch.cuda.synchronize()
+        runs.append((losses, tr.flat_p.clone()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_select_normalize_pad_equals_normalise_then_pad():
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    g = torch.Generator().manual_seed(3)
+    raw = (torch.rand(2, 15, 37, 52, generator=g) * 9000).cuda()
+    order = [4, 5, 2, 1, 0, 3]
+    got = ops.select_normalize_pad(raw, [stats.BAND6[c] for c in order], [stats.MEAN6[c] for c in order], [stats.STD6[c] for c in order], 5, 6, 7, 5)
+    x = ops.select_normalize(raw, stats.BAND6, stats.MEAN6, stats.STD6)
+    want = torch.nn.functional.pad(x[:, order], (7, 5, 5, 6), mode="reflect")
+    assert torch.equal(got, want)

@@ -300,10 +300,18 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         by = sum(nb(p["x"]) + nb(p["u2"]) + nb(p.get("c1")) + nb(p.get("c2")) for p in problems)
         return (2.0 * 2 * 9 * 16 * 16 + 2.0 * 4 * 16 * 16) * Bn * 32 * 32 * n, by, f"level2 fwd (2 x conv 16->16 + convT 16) @32x32 x{n}"
 
+    def c_level2_bwd(self, problems):
+        p0 = problems[0]
+        Bn = p0["g2"].shape[0]
+        n = len(problems)
+        by = sum(nb(p["g2"]) + nb(p["c1"]) + nb(p["x"]) + nb(p["act"]) + 2 * nb(p["out"]) for p in problems)
+        return 4 * 2.0 * 9 * 16 * 16 * Bn * 32 * 32 * n, by, f"level2 bwd (2 x (dgrad + wgrad) 16<->16, pool scatter) @32x32 x{n}"
+
     saved_graph = trainer.use_graph
     trainer.use_graph = False
     patches = [wrap(ops, "conv3x3_fwd_group", "conv_fwd", c_fwd), wrap(ops, "conv3x3_dgrad_group", "conv_dgrad", c_dgrad),
                wrap(ops, "level2_fwd_group", "level2_fused", c_level2),
+               wrap(ops.WgradBatch, "level2_bwd_group", "level2_fused", c_level2_bwd),
                wrap(ops.WgradBatch, "conv3x3_group", "conv_wgrad", c_wgrad_g), wrap(ops.WgradBatch, "conv3x3", "conv_wgrad", c_wgrad_1),
                wrap(ops.WgradBatch, "conv3x3_bwd_group", "conv_bwd_fused", c_bwd),
                wrap(ops, "convt2x2_group", "convt", c_convt), wrap(ops, "convt2x2_dgrad_group", "convt", c_convt_d),

@@ -237,6 +237,8 @@ typedef struct pc_level2_bwd_desc {
 int64_t pc_level2_bwd_ws_bytes(int B);
 int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const pc_src* act, const pc_dst* out);
 int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream);
+/* debug: 16 x int64 buffer receiving wall-clock (100 MHz) phase stamps of workgroup (0, 0) of pc_level2_bwd_group (NULL = off) */
+void pc_debug_level2_ts(void* buf);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */

@@ -18,6 +18,10 @@
 // one apart: the overlapping lanes read the same dwords) or the dx = 2 taps of two neighbouring channels (a channel stride
 // apart: disjoint banks).
 #include "common.h"
+#include <type_traits>
+
+static long long* g_l2_ts = nullptr;       // debug: phase timestamps of workgroup (0, 0) (tools/level2_phases.py)
+extern "C" void pc_debug_level2_ts(void* buf) { g_l2_ts = (long long*)buf; }
 
 namespace {
 
@@ -224,10 +228,16 @@ __global__ __launch_bounds__(512) void level2_fwd_kernel(const L2Args args) {
 // Weight-gradient mapping: M = co, N = ci, K = 4 consecutive pixels of a row; per 4-pixel group ONE A read (G) feeds the 9
 // tap MFMAs, whose B operands are the 9 shifted reads of x.  Every wave writes its own partial (8 per tile) in the layout of
 // pc_wgrad_reduce_batch (kind 0, Cin = Cout = 16): no cross-wave reduction.
-constexpr int B2_CS = 34 * L2_RS + 28;          // 1252 == 4 (mod 32)
+// Work split: TWO workgroups per tile (rows 0..15 and 16..31: 128 tile-problems would fill only half of the 256 CUs).  Each
+// recomputes the one-row halo of G1 it needs (18 rows instead of 16: the four extra 16-px units go to waves 0..3) and stages
+// 20 rows of G2 / 18 rows of c1 and x; its weight-gradient sums cover its own 16 rows.
+constexpr int B2_ROWS = 22;                      // image rows: global rows r0 - 3 .. r0 + 18 (r0 = first row of the half)
+constexpr int B2_CS = B2_ROWS * L2_RS + 12;      // 804 == 4 (mod 32)
 constexpr int B2_BUF = 16 * B2_CS;
-constexpr size_t B2_LDS = (size_t)(2 * B2_BUF) * sizeof(float);
+constexpr int B2_SCR = 4 * (9 * 64 * 4 + 16);   // reduction scratch: 4 wave slots x (9 taps x 64 lanes x 4 + 16 bias sums) floats
+constexpr size_t B2_LDS = (size_t)(2 * B2_BUF + B2_SCR) * sizeof(float);
 constexpr int B2_EC = 16 * 16 * 9 + 16;          // floats of one partial (WgradCfg::EC of conv3x3_wgrad.hip)
+constexpr int B2_PARTIALS = 2;                   // partials per tile and layer: one per half-tile workgroup
 
 struct B2Prob {
     const float* g2; int64_t g2_bs, g2_cs; int g2_rs;
@@ -238,9 +248,9 @@ struct B2Prob {
     const float* act; int64_t a_bs, a_cs; int a_rs;     // b2: full-resolution activations that were pooled (B,16,64,64)
     pc_bn act_bn;                                // BN of the layer that produced b2
     float* out; int64_t o_bs, o_cs; int o_rs;    // G_b2 (B,16,64,64), accumulated
-    float* ws2; float* ws1;                      // partials: [B * 8][B2_EC]
+    float* ws2; float* ws1;                      // partials: [B * B2_PARTIALS][B2_EC]
 };
-struct B2Args { B2Prob pr[PC_MAX_GROUP]; };
+struct B2Args { B2Prob pr[PC_MAX_GROUP]; long long* ts; };
 
 // K-slot k = 4 m + lk (m = 0..35) -> tap (input channel ci 0..15, dy, dx) of the data-gradient convolutions
 __device__ __forceinline__ void b2_tap(int k, int& ci, int& dy, int& dx) {
@@ -252,24 +262,32 @@ __device__ __forceinline__ void b2_tap(int k, int& ci, int& dy, int& dx) {
 __global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const B2Prob& q = args.pr[blockIdx.y];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x >> 1, hf = blockIdx.x & 1, r0 = 16 * hf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     float* const img0 = lds;                    // G2, later x
     float* const img1 = lds + B2_BUF;           // c1, later G1
+    auto stamp = [&](int i) {
+        if (args.ts && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) args.ts[i] = wall_clock64();
+    };
+    stamp(0);
 
-    auto stage = [&](const float* src, int64_t bs, int64_t cs, int rs, float* img) {
-        f32x4 t[8];
+    // rows [lo, lo + NR) of a (B,16,32,32) tensor -> registers (zeros outside the tile); image row of global row gr = gr - r0 + 3
+    auto fetch = [&](const float* src, int64_t bs, int64_t cs, int rs, int lo, int nr, f32x4 (&t)[5]) {
         const float* sp = src + b * bs;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i, ch = idx >> 8, row = (idx >> 3) & 31, seg = idx & 7;
-            t[i] = *reinterpret_cast<const f32x4*>(sp + ch * cs + (int64_t)row * rs + 4 * seg);
+        for (int i = 0; i < 5; ++i) {
+            const int idx = tid + 512 * i, ch = idx / (nr * 8), rem = idx - ch * nr * 8, row = rem >> 3, seg = rem & 7;
+            const int gr = lo + row;
+            const bool ok = ch < 16 && (unsigned)gr < 32u;
+            t[i] = ok ? *reinterpret_cast<const f32x4*>(sp + ch * cs + (int64_t)gr * rs + 4 * seg) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto commit = [&](float* img, int lo, int nr, const f32x4 (&t)[5]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i, ch = idx >> 8, row = (idx >> 3) & 31, seg = idx & 7;
-            *reinterpret_cast<f32x4*>(img + ch * B2_CS + (row + 1) * L2_RS + 4 + 4 * seg) = t[i];
+        for (int i = 0; i < 5; ++i) {
+            const int idx = tid + 512 * i, ch = idx / (nr * 8), rem = idx - ch * nr * 8, row = rem >> 3, seg = rem & 7;
+            if (ch < 16) *reinterpret_cast<f32x4*>(img + ch * B2_CS + (lo + row - r0 + 3) * L2_RS + 4 + 4 * seg) = t[i];
         }
     };
     // data-gradient weights of layer `w` ([co][ci][3][3]): B[k = tap (input channel co_in, dy, dx)][n = li = output channel ci_out]
@@ -282,43 +300,39 @@ __global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
             wv[m] = w[(ci * 16 + li) * 9 + 8 - (3 * dy + dx)];
         }
     };
+    f32x4 tg[5], tc[5];
+    fetch(q.g2, q.g2_bs, q.g2_cs, q.g2_rs, r0 - 2, 20, tg);
+    fetch(q.c1, q.c1_bs, q.c1_cs, q.c1_rs, r0 - 1, 18, tc);
     float wv[36];
     load_wT(q.w2, wv);
     {
-        // halo / pad zeros of both images: per channel row 0 (9 pieces), row 33 + pad (36 + 28 floats = 16 pieces),
-        // cols 0..3 of rows 1..32 (32 pieces) = 57 pieces
-        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int e = tid; e < 2 * 16 * 57; e += 512) {
-            const int img = e / (16 * 57), r = e - img * 16 * 57, ch = r / 57, pc = r - ch * 57;
-            float* base = lds + img * B2_BUF + ch * B2_CS;
-            int off;
-            if (pc < 9) off = 4 * pc;
-            else if (pc < 25) off = 33 * L2_RS + 4 * (pc - 9);
-            else off = (pc - 25 + 1) * L2_RS;
-            *reinterpret_cast<f32x4*>(base + off) = z;
-        }
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};          // everything that is not staged below must read as zero
+        for (int e = tid; e < 2 * B2_BUF / 4; e += 512) *reinterpret_cast<f32x4*>(lds + 4 * e) = z;
     }
-    stage(q.g2, q.g2_bs, q.g2_cs, q.g2_rs, img0);
-    stage(q.c1, q.c1_bs, q.c1_cs, q.c1_rs, img1);
+    __syncthreads();
+    commit(img0, r0 - 2, 20, tg);
+    commit(img1, r0 - 1, 18, tc);
+    // tap offsets (floats) of the 36 steps relative to an output pixel's image position: channel, row dy - 1, column dx - 1
     int aoff[36];
 #pragma unroll
     for (int m = 0; m < 36; ++m) {
         int ci, dy, dx;
         b2_tap(4 * m + lk, ci, dy, dx);
-        aoff[m] = ci * B2_CS + (4 * wave + dy) * L2_RS + dx + 3 + li;
+        aoff[m] = ci * B2_CS + (dy - 1) * L2_RS + dx + 3 + li;
     }
     __syncthreads();
+    stamp(1);
 
-    // ---- weight gradient of one layer: G image x X image over this wave's 4 rows -> its own partial in ws
+    // ---- weight gradient of one layer over this wave's 2 rows (image rows 2 wave + 3, + 4) -> its own partial in ws
     auto wgrad = [&](const float* gimg, const float* ximg, float* ws) {
         f32x4 acc[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float dbs = 0.f;
-        const float* gl = gimg + li * B2_CS + (4 * wave + 1) * L2_RS + 4 + lk;        // A: (co = li, px + lk)
-        const float* xl = ximg + li * B2_CS + (4 * wave) * L2_RS + 3 + lk;            // B: (ci = li, row + dy, px + lk + dx)
-#pragma unroll 1
-        for (int r = 0; r < 4; ++r) {
+        const float* gl = gimg + li * B2_CS + (2 * wave + 3) * L2_RS + 4 + lk;        // A: (co = li, px + lk)
+        const float* xl = ximg + li * B2_CS + (2 * wave + 2) * L2_RS + 3 + lk;        // B: (ci = li, row + dy - 1, px + lk + dx - 1)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
                 const float a = gl[r * L2_RS + 4 * g4];
@@ -330,102 +344,157 @@ __global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
                 for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[t], acc[t], 0, 0, 0);
             }
         }
-        // D[co = 4 lk + e][ci = li] -> partial[co][ci][tap];  db[co]: lanes (li = co, lk) hold the sums over their pixels
-        float* pw = ws + (int64_t)(b * 8 + wave) * B2_EC;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pw[(4 * lk + e) * 144 + li * 9 + t] = acc[t][e];
+        // the 8 waves' sums -> ONE partial per workgroup, in a fixed order (deterministic): waves 4..7 park theirs in the scratch
+        // slots, waves 0..3 add them and park the result, then all threads add the four slots and write the partial
+        // (D[co = 4 lk + e][ci = li] of tap t sits at slot[(t * 64 + lane) * 4 + e]; bias sums of lanes lk == 0 at slot[2304 + co])
         dbs += __shfl_xor(dbs, 16);
         dbs += __shfl_xor(dbs, 32);
-        if (lk == 0) pw[2304 + li] = dbs;
+        float* const scr = lds + 2 * B2_BUF;
+        constexpr int SLOT = 9 * 64 * 4 + 16;
+        float* const mine = scr + (wave & 3) * SLOT;
+        if (wave >= 4) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(mine + (t * 64 + lane) * 4) = acc[t];
+            if (lk == 0) mine[2304 + li] = dbs;
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(mine + (t * 64 + lane) * 4);
+                *reinterpret_cast<f32x4*>(mine + (t * 64 + lane) * 4) = acc[t] + o;
+            }
+            if (lk == 0) mine[2304 + li] += dbs;
+        }
+        __syncthreads();
+        float* pw = ws + (int64_t)(b * 2 + hf) * B2_EC;
+        for (int o = tid; o < B2_EC; o += 512) {
+            float v;
+            if (o < 2304) {
+                const int co = o / 144, rem = o - co * 144, ci = rem / 9, t = rem - ci * 9;
+                const int idx = (t * 64 + (co >> 2) * 16 + ci) * 4 + (co & 3);
+                v = (scr[idx] + scr[SLOT + idx]) + (scr[2 * SLOT + idx] + scr[3 * SLOT + idx]);
+            } else {
+                const int idx = 2304 + (o - 2304);
+                v = (scr[idx] + scr[SLOT + idx]) + (scr[2 * SLOT + idx] + scr[3 * SLOT + idx]);
+            }
+            pw[o] = v;
+        }
+        // (the next use of the scratch is a whole phase and at least one barrier away)
     };
-    // ---- data-gradient convolution of an image with the register weights: acc[r][h] = (channel li, row 4 wave + r, x = 16 h + 4 lk + e)
-    auto dgrad = [&](const float* img, f32x4 (&acc)[4][2]) {
+    // ---- data-gradient convolution with the register weights for NU units; unit u: output pixels (image row urow[u], x = ux[u] + M index)
+    // acc[u] = (channel li, x = ux + 4 lk + e)
+    auto dgrad = [&](const float* img, auto& acc, const int (&uoff)[5], auto NU) {
+        constexpr int nu = decltype(NU)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < nu; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 36; ++m) {
-            float av[8];
+            float av[nu];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = img[aoff[m] + (u >> 1) * L2_RS + (u & 1) * 16];
+            for (int u = 0; u < nu; ++u) av[u] = img[aoff[m] + uoff[u]];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc[u >> 1][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[m], acc[u >> 1][u & 1], 0, 0, 0);
+            for (int u = 0; u < nu; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[m], acc[u], 0, 0, 0);
         }
     };
+    // units of this wave: its two rows x two halves (image rows 2 wave + 3, + 4); the fifth: one half of a G1 halo row (image row 2
+    // or 19, waves 0..3; the other waves repeat their first unit and drop it)
+    int uoff[5], urow[5], ucol[5];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { urow[u] = 2 * wave + 3 + (u >> 1); ucol[u] = 16 * (u & 1); }
+    urow[4] = wave < 2 ? 2 : (wave < 4 ? 19 : urow[0]);
+    ucol[4] = wave < 4 ? 16 * (wave & 1) : ucol[0];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) uoff[u] = urow[u] * L2_RS + ucol[u];
 
     wgrad(img0, img1, q.ws2);                      // dW2, db2: G2 x c1
+    stamp(2);
+    f32x4 tx[5];
+    fetch(q.x, q.x_bs, q.x_cs, q.x_rs, r0 - 1, 18, tx);      // the pooled input: in flight during the data gradient below
     __syncthreads();                               // every wave has finished reading c1's neighbour rows
+    stamp(3);
     {
-        f32x4 acc[4][2];
-        dgrad(img0, acc);                          // conv(G2, w2^T)
+        f32x4 acc[5];
+        dgrad(img0, acc, uoff, std::integral_constant<int, 5>());      // conv(G2, w2^T) on 18 rows
         float sc, sh;
         pc_bn_fold(q.bn1, li, sc, sh);
         (void)sh;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int u = 0; u < 5; ++u) {
+            if (u == 4 && wave >= 4) continue;
+            float* p1 = img1 + li * B2_CS + urow[u] * L2_RS + 4 + ucol[u] + 4 * lk;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p1);
+            f32x4 v;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float* p1 = img1 + li * B2_CS + (4 * wave + r + 1) * L2_RS + 4 + 16 * h + 4 * lk;
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p1);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = c[e] > 0.f ? acc[r][h][e] * sc : 0.f;
-                *reinterpret_cast<f32x4*>(p1) = v;      // G1 over c1, same positions
-            }
+            for (int e = 0; e < 4; ++e) v[e] = c[e] > 0.f ? acc[u][e] * sc : 0.f;
+            *reinterpret_cast<f32x4*>(p1) = v;      // G1 over c1, same positions (rows outside the tile: c1 = 0 -> G1 = 0)
+        }
     }
-    load_wT(q.w1, wv);
+    stamp(4);
+    load_wT(q.w1, wv);                             // in flight during the weight gradient below
     __syncthreads();                               // G1 complete, G2 dead
-    stage(q.x, q.x_bs, q.x_cs, q.x_rs, img0);
-    __syncthreads();
-    wgrad(img1, img0, q.ws1);                      // dW1, db1: G1 x pooled input
     {
-        f32x4 acc[4][2];
-        dgrad(img1, acc);                          // Gp = conv(G1, w1^T): gradient w.r.t. the pooled map
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};          // G2 rows r0 - 2 and r0 + 17 are not overwritten by x: clear them
+        for (int e = tid; e < 16 * 2 * 8; e += 512) {
+            const int ch = e >> 4, rr = (e >> 3) & 1, seg = e & 7;
+            *reinterpret_cast<f32x4*>(img0 + ch * B2_CS + (rr ? 20 : 1) * L2_RS + 4 + 4 * seg) = z;
+        }
+    }
+    commit(img0, r0 - 1, 18, tx);
+    __syncthreads();
+    stamp(5);
+    wgrad(img1, img0, q.ws1);                      // dW1, db1: G1 x pooled input
+    stamp(6);
+    {
+        // MaxPool2d(2) backward: the lane's four pooled pixels cover 2 rows x 8 full-resolution pixels.  Its loads (the pooled
+        // activations and the gradient accumulated so far: 100 MB over the launch) are issued BEFORE the last data gradient
         float sc, sh;
         pc_bn_fold(q.act_bn, li, sc, sh);
         (void)sh;
-        // MaxPool2d(2) backward: the lane's four pooled pixels cover 2 rows x 8 full-resolution pixels
-#pragma unroll 1
-        for (int r = 0; r < 4; ++r)
+        f32x4 A[4][2][2], O[4][2][2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int y = 4 * wave + r, x = 16 * h + 4 * lk;
-                const float* a0 = q.act + b * q.a_bs + li * q.a_cs + (int64_t)(2 * y) * q.a_rs + 2 * x;
-                float* o0 = q.out + b * q.o_bs + li * q.o_cs + (int64_t)(2 * y) * q.o_rs + 2 * x;
-                f32x4 A[2][2], O[2][2];
+        for (int u = 0; u < 4; ++u) {
+            const int y = r0 + 2 * wave + (u >> 1), x = ucol[u] + 4 * lk;
+            const float* a0 = q.act + b * q.a_bs + li * q.a_cs + (int64_t)(2 * y) * q.a_rs + 2 * x;
+            const float* o0 = q.out + b * q.o_bs + li * q.o_cs + (int64_t)(2 * y) * q.o_rs + 2 * x;
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        A[rr][hh] = *reinterpret_cast<const f32x4*>(a0 + rr * q.a_rs + 4 * hh);
-                        O[rr][hh] = *reinterpret_cast<const f32x4*>(o0 + rr * q.o_rs + 4 * hh);
-                    }
-                const f32x4 v = acc[r][h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int hh = e >> 1, c = (e & 1) * 2;
-                    const float w00 = A[0][hh][c], w01 = A[0][hh][c + 1], w10 = A[1][hh][c], w11 = A[1][hh][c + 1];
-                    int am = 0;
-                    float mx = w00;
-                    if (w01 > mx) { mx = w01; am = 1; }
-                    if (w10 > mx) { mx = w10; am = 2; }
-                    if (w11 > mx) { mx = w11; am = 3; }
-                    const float g = mx > 0.f ? v[e] * sc : 0.f;
-                    O[0][hh][c] += am == 0 ? g : 0.f;
-                    O[0][hh][c + 1] += am == 1 ? g : 0.f;
-                    O[1][hh][c] += am == 2 ? g : 0.f;
-                    O[1][hh][c + 1] += am == 3 ? g : 0.f;
+                for (int hh = 0; hh < 2; ++hh) {
+                    A[u][rr][hh] = *reinterpret_cast<const f32x4*>(a0 + rr * q.a_rs + 4 * hh);
+                    O[u][rr][hh] = *reinterpret_cast<const f32x4*>(o0 + rr * q.o_rs + 4 * hh);
                 }
+        }
+        f32x4 acc[5];
+        dgrad(img1, acc, uoff, std::integral_constant<int, 4>());      // Gp = conv(G1, w1^T): gradient w.r.t. the pooled map
+        stamp(7);
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+        for (int u = 0; u < 4; ++u) {
+            const int y = r0 + 2 * wave + (u >> 1), x = ucol[u] + 4 * lk;
+            float* o0 = q.out + b * q.o_bs + li * q.o_cs + (int64_t)(2 * y) * q.o_rs + 2 * x;
+            const f32x4 v = acc[u];
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4*>(o0 + rr * q.o_rs + 4 * hh) = O[rr][hh];
+            for (int e = 0; e < 4; ++e) {
+                const int hh = e >> 1, c = (e & 1) * 2;
+                const float w00 = A[u][0][hh][c], w01 = A[u][0][hh][c + 1], w10 = A[u][1][hh][c], w11 = A[u][1][hh][c + 1];
+                int am = 0;
+                float mx = w00;
+                if (w01 > mx) { mx = w01; am = 1; }
+                if (w10 > mx) { mx = w10; am = 2; }
+                if (w11 > mx) { mx = w11; am = 3; }
+                const float g = mx > 0.f ? v[e] * sc : 0.f;
+                O[u][0][hh][c] += am == 0 ? g : 0.f;
+                O[u][0][hh][c + 1] += am == 1 ? g : 0.f;
+                O[u][1][hh][c] += am == 2 ? g : 0.f;
+                O[u][1][hh][c + 1] += am == 3 ? g : 0.f;
             }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4*>(o0 + rr * q.o_rs + 4 * hh) = O[u][rr][hh];
+        }
     }
+    stamp(8);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -473,7 +542,7 @@ extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, vo
     return 0;
 }
 
-extern "C" int64_t pc_level2_bwd_ws_bytes(int B) { return (int64_t)B * 8 * B2_EC * (int64_t)sizeof(float); }
+extern "C" int64_t pc_level2_bwd_ws_bytes(int B) { return (int64_t)B * B2_PARTIALS * B2_EC * (int64_t)sizeof(float); }
 
 static bool src_ok(const pc_src* s, int Cc, int Hh, int Ww) {
     return s && s->C == Cc && s->H == Hh && s->W == Ww && s->mode == PC_SRC_DIRECT && !s->oy && !s->ox &&
@@ -489,6 +558,7 @@ extern "C" int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src
 extern "C" int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream) {
     if (n < 1 || n > PC_MAX_GROUP || B < 1 || !d || !nwg_out) return PC_EINVAL;
     B2Args a;
+    a.ts = g_l2_ts;
     for (int i = 0; i < n; ++i) {
         const pc_level2_bwd_desc& s = d[i];
         if (!s.w1 || !s.w2 || !s.bn1 || !s.act_bn || !s.ws1 || !s.ws2 || !pc_level2_bwd_ok(s.g2, s.c1, s.x, s.act, s.out)) return PC_EINVAL;
@@ -507,8 +577,8 @@ extern "C" int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, in
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(level2_bwd_kernel, dim3(B, n), dim3(512), B2_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(level2_bwd_kernel, dim3(2 * B, n), dim3(512), B2_LDS, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();
-    *nwg_out = 8 * B;
+    *nwg_out = B2_PARTIALS * B;
     return 0;
 }

@@ -357,19 +357,27 @@ class UNetEngine:
             finish()
             return
         # encoder
-        if fuse:
-            G_c1 = bwd8("d2b", G_c2, "c1", "d2a", {s: E(16, H2, W2) for s in S}, cin_total=16)
+        if FUSED_LEVEL2 and not bf and all(A[s].get("pb2") is not None and
+                                            ops.level2_bwd_ok(G_c2[s], A[s]["c1"], A[s]["pb2"], A[s]["b2"], G_b2[s]) for s in S):
+            # the 32 x 32 level: both weight gradients, the data gradient chain d2b -> d2a and the pooling scatter in one launch
+            wb.level2_bwd_group([{"g2": G_c2[s], "c1": A[s]["c1"], "x": A[s]["pb2"], "w1": ly(s, "d2a").w, "w2": ly(s, "d2b").w,
+                                  "bn1": ly(s, "d2a").bn_nobias, "act": A[s]["b2"], "act_bn": ly(s, "d1b").bn_nobias, "out": G_b2[s],
+                                  "dw1": grads[prefix + ly(s, "d2a").wname], "db1": grads[prefix + ly(s, "d2a").bname],
+                                  "dw2": grads[prefix + ly(s, "d2b").wname], "db2": grads[prefix + ly(s, "d2b").bname]} for s in S])
         else:
-            wgs("d2b", "c1", G_c2)
-            G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
-        if fuse and all(A[s].get("pb2") is not None for s in S):
-            bwd8("d2a", G_c1, "pb2", "d1b", G_b2, cin_total=16, pool_key="b2")
-        else:
-            if all(A[s].get("pb2") is not None for s in S):
-                wgs("d2a", "pb2", G_c1)               # the pooled map was saved by the forward pass
+            if fuse:
+                G_c1 = bwd8("d2b", G_c2, "c1", "d2a", {s: E(16, H2, W2) for s in S}, cin_total=16)
             else:
-                wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
-            dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
+                wgs("d2b", "c1", G_c2)
+                G_c1 = dg("d2b", G_c2, {s: E(16, H2, W2) for s in S}, 0, 16, {s: A[s]["c1"] for s in S}, "d2a")
+            if fuse and all(A[s].get("pb2") is not None for s in S):
+                bwd8("d2a", G_c1, "pb2", "d1b", G_b2, cin_total=16, pool_key="b2")
+            else:
+                if all(A[s].get("pb2") is not None for s in S):
+                    wgs("d2a", "pb2", G_c1)               # the pooled map was saved by the forward pass
+                else:
+                    wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
+                dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
         if fuse:
             G_b1 = bwd8("d1b", G_b2, "b1", "d1a", {s: E(16, H1, W1) for s in S}, cin_total=16)
         else:

@@ -211,6 +211,15 @@ def level2_fwd_ok(x, u2):
     return bool(L.lib().pc_level2_fwd_ok(C.byref(sx), C.byref(du)))
 
 
+def level2_bwd_ok(g2, c1, x, act, out):
+    """Does the one-launch backward of the 32 x 32 level (pc_level2_bwd_group) take these tensors?"""
+    for t, shp in ((g2, (16, 32, 32)), (c1, (16, 32, 32)), (x, (16, 32, 32)), (act, (16, 64, 64)), (out, (16, 64, 64))):
+        if t is None or t.dim() != 4 or tuple(t.shape[1:]) != shp or t.dtype != torch.float32 or t.stride(3) != 1:
+            return False
+    sg, sc, sx, sa, do = L.src(g2), L.src(c1), L.src(x), L.src(act), L.dst(out)
+    return bool(L.lib().pc_level2_bwd_ok(C.byref(sg), C.byref(sc), C.byref(sx), C.byref(sa), C.byref(do)))
+
+
 def level2_fwd_group(problems):
     """DoubleConv(16,16) + ConvTranspose2d(16,16,2,2) of the 32 x 32 level in ONE launch (networks.py:253-271,302): problems =
     list (<= 4) of dicts {x (pooled input), w1, bn1, w2, bn2, wt, bt, u2 (out), c1 / c2 (optional outs: saved activations)}."""
@@ -513,9 +522,11 @@ class WgradBatch:
         self.slot_bytes = int(max(L.lib().pc_conv3x3_wgrad_ws_bytes(32, 8), L.lib().pc_convt2x2_wgrad_ws_bytes(16)))
         self.slot = 0
 
-    def _slice(self):
+    def _slice(self, nbytes=0):
+        """One workspace slot (or as many consecutive slots as ``nbytes`` needs)."""
+        k = max(1, -(-int(nbytes) // self.slot_bytes))
         key = str(self.device)
-        need = (self.slot + 1) * self.slot_bytes
+        need = (self.slot + k) * self.slot_bytes
         buf = WgradBatch._ws.get(key)
         if buf is None or buf.numel() < need:
             if buf is not None:
@@ -523,7 +534,7 @@ class WgradBatch:
             nbuf = torch.empty(max(need, 32 * self.slot_bytes), dtype=torch.uint8, device=self.device)
             WgradBatch._ws[key] = buf = nbuf
         ptr_ = buf.data_ptr() + self.slot * self.slot_bytes
-        self.slot += 1
+        self.slot += k
         return ptr_
 
     def conv3x3(self, a, g, cout, dw, db, b=None, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), chmap=(0, 1, 2, 3),
@@ -594,6 +605,30 @@ class WgradBatch:
         for ws, pr in zip(slots, problems):
             self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, pr["x"].shape[1], Cg, 0, cin_total * 9,
                                  (c0 + int(pr.get("c0_add", 0))) * 9))
+
+    def level2_bwd_group(self, problems):
+        """Backward of down2's DoubleConv (the 32 x 32 level) in ONE launch: problems = list of {g2 (dL/d conv2 output, masked),
+        c1, x (pooled input), w1, w2, bn1 (BN of conv1: relu'(c1) factor), act (b2, full resolution), act_bn, out (G_b2, +=),
+        dw1, db1, dw2, db2}.  Queues the two layers' weight / bias gradient partials; the data gradients never leave the kernel."""
+        n = len(problems)
+        B = problems[0]["g2"].shape[0]
+        nbytes = int(L.lib().pc_level2_bwd_ws_bytes(B))
+        descs = (L.PcLevel2BwdDesc * n)()
+        keep, slices = [], []
+        for i, pr in enumerate(problems):
+            sg, sc, sx, sa, do = L.src(pr["g2"]), L.src(pr["c1"]), L.src(pr["x"]), L.src(pr["act"]), L.dst(pr["out"])
+            ws1, ws2 = self._slice(nbytes), self._slice(nbytes)
+            keep += [sg, sc, sx, sa, do]
+            slices.append((ws1, ws2))
+            descs[i].g2, descs[i].c1, descs[i].x, descs[i].act, descs[i].out = C.pointer(sg), C.pointer(sc), C.pointer(sx), C.pointer(sa), C.pointer(do)
+            descs[i].w1, descs[i].w2 = pr["w1"].data_ptr(), pr["w2"].data_ptr()
+            descs[i].bn1, descs[i].act_bn = C.pointer(pr["bn1"]), C.pointer(pr["act_bn"])
+            descs[i].ws1, descs[i].ws2 = ws1, ws2
+        nwg = C.c_int(0)
+        L.check(L.lib().pc_level2_bwd_group(n, descs, B, C.byref(nwg), L.stream_ptr()), "pc_level2_bwd_group")
+        for (ws1, ws2), pr in zip(slices, problems):
+            self.entries.append((ws1, pr["dw1"], pr["db1"], nwg.value, 16, 16, 0))
+            self.entries.append((ws2, pr["dw2"], pr["db2"], nwg.value, 16, 16, 0))
 
     def convt2x2(self, x, g, dw, db):
         B, Cc, H, W = x.shape

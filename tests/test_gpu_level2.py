@@ -131,3 +131,83 @@ def test_select_normalize_pad_equals_normalise_then_pad():
     x = ops.select_normalize(raw, stats.BAND6, stats.MEAN6, stats.STD6)
     want = torch.nn.functional.pad(x[:, order], (7, 5, 5, 6), mode="reflect")
     assert torch.equal(got, want)
+
+
+def test_level2_bwd_group_vs_autograd():
+    """pc_level2_bwd_group (both weight / bias gradients, the data-gradient chain through the two convolutions and the pooling
+    scatter in one launch) against torch autograd (float64) of  pool -> conv+BN+ReLU -> conv+BN+ReLU  on the same operands."""
+    from popcorn_amd import _lib as L
+    from popcorn_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, nprob = 3, 2
+    wb = ops.WgradBatch(torch.device("cuda"))
+    probs, refs, keep = [], [], []
+    for i in range(nprob):
+        b2 = torch.relu(torch.randn(B, 16, 64, 64, generator=g)).double().requires_grad_(True)       # post-ReLU activations (some zeros)
+        w1 = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+        w2 = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+        p1, p2 = _bn(16, g), _bn(16, g)
+        bias1 = p1[0].double().requires_grad_(True)
+        bias2 = p2[0].double().requires_grad_(True)
+
+        def layer(x, w, bias, p):
+            _, gamma, beta, mean, var = p
+            y = F.conv2d(x, w, bias, padding=1)
+            return torch.relu((y - mean.double().view(1, -1, 1, 1)) / torch.sqrt(var.double().view(1, -1, 1, 1) + 1e-5)
+                              * gamma.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1))
+        x = F.max_pool2d(b2, 2)
+        c1 = layer(x, w1, bias1, p1)
+        c2 = layer(c1, w2, bias2, p2)
+        gout = torch.randn(B, 16, 32, 32, generator=g).double()          # dL/dc2 (post-ReLU)
+        c2.backward(gout)
+        # what the kernel receives: dL/d(conv2 output) = gout * relu'(c2) * bn2 scale
+        s2 = (p2[1] / torch.sqrt(p2[4] + 1e-5)).double().view(1, -1, 1, 1)
+        g2 = (gout * (c2.detach() > 0) * s2).float()
+        # the producer of b2 is a conv+BN+ReLU layer: the scatter multiplies by relu'(b2) * its BN scale -- emulate with a BN of scale 1.7
+        pa = (torch.zeros(16), torch.full((16,), 1.7), torch.zeros(16), torch.zeros(16), torch.ones(16) - 1e-5)
+        out0 = torch.randn(B, 16, 64, 64, generator=g)
+        refs.append((w1.grad.float(), bias1.grad.float(), w2.grad.float(), bias2.grad.float(),
+                     out0 + (b2.grad * 1.7).float() * (b2.detach() > 0)))
+        d1 = [t.cuda() for t in p1]
+        da = [t.cuda() for t in pa]
+        pr = {"g2": g2.cuda(), "c1": c1.detach().float().cuda(), "x": x.detach().float().cuda(), "w1": w1.detach().float().cuda(),
+              "w2": w2.detach().float().cuda(), "bn1": L.bn(None, d1[1], d1[2], d1[3], d1[4], 1e-5), "act": b2.detach().float().cuda(),
+              "act_bn": L.bn(None, da[1], da[2], da[3], da[4], 1e-5), "out": out0.cuda(),
+              "dw1": torch.full((16, 16, 3, 3), float("nan"), device="cuda"), "db1": torch.full((16,), float("nan"), device="cuda"),
+              "dw2": torch.full((16, 16, 3, 3), float("nan"), device="cuda"), "db2": torch.full((16,), float("nan"), device="cuda")}
+        assert ops.level2_bwd_ok(pr["g2"], pr["c1"], pr["x"], pr["act"], pr["out"])
+        keep.append((d1, da))
+        probs.append(pr)
+    wb.level2_bwd_group(probs)
+    wb.finish()
+    torch.cuda.synchronize()
+    for pr, (rw1, rb1, rw2, rb2, rout) in zip(probs, refs):
+        for name, ref in (("dw2", rw2), ("db2", rb2), ("dw1", rw1), ("db1", rb1), ("out", rout)):
+            got = pr[name].cpu()
+            err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+            assert err < 5e-5, (name, err)
+
+
+def test_unet_backward_fused_level_equals_layerwise(monkeypatch):
+    """Whole train-step gradients with the one-launch 32 x 32 level (forward + backward) against the layer-by-layer launches."""
+    from popcorn_amd import engine as E
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=9, device="cuda", region="disc")
+    x = ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(E, "FUSED_LEVEL2", flag)
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(4)
+        tr.step({"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]})
+        torch.cuda.synchronize()
+        grads[flag] = {k: v.clone() for k, v in tr.grads.items()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6), k

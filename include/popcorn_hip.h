@@ -137,6 +137,45 @@ int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);
 int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,
                                  void* stream);
 
+/* ---- the first conv of an Up block WITHOUT the up-sampled map (PC_PREC_FP32): for an exactly 2x geometry,
+ *     conv3x3(torch.cat([skip, ConvTranspose2d(C, C, 2, 2)(z)]))        (networks.py:302-318)
+ * is computed from `skip` (Cs channels, H x W) and the LOW-resolution map z (C channels, H/2 x W/2) directly: conv3x3 o convT is a
+ * linear map with a 2 x 2 low-resolution neighbourhood per output-pixel parity, whose weights (and the transposed conv's bias seen
+ * through the taps that stay inside the image) are composed from w [8][Cs + C][3][3], wt [C][C][2][2], bt [C] into `ws`
+ * (pc_conv3x3_up_ws_bytes(C) bytes) by a small first launch.  The up-sampled tensor is neither written nor read, and its half of
+ * the convolution costs 2/3 of the MFMAs on a quarter of the input bytes.  (Cs, C) = (8, 8) or (16, 16), Cout = 8, H % 4 == 0,
+ * W % 32 == 0, aligned planar fp32 (pc_conv3x3_up_fwd_ok); otherwise PC_EINVAL and the callers run pc_convt2x2_fwd_group +
+ * pc_conv3x3_bn_relu_fwd_group. */
+typedef struct pc_conv_up_fwd_desc {
+    const pc_src* skip; const pc_src* z; const float* w; const float* wt; const float* bt; const pc_bn* bn; const pc_dst* out; void* ws;
+} pc_conv_up_fwd_desc;
+int64_t pc_conv3x3_up_ws_bytes(int C);
+int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C);
+int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int relu, int B, int H, int W, int Cs, int C, void* stream);
+/* Backward of that up-sampled half, again without the up-sampled tensor: from g = dL/d(conv output) (8 channels, H x W, already times
+ * relu' * bn scale of the conv's layer) and z, ONE pass over g produces
+ *   gz (optional) = relu'(z) * z_bn scale * dL/dz                    (what pc_convt2x2_bwd_group wrote for the transposed conv's input)
+ *   dw[:, Cs:Cs + C] (=|+=), dwt, dbt                                 (gradients of w's up-sampled half, wt and bt; chain rule through the
+ *                                                                     composed weights, incl. the bias seen through the in-image taps)
+ * fwd_ws = the workspace the forward call filled (composed operand images), ws = pc_conv3x3_up_bwd_ws_bytes(B, H, C) bytes of scratch.
+ * Three launches (the pass, the reduction over its workgroups, the chain rule).  Replaces the up-sampled column block's share of
+ * pc_conv3x3_bwd_group / pc_conv3x3_dgrad_group + pc_conv3x3_wgrad_partial_group, pc_convt2x2_bwd_group and pc_convt2x2_fwd_group.
+ * The skip half of w and the bias gradient of the conv still come from the skip column block's launch. */
+typedef struct pc_conv_up_bwd_desc {
+    const pc_src* g; const pc_src* z; const pc_bn* z_bn; const pc_dst* gz;
+    const float* w; const float* wt; const float* bt; const void* fwd_ws; void* ws;
+    float* dw; float* dwt; float* dbt;
+} pc_conv_up_bwd_desc;
+int64_t pc_conv3x3_up_bwd_ws_bytes(int B, int H, int C);
+int pc_conv3x3_up_bwd_ok(const pc_src* g, const pc_src* z, const pc_dst* gz, int H, int W, int Cs, int C);
+int pc_conv3x3_up_bwd_group(int n, const pc_conv_up_bwd_desc* d, int accumulate, int B, int H, int W, int Cs, int C, void* stream);
+/* The same in pieces, for callers that batch the reduction with their other weight-gradient reductions: the pass alone (partials
+ * [*nwg_out][*part_out] floats at d[i].ws), then pc_wgrad_reduce_batch with a kind-2 entry {partial = ws, dw = ws + nwg * part,
+ * Cin = part} per problem, then the chain rule. */
+int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc* d, int B, int H, int W, int Cs, int C, int* nwg_out,
+                                    int* part_out, void* stream);
+int pc_conv3x3_up_chain_group(int n, const pc_conv_up_bwd_desc* d, int accumulate, int nwg, int Cs, int C, void* stream);
+
 /* ---- conv3x3 data gradient (autograd of the op above w.r.t. its input).
  * g: gradient w.r.t. the conv output (already multiplied by relu-mask * bn-scale), Cg = forward Cout channels.
  * Produces the gradient for forward input channels [c0, c0+Cn) of a forward weight w: [Cg][Cin_total][3][3].
@@ -219,7 +258,8 @@ int pc_convt2x2_bwd_group(int n, const pc_convt_bwd_desc* d, int B, int H, int W
 typedef struct pc_level2_fwd_desc {
     const pc_src* x; const float* w1; const pc_bn* bn1; const float* w2; const pc_bn* bn2; const float* wt; const float* bt;
     const pc_dst* c1; const pc_dst* c2;   /* optional (NULL: not written) */
-    const pc_dst* u2;
+    const pc_dst* u2;                     /* optional when c2 is given: NULL skips the transposed conv (a consumer that takes c2
+                                             through pc_conv3x3_up_fwd_group needs no up-sampled map) */
 } pc_level2_fwd_desc;
 int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2);
 int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream);
@@ -243,7 +283,7 @@ typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */
     int32_t nwg, Cin, Cout; /* convT: Cin = Cout = C */
-    int32_t kind;           /* 0: conv3x3, 1: convT 2x2 */
+    int32_t kind;           /* 0: conv3x3, 1: convT 2x2, 2: raw sum of Cin floats per partial into dw (pc_conv3x3_up_bwd_partial_group) */
     int32_t accumulate;
     int32_t dw_co_stride;   /* conv3x3: elements between output channels of dw (0 = Cin * 9); > Cin * 9 when the entry is one
                                8-channel column block of a wider weight gradient (dw then points at its first column) */

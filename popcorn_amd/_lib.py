@@ -80,6 +80,17 @@ class PcLevel2FwdDesc(C.Structure):
                 ("wt", C.c_void_p), ("bt", C.c_void_p), ("c1", C.POINTER(PcDst)), ("c2", C.POINTER(PcDst)), ("u2", C.POINTER(PcDst))]
 
 
+class PcConvUpFwdDesc(C.Structure):
+    _fields_ = [("skip", C.POINTER(PcSrc)), ("z", C.POINTER(PcSrc)), ("w", C.c_void_p), ("wt", C.c_void_p), ("bt", C.c_void_p),
+                ("bn", C.POINTER(PcBn)), ("out", C.POINTER(PcDst)), ("ws", C.c_void_p)]
+
+
+class PcConvUpBwdDesc(C.Structure):
+    _fields_ = [("g", C.POINTER(PcSrc)), ("z", C.POINTER(PcSrc)), ("z_bn", C.POINTER(PcBn)), ("gz", C.POINTER(PcDst)),
+                ("w", C.c_void_p), ("wt", C.c_void_p), ("bt", C.c_void_p), ("fwd_ws", C.c_void_p), ("ws", C.c_void_p),
+                ("dw", C.c_void_p), ("dwt", C.c_void_p), ("dbt", C.c_void_p)]
+
+
 class PcLevel2BwdDesc(C.Structure):
     _fields_ = [("g2", C.POINTER(PcSrc)), ("c1", C.POINTER(PcSrc)), ("x", C.POINTER(PcSrc)), ("w1", C.c_void_p), ("w2", C.c_void_p),
                 ("bn1", C.POINTER(PcBn)), ("act", C.POINTER(PcSrc)), ("act_bn", C.POINTER(PcBn)), ("out", C.POINTER(PcDst)),
@@ -122,7 +133,7 @@ def lib():
         _lib = cand
         _lib.pc_error_string.restype = C.c_char_p
         for name in ("pc_conv3x3_wgrad_ws_bytes", "pc_convt2x2_wgrad_ws_bytes", "pc_head_ws_bytes",
-                     "pc_compact_ws_bytes", "pc_unet_ws_bytes", "pc_level2_bwd_ws_bytes"):
+                     "pc_compact_ws_bytes", "pc_unet_ws_bytes", "pc_level2_bwd_ws_bytes", "pc_conv3x3_up_ws_bytes", "pc_conv3x3_up_bwd_ws_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib

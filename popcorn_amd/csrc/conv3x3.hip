@@ -70,6 +70,11 @@ struct ConvProb {
     pc_dst pool_out;      // FWD: 2x2-max-pooled copy of the output (ptr NULL = not wanted)
     const float* dot_w;   // FWD (EPI_DOT): weights of a following 1x1 conv over this layer's 8 channels ...
     pc_dst dot_out;       // ... whose partial sum replaces the output (ptr NULL = ordinary output)
+    // FWD with ZC > 0 (pc_conv3x3_up_fwd_group): the up-sampled half of an Up block's concatenated input, never materialised --
+    // z is the LOW-resolution map (ZC channels, H/2 x W/2) the transposed conv would have up-sampled; wz / tb come from
+    // compose_up_kernel (composed 2x2-neighbourhood weights per output parity; bias-through-the-taps table)
+    const float* z; int64_t z_bs, z_cs; int z_rs;
+    const float* wz; const float* tb;
 };
 
 struct ConvArgs {
@@ -106,10 +111,18 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 // count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
 // write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
 enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3 };   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
-template <int CIN, int COUT, int MODE, int LD, int EPI>
+template <int CIN, int COUT, int MODE, int LD, int EPI, int ZC = 0>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr int NCHUNK = CIN / CHUNK;
+    // ZC > 0: ZC more input "channels" that exist only at HALF the resolution -- the map z that ConvTranspose2d(ZC, ZC, 2, 2) would
+    // have up-sampled into the second half of torch.cat([skip, up]) (networks.py:302-318).  conv3x3(convT(z)) is a linear map
+    // with a 2 x 2 low-resolution neighbourhood per output-pixel parity (pY, pX); its weights are composed once per step
+    // (compose_up_kernel) and every 8 low-resolution channels are one more stage of the strip: a 4-row x 18-column piece of z
+    // in the wave's LDS region (a quarter of a regular chunk's bytes) and 64 MFMAs instead of 96 -- K = the 3 low-res rows a row
+    // pair touches, one MFMA per (channel, column tap tj, x parity j); the up-sampled map is neither written nor read.
+    constexpr int NZ = ZC / 8;                          // composed stages per strip
+    constexpr int NST = NCHUNK + NZ;                    // stages per strip
     constexpr int NB = COUT / 8;
     constexpr bool STAGED = LD != LD_GENERIC;
     constexpr int NIT = CHUNK;                           // one 16-byte segment per channel per lane
@@ -125,7 +138,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // registers but 97-107 with one ds_read_b32 per MFMA -- the conv kernels' MFMA phase was LDS-operand-issue bound, not power
     // bound).  The strip image becomes [row][channel][40] with a row-plane stride == 32 (mod 64) dwords: the two rows a 32-lane
     // half of a b64 read touches fall on complementary bank halves.
-    constexpr bool P2 = CONV_P2 && !N16 && CHUNK == 8;
+    constexpr bool P2 = (CONV_P2 || ZC > 0) && !N16 && CHUNK == 8;
+    static_assert(ZC == 0 || (P2 && MODE == MODE_FWD && LD == LD_DIRECT && EPI == EPI_NONE && COUT == 8), "composed up-sampling stage");
+    constexpr int ZROW = 48, ZCH = 4 * ZROW;            // low-res piece: [8 ch][4 rows][48] floats (rows 16 banks apart)
+    constexpr int WZ_L = 36;                            // composed weight image: [stage][lane][32 (+4 pad)] floats
     constexpr int LCH = P2 ? 40 : CSW;                   // floats between channels of the strip image
     constexpr int LROW = P2 ? 8 * 40 + 32 : RS;          // floats between rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -214,12 +230,42 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         }
     };
 
+    // ---- composed stage: 8 low-res channels x 4 rows (y0/2 - 1 ..) x 18 columns (x0/2 - 1 ..) = 576 floats: lane = (channel, row,
+    // half of the 18 columns), 9 consecutive floats each -- one address per lane, immediate offsets (a generic element index per
+    // load cost 50 registers of hoisted address arithmetic)
+    float Rz[ZC > 0 ? 9 : 1];
+    bool pend_z = false;                                 // the prefetch in flight is a low-res piece (wave-uniform)
+    const int z_ch = lane >> 3, z_row = (lane >> 1) & 3, z_half = lane & 1;
+    auto issue_z = [&](int zc, int b, int y0, int x0) {
+        if constexpr (ZC > 0) {
+            const int Hh = p.H >> 1, Wh = p.W >> 1;
+            int I = (y0 >> 1) - 1 + z_row;
+            I = I < 0 ? 0 : (I >= Hh ? Hh - 1 : I);                            // clamped: masked when it is written to LDS
+            const int c0 = (x0 >> 1) - 1 + 9 * z_half;                          // first of the lane's 9 columns (>= -1)
+            const float* rowp = q.z + b * q.z_bs + (int64_t)(zc * 8 + z_ch) * q.z_cs + (int64_t)I * q.z_rs;
+            Rz[0] = rowp[c0 < 0 ? 0 : c0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) Rz[k] = rowp[c0 + k];
+            Rz[8] = rowp[c0 + 8 < Wh ? c0 + 8 : Wh - 1];
+        }
+    };
+    auto commit_z = [&](int y0, int x0) {        // the coordinates of the strip whose piece is pending
+        if constexpr (ZC > 0) {
+            const int Hh = p.H >> 1, Wh = p.W >> 1;
+            const bool rok = (unsigned)((y0 >> 1) - 1 + z_row) < (unsigned)Hh;
+            const int c0 = (x0 >> 1) - 1 + 9 * z_half;
+            float* d = wl + z_ch * ZCH + z_row * ZROW + 9 * z_half;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = rok && (unsigned)(c0 + k) < (unsigned)Wh ? Rz[k] : 0.f;
+        }
+    };
+
     // strips: tile-major so that the 4 waves of a workgroup take the 4 strips of one 32 x 16 tile (shared halo rows
     // hit in L1/L2); workgroups walk the tiles in the XCD-aware order.
     const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int nstages = my_tiles * NCHUNK;
+    const int nstages = my_tiles * NST;
     auto strip_coords = [&](int stage, int& b, int& y0, int& x0) {
-        const int t = blockIdx.x + (stage / NCHUNK) * gridDim.x;
+        const int t = blockIdx.x + (stage / NST) * gridDim.x;
         const int tile = pc_xcd_remap(t, p.ntiles);
         b = (int)pc_div((uint32_t)tile, p.div_tpi);
         const int rem = tile - b * p.tiles_x * p.tiles_y;
@@ -245,6 +291,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // trip, in flight together with the first strip), the LDS image is zeroed meanwhile, and only then are they consumed
     // -- the prologue used to be three dependent round trips (zero fill + barrier, weights, BN), ~4.6 us of every launch.
     float* const w2 = lds + 4 * WAVE_F;
+    float* const wzimg = w2 + (N16 ? 16 * W16_S : 4 * W_DYS);          // ZC > 0: composed weights [stage][lane][WZ_L]
+    float wzreg[ZC > 0 ? NZ * 8 : 1];
+    if constexpr (ZC > 0) {
+#pragma unroll
+        for (int k = 0; k < NZ * 8; ++k) wzreg[k] = q.wz[tid + 256 * k];          // NZ * 2048 floats, coalesced
+    }
     constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
     float wreg[NWR];
 #pragma unroll
@@ -270,6 +322,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         // writes below, so one barrier covers both
         if constexpr (!N16)
             for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
+        if constexpr (ZC > 0) {
+#pragma unroll
+            for (int k = 0; k < NZ * 8; ++k) {
+                const int e = tid + 256 * k, zc = e >> 11, r = e & 2047;          // global order [stage][lane][32]
+                wzimg[zc * 64 * WZ_L + (r >> 5) * WZ_L + (r & 31)] = wzreg[k];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NWR; ++k) {
             const int e = tid + k * 256;
@@ -329,6 +388,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // unable to count how many prefetch loads were issued since, emits `s_waitcnt vmcnt(0)` in front of the epilogue --
     // draining the just-issued prefetch loads of the next strip on EVERY strip (load, store and MFMA phases add up
     // instead of overlapping: tools/ablate_conv.py).  An empty asm use forces the one wait to happen before the loop.
+    // ZC > 0: the transposed conv's bias reaches the output through every tap whose up-sampled pixel lies inside the image: the full
+    // sum S joins the shift, the border rows / columns / corners subtract their missing taps (tb[co] = {R0, R2, C0, C2, T00, T02,
+    // T20, T22, S}: sums over the taps of row dy = 0 / 2, column dx = 0 / 2, the four corner taps, all nine)
+    float zb[ZC > 0 ? 8 : 1];
+    if constexpr (ZC > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zb[k] = q.tb[col * 9 + k];
+        e_shift[0] += q.tb[col * 9 + 8] * e_scale[0];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : : "v"(zb[k]));
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) asm volatile("" : : "v"(e_scale[nb]), "v"(e_shift[nb]));
     const act_t* const act = reinterpret_cast<const act_t*>(q.act);
@@ -633,15 +703,20 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 
     f32x4 acc[4][NB];
     for (int stage = 0; stage < nstages; ++stage) {
-        const int ch = stage % NCHUNK;
+        const int ch = stage % NST;
         if (!(p.dbg & 1)) {
-            if (STAGED) commit();
+            if (ZC > 0 && pend_z) commit_z(y0, x0);
+            else if (STAGED) commit();
             else load_generic(ch, b, y0, x0);
         }
         int nb_ = b, ny0 = y0, nx0 = x0;
         if (stage + 1 < nstages) {
-            if ((stage + 1) % NCHUNK == 0) strip_coords(stage + 1, nb_, ny0, nx0);
-            if (STAGED && !(p.dbg & 1)) issue((stage + 1) % NCHUNK, nb_, ny0, nx0);
+            const int nch = (stage + 1) % NST;
+            if (nch == 0) strip_coords(stage + 1, nb_, ny0, nx0);
+            if (STAGED && !(p.dbg & 1)) {
+                if (ZC > 0 && nch >= NCHUNK) { issue_z(nch - NCHUNK, nb_, ny0, nx0); pend_z = true; }
+                else { issue(nch, nb_, ny0, nx0); pend_z = false; }
+            }
         }
         if (have_prev) {
             if (!(p.dbg & 4)) epilogue();
@@ -653,7 +728,31 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!(p.dbg & 2)) {
+        if (ZC > 0 && ch >= NCHUNK) {
+            if constexpr (ZC > 0) {
+                if (!(p.dbg & 2)) {
+                    // composed stage: B[k = low-res row lk][n = (s, co)] of (channel ci, column tap tj, x parity j) = register 4 ci + 2 tj + j
+                    const float* wzl = wzimg + (ch - NCHUNK) * 64 * WZ_L + lane * WZ_L;
+                    const float* zl = wl + lk * ZROW + li;                  // A: (pixel pair i = li, low-res row rp + lk), column li + tj + j
+#pragma unroll 1
+                    for (int ci = 0; ci < 8; ++ci) {
+                        const f32x4 bz = *reinterpret_cast<const f32x4*>(wzl + 4 * ci);       // [2 tj + j] of this channel
+                        float zv[2][3];
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) zv[rp][c3] = zl[ci * ZCH + rp * ZROW + c3];
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int rp = 0; rp < 2; ++rp)
+                                    acc[rp * 2 + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[rp][tj + j], bz[2 * tj + j], acc[rp * 2 + j][0], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (!(p.dbg & 2)) {
             load_bw(ch);                    // re-read every stage, also when CIN == CHUNK: not live across the epilogue
             const float* lrow = wl + lk * RS + (COL0 - 1) + li;
             if constexpr (P2) {
@@ -705,7 +804,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 }
             }
         }
-        if (ch == NCHUNK - 1) {
+        if (ch == NST - 1) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -715,6 +814,19 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         const int rp = u >> 1, h = u & 1;
                         const f32x4 a0 = acc[rp * 2][nb], a1 = acc[rp * 2 + 1][nb];
                         pacc[u][nb] = f32x4{a0[2 * h], a1[2 * h], a0[2 * h + 1], a1[2 * h + 1]};
+                        if constexpr (ZC > 0) {
+                            // border pixels: the taps whose up-sampled pixel falls outside the image carry no bias
+                            const int Y = y0 + 2 * rp + s_row, X0 = x0 + 8 * lk + 4 * h;
+                            const bool top = Y == 0, bot = Y == p.H - 1;
+                            const float rowt = top ? zb[0] : (bot ? zb[1] : 0.f);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool lft = X0 + e == 0, rgt = X0 + e == p.W - 1;
+                                float c = rowt + (lft ? zb[2] : (rgt ? zb[3] : 0.f));
+                                c -= top ? (lft ? zb[4] : (rgt ? zb[5] : 0.f)) : (bot ? (lft ? zb[6] : (rgt ? zb[7] : 0.f)) : 0.f);
+                                pacc[u][nb][e] -= c;
+                            }
+                        }
                     } else {
                         pacc[u][nb] = acc[u][nb];
                     }
@@ -728,15 +840,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     if (p.ts && tid == 0) p.ts[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-template <int CIN, int COUT, int MODE, int LD, int EPI>
+template <int CIN, int COUT, int MODE, int LD, int EPI, int ZC = 0>
 int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
     constexpr bool N16 = COUT == 16 && CHUNK == 8;
-    constexpr bool P2 = CONV_P2 && !N16 && CHUNK == 8;
-    const size_t lds = ((size_t)4 * (P2 ? SROWS * (8 * 40 + 32) : CHUNK * CSW) + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16))) * sizeof(float);   // wave strips + weight image
+    constexpr bool P2 = (CONV_P2 || ZC > 0) && !N16 && CHUNK == 8;
+    const size_t lds = ((size_t)4 * (P2 ? SROWS * (8 * 40 + 32) : CHUNK * CSW) + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16)) +
+                        (ZC / 8) * 64 * 36) * sizeof(float);   // wave strips + weight image (+ composed weight image)
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, ZC>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -744,7 +857,7 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, lds);
         if (getenv("POPCORN_CONV_DBG"))
-            fprintf(stderr, "conv3x3<%d,%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD,
+            fprintf(stderr, "conv3x3<%d,%d,%d,%d,z%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD, ZC,
                     fa.numRegs, lds, resident);
     }
     // Persistent workgroups, all resident at once (one wave of a 256-thread workgroup per SIMD; the register count
@@ -759,7 +872,7 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
         grid = 768 / nprob < 128 ? 128 : 768 / nprob;
         if (grid > p.ntiles) grid = p.ntiles;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, ZC>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -1395,4 +1508,160 @@ extern "C" int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Ci
     p.accumulate = accumulate;
     p.B = B; p.H = H; p.W = W;
     return dispatch_conv<MODE_DGRAD>(p, n, Cg, Cn, (hipStream_t)stream);
+}
+
+
+// =====================================================================================================================
+// Up block without the up-sampled map:  conv3x3(cat[skip, ConvTranspose2d(z)]) = conv3x3(skip; W[:, :Cs]) + a parity-dependent
+// 2 x 2-neighbourhood map of z + the transposed conv's bias through the taps (networks.py:302-318).
+// compose_up_kernel builds, once per call (the weights change every step):
+//   wz[stage][lane = 16 lk + li][4 ci + 2 tj + j] = sum over c' and the taps (dy, dx) that land on (low-res row offset v = lk - 1,
+//       sub-row a) / (column offset tj + j - 1, sub-column b) for output parity (pY = li >> 3, pX = j):
+//       W[co = li & 7][Cs + c'][dy][dx] * Wt[8 stage + ci][c'][a][b]                                   (0 for lk == 3)
+//   tb[co] = {R0, R2, C0, C2, T00, T02, T20, T22, S} with T[co][dy][dx] = sum_c' W[co][Cs + c'][dy][dx] * bt[c']
+namespace {
+struct ComposeArgs {
+    const float* w[PC_MAX_GROUP]; const float* wt[PC_MAX_GROUP]; const float* bt[PC_MAX_GROUP]; float* ws[PC_MAX_GROUP];
+    int Cs, C;
+};
+__device__ __forceinline__ void up_rowmap(int p, int d, int& v, int& a) {      // parity p, tap d -> low-res offset index v (0..2), sub-pixel a
+    const int t = p + d - 1;
+    const int i = t < 0 ? -1 : (t >> 1);
+    v = i + 1;
+    a = t - 2 * i;
+}
+__global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
+    // the two small weight tensors go to LDS first (coalesced), the 64-term sums then read LDS (the direct form spent 18 us
+    // of dependent L2 round trips per call)
+    __shared__ float sW[8 * 16 * 9], sT[16 * 16 * 4], sB[16];
+    const float* W = a.w[blockIdx.y];
+    const float* Wt = a.wt[blockIdx.y];
+    const float* bt = a.bt[blockIdx.y];
+    float* ws = a.ws[blockIdx.y];
+    const int C = a.C, Cs = a.Cs, Ct = Cs + C;
+    for (int e = threadIdx.x; e < 8 * C * 9; e += 256) {
+        const int co = e / (C * 9), r = e - co * C * 9;
+        sW[e] = W[(co * Ct + Cs) * 9 + r];                      // [co][c'][tap] of the up half
+    }
+    for (int e = threadIdx.x; e < C * C * 4; e += 256) sT[e] = Wt[e];
+    if (threadIdx.x < C) sB[threadIdx.x] = bt ? bt[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int nwz = (C / 8) * 2048;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nwz + 72 + 2048; e += gridDim.x * 256) {
+        if (e >= nwz + 72) {
+            // operand image of the BACKWARD data gradient (up_bwd.hip): wd[(4 (4 co + r) + c) * 16 + ci] = Kd[co][ci][r][c], the weight
+            // of output pixel (2i - 1 + r, 2j - 1 + c) in dL/dz[ci][i][j]: window row r -> (pY, v) = (1,2), (0,1), (1,1), (0,0)
+            const int k = e - nwz - 72, ci = k & 15, c = (k >> 4) & 3, r = (k >> 6) & 3, co = k >> 8;
+            float acc = 0.f;
+            if (ci < C) {
+                const int pY = (r & 1) ^ 1, v = r == 0 ? 2 : (r == 3 ? 0 : 1);
+                const int pX = (c & 1) ^ 1, c3 = c == 0 ? 2 : (c == 3 ? 0 : 1);
+                for (int dy = 0; dy < 3; ++dy) {
+                    int vv, sa;
+                    up_rowmap(pY, dy, vv, sa);
+                    if (vv != v) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        int cc, sb;
+                        up_rowmap(pX, dx, cc, sb);
+                        if (cc != c3) continue;
+                        for (int cp = 0; cp < C; ++cp) acc += sW[(co * C + cp) * 9 + dy * 3 + dx] * sT[((ci * C + cp) * 2 + sa) * 2 + sb];
+                    }
+                }
+            }
+            ws[e] = acc;
+        } else if (e < nwz) {
+            const int stage = e >> 11, r = e & 2047, lane = r >> 5, qq = r & 31;
+            const int lk = lane >> 4, li = lane & 15, pY = li >> 3, co = li & 7;
+            const int ci = stage * 8 + (qq >> 2), tj = (qq >> 1) & 1, j = qq & 1;
+            float acc = 0.f;
+            if (lk < 3) {
+                for (int dy = 0; dy < 3; ++dy) {
+                    int v, sa;
+                    up_rowmap(pY, dy, v, sa);
+                    if (v != lk) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        int c3, sb;
+                        up_rowmap(j, dx, c3, sb);
+                        if (c3 != tj + j) continue;
+                        for (int c = 0; c < C; ++c) acc += sW[(co * C + c) * 9 + dy * 3 + dx] * sT[((ci * C + c) * 2 + sa) * 2 + sb];
+                    }
+                }
+            }
+            ws[e] = acc;
+        } else {
+            const int k = e - nwz, co = k / 9, which = k - 9 * co;
+            float T[3][3];
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    float t = 0.f;
+                    for (int c = 0; c < C; ++c) t += sW[(co * C + c) * 9 + dy * 3 + dx] * sB[c];
+                    T[dy][dx] = t;
+                }
+            float v;
+            switch (which) {
+                case 0: v = T[0][0] + T[0][1] + T[0][2]; break;
+                case 1: v = T[2][0] + T[2][1] + T[2][2]; break;
+                case 2: v = T[0][0] + T[1][0] + T[2][0]; break;
+                case 3: v = T[0][2] + T[1][2] + T[2][2]; break;
+                case 4: v = T[0][0]; break;
+                case 5: v = T[0][2]; break;
+                case 6: v = T[2][0]; break;
+                case 7: v = T[2][2]; break;
+                default: v = T[0][0] + T[0][1] + T[0][2] + T[1][0] + T[1][1] + T[1][2] + T[2][0] + T[2][1] + T[2][2]; break;
+            }
+            ws[nwz + k] = v;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int64_t pc_conv3x3_up_ws_bytes(int C) { return (int64_t)((C / 8) * 2048 + 72 + 2048) * sizeof(float); }
+
+extern "C" int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C) {
+    if (g_pc_precision != PC_PREC_FP32 || !skip || !z || !out) return 0;
+    if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W & 31)) return 0;
+    if (skip->C != Cs || z->C != C || z->H * 2 != H || z->W * 2 != W || z->mode != PC_SRC_DIRECT || z->oy || z->ox) return 0;
+    if (z->dtype != PC_F32 || !pc_planar(*z) || skip->dtype != PC_F32 || !pc_planar(*skip) || out->dtype != PC_F32 || !pc_planar(*out)) return 0;
+    if (conv_src_mode(*skip, H, W) != 1) return 0;
+    return (out->rstride % 4 == 0) && (out->cstride % 4 == 0) && (out->bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out->ptr) & 15) == 0);
+}
+
+extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int relu, int B, int H, int W, int Cs, int C, void* stream) {
+    if (n < 1 || n > MAXG || !d) return PC_EINVAL;
+    ConvArgs p{};
+    ComposeArgs ca{};
+    ca.Cs = Cs; ca.C = C;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].skip || !d[i].z || !d[i].w || !d[i].wt || !d[i].bn || !d[i].out || !d[i].ws ||
+            !pc_conv3x3_up_fwd_ok(d[i].skip, d[i].z, d[i].out, H, W, Cs, C))
+            return PC_EINVAL;
+        ConvProb& q = p.pr[i];
+        q.a = *d[i].skip;
+        q.w = d[i].w;
+        q.bn = *d[i].bn;
+        q.out = *d[i].out;
+        q.z = d[i].z->ptr; q.z_bs = d[i].z->bstride; q.z_cs = d[i].z->cstride; q.z_rs = d[i].z->rstride;
+        q.wz = (const float*)d[i].ws;
+        q.tb = (const float*)d[i].ws + (C / 8) * 2048;
+        q.fast_a = 1;
+        ca.w[i] = d[i].w; ca.wt[i] = d[i].wt; ca.bt[i] = d[i].bt; ca.ws[i] = (float*)d[i].ws;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(compose_up_kernel, dim3(((C / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, st, ca);
+    PC_CHECK_LAUNCH();
+    p.w_co_stride = (Cs + C) * 9;
+    p.w_ci_stride = 9;
+    p.relu = relu;
+    p.B = B; p.H = H; p.W = W;
+    p.vec_ok = 1;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.ntiles <= 0) return 0;
+    p.div_tx = pc_make_fastdiv(p.tiles_x);
+    p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
+    p.dbg = g_conv_dbg;
+    p.ts = g_conv_ts;
+    if (Cs == 8) return launch_conv_po<8, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 8>(p, n, st);
+    return launch_conv_po<16, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 16>(p, n, st);
 }

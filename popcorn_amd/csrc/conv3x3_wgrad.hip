@@ -892,7 +892,7 @@ constexpr int cinc_of(int cin) { return cin < 16 ? cin : 16; }
 constexpr int RB_MAX = 32;
 struct RbEntry {
     const float* partial; float* dw; float* db;
-    int nwg, Cin, Cout, kind, accumulate;     // kind 0: conv3x3, 1: convT 2x2 (C = Cin)
+    int nwg, Cin, Cout, kind, accumulate;     // kind 0: conv3x3, 1: convT 2x2 (C = Cin), 2: raw sum of Cin floats
     int dw_co_stride;                         // conv3x3: elements between output channels of dw (0 = Cin * 9)
 };
 struct RbArgs { RbEntry e[RB_MAX]; };
@@ -926,6 +926,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
         } else if (o < n_out) {
             const int co = o - n_w;
             for (int w = slice; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * EC + q.Cout * CINC * 9 + co];
+        }
+    } else if (q.kind == 2) {
+        // raw sum of Cin floats per partial (up_bwd.hip: composed-weight gradient accumulators + border sums; the chain-rule
+        // launch that follows turns the total into parameter gradients)
+        n_w = n_out = q.Cin;
+        if (o < n_w) {
+            int w = slice;
+            for (; w + 16 < q.nwg; w += 32) {
+                s0 += q.partial[(int64_t)w * q.Cin + o];
+                s1 += q.partial[(int64_t)(w + 16) * q.Cin + o];
+            }
+            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * q.Cin + o];
         }
     } else {
         const int C = q.Cin, NBK = C / 4, E = NBK * 256 + NBK * 64;
@@ -965,7 +977,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
         if (q.kind == 0 && q.dw_co_stride > 0 && o < n_w) od = (int64_t)(o / (q.Cin * 9)) * q.dw_co_stride + o % (q.Cin * 9);
         float* dstp = o < n_w ? q.dw + od : q.db + (o - n_w);
         if (o >= n_w && q.db == nullptr) return;
-        *dstp = q.accumulate ? *dstp + tot : tot;
+        *dstp = (q.accumulate && q.kind != 2) ? *dstp + tot : tot;
     }
 }
 
@@ -988,7 +1000,7 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
             const pc_wgrad_reduce_desc& s = d[base + i];
             if (!s.partial || !s.dw || s.nwg < 1) return PC_EINVAL;
             a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride};
-            const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : s.Cin * s.Cin * 4 + s.Cin;
+            const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : (s.kind == 2 ? s.Cin : s.Cin * s.Cin * 4 + s.Cin);
             if (n_out > max_out) max_out = n_out;
         }
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((max_out + 15) / 16, m), dim3(256), 0, st, a);

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512) void level2_fwd_kernel(const L2Args args) {
     };
     conv(bufA, bufB, q.w1, q.w2, 0, q.bn1, q.c1, q.c1_bs, q.c1_cs, q.c1_rs);
     conv(bufB, bufA, q.w2, nullptr, 0, q.bn2, q.c2, q.c2_bs, q.c2_cs, q.c2_rs);
+    if (!q.u2) return;                             // nobody reads the up-sampled map of this problem (wave-uniform: whole workgroup)
     __syncthreads();                               // c2 complete in bufA
 
     // ---- ConvTranspose2d(16, 16, 2, 2): out[co][2i+a][2j+b] = bias[co] + sum_ci c2[ci][i][j] * wt[ci][co][a][b]
@@ -505,10 +506,10 @@ bool plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) 
 }  // namespace
 
 extern "C" int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2) {
-    if (g_pc_precision != PC_PREC_FP32 || !x || !u2) return 0;
+    if (g_pc_precision != PC_PREC_FP32 || !x) return 0;
     if (x->C != 16 || x->H != 32 || x->W != 32 || x->mode != PC_SRC_DIRECT || x->oy || x->ox) return 0;
     return plane_ok(x->ptr, x->bstride, x->cstride, x->rstride, x->xstride, x->dtype) &&
-           plane_ok(u2->ptr, u2->bstride, u2->cstride, u2->rstride, u2->xstride, u2->dtype);
+           (!u2 || plane_ok(u2->ptr, u2->bstride, u2->cstride, u2->rstride, u2->xstride, u2->dtype));
 }
 
 extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream) {
@@ -516,7 +517,7 @@ extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, vo
     L2Args a;
     for (int i = 0; i < n; ++i) {
         const pc_level2_fwd_desc& s = d[i];
-        if (!s.x || !s.u2 || !s.w1 || !s.w2 || !s.wt || !s.bn1 || !s.bn2 || !pc_level2_fwd_ok(s.x, s.u2)) return PC_EINVAL;
+        if (!s.x || (!s.u2 && !s.c2) || !s.w1 || !s.w2 || !s.wt || !s.bn1 || !s.bn2 || !pc_level2_fwd_ok(s.x, s.u2)) return PC_EINVAL;
         L2Prob& p = a.pr[i];
         p.x = s.x->ptr; p.x_bs = s.x->bstride; p.x_cs = s.x->cstride; p.x_rs = s.x->rstride;
         p.w1 = s.w1; p.w2 = s.w2; p.wt = s.wt; p.bt = s.bt; p.bn1 = *s.bn1; p.bn2 = *s.bn2;
@@ -529,7 +530,8 @@ extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, vo
             if (!plane_ok(s.c2->ptr, s.c2->bstride, s.c2->cstride, s.c2->rstride, s.c2->xstride, s.c2->dtype)) return PC_EINVAL;
             p.c2 = s.c2->ptr; p.c2_bs = s.c2->bstride; p.c2_cs = s.c2->cstride; p.c2_rs = s.c2->rstride;
         }
-        p.u2 = s.u2->ptr; p.u2_bs = s.u2->bstride; p.u2_cs = s.u2->cstride; p.u2_rs = s.u2->rstride;
+        p.u2 = nullptr; p.u2_bs = p.u2_cs = 0; p.u2_rs = 0;
+        if (s.u2) { p.u2 = s.u2->ptr; p.u2_bs = s.u2->bstride; p.u2_cs = s.u2->cstride; p.u2_rs = s.u2->rstride; }
     }
     static bool attr = false;
     if (!attr) {

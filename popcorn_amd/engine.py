@@ -68,6 +68,9 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
 FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
 # fp32: the whole 32 x 32 level (down2's DoubleConv + up2's transposed conv) in one launch (POPCORN_FUSED_LEVEL2=0: three launches)
 FUSED_LEVEL2 = os.environ.get("POPCORN_FUSED_LEVEL2", "1") != "0"
+# fp32: the first conv of an Up block reads the LOW-resolution map through composed (transposed conv o conv) weights instead of an
+# up-sampled tensor (POPCORN_COMPOSED_UP=0: transposed-conv launch + two-source conv)
+COMPOSED_UP = os.environ.get("POPCORN_COMPOSED_UP", "1") != "0"
 # fp32: padded + channel-gathered input materialised once per forward pass (POPCORN_PADDED_INPUT=0: reflect loaders; A/B switch)
 PADDED_INPUT = os.environ.get("POPCORN_PADDED_INPUT", "1") != "0"
 
@@ -301,58 +304,83 @@ class UNetEngine:
                 wgts(tag, xs, gviews)
                 ops.convt2x2_dgrad_group(probs)
 
+        def up_bwd(ttag, tag, gs, z_key, z_act, ws_key, gz):
+            """composed Up block (the forward never made the up-sampled tensor): gradient of the conv's up-sampled weight half, of the
+            transposed conv's weight / bias, and (gz) of the low-resolution map, from one pass over gs"""
+            wb.up_bwd_group([{"g": gs[s], "z": A[s][z_key], "z_bn": ly(s, z_act).bn_nobias, "gz": None if gz is None else gz[s],
+                              "w": ly(s, tag).w, "wt": ly(s, ttag).w, "bt": ly(s, ttag).b, "fwd_ws": A[s][ws_key],
+                              "dw": grads[prefix + ly(s, tag).wname], "dwt": grads[prefix + ly(s, ttag).wname],
+                              "dbt": grads[prefix + ly(s, ttag).bname]} for s in S])
+
+        composed1 = all(A[s].get("ws_up1") is not None for s in S)
+        composed2 = all(A[s].get("ws_up2") is not None for s in S)
         G_f2 = {s: G[:, f0:f0 + 8] for s, _, _, f0 in self.streams}
         if fuse8(G_f2, "f1"):
             G_f1 = bwd8("up1b", G_f2, "f1", "up1a", {s: E(8, Hp, Wp) for s in S})
         else:
             wgs("up1b", "f1", G_f2)
             G_f1 = dg("up1b", G_f2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["f1"] for s in S}, "up1a")
-        if not encoder_no_grad and fuse8(G_f1, "a2") and fuse8(G_f1, "u1", "o1"):
-            G_a2, g_u1 = bwd_cat("up1a", G_f1, "a2", "inc2", "u1", "o1", 8, 16, Hp, Wp)
+        G_e2 = {s: E(8, H1, W1) for s in S}
+        if composed1:
+            # skip column block: data + weight gradient (and the bias gradient) in one launch; up-sampled block: up_bwd
+            G_a2 = bwd8("up1a", G_f1, "a2", "inc2", {s: E(8, Hp, Wp) for s in S}, c0=0, cin_total=16)
+            up_bwd("up1t", "up1a", G_f1, "e2", "up2b", "ws_up1", G_e2)
         else:
-            wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
-            if not encoder_no_grad:
-                G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
-            g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
-        G_e2, probs = {}, []
-        g_u1vs = {}
-        for s in S:
-            oy, ox = A[s]["o1"]
-            g_u1v = g_u1vs[s] = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
-            G_e2[s] = E(8, H1, W1)
-            probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
-        ct_bwd("up1t", "e2", "up2b", g_u1vs, G_e2, probs)
+            if not encoder_no_grad and fuse8(G_f1, "a2") and fuse8(G_f1, "u1", "o1"):
+                G_a2, g_u1 = bwd_cat("up1a", G_f1, "a2", "inc2", "u1", "o1", 8, 16, Hp, Wp)
+            else:
+                wgs("up1a", "a2", G_f1, b_key="u1", off_key="o1")
+                if not encoder_no_grad:
+                    G_a2 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a2"] for s in S}, "inc2")
+                g_u1 = dg("up1a", G_f1, {s: E(8, Hp, Wp) for s in S}, 8, 8)
+            probs = []
+            g_u1vs = {}
+            for s in S:
+                oy, ox = A[s]["o1"]
+                g_u1v = g_u1vs[s] = g_u1[s][:, :, oy:oy + 2 * H1, ox:ox + 2 * W1]
+                probs.append({"g": g_u1v, "w": ly(s, "up1t").w, "out": G_e2[s], "act": A[s]["e2"], "act_bn": ly(s, "up2b").bn_nobias})
+            ct_bwd("up1t", "e2", "up2b", g_u1vs, G_e2, probs)
         if fuse8(G_e2, "e1"):
             G_e1 = bwd8("up2b", G_e2, "e1", "up2a", {s: E(8, H1, W1) for s in S})
         else:
             wgs("up2b", "e1", G_e2)
             G_e1 = dg("up2b", G_e2, {s: E(8, H1, W1) for s in S}, 0, 8, {s: A[s]["e1"] for s in S}, "up2a")
-        if fuse and not encoder_no_grad:
-            G_b2, g_u2 = bwd_cat("up2a", G_e1, "b2", "d1b", "u2", "o2", 16, 32, H1, W1)
-        else:
-            wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
-            if not encoder_no_grad and 2 * len(S) <= L.PC_MAX_GROUP:
-                # both column blocks in one launch: the four problems read the same gradient
-                G_b2, g_u2 = {s: E(16, H1, W1) for s in S}, {s: E(16, H1, W1) for s in S}
-                ops.conv3x3_dgrad_group(
-                    [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": G_b2[s], "act": A[s]["b2"], "act_bn": ly(s, "d1b").bn_nobias} for s in S] +
-                    [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": g_u2[s], "c0_add": 16} for s in S], 0, 16)
-            else:
-                if not encoder_no_grad:
-                    G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
-                g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
-        G_c2, probs = {}, []
-        g_u2vs = {}
-        for s in S:
-            oy, ox = A[s]["o2"]
-            g_u2v = g_u2vs[s] = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
+        G_c2 = {}
+        if composed2:
+            # skip column block (16 channels @ H1 x W1): weight gradient into the first 16 input columns, data gradient masked by d1b
+            wb.conv3x3_group([{"a": A[s]["b2"], "g": G_e1[s], "dw": grads[prefix + ly(s, "up2a").wname],
+                               "db": grads[prefix + ly(s, "up2a").bname]} for s in S], ly(S[0], "up2a").w.shape[0], cin_total=32)
             if not encoder_no_grad:
-                G_c2[s] = E(16, H2, W2)
-                probs.append({"g": g_u2v, "w": ly(s, "up2t").w, "out": G_c2[s], "act": A[s]["c2"], "act_bn": ly(s, "d2b").bn_nobias})
-        if probs:
-            ct_bwd("up2t", "c2", "d2b", g_u2vs, G_c2, probs)
+                G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+                G_c2 = {s: E(16, H2, W2) for s in S}
+            up_bwd("up2t", "up2a", G_e1, "c2", "d2b", "ws_up2", None if encoder_no_grad else G_c2)
         else:
-            wgts("up2t", {s: A[s]["c2"] for s in S}, g_u2vs)
+            if fuse and not encoder_no_grad:
+                G_b2, g_u2 = bwd_cat("up2a", G_e1, "b2", "d1b", "u2", "o2", 16, 32, H1, W1)
+            else:
+                wgs("up2a", "b2", G_e1, b_key="u2", off_key="o2")
+                if not encoder_no_grad and 2 * len(S) <= L.PC_MAX_GROUP:
+                    # both column blocks in one launch: the four problems read the same gradient
+                    G_b2, g_u2 = {s: E(16, H1, W1) for s in S}, {s: E(16, H1, W1) for s in S}
+                    ops.conv3x3_dgrad_group(
+                        [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": G_b2[s], "act": A[s]["b2"], "act_bn": ly(s, "d1b").bn_nobias} for s in S] +
+                        [{"g": G_e1[s], "w": ly(s, "up2a").w, "out": g_u2[s], "c0_add": 16} for s in S], 0, 16)
+                else:
+                    if not encoder_no_grad:
+                        G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+                    g_u2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 16, 16)
+            probs = []
+            g_u2vs = {}
+            for s in S:
+                oy, ox = A[s]["o2"]
+                g_u2v = g_u2vs[s] = g_u2[s][:, :, oy:oy + 2 * H2, ox:ox + 2 * W2]
+                if not encoder_no_grad:
+                    G_c2[s] = E(16, H2, W2)
+                    probs.append({"g": g_u2v, "w": ly(s, "up2t").w, "out": G_c2[s], "act": A[s]["c2"], "act_bn": ly(s, "d2b").bn_nobias})
+            if probs:
+                ct_bwd("up2t", "c2", "d2b", g_u2vs, G_c2, probs)
+            else:
+                wgts("up2t", {s: A[s]["c2"] for s in S}, g_u2vs)
         if encoder_no_grad:
             finish()
             return
@@ -514,19 +542,36 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     a2 = conv("inc2", a1, 8, Hp, Wp, pooled=pa2)
     b1 = down("d1a", a2, pa2, 16, H1, W1)
     b2 = conv("d1b", b1, 16, H1, W1, pooled=pb2)
-    def convt(tag, ins, c, h, w):
-        outs = {k: E(c, h, w) for k in keys}
-        ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in keys])
+    def convt(tag, ins, c, h, w, only=None):
+        """only: the keys that need the up-sampled tensor (the others get None)"""
+        ks = keys if only is None else [k for k in keys if k in only]
+        outs = {k: (E(c, h, w) if k in ks else None) for k in keys}
+        if ks:
+            ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in ks])
         return outs
 
+    def up_conv(tag, ttag, skip, z, c, h, w):
+        """first conv of an Up block straight from the low-resolution map z (composed weights): (outs, workspaces), or None"""
+        if not (COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (h, w) == (2 * z[keys[0]].shape[2], 2 * z[keys[0]].shape[3])):
+            return None
+        outs = {k: E(c, h, w) for k in keys}
+        if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or w not in (64, 128):
+            return None
+        ws = ops.conv3x3_up_fwd_group([{"skip": skip[k], "z": z[k], "w": ly(k, tag).w, "wt": ly(k, ttag).w, "bt": ly(k, ttag).b,
+                                        "bn": ly(k, tag).bn, "out": outs[k]} for k in keys])
+        return outs, dict(zip(keys, ws))
+
+    # with the composed first conv nobody reads the up-sampled tensors u2 / u1 -- not even the backward pass (up_bwd.hip)
+    compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and W1 in (64, 128)
+    compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and Wp in (64, 128)
     u2 = None
     if FUSED_LEVEL2 and L.act_dtype() == torch.float32 and pb2 and (H2, W2) == (32, 32):
         # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with
-        # the 16 x 32 x 32 maps in LDS; c1 / c2 go to HBM only for the networks whose backward pass reads them
-        u2 = {k: E(16, 2 * H2, 2 * W2) for k in keys}
+        # the 16 x 32 x 32 maps in LDS; c1 / c2 / u2 go to HBM only for whoever reads them
+        u2 = {k: (None if compose2 else E(16, 2 * H2, 2 * W2)) for k in keys}
         if all(ops.level2_fwd_ok(pb2[k], u2[k]) for k in keys):
             c1 = {k: (E(16, H2, W2) if saves[k[0]] else None) for k in keys}
-            c2 = {k: (E(16, H2, W2) if saves[k[0]] else None) for k in keys}
+            c2 = {k: (E(16, H2, W2) if (saves[k[0]] or compose2) else None) for k in keys}
             ops.level2_fwd_group([{"x": pb2[k], "w1": ly(k, "d2a").w, "bn1": ly(k, "d2a").bn, "w2": ly(k, "d2b").w,
                                    "bn2": ly(k, "d2b").bn, "wt": ly(k, "up2t").w, "bt": ly(k, "up2t").b, "c1": c1[k], "c2": c2[k],
                                    "u2": u2[k]} for k in keys])
@@ -535,13 +580,26 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     if u2 is None:
         c1 = down("d2a", b2, pb2, 16, H2, W2)
         c2 = conv("d2b", c1, 16, H2, W2)
-        u2 = convt("up2t", c2, 16, 2 * H2, 2 * W2)
+        u2 = {k: None for k in keys}
     o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
-    e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
+    r = up_conv("up2a", "up2t", b2, c2, 8, H1, W1) if compose2 else None
+    ws_up2 = {}
+    if r is None:
+        if any(u2[k] is None for k in keys):
+            u2 = convt("up2t", c2, 16, 2 * H2, 2 * W2)
+        e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
+    else:
+        e1, ws_up2 = r
     e2 = conv("up2b", e1, 8, H1, W1)
-    u1 = convt("up1t", e2, 8, 2 * H1, 2 * W1)
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
-    f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
+    r = up_conv("up1a", "up1t", a2, e2, 8, Hp, Wp) if compose1 else None
+    ws_up1 = {}
+    if r is None:
+        u1 = convt("up1t", e2, 8, 2 * H1, 2 * W1)
+        f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
+    else:
+        f1, ws_up1 = r
+        u1 = {k: None for k in keys}
     f0s = {s: f0 for s, _, _, f0 in streams}
     probs = []
     for k in keys:
@@ -564,7 +622,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         for s, _, _, _ in streams:
             k = (e, s)
             sv[s] = dict(a1=a1[k], a2=a2[k], b1=b1[k], b2=b2[k], c1=c1[k], c2=c2[k], u2=u2[k], e1=e1[k], e2=e2[k],
-                         u1=u1[k], f1=f1[k], o1=o1, o2=o2, pa2=pa2.get(k), pb2=pb2.get(k))
+                         u1=u1[k], f1=f1[k], o1=o1, o2=o2, pa2=pa2.get(k), pb2=pb2.get(k), ws_up1=ws_up1.get(k), ws_up2=ws_up2.get(k))
         sv["X"] = X
         sv["Xp"] = Xp                       # per stream: the padded, gathered input (fp32 path) or None
         sv["geom"] = (pad_top, pad_left, Hp, Wp)

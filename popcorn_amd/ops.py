@@ -203,12 +203,98 @@ def convt2x2_group(problems):
 
 def level2_fwd_ok(x, u2):
     """Does the one-launch 32 x 32 level (pc_level2_fwd_group) take these tensors?  x: (B,16,32,32) pooled map, u2: (B,16,64,64)."""
-    if x is None or x.dim() != 4 or tuple(x.shape[1:]) != (16, 32, 32) or tuple(u2.shape[1:]) != (16, 64, 64):
+    if x is None or x.dim() != 4 or tuple(x.shape[1:]) != (16, 32, 32) or x.dtype != torch.float32 or x.stride(3) != 1:
         return False
-    if x.dtype != torch.float32 or u2.dtype != torch.float32 or x.stride(3) != 1 or u2.stride(3) != 1:
+    if u2 is not None and (tuple(u2.shape[1:]) != (16, 64, 64) or u2.dtype != torch.float32 or u2.stride(3) != 1):
         return False
-    sx, du = L.src(x), L.dst(u2)
-    return bool(L.lib().pc_level2_fwd_ok(C.byref(sx), C.byref(du)))
+    sx = L.src(x)
+    du = L.dst(u2) if u2 is not None else None
+    return bool(L.lib().pc_level2_fwd_ok(C.byref(sx), C.byref(du) if du is not None else None))
+
+
+def conv3x3_up_fwd_ok(skip, z, out):
+    """Does pc_conv3x3_up_fwd_group (first conv of an Up block computed from the LOW-resolution map, no up-sampled tensor) take
+    these tensors?  skip (B,Cs,H,W), z (B,C,H/2,W/2), out (B,8,H,W)."""
+    if skip is None or z is None or skip.dtype != torch.float32 or z.dtype != torch.float32 or out.dtype != torch.float32:
+        return False
+    if skip.stride(3) != 1 or z.stride(3) != 1 or out.stride(3) != 1:
+        return False
+    B, Cs, H, W = skip.shape
+    ss, sz, do = L.src(skip), L.src(z), L.dst(out)
+    return bool(L.lib().pc_conv3x3_up_fwd_ok(C.byref(ss), C.byref(sz), C.byref(do), H, W, Cs, z.shape[1]))
+
+
+def conv3x3_up_fwd_group(problems, relu=True):
+    """conv3x3(cat[skip, ConvTranspose2d(z)]) + BN + ReLU without materialising the up-sampled map (networks.py:302-318):
+    problems = list (<= 4) of dicts {skip, z, w ([8][Cs + C][3][3]), wt ([C][C][2][2]), bt ([C]), bn, out}."""
+    n = len(problems)
+    assert 1 <= n <= L.PC_MAX_GROUP
+    skip0, z0 = problems[0]["skip"], problems[0]["z"]
+    L.require_device(skip0, z0)
+    B, Cs, H, W = skip0.shape
+    Cz = z0.shape[1]
+    nbytes = int(L.lib().pc_conv3x3_up_ws_bytes(Cz))
+    keep, slots = [], []
+    descs = (L.PcConvUpFwdDesc * n)()
+    for i, pr in enumerate(problems):
+        # composed operand images of this call (forward stages, bias table, the backward's data-gradient image): a fresh tensor
+        # per problem -- the backward pass of a saved network reads it again (under graph capture it lives in the graph's pool)
+        slots.append(torch.empty(nbytes, dtype=torch.uint8, device=skip0.device))
+        ss, sz, do = L.src(pr["skip"]), L.src(pr["z"]), L.dst(pr["out"])
+        keep += [ss, sz, do]
+        descs[i].skip, descs[i].z, descs[i].out = C.pointer(ss), C.pointer(sz), C.pointer(do)
+        descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
+        descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
+        descs[i].bn = C.pointer(pr["bn"])
+        descs[i].ws = slots[i].data_ptr()
+    L.check(L.lib().pc_conv3x3_up_fwd_group(n, descs, int(relu), B, H, W, Cs, Cz, L.stream_ptr()), "pc_conv3x3_up_fwd_group")
+    return slots
+
+
+_up_bwd_ws = {}
+
+
+def conv3x3_up_bwd_ok(g, z, gz):
+    if g is None or z is None or g.dtype != torch.float32 or z.dtype != torch.float32 or g.stride(3) != 1 or z.stride(3) != 1:
+        return False
+    if gz is not None and (gz.dtype != torch.float32 or gz.stride(3) != 1):
+        return False
+    B, Cg, H, W = g.shape
+    sg, sz = L.src(g), L.src(z)
+    dz = L.dst(gz) if gz is not None else None
+    return bool(L.lib().pc_conv3x3_up_bwd_ok(C.byref(sg), C.byref(sz), C.byref(dz) if dz is not None else None, H, W, z.shape[1], z.shape[1]))
+
+
+def conv3x3_up_bwd_group(problems, accumulate=False):
+    """Backward of the up-sampled half of an Up block's first conv from the low-resolution map (pc_conv3x3_up_bwd_group):
+    problems = list of {g (B,8,H,W), z (B,C,H/2,W/2), z_bn, gz (out, optional), w, wt, bt, fwd_ws (slot returned by
+    conv3x3_up_fwd_group), dw (full conv weight gradient [8][Cs + C][3][3]), dwt, dbt}."""
+    n = len(problems)
+    g0, z0 = problems[0]["g"], problems[0]["z"]
+    L.require_device(g0, z0)
+    B, Cg, H, W = g0.shape
+    Cz = z0.shape[1]
+    nbytes = int(L.lib().pc_conv3x3_up_bwd_ws_bytes(B, H, Cz))
+    key = (str(g0.device), Cz, nbytes)
+    slots = _up_bwd_ws.setdefault(key, [])
+    keep = []
+    descs = (L.PcConvUpBwdDesc * n)()
+    for i, pr in enumerate(problems):
+        if len(slots) <= i:
+            slots.append(torch.empty(nbytes, dtype=torch.uint8, device=g0.device))
+        sg, sz = L.src(pr["g"]), L.src(pr["z"])
+        dz = L.dst(pr["gz"]) if pr.get("gz") is not None else None
+        keep += [sg, sz, dz]
+        descs[i].g, descs[i].z = C.pointer(sg), C.pointer(sz)
+        descs[i].z_bn = C.pointer(pr["z_bn"])
+        descs[i].gz = C.pointer(dz) if dz is not None else None
+        descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
+        descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
+        descs[i].fwd_ws = pr["fwd_ws"].data_ptr()
+        descs[i].ws = slots[i].data_ptr()
+        descs[i].dw, descs[i].dwt = pr["dw"].data_ptr(), pr["dwt"].data_ptr()
+        descs[i].dbt = pr["dbt"].data_ptr() if pr.get("dbt") is not None else None
+    L.check(L.lib().pc_conv3x3_up_bwd_group(n, descs, int(accumulate), B, H, W, Cz, Cz, L.stream_ptr()), "pc_conv3x3_up_bwd_group")
 
 
 def level2_bwd_ok(g2, c1, x, act, out):
@@ -225,12 +311,13 @@ def level2_fwd_group(problems):
     list (<= 4) of dicts {x (pooled input), w1, bn1, w2, bn2, wt, bt, u2 (out), c1 / c2 (optional outs: saved activations)}."""
     n = len(problems)
     assert 1 <= n <= L.PC_MAX_GROUP
-    L.require_device(problems[0]["x"], problems[0]["u2"])
+    L.require_device(problems[0]["x"])
     B = problems[0]["x"].shape[0]
     keep = []
     descs = (L.PcLevel2FwdDesc * n)()
     for i, pr in enumerate(problems):
-        sx, du = L.src(pr["x"]), L.dst(pr["u2"])
+        sx = L.src(pr["x"])
+        du = L.dst(pr["u2"]) if pr.get("u2") is not None else None
         d1 = L.dst(pr["c1"]) if pr.get("c1") is not None else None
         d2 = L.dst(pr["c2"]) if pr.get("c2") is not None else None
         keep += [sx, du, d1, d2]
@@ -240,7 +327,7 @@ def level2_fwd_group(problems):
         descs[i].bn1, descs[i].bn2 = C.pointer(pr["bn1"]), C.pointer(pr["bn2"])
         descs[i].c1 = C.pointer(d1) if d1 is not None else None
         descs[i].c2 = C.pointer(d2) if d2 is not None else None
-        descs[i].u2 = C.pointer(du)
+        descs[i].u2 = C.pointer(du) if du is not None else None
     L.check(L.lib().pc_level2_fwd_group(n, descs, B, L.stream_ptr()), "pc_level2_fwd_group")
 
 
@@ -519,6 +606,8 @@ class WgradBatch:
         self.device = device
         self.accumulate = accumulate
         self.entries = []
+        self.raw_entries = []           # (partials ptr, total ptr, nwg, floats): raw sums (kind 2)
+        self.chains = []                # composed Up blocks: chain-rule launches that follow the reduction
         self.slot_bytes = int(max(L.lib().pc_conv3x3_wgrad_ws_bytes(32, 8), L.lib().pc_convt2x2_wgrad_ws_bytes(16)))
         self.slot = 0
 
@@ -552,8 +641,9 @@ class WgradBatch:
                 "pc_conv3x3_wgrad_partial")
         self.entries.append((ws, dw, db, nwg.value, Ca + Cb, cout, 0))
 
-    def conv3x3_group(self, problems, cout, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), a_channels=None):
-        """problems: list of dicts {a, g, dw, db, b (opt), b_offset (opt), chmap (opt)} of identical geometry -> one launch"""
+    def conv3x3_group(self, problems, cout, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0), a_channels=None, cin_total=None):
+        """problems: list of dicts {a, g, dw, db, b (opt), b_offset (opt), chmap (opt)} of identical geometry -> one launch.
+        cin_total: dw is the gradient of a wider weight [cout][cin_total][3][3] whose FIRST Ca (+ Cb) input channels these are"""
         n = len(problems)
         g0, a0 = problems[0]["g"], problems[0]["a"]
         B, Cg, H, W = g0.shape
@@ -574,7 +664,10 @@ class WgradBatch:
         L.check(L.lib().pc_conv3x3_wgrad_partial_group(n, descs, B, H, W, Ca + Cb, cout, C.byref(nwg), L.stream_ptr()),
                 "pc_conv3x3_wgrad_partial_group")
         for ws, pr in zip(slots, problems):
-            self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
+            if cin_total is None:
+                self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
+            else:
+                self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0, cin_total * 9, 0))
 
     def conv3x3_bwd_group(self, problems, cin_total, c0, accumulate=False):
         """bf16 mode: data gradient + weight-gradient partials of a conv layer (g: 8 / 16 channels, x: an 8- or 16-channel column
@@ -605,6 +698,38 @@ class WgradBatch:
         for ws, pr in zip(slots, problems):
             self.entries.append((ws, pr["dw"], pr.get("db"), nwg.value, pr["x"].shape[1], Cg, 0, cin_total * 9,
                                  (c0 + int(pr.get("c0_add", 0))) * 9))
+
+    def up_bwd_group(self, problems):
+        """Composed Up block backward, deferred form: the pass now (data gradient written, partials queued), the reduction inside
+        this batch's one reduce launch, the chain rule right after it (``finish``).  problems: as ops.conv3x3_up_bwd_group."""
+        n = len(problems)
+        g0, z0 = problems[0]["g"], problems[0]["z"]
+        B, Cg, H, W = g0.shape
+        Cz = z0.shape[1]
+        nbytes = int(L.lib().pc_conv3x3_up_bwd_ws_bytes(B, H, Cz))
+        descs = (L.PcConvUpBwdDesc * n)()
+        keep, slots = [], []
+        for i, pr in enumerate(problems):
+            sg, sz = L.src(pr["g"]), L.src(pr["z"])
+            dz = L.dst(pr["gz"]) if pr.get("gz") is not None else None
+            ws = self._slice(nbytes)
+            keep += [sg, sz, dz]
+            slots.append(ws)
+            descs[i].g, descs[i].z = C.pointer(sg), C.pointer(sz)
+            descs[i].z_bn = C.pointer(pr["z_bn"])
+            descs[i].gz = C.pointer(dz) if dz is not None else None
+            descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
+            descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
+            descs[i].fwd_ws = pr["fwd_ws"].data_ptr()
+            descs[i].ws = ws
+            descs[i].dw, descs[i].dwt = pr["dw"].data_ptr(), pr["dwt"].data_ptr()
+            descs[i].dbt = pr["dbt"].data_ptr() if pr.get("dbt") is not None else None
+        nwg, part = C.c_int(0), C.c_int(0)
+        L.check(L.lib().pc_conv3x3_up_bwd_partial_group(n, descs, B, H, W, Cz, Cz, C.byref(nwg), C.byref(part), L.stream_ptr()),
+                "pc_conv3x3_up_bwd_partial_group")
+        for ws in slots:
+            self.raw_entries.append((ws, ws + 4 * nwg.value * part.value, nwg.value, part.value))
+        self.chains.append((descs, keep, n, nwg.value, Cz, list(problems)))
 
     def level2_bwd_group(self, problems):
         """Backward of down2's DoubleConv (the 32 x 32 level) in ONE launch: problems = list of {g2 (dL/d conv2 output, masked),
@@ -678,7 +803,7 @@ class WgradBatch:
             self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Cc, Cc, 1))
 
     def finish(self):
-        n = len(self.entries)
+        n = len(self.entries) + len(self.raw_entries)
         if n == 0:
             return
         d = (L.PcWgradReduceDesc * n)()
@@ -689,6 +814,13 @@ class WgradBatch:
             d[i].dw_co_stride = ent[7] if len(ent) > 7 else 0
             d[i].db = 0 if db is None else db.data_ptr()
             d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate = nwg, cin, cout, kind, int(self.accumulate)
+        for j, (pp, tot, nwg, part) in enumerate(self.raw_entries):
+            i = len(self.entries) + j
+            d[i].partial, d[i].dw, d[i].db = pp, tot, 0
+            d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate, d[i].dw_co_stride = nwg, part, 0, 2, 0, 0
         L.check(L.lib().pc_wgrad_reduce_batch(n, d, L.stream_ptr()), "pc_wgrad_reduce_batch")
-        self.entries = []
+        for descs, keep, cn, nwg, Cz, probs in self.chains:
+            L.check(L.lib().pc_conv3x3_up_chain_group(cn, descs, int(self.accumulate), nwg, Cz, Cz, L.stream_ptr()),
+                    "pc_conv3x3_up_chain_group")
+        self.entries, self.raw_entries, self.chains = [], [], []
         self.slot = 0

@@ -84,11 +84,11 @@ def test_unet_forward_fused_level_equals_layerwise(monkeypatch):
         monkeypatch.setattr(E, "FUSED_LEVEL2", flag)
         (f_b, f_u), (_, saved) = E.forward_multi([eng_b, eng_u], X, 14, 14, 128, 128, [False, True], logit_only=[True, False])
         torch.cuda.synchronize()
-        outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("c1", "c2", "u2", "e1")} for s in ("sar_stream", "optical_stream")})
+        outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("c1", "c2", "e1")} for s in ("sar_stream", "optical_stream")})
     for a, b in ((outs[True][0], outs[False][0]), (outs[True][1], outs[False][1])):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
     for s in ("sar_stream", "optical_stream"):
-        for k in ("c1", "c2", "u2", "e1"):
+        for k in ("c1", "c2", "e1"):
             a, b = outs[True][2][s][k], outs[False][2][s][k]
             assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (s, k)
 
@@ -211,3 +211,91 @@ def test_unet_backward_fused_level_equals_layerwise(monkeypatch):
     for k in grads[True]:
         a, b = grads[True][k], grads[False][k]
         assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize("Cs,hw", [(8, (32, 64)), (16, (36, 32)), (8, (128, 128))])
+def test_conv3x3_up_fwd_group_vs_convt_then_conv(Cs, hw):
+    """pc_conv3x3_up_fwd_group (the first conv of an Up block from the LOW-resolution map: composed 2x2-neighbourhood weights per
+    output parity, transposed-conv bias through the in-image taps; no up-sampled tensor) against torch float64
+    conv3x3(cat[skip, conv_transpose2d(z)]) + BN + ReLU -- borders, corners and interior."""
+    from popcorn_amd import _lib as L
+    from popcorn_amd import ops
+    g = torch.Generator().manual_seed(31 + Cs)
+    H, W = hw
+    B, Cz, nprob = 2, Cs, 3
+    probs, refs, keep = [], [], []
+    for i in range(nprob):
+        skip = torch.randn(B, Cs, H, W, generator=g)
+        z = torch.randn(B, Cz, H // 2, W // 2, generator=g)
+        w = torch.randn(8, Cs + Cz, 3, 3, generator=g) * 0.1
+        wt = torch.randn(Cz, Cz, 2, 2, generator=g) * 0.2
+        bt = torch.randn(Cz, generator=g)
+        p = _bn(8, g)
+        u = F.conv_transpose2d(z.double(), wt.double(), bt.double(), stride=2)
+        refs.append(_ref_layer(torch.cat([skip.double(), u], 1), w, p).float())
+        dv = [t.cuda() for t in (skip, z, w, wt, bt)]
+        dp = [t.cuda() for t in p]
+        pr = {"skip": dv[0], "z": dv[1], "w": dv[2], "wt": dv[3], "bt": dv[4], "bn": L.bn(dp[0], dp[1], dp[2], dp[3], dp[4], 1e-5),
+              "out": torch.full((B, 8, H, W), float("nan"), device="cuda")}
+        assert ops.conv3x3_up_fwd_ok(pr["skip"], pr["z"], pr["out"])
+        keep.append((dv, dp))
+        probs.append(pr)
+    ops.conv3x3_up_fwd_group(probs)
+    torch.cuda.synchronize()
+    for pr, ref in zip(probs, refs):
+        got = pr["out"].cpu()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-5, err
+        # the image border separately (bias-through-taps corrections)
+        for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
+                   (slice(None), slice(None), slice(None), -1)):
+            assert (got[sl] - ref[sl]).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("Cs,hw", [(8, (128, 128)), (16, (64, 64)), (8, (64, 64))])
+def test_conv3x3_up_bwd_group_vs_autograd(Cs, hw):
+    """pc_conv3x3_up_bwd_group (backward of the up-sampled half of an Up block's first conv from the LOW-resolution map: data
+    gradient through the composed 4 x 4 stride-2 window, weight gradient of the composed weights + parity / border sums, chain
+    rule to the module's own parameters) against torch autograd (float64) of conv3x3(conv_transpose2d(z, Wt, bt), W[:, Cs:])."""
+    from popcorn_amd import _lib as L
+    from popcorn_amd import ops
+    g = torch.Generator().manual_seed(41 + Cs + hw[0])
+    H, W = hw
+    B, Cz, nprob = 2, Cs, 2
+    probs, refs, keep = [], [], []
+    fwd = []
+    for i in range(nprob):
+        z = torch.relu(torch.randn(B, Cz, H // 2, W // 2, generator=g)).double().requires_grad_(True)
+        w = (torch.randn(8, Cs + Cz, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+        wt = (torch.randn(Cz, Cz, 2, 2, generator=g) * 0.2).double().requires_grad_(True)
+        bt = torch.randn(Cz, generator=g).double().requires_grad_(True)
+        G = torch.randn(B, 8, H, W, generator=g)
+        u = F.conv_transpose2d(z, wt, bt, stride=2)
+        y = F.conv2d(u, w[:, Cs:], None, padding=1)
+        (y * G.double()).sum().backward()
+        pz = _bn(Cz, g)
+        sz = (pz[1] / torch.sqrt(pz[4] + 1e-5)).double().view(1, -1, 1, 1)
+        refs.append(((z.grad * (z.detach() > 0) * sz).float(), w.grad[:, Cs:].float(), wt.grad.float(), bt.grad.float()))
+        dz = [t.cuda() for t in pz]
+        skip = torch.randn(B, Cs, H, W, generator=g).cuda()
+        pb = _bn(8, g)
+        db = [t.cuda() for t in pb]
+        f = {"skip": skip, "z": z.detach().float().cuda(), "w": w.detach().float().cuda(), "wt": wt.detach().float().cuda(),
+             "bt": bt.detach().float().cuda(), "bn": L.bn(db[0], db[1], db[2], db[3], db[4], 1e-5), "out": torch.empty(B, 8, H, W, device="cuda")}
+        fwd.append(f)
+        keep.append((dz, db))
+        probs.append({"g": G.cuda(), "z": f["z"], "z_bn": L.bn(None, dz[1], dz[2], dz[3], dz[4], 1e-5),
+                      "gz": torch.full((B, Cz, H // 2, W // 2), float("nan"), device="cuda"), "w": f["w"], "wt": f["wt"], "bt": f["bt"],
+                      "dw": torch.full((8, Cs + Cz, 3, 3), 7.0, device="cuda"), "dwt": torch.full((Cz, Cz, 2, 2), float("nan"), device="cuda"),
+                      "dbt": torch.full((Cz,), float("nan"), device="cuda")})
+    slots = ops.conv3x3_up_fwd_group(fwd)
+    for pr, sl in zip(probs, slots):
+        pr["fwd_ws"] = sl
+        assert ops.conv3x3_up_bwd_ok(pr["g"], pr["z"], pr["gz"])
+    ops.conv3x3_up_bwd_group(probs)
+    torch.cuda.synchronize()
+    for pr, (rgz, rdw, rdwt, rdbt) in zip(probs, refs):
+        assert torch.equal(pr["dw"][:, :Cs].cpu(), torch.full((8, Cs, 3, 3), 7.0))        # the skip half is not this call's business
+        for name, got, ref in (("gz", pr["gz"], rgz), ("dw", pr["dw"][:, Cs:], rdw), ("dwt", pr["dwt"], rdwt), ("dbt", pr["dbt"], rdbt)):
+            err = (got.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+            assert err < 5e-5, (name, err)

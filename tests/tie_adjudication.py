@@ -1,0 +1,89 @@
+"""Adjudication of a gradient mismatch between the HIP path and an fp32 reference ("Gradient parity and ties").
+
+The backward pass contains discrete decisions -- the ReLU mask of every layer and the arg-max of every 2 x 2 pooling window -- and an
+activation within fp32 rounding of a tie flips one of them in one of two fp32 evaluations; the affected gradients then move by
+~1e-3 relative in ALL layers below.  A mismatch above the 2e-4 bar is accepted ONLY when it is proven to be of that kind:
+
+  1. at least one decision differs between the HIP forward and the fp32 CPU oracle, compared site by site: the ReLU masks and pooling
+     arg-maxes of the trainable U-Net (``O.TieProbe`` against the HIP forward's saved activations) and the ReLU masks of the head's
+     three hidden layers and of the final ``relu(out[:, 0])`` on the selected pixels (the head evaluated on either side's features:
+     a feature difference of a few 1e-7 is enough to move a hidden unit across zero);
+  2. ONE of the two fp32 gradient sets is the neighbour of the exact (fp64 oracle) gradients (<= 2e-4) and the other is no further
+     than one flipped decision explains (< 5e-3);
+  3. (checked by the callers) the forward results / losses agree to rounding.
+
+Used by tests/test_gpu_fuzz.py (random geometries) and by the golden-fixture gradient tests of tests/test_gpu_model.py."""
+import torch
+
+from oracle import popcorn_oracle as O
+
+
+def rel(a, r):
+    return ((a.double() - r.double()).abs().max() / max(r.abs().max().item(), 1e-3)).item()
+
+
+def hip_decision_sites(sd, x_dev, encoder_no_grad=False):
+    """Saved activations of the trainable U-Net's HIP forward (a fresh model with the given parameters), in the order the probe
+    records the oracle's: per stream the conv+BN+ReLU layers that carry gradient (encoder_no_grad: the decoder only) and the
+    inputs of the two poolings (none under encoder_no_grad)."""
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.model.popcorn import pad_geometry
+    model2 = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    model2.load_state_dict(sd)
+    H, W = x_dev.shape[2:]
+    pt, pb, pl, pr = pad_geometry(H, W, False)
+    _, saved = model2.engines()[0].forward(x_dev, pt, pl, H + pt + pb, W + pl + pr, save=True)
+    acts, pools = [], []
+    for s in ("sar_stream", "optical_stream"):
+        sv = saved[s]
+        acts += [sv[k].cpu() for k in (("e1", "e2", "f1") if encoder_no_grad else ("a1", "a2", "b1", "b2", "c1", "c2", "e1", "e2", "f1"))]
+        f0 = 0 if s == "sar_stream" else 8
+        acts.append(saved["feats"][:, f0:f0 + 8].cpu())
+        if not encoder_no_grad:
+            pools += [sv["a2"].cpu(), sv["b2"].cpu()]
+    feats = saved["feats"][:, :, pt:pt + H, pl:pl + W].cpu()
+    return acts, pools, feats
+
+
+def head_decisions(sd, feats, mask):
+    """ReLU masks of the head (popcorn.py:80-85) on the selected pixels of a cropped (B,16,H,W) feature map."""
+    import torch.nn.functional as F
+    x = feats.permute(1, 0, 2, 3).reshape(feats.shape[1], -1, 1)[:, mask.reshape(-1)]
+    out = []
+    for i in (0, 2, 4):
+        x = F.conv2d(x, sd[f"head.{i}.weight"], sd[f"head.{i}.bias"])
+        out.append(x > 0)
+        x = F.relu(x)
+    out.append(F.conv2d(x, sd["head.6.weight"], sd["head.6.bias"])[0:1] > 0)
+    return out
+
+
+def assert_tie_flip(sd, cpu_sample, x_dev, hip_grads, ref_grads, seed, worst, **flags):
+    """Raises unless the mismatch ``worst`` between ``hip_grads`` and ``ref_grads`` (both {name: cpu tensor}) is a proven
+    decision flip (see the module docstring).  ``sd``: CPU state dict; ``cpu_sample``: the oracle's inputs; ``seed``: the torch
+    seed in front of the forward (selection grid)."""
+    torch.manual_seed(seed)
+    with O.TieProbe() as probe32:
+        O.train_step_grads(sd, dict(cpu_sample), **flags)
+    acts, pools, hip_feats = hip_decision_sites(sd, x_dev, bool(flags.get("encoder_no_grad")))
+    assert len(acts) == len(probe32.acts) and len(pools) == len(probe32.pools), (len(acts), len(probe32.acts), len(pools), len(probe32.pools))
+    flips = probe32.decisions_differ(acts, pools)
+    # the head's own decisions on the selected pixels, from either side's features
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        fo = O.popcorn_forward(sd, dict(cpu_sample), padding=False, sparse=True, return_features=True)
+    H, W = x_dev.shape[2:]
+    from popcorn_amd.model.popcorn import pad_geometry
+    pt, _, pl, _ = pad_geometry(H, W, False)
+    ref_feats = fo["features"][:, :, pt:pt + H, pl:pl + W]
+    for a, b in zip(head_decisions(sd, ref_feats, fo["mask"]), head_decisions(sd, hip_feats, fo["mask"])):
+        flips += int((a != b).sum())
+    assert flips > 0, ("no differing decision between the HIP forward and the fp32 oracle: a real mismatch", worst)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    cpu64 = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_sample.items()}
+    torch.manual_seed(seed)
+    l64, _, g64, _ = O.train_step_grads(sd64, cpu64, **flags)
+    w_hip = max(rel(hip_grads[n], g64[n]) for n in g64)
+    w_ref = max(rel(ref_grads[n], g64[n]) for n in g64)
+    assert min(w_hip, w_ref) < 2e-4 and max(w_hip, w_ref) < 5e-3, (worst, flips, w_hip, w_ref)
+    return l64, flips, w_hip, w_ref

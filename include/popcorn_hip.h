@@ -152,6 +152,10 @@ typedef struct pc_conv_up_fwd_desc {
 int64_t pc_conv3x3_up_ws_bytes(int C);
 int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C);
 int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int relu, int B, int H, int W, int Cs, int C, void* stream);
+/* The composition alone, for up to 2 * PC_MAX_GROUP convolutions of any mix of the two (Cs, C) shapes in ONE launch (only w, wt, bt, ws of
+ * the descriptors are read); pc_conv3x3_up_fwd_group called with relu | PC_UP_PRECOMPOSED then takes ws as it is. */
+#define PC_UP_PRECOMPOSED 2
+int pc_conv3x3_up_compose_group(int n, const pc_conv_up_fwd_desc* d, const int* Cs, const int* C, void* stream);
 /* Backward of that up-sampled half, again without the up-sampled tensor: from g = dL/d(conv output) (8 channels, H x W, already times
  * relu' * bn scale of the conv's layer) and z, ONE pass over g produces
  *   gz (optional) = relu'(z) * z_bn scale * dL/dz                    (what pc_convt2x2_bwd_group wrote for the transposed conv's input)
@@ -175,6 +179,9 @@ int pc_conv3x3_up_bwd_group(int n, const pc_conv_up_bwd_desc* d, int accumulate,
 int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc* d, int B, int H, int W, int Cs, int C, int* nwg_out,
                                     int* part_out, void* stream);
 int pc_conv3x3_up_chain_group(int n, const pc_conv_up_bwd_desc* d, int accumulate, int nwg, int Cs, int C, void* stream);
+/* the chain rules of an (8, 8) level and a (16, 16) level in one launch */
+int pc_conv3x3_up_chain_both(int n8, const pc_conv_up_bwd_desc* d8, int nwg8, int n16, const pc_conv_up_bwd_desc* d16, int nwg16,
+                             int accumulate, void* stream);
 
 /* ---- conv3x3 data gradient (autograd of the op above w.r.t. its input).
  * g: gradient w.r.t. the conv output (already multiplied by relu-mask * bn-scale), Cg = forward Cout channels.

@@ -1520,9 +1520,10 @@ extern "C" int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Ci
 //       W[co = li & 7][Cs + c'][dy][dx] * Wt[8 stage + ci][c'][a][b]                                   (0 for lk == 3)
 //   tb[co] = {R0, R2, C0, C2, T00, T02, T20, T22, S} with T[co][dy][dx] = sum_c' W[co][Cs + c'][dy][dx] * bt[c']
 namespace {
+constexpr int COMPOSE_MAX = 2 * PC_MAX_GROUP;      // both Up levels of a forward pass in one launch
 struct ComposeArgs {
-    const float* w[PC_MAX_GROUP]; const float* wt[PC_MAX_GROUP]; const float* bt[PC_MAX_GROUP]; float* ws[PC_MAX_GROUP];
-    int Cs, C;
+    const float* w[COMPOSE_MAX]; const float* wt[COMPOSE_MAX]; const float* bt[COMPOSE_MAX]; float* ws[COMPOSE_MAX];
+    int Cs[COMPOSE_MAX], C[COMPOSE_MAX];
 };
 __device__ __forceinline__ void up_rowmap(int p, int d, int& v, int& a) {      // parity p, tap d -> low-res offset index v (0..2), sub-pixel a
     const int t = p + d - 1;
@@ -1538,7 +1539,7 @@ __global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
     const float* Wt = a.wt[blockIdx.y];
     const float* bt = a.bt[blockIdx.y];
     float* ws = a.ws[blockIdx.y];
-    const int C = a.C, Cs = a.Cs, Ct = Cs + C;
+    const int C = a.C[blockIdx.y], Cs = a.Cs[blockIdx.y], Ct = Cs + C;
     for (int e = threadIdx.x; e < 8 * C * 9; e += 256) {
         const int co = e / (C * 9), r = e - co * C * 9;
         sW[e] = W[(co * Ct + Cs) * 9 + r];                      // [co][c'][tap] of the up half
@@ -1626,11 +1627,29 @@ extern "C" int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const p
     return (out->rstride % 4 == 0) && (out->cstride % 4 == 0) && (out->bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out->ptr) & 15) == 0);
 }
 
+// composed operand images of up to 2 * PC_MAX_GROUP Up-block convolutions (any mix of (Cs, C) = (8, 8) / (16, 16)) in ONE launch:
+// d[i].ws <- compose(d[i].w, d[i].wt, d[i].bt); a following pc_conv3x3_up_fwd_group(..., relu | PC_UP_PRECOMPOSED, ...) skips its own
+extern "C" int pc_conv3x3_up_compose_group(int n, const pc_conv_up_fwd_desc* d, const int* Cs, const int* C, void* stream) {
+    if (n < 1 || n > COMPOSE_MAX || !d || !Cs || !C) return PC_EINVAL;
+    ComposeArgs ca{};
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].w || !d[i].wt || !d[i].ws || !((Cs[i] == 8 && C[i] == 8) || (Cs[i] == 16 && C[i] == 16))) return PC_EINVAL;
+        ca.w[i] = d[i].w; ca.wt[i] = d[i].wt; ca.bt[i] = d[i].bt; ca.ws[i] = (float*)d[i].ws;
+        ca.Cs[i] = Cs[i]; ca.C[i] = C[i];
+        if (C[i] > cmax) cmax = C[i];
+    }
+    hipLaunchKernelGGL(compose_up_kernel, dim3(((cmax / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, ca);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int relu, int B, int H, int W, int Cs, int C, void* stream) {
     if (n < 1 || n > MAXG || !d) return PC_EINVAL;
+    const bool precomposed = (relu & PC_UP_PRECOMPOSED) != 0;
+    relu &= 1;
     ConvArgs p{};
     ComposeArgs ca{};
-    ca.Cs = Cs; ca.C = C;
     for (int i = 0; i < n; ++i) {
         if (!d[i].skip || !d[i].z || !d[i].w || !d[i].wt || !d[i].bn || !d[i].out || !d[i].ws ||
             !pc_conv3x3_up_fwd_ok(d[i].skip, d[i].z, d[i].out, H, W, Cs, C))
@@ -1645,10 +1664,13 @@ extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int 
         q.tb = (const float*)d[i].ws + (C / 8) * 2048;
         q.fast_a = 1;
         ca.w[i] = d[i].w; ca.wt[i] = d[i].wt; ca.bt[i] = d[i].bt; ca.ws[i] = (float*)d[i].ws;
+        ca.Cs[i] = Cs; ca.C[i] = C;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(compose_up_kernel, dim3(((C / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, st, ca);
-    PC_CHECK_LAUNCH();
+    if (!precomposed) {
+        hipLaunchKernelGGL(compose_up_kernel, dim3(((C / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, st, ca);
+        PC_CHECK_LAUNCH();
+    }
     p.w_co_stride = (Cs + C) * 9;
     p.w_ci_stride = 9;
     p.relu = relu;

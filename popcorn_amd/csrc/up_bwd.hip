@@ -279,9 +279,8 @@ struct UcArgs { UcProb pr[PC_MAX_GROUP]; int Cs, C, accumulate; };
 constexpr int UC_SLICES = 8;          // blocks per problem: each rebuilds the (small) canonical table and takes every 8th output
 
 template <int C>
-__global__ __launch_bounds__(256) void up_chain_kernel(const UcArgs a) {
-    const UcProb& q = a.pr[blockIdx.x];
-    const int slice = blockIdx.y;
+__device__ __forceinline__ void up_chain_body(const UcArgs& a, int prob, int slice) {
+    const UcProb& q = a.pr[prob];
     constexpr int NACC = UbCfg<C>::NACC;
     // canonical dWeff[pY][pX][co][ci (C real + 1 "ones")][v][c3], (v, c3) in 0..2 (only the parity's 2 x 2 entries are non-zero)
     __shared__ float E[2 * 2 * 8 * (C + 1) * 9];
@@ -388,6 +387,15 @@ __global__ __launch_bounds__(256) void up_chain_kernel(const UcArgs a) {
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void up_chain_kernel(const UcArgs a) { up_chain_body<C>(a, blockIdx.x, blockIdx.y); }
+
+// both Up levels (8- and 16-channel) of a backward pass in one launch: blocks [0, n8) -> the 8-channel problems
+__global__ __launch_bounds__(256) void up_chain_both_kernel(const UcArgs a8, const UcArgs a16, int n8) {
+    if ((int)blockIdx.x < n8) up_chain_body<8>(a8, blockIdx.x, blockIdx.y);
+    else up_chain_body<16>(a16, blockIdx.x - n8, blockIdx.y);
+}
+
 bool ub_plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) {
     return p && dtype == PC_F32 && xs <= 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
 }
@@ -462,6 +470,28 @@ extern "C" int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc*
     *nwg_out = nwg;
     *part_out = C == 16 ? UbCfg<16>::PART : UbCfg<8>::PART;
     return rc;
+}
+
+// the chain rule of an 8-channel level (n8 problems) and a 16-channel level (n16 problems) in ONE launch
+extern "C" int pc_conv3x3_up_chain_both(int n8, const pc_conv_up_bwd_desc* d8, int nwg8, int n16, const pc_conv_up_bwd_desc* d16, int nwg16,
+                                        int accumulate, void* stream) {
+    if (n8 < 1 || n8 > PC_MAX_GROUP || n16 < 1 || n16 > PC_MAX_GROUP || !d8 || !d16) return PC_EINVAL;
+    UcArgs a8{}, a16{};
+    for (int i = 0; i < n8; ++i) {
+        const pc_conv_up_bwd_desc& s = d8[i];
+        if (!s.w || !s.wt || !s.ws || !s.dw || !s.dwt) return PC_EINVAL;
+        a8.pr[i] = UcProb{(const float*)s.ws + (int64_t)nwg8 * UbCfg<8>::PART, s.w, s.wt, s.bt, s.dw, s.dwt, s.dbt};
+    }
+    for (int i = 0; i < n16; ++i) {
+        const pc_conv_up_bwd_desc& s = d16[i];
+        if (!s.w || !s.wt || !s.ws || !s.dw || !s.dwt) return PC_EINVAL;
+        a16.pr[i] = UcProb{(const float*)s.ws + (int64_t)nwg16 * UbCfg<16>::PART, s.w, s.wt, s.bt, s.dw, s.dwt, s.dbt};
+    }
+    a8.Cs = 8; a8.C = 8; a8.accumulate = accumulate;
+    a16.Cs = 16; a16.C = 16; a16.accumulate = accumulate;
+    hipLaunchKernelGGL(up_chain_both_kernel, dim3(n8 + n16, UC_SLICES), dim3(256), 0, (hipStream_t)stream, a8, a16, n8);
+    PC_CHECK_LAUNCH();
+    return 0;
 }
 
 // chain rule from the reduced totals (d[i].ws + nwg * part) to dw[:, Cs:], dwt, dbt

@@ -558,12 +558,18 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or w not in (64, 128):
             return None
         ws = ops.conv3x3_up_fwd_group([{"skip": skip[k], "z": z[k], "w": ly(k, tag).w, "wt": ly(k, ttag).w, "bt": ly(k, ttag).b,
-                                        "bn": ly(k, tag).bn, "out": outs[k]} for k in keys])
+                                        "bn": ly(k, tag).bn, "out": outs[k], "ws": precomp.get((tag, k))} for k in keys])
         return outs, dict(zip(keys, ws))
 
     # with the composed first conv nobody reads the up-sampled tensors u2 / u1 -- not even the backward pass (up_bwd.hip)
     compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and W1 in (64, 128)
     compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and Wp in (64, 128)
+    precomp = {}
+    if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
+        # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)
+        lst = [("up2a", "up2t", k) for k in keys] + [("up1a", "up1t", k) for k in keys]
+        wss = ops.conv3x3_up_compose([{"w": ly(k, t).w, "wt": ly(k, tt).w, "bt": ly(k, tt).b} for t, tt, k in lst])
+        precomp = {(t, k): w_ for (t, tt, k), w_ in zip(lst, wss)}
     u2 = None
     if FUSED_LEVEL2 and L.act_dtype() == torch.float32 and pb2 and (H2, W2) == (32, 32):
         # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with

@@ -224,9 +224,29 @@ def conv3x3_up_fwd_ok(skip, z, out):
     return bool(L.lib().pc_conv3x3_up_fwd_ok(C.byref(ss), C.byref(sz), C.byref(do), H, W, Cs, z.shape[1]))
 
 
+def conv3x3_up_compose(problems):
+    """Composed operand images for a list (<= 8) of Up-block convolutions {w, wt, bt} (any mix of the 8 + 8 and 16 + 16 channel
+    shapes) in ONE launch.  Returns one workspace tensor per problem (pass it as ``ws`` to conv3x3_up_fwd_group)."""
+    n = len(problems)
+    assert 1 <= n <= 2 * L.PC_MAX_GROUP
+    dev = problems[0]["w"].device
+    descs = (L.PcConvUpFwdDesc * n)()
+    cs, cz, slots = (C.c_int * n)(), (C.c_int * n)(), []
+    for i, pr in enumerate(problems):
+        Cz = pr["wt"].shape[0]
+        cs[i], cz[i] = pr["w"].shape[1] - Cz, Cz
+        slots.append(torch.empty(int(L.lib().pc_conv3x3_up_ws_bytes(Cz)), dtype=torch.uint8, device=dev))
+        descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
+        descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
+        descs[i].ws = slots[i].data_ptr()
+    L.check(L.lib().pc_conv3x3_up_compose_group(n, descs, cs, cz, L.stream_ptr()), "pc_conv3x3_up_compose_group")
+    return slots
+
+
 def conv3x3_up_fwd_group(problems, relu=True):
     """conv3x3(cat[skip, ConvTranspose2d(z)]) + BN + ReLU without materialising the up-sampled map (networks.py:302-318):
-    problems = list (<= 4) of dicts {skip, z, w ([8][Cs + C][3][3]), wt ([C][C][2][2]), bt ([C]), bn, out}."""
+    problems = list (<= 4) of dicts {skip, z, w ([8][Cs + C][3][3]), wt ([C][C][2][2]), bt ([C]), bn, out, ws (optional: the
+    workspace conv3x3_up_compose filled for this problem)}.  Returns the workspaces (the backward pass reads them again)."""
     n = len(problems)
     assert 1 <= n <= L.PC_MAX_GROUP
     skip0, z0 = problems[0]["skip"], problems[0]["z"]
@@ -234,12 +254,13 @@ def conv3x3_up_fwd_group(problems, relu=True):
     B, Cs, H, W = skip0.shape
     Cz = z0.shape[1]
     nbytes = int(L.lib().pc_conv3x3_up_ws_bytes(Cz))
+    pre = all(pr.get("ws") is not None for pr in problems)
     keep, slots = [], []
     descs = (L.PcConvUpFwdDesc * n)()
     for i, pr in enumerate(problems):
         # composed operand images of this call (forward stages, bias table, the backward's data-gradient image): a fresh tensor
         # per problem -- the backward pass of a saved network reads it again (under graph capture it lives in the graph's pool)
-        slots.append(torch.empty(nbytes, dtype=torch.uint8, device=skip0.device))
+        slots.append(pr["ws"] if pre else torch.empty(nbytes, dtype=torch.uint8, device=skip0.device))
         ss, sz, do = L.src(pr["skip"]), L.src(pr["z"]), L.dst(pr["out"])
         keep += [ss, sz, do]
         descs[i].skip, descs[i].z, descs[i].out = C.pointer(ss), C.pointer(sz), C.pointer(do)
@@ -247,7 +268,8 @@ def conv3x3_up_fwd_group(problems, relu=True):
         descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
         descs[i].bn = C.pointer(pr["bn"])
         descs[i].ws = slots[i].data_ptr()
-    L.check(L.lib().pc_conv3x3_up_fwd_group(n, descs, int(relu), B, H, W, Cs, Cz, L.stream_ptr()), "pc_conv3x3_up_fwd_group")
+    L.check(L.lib().pc_conv3x3_up_fwd_group(n, descs, int(relu) | (2 if pre else 0), B, H, W, Cs, Cz, L.stream_ptr()),
+            "pc_conv3x3_up_fwd_group")
     return slots
 
 
@@ -819,8 +841,14 @@ class WgradBatch:
             d[i].partial, d[i].dw, d[i].db = pp, tot, 0
             d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate, d[i].dw_co_stride = nwg, part, 0, 2, 0, 0
         L.check(L.lib().pc_wgrad_reduce_batch(n, d, L.stream_ptr()), "pc_wgrad_reduce_batch")
-        for descs, keep, cn, nwg, Cz, probs in self.chains:
-            L.check(L.lib().pc_conv3x3_up_chain_group(cn, descs, int(self.accumulate), nwg, Cz, Cz, L.stream_ptr()),
-                    "pc_conv3x3_up_chain_group")
+        c8 = [c for c in self.chains if c[4] == 8]
+        c16 = [c for c in self.chains if c[4] == 16]
+        if len(c8) == 1 and len(c16) == 1 and len(self.chains) == 2:        # the two Up levels of a U-Net backward: one launch
+            L.check(L.lib().pc_conv3x3_up_chain_both(c8[0][2], c8[0][0], c8[0][3], c16[0][2], c16[0][0], c16[0][3],
+                                                     int(self.accumulate), L.stream_ptr()), "pc_conv3x3_up_chain_both")
+        else:
+            for descs, keep, cn, nwg, Cz, probs in self.chains:
+                L.check(L.lib().pc_conv3x3_up_chain_group(cn, descs, int(self.accumulate), nwg, Cz, Cz, L.stream_ptr()),
+                        "pc_conv3x3_up_chain_group")
         self.entries, self.raw_entries, self.chains = [], [], []
         self.slot = 0

@@ -307,11 +307,37 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         by = sum(nb(p["g2"]) + nb(p["c1"]) + nb(p["x"]) + nb(p["act"]) + 2 * nb(p["out"]) for p in problems)
         return 4 * 2.0 * 9 * 16 * 16 * Bn * 32 * 32 * n, by, f"level2 bwd (2 x (dgrad + wgrad) 16<->16, pool scatter) @32x32 x{n}"
 
+    def c_up_fwd(problems, relu=True):
+        # first conv of an Up block from the low-resolution map: algorithmic work = the conv over cat[skip, up-sampled] it replaces
+        # (+ the transposed conv that made the up-sampled half); compulsory bytes: skip + low-res map in, output out
+        p0 = problems[0]
+        Bn, Cs, H, W = p0["skip"].shape
+        Cz = p0["z"].shape[1]
+        n = len(problems)
+        by = sum(nb(p["skip"]) + nb(p["z"]) + nb(p["out"]) for p in problems)
+        fl = (2.0 * 9 * (Cs + Cz) * 8 * H * W + 2.0 * 4 * Cz * Cz * (H // 2) * (W // 2)) * Bn * n
+        return fl, by, f"up-conv fwd ({Cs}+{Cz}@half)->8 @{H}x{W} x{n} (conv3x3 o convT composed, no up-sampled map)"
+
+    def c_up_bwd(self, problems):
+        p0 = problems[0]
+        Bn, Cg, H, W = p0["g"].shape
+        Cz = p0["z"].shape[1]
+        n = len(problems)
+        by = sum(nb(p["g"]) + nb(p["z"]) + nb(p.get("gz")) for p in problems)
+        # data + weight gradient of the up-sampled column block (2 x 2*9*Cz*8 per px) + the transposed conv's backward (2 x 2*4*Cz*Cz per low-res px)
+        fl = (2 * 2.0 * 9 * Cz * 8 * H * W + 2 * 2.0 * 4 * Cz * Cz * (H // 2) * (W // 2)) * Bn * n
+        return fl, by, f"up-conv bwd (up-sampled half, {Cz}@half) @{H}x{W} x{n} (one pass over the gradient)"
+
+    def c_compose(problems):
+        return 0.0, 0, f"compose conv3x3 o convT weights x{len(problems)}"
+
     saved_graph = trainer.use_graph
     trainer.use_graph = False
     patches = [wrap(ops, "conv3x3_fwd_group", "conv_fwd", c_fwd), wrap(ops, "conv3x3_dgrad_group", "conv_dgrad", c_dgrad),
                wrap(ops, "level2_fwd_group", "level2_fused", c_level2),
                wrap(ops.WgradBatch, "level2_bwd_group", "level2_fused", c_level2_bwd),
+               wrap(ops, "conv3x3_up_fwd_group", "up_composed", c_up_fwd), wrap(ops.WgradBatch, "up_bwd_group", "up_composed", c_up_bwd),
+               wrap(ops, "conv3x3_up_compose", "up_composed", c_compose),
                wrap(ops.WgradBatch, "conv3x3_group", "conv_wgrad", c_wgrad_g), wrap(ops.WgradBatch, "conv3x3", "conv_wgrad", c_wgrad_1),
                wrap(ops.WgradBatch, "conv3x3_bwd_group", "conv_bwd_fused", c_bwd),
                wrap(ops, "convt2x2_group", "convt", c_convt), wrap(ops, "convt2x2_dgrad_group", "convt", c_convt_d),

@@ -6,7 +6,7 @@ tools/bf16_training_quality.py (the table in DESIGN.md section 7)."""
 import torch
 
 
-def run(steps=200, B=16, nbatches=8, lr=1e-3, wd=5e-7, use_graph=True):
+def run(steps=200, B=16, nbatches=8, lr=5e-4, wd=5e-7, use_graph=True):
     from popcorn_amd import ops
     from popcorn_amd.data import stats
     from popcorn_amd.data.synthetic import make_raw_batch
@@ -59,6 +59,9 @@ def run(steps=200, B=16, nbatches=8, lr=1e-3, wd=5e-7, use_graph=True):
            "loss_last_epoch": {p: sum(out[p]["loss"][-k:]) / k for p in out},
            "loss_last_5_epochs": {p: sum(out[p]["loss"][-5 * k:]) / (5 * k) for p in out},
            "r2_first_epoch": {p: out[p]["r2"][0] for p in out}, "r2_last_epoch": {p: out[p]["r2"][-1] for p in out},
+           "r2_last_5_epochs": {p: sum(out[p]["r2"][-5:]) / 5 for p in out},
+           "r2_median_last_10_epochs": {p: sorted(out[p]["r2"][-10:])[5] for p in out},
+           "loss_median_last_10_epochs": {p: sorted(sum(out[p]["loss"][i:i + k]) / k for i in range(steps - 10 * k, steps, k))[5] for p in out},
            "r2_trajectory": {p: [round(v, 4) for v in out[p]["r2"]] for p in out},
            "loss_trajectory_epoch_means": {p: [round(sum(out[p]["loss"][i:i + k]) / k, 5) for i in range(0, steps - k + 1, k)] for p in out},
            "param_distance_bf16_vs_fp32": d, "param_distance_fp32_moved": moved, "relative_param_distance": d / max(moved, 1e-12)}

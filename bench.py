@@ -66,6 +66,10 @@ def parse():
                     help="skip the extra objects of the line: `bf16` (config 4's precision, same process), `soak` (N = 1: one "
                          "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
     ap.add_argument("--soak-steps", type=int, default=1500)
+    ap.add_argument("--prewarm-seconds", type=float, default=3.0,
+                    help="untimed steps in front of the W warm-up steps until this much wall time has passed: the part's clocks settle "
+                         "into their sustained state only after ~3 s of load (30-step blocks right after start-up read 1.81 ms, the same "
+                         "blocks after 3 s 1.78 ms, a 1500-step block 1.77 ms); 0 = off")
     return ap.parse_args()
 
 
@@ -639,6 +643,21 @@ def main():
     model, trainer, sample, step, sd_cpu = build(args.precision)
 
     torch.manual_seed(1600 + rank)
+    prewarm_steps = 0
+    if args.prewarm_seconds > 0:
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while True:                                    # same count on every rank: the decision is rank 0's
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            prewarm_steps += 50
+            go = torch.tensor([1.0 if time.perf_counter() - t0 < args.prewarm_seconds else 0.0], device=dev)
+            if world > 1:
+                dist.broadcast(go, 0)
+            if go.item() == 0.0:
+                break
     for _ in range(max(args.warmup, 1)):
         step()
 
@@ -704,7 +723,9 @@ def main():
                        "parallelism": f"dp{world}", "graph": not args.no_graph,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "collectives": bool(trainer.reducer.active)},
-            "timing": f"median of {len(blocks)} blocks of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
+            "timing": f"median of {len(blocks)} blocks of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks; "
+                      f"{prewarm_steps} untimed steps ({args.prewarm_seconds} s) + {args.warmup} warm-up steps in front (clock settling, see --prewarm-seconds)",
+            "prewarm_steps": prewarm_steps,
             "ms_per_step_blocks": [round(b / args.steps * 1e3, 4) for b in blocks],
             "per_rank_ms_per_step": per_rank,
             "final_loss": round(loss_val, 6),

@@ -422,7 +422,7 @@ int launch_up_bwd(const UbArgs& a, int n, int nwg, hipStream_t st) {
     return 0;
 }
 
-constexpr int UB_MAX_WG = 512;       // persistent workgroups per problem (2 per CU)
+constexpr int UB_MAX_WG = 256;       // persistent workgroups per problem (2 per CU)
 
 }  // namespace
 

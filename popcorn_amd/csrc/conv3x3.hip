@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // half of a b64 read touches fall on complementary bank halves.
     constexpr bool P2 = (CONV_P2 || ZC > 0) && !N16 && CHUNK == 8;
     static_assert(ZC == 0 || (P2 && MODE == MODE_FWD && LD == LD_DIRECT && EPI == EPI_NONE && COUT == 8), "composed up-sampling stage");
-    constexpr int ZROW = 48, ZCH = 4 * ZROW;            // low-res piece: [8 ch][4 rows][48] floats (rows 16 banks apart)
-    constexpr int WZ_L = 36;                            // composed weight image: [stage][lane][32 (+4 pad)] floats
+    constexpr int ZROW = 48, ZCH = 4 * ZROW + 16;       // low-res piece: [8 ch][4 rows][48] floats; ZROW == ZCH - 2 ZROW == 16 (mod 32)
+    constexpr int WZ_L = 28;                            // composed weight image: [stage][lane][24 (+4 pad)] floats
     constexpr int LCH = P2 ? 40 : CSW;                   // floats between channels of the strip image
     constexpr int LROW = P2 ? 8 * 40 + 32 : RS;          // floats between rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -292,10 +292,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // -- the prologue used to be three dependent round trips (zero fill + barrier, weights, BN), ~4.6 us of every launch.
     float* const w2 = lds + 4 * WAVE_F;
     float* const wzimg = w2 + (N16 ? 16 * W16_S : 4 * W_DYS);          // ZC > 0: composed weights [stage][lane][WZ_L]
-    float wzreg[ZC > 0 ? NZ * 8 : 1];
+    float wzreg[ZC > 0 ? NZ * 6 : 1];
     if constexpr (ZC > 0) {
 #pragma unroll
-        for (int k = 0; k < NZ * 8; ++k) wzreg[k] = q.wz[tid + 256 * k];          // NZ * 2048 floats, coalesced
+        for (int k = 0; k < NZ * 6; ++k) wzreg[k] = q.wz[tid + 256 * k];          // NZ * 1536 floats, coalesced
     }
     constexpr int NWR = (COUT * CIN * 9 + 255) / 256;
     float wreg[NWR];
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             for (int e = tid; e < W_DYS; e += 256) w2[3 * W_DYS + e] = 0.f;
         if constexpr (ZC > 0) {
 #pragma unroll
-            for (int k = 0; k < NZ * 8; ++k) {
-                const int e = tid + 256 * k, zc = e >> 11, r = e & 2047;          // global order [stage][lane][32]
-                wzimg[zc * 64 * WZ_L + (r >> 5) * WZ_L + (r & 31)] = wzreg[k];
+            for (int k = 0; k < NZ * 6; ++k) {
+                const int e = tid + 256 * k, zc = e / 1536, r = e - zc * 1536;    // global order [stage][lane][24]
+                wzimg[zc * 64 * WZ_L + (r / 24) * WZ_L + (r % 24)] = wzreg[k];
             }
         }
 #pragma unroll
@@ -732,16 +732,20 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
             if constexpr (ZC > 0) {
                 if (!(p.dbg & 2)) {
                     // composed stage: B[k = low-res row lk][n = (s, co)] of (channel ci, column tap tj, x parity j) = register 4 ci + 2 tj + j
+                    // K-slot q = 4 m + lk (m = 0..5) = (channel q / 3, low-res row q % 3 of the pair's three): 24 (channel, row) slots in
+                    // 6 MFMAs per (column tap tj, x parity j, row pair) = 48 per stage (one K-slot per row with a 4th unused slot took 64);
+                    // the two slots a 32-lane half reads together are 16 banks apart
                     const float* wzl = wzimg + (ch - NCHUNK) * 64 * WZ_L + lane * WZ_L;
-                    const float* zl = wl + lk * ZROW + li;                  // A: (pixel pair i = li, low-res row rp + lk), column li + tj + j
-#pragma unroll 1
-                    for (int ci = 0; ci < 8; ++ci) {
-                        const f32x4 bz = *reinterpret_cast<const f32x4*>(wzl + 4 * ci);       // [2 tj + j] of this channel
+                    const float* zl = wl + li;                              // A: column li + tj + j of (channel, row) slot lk of step m
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        const int qs = 4 * m + lk, zci = qs / 3, zv_ = qs - 3 * zci;
+                        const f32x4 bz = *reinterpret_cast<const f32x4*>(wzl + 4 * m);        // [2 tj + j] of this step
                         float zv[2][3];
 #pragma unroll
                         for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
-                            for (int c3 = 0; c3 < 3; ++c3) zv[rp][c3] = zl[ci * ZCH + rp * ZROW + c3];
+                            for (int c3 = 0; c3 < 3; ++c3) zv[rp][c3] = zl[zci * ZCH + (rp + zv_) * ZROW + c3];
 #pragma unroll
                         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -846,7 +850,7 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr bool N16 = COUT == 16 && CHUNK == 8;
     constexpr bool P2 = (CONV_P2 || ZC > 0) && !N16 && CHUNK == 8;
     const size_t lds = ((size_t)4 * (P2 ? SROWS * (8 * 40 + 32) : CHUNK * CSW) + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16)) +
-                        (ZC / 8) * 64 * 36) * sizeof(float);   // wave strips + weight image (+ composed weight image)
+                        (ZC / 8) * 64 * 28) * sizeof(float);   // wave strips + weight image (+ composed weight image)
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
     if (!resident) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, ZC>);
@@ -1515,9 +1519,9 @@ extern "C" int pc_conv3x3_dgrad_group(int n, const pc_conv_dgrad_desc* d, int Ci
 // Up block without the up-sampled map:  conv3x3(cat[skip, ConvTranspose2d(z)]) = conv3x3(skip; W[:, :Cs]) + a parity-dependent
 // 2 x 2-neighbourhood map of z + the transposed conv's bias through the taps (networks.py:302-318).
 // compose_up_kernel builds, once per call (the weights change every step):
-//   wz[stage][lane = 16 lk + li][4 ci + 2 tj + j] = sum over c' and the taps (dy, dx) that land on (low-res row offset v = lk - 1,
-//       sub-row a) / (column offset tj + j - 1, sub-column b) for output parity (pY = li >> 3, pX = j):
-//       W[co = li & 7][Cs + c'][dy][dx] * Wt[8 stage + ci][c'][a][b]                                   (0 for lk == 3)
+//   wz[stage][lane = 16 lk + li][4 m + 2 tj + j], K-slot q = 4 m + lk = (channel ci = q / 3, low-res row offset index v = q % 3):
+//       sum over c' and the taps (dy, dx) that land on (v, sub-row a) / (column offset tj + j - 1, sub-column b) for output parity
+//       (pY = li >> 3, pX = j) of  W[co = li & 7][Cs + c'][dy][dx] * Wt[8 stage + ci][c'][a][b]
 //   tb[co] = {R0, R2, C0, C2, T00, T02, T20, T22, S} with T[co][dy][dx] = sum_c' W[co][Cs + c'][dy][dx] * bt[c']
 namespace {
 constexpr int COMPOSE_MAX = 2 * PC_MAX_GROUP;      // both Up levels of a forward pass in one launch
@@ -1547,7 +1551,7 @@ __global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
     for (int e = threadIdx.x; e < C * C * 4; e += 256) sT[e] = Wt[e];
     if (threadIdx.x < C) sB[threadIdx.x] = bt ? bt[threadIdx.x] : 0.f;
     __syncthreads();
-    const int nwz = (C / 8) * 2048;
+    const int nwz = (C / 8) * 1536;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nwz + 72 + 2048; e += gridDim.x * 256) {
         if (e >= nwz + 72) {
             // operand image of the BACKWARD data gradient (up_bwd.hip): wd[(4 (4 co + r) + c) * 16 + ci] = Kd[co][ci][r][c], the weight
@@ -1571,21 +1575,20 @@ __global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
             }
             ws[e] = acc;
         } else if (e < nwz) {
-            const int stage = e >> 11, r = e & 2047, lane = r >> 5, qq = r & 31;
+            const int stage = e / 1536, r = e - stage * 1536, lane = r / 24, qq = r - lane * 24;
             const int lk = lane >> 4, li = lane & 15, pY = li >> 3, co = li & 7;
-            const int ci = stage * 8 + (qq >> 2), tj = (qq >> 1) & 1, j = qq & 1;
+            const int m = qq >> 2, tj = (qq >> 1) & 1, j = qq & 1;
+            const int qs = 4 * m + lk, ci = stage * 8 + qs / 3, vrow = qs % 3;
             float acc = 0.f;
-            if (lk < 3) {
-                for (int dy = 0; dy < 3; ++dy) {
-                    int v, sa;
-                    up_rowmap(pY, dy, v, sa);
-                    if (v != lk) continue;
-                    for (int dx = 0; dx < 3; ++dx) {
-                        int c3, sb;
-                        up_rowmap(j, dx, c3, sb);
-                        if (c3 != tj + j) continue;
-                        for (int c = 0; c < C; ++c) acc += sW[(co * C + c) * 9 + dy * 3 + dx] * sT[((ci * C + c) * 2 + sa) * 2 + sb];
-                    }
+            for (int dy = 0; dy < 3; ++dy) {
+                int v, sa;
+                up_rowmap(pY, dy, v, sa);
+                if (v != vrow) continue;
+                for (int dx = 0; dx < 3; ++dx) {
+                    int c3, sb;
+                    up_rowmap(j, dx, c3, sb);
+                    if (c3 != tj + j) continue;
+                    for (int c = 0; c < C; ++c) acc += sW[(co * C + c) * 9 + dy * 3 + dx] * sT[((ci * C + c) * 2 + sa) * 2 + sb];
                 }
             }
             ws[e] = acc;
@@ -1616,7 +1619,7 @@ __global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
 }
 }  // namespace
 
-extern "C" int64_t pc_conv3x3_up_ws_bytes(int C) { return (int64_t)((C / 8) * 2048 + 72 + 2048) * sizeof(float); }
+extern "C" int64_t pc_conv3x3_up_ws_bytes(int C) { return (int64_t)((C / 8) * 1536 + 72 + 2048) * sizeof(float); }
 
 extern "C" int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C) {
     if (g_pc_precision != PC_PREC_FP32 || !skip || !z || !out) return 0;
@@ -1639,7 +1642,7 @@ extern "C" int pc_conv3x3_up_compose_group(int n, const pc_conv_up_fwd_desc* d, 
         ca.Cs[i] = Cs[i]; ca.C[i] = C[i];
         if (C[i] > cmax) cmax = C[i];
     }
-    hipLaunchKernelGGL(compose_up_kernel, dim3(((cmax / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, ca);
+    hipLaunchKernelGGL(compose_up_kernel, dim3(((cmax / 8) * 1536 + 72 + 2048 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, ca);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -1661,14 +1664,14 @@ extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int 
         q.out = *d[i].out;
         q.z = d[i].z->ptr; q.z_bs = d[i].z->bstride; q.z_cs = d[i].z->cstride; q.z_rs = d[i].z->rstride;
         q.wz = (const float*)d[i].ws;
-        q.tb = (const float*)d[i].ws + (C / 8) * 2048;
+        q.tb = (const float*)d[i].ws + (C / 8) * 1536;
         q.fast_a = 1;
         ca.w[i] = d[i].w; ca.wt[i] = d[i].wt; ca.bt[i] = d[i].bt; ca.ws[i] = (float*)d[i].ws;
         ca.Cs[i] = Cs; ca.C[i] = C;
     }
     hipStream_t st = (hipStream_t)stream;
     if (!precomposed) {
-        hipLaunchKernelGGL(compose_up_kernel, dim3(((C / 8) * 2048 + 72 + 2048 + 255) / 256, n), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(compose_up_kernel, dim3(((C / 8) * 1536 + 72 + 2048 + 255) / 256, n), dim3(256), 0, st, ca);
         PC_CHECK_LAUNCH();
     }
     p.w_co_stride = (Cs + C) * 9;

@@ -461,7 +461,7 @@ extern "C" int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc*
         p.z_bn = *s.z_bn;
         p.gz = nullptr; p.gz_bs = p.gz_cs = 0; p.gz_rs = 0;
         if (s.gz) { p.gz = s.gz->ptr; p.gz_bs = s.gz->bstride; p.gz_cs = s.gz->cstride; p.gz_rs = s.gz->rstride; }
-        p.wd = (const float*)s.fwd_ws + (C / 8) * 2048 + 72;
+        p.wd = (const float*)s.fwd_ws + (C / 8) * 1536 + 72;
         p.part = (float*)s.ws;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -531,7 +531,7 @@ extern "C" int pc_conv3x3_up_bwd_group(int n, const pc_conv_up_bwd_desc* d, int 
         p.z_bn = *s.z_bn;
         p.gz = nullptr; p.gz_bs = p.gz_cs = 0; p.gz_rs = 0;
         if (s.gz) { p.gz = s.gz->ptr; p.gz_bs = s.gz->bstride; p.gz_cs = s.gz->cstride; p.gz_rs = s.gz->rstride; }
-        p.wd = (const float*)s.fwd_ws + (C / 8) * 2048 + 72;        // the data-gradient operand image written by compose_up_kernel
+        p.wd = (const float*)s.fwd_ws + (C / 8) * 1536 + 72;        // the data-gradient operand image written by compose_up_kernel
         p.part = (float*)s.ws;
         ur.part[i] = p.part;
         ur.total[i] = p.part + (int64_t)nwg * PART;

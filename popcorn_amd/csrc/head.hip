@@ -309,7 +309,7 @@ struct HeadBwdArgs {
     pc_dst g_feat;
     pc_bn fbn[2];                // BN of the layers that produced feat channels 0-7 / 8-15 (fuse_feat_bn)
     int fuse_feat_bn;            // 1: g_feat *= (feat > 0) * bn_scale  (ReLU + frozen-BN backward of those layers)
-    int dbg;                     // ablation (tools/ablate_head.py): 1 consumer idle, 2 no hand-off, 4 no per-group global loads
+    int dbg;                     // ablation (tools/ablate_head.py): 1 consumer idle, 2 no hand-off
     float* partial;              // [nwg][PE_TOTAL]
     int total_groups;
     int Hp, Wp;                  // extent of the padded feature / gradient maps
@@ -339,6 +339,43 @@ __device__ __forceinline__ void head_dgrad64(const float* lds, int t_off, int la
             for (int mi = 0; mi < 4; ++mi)
                 out[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi][r], g[mb][r], out[mi], 0, 0, 0);
     }
+}
+
+// The same two contractions for the producer waves of head_bwd_pc_kernel, software-pipelined by hand: with ONE wave of that role
+// per SIMD nothing hides an LDS round trip, and hipcc sinks the fragment reads to just in front of their first use (a
+// lgkmcnt wait of ~150 cycles per 16 MFMAs) and re-serialises the 4 accumulator chains in places (a dependent MFMA issues
+// 40 cycles after its predecessor, not 32).  Here the fragments of K-block mb+1 are in flight during the 16 MFMAs of block
+// mb, and a scheduling barrier per K-step pins the 4-way accumulator interleave.
+__device__ __forceinline__ void head_mm64_pf(const float* lds, int off, int lane, const f32x4 (&in)[4], f32x4 (&acc)[4]) {
+    f32x4 a4[2][4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) a4[0][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + 0) * 64 + lane) * 4]);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        if (mb < 3) {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+                a4[(mb + 1) & 1][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + mb + 1) * 64 + lane) * 4]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+                acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb & 1][mo][r], in[mb][r], acc[mo], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+__device__ __forceinline__ void head_layer64_pf(const float* lds, int a_off, int b_off, int lane, int lk,
+                                                const f32x4 (&h)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
+    head_mm64_pf(lds, a_off, lane, h, acc);
+}
+__device__ __forceinline__ void head_dgrad64_pf(const float* lds, int t_off, int lane, const f32x4 (&g)[4], f32x4 (&out)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) out[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    head_mm64_pf(lds, t_off, lane, g, out);
 }
 
 // scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a [64][SCR_LD] matrix whose columns are
@@ -582,6 +619,23 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
     }
 }
 
+// Phase profile of the producer waves (debug builds only: make CXXFLAGS+=-DPOPCORN_HEAD_PROF; tools/ablate_head.py prints it)
+#ifdef POPCORN_HEAD_PROF
+__device__ long long g_head_prof[256 * 16];
+#define HP_DECL long long hp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long hp_t = 0, hp_a = 0; int hp_last = -1
+#define HP_ACQ0 hp_a = (long long)__builtin_readcyclecounter()
+#define HP_ACQ1 hp_acc[9] += (long long)__builtin_readcyclecounter() - hp_a
+#define HP_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)__builtin_readcyclecounter(); \
+                        if (hp_last >= 0) hp_acc[hp_last] += t_ - hp_t; hp_t = t_; hp_last = (k); } while (0)
+#define HP_DUMP do { HP_MARK(8); if (wave == 0 && lane == 0) for (int k_ = 0; k_ < 10; ++k_) g_head_prof[blockIdx.x * 16 + k_] = hp_acc[k_]; } while (0)
+#else
+#define HP_DECL
+#define HP_ACQ0
+#define HP_ACQ1
+#define HP_MARK(k)
+#define HP_DUMP
+#endif
+
 // ---- head backward, producer / consumer form ----------------------------------------------------------------------
 // The single-role kernel above needs 209 accumulator registers per wave for the three weight-gradient GEMMs, which
 // pins it at ONE wave per SIMD: every global-load, LDS round trip and VALU stretch of that wave idles the matrix pipe
@@ -614,9 +668,12 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
     __syncthreads();
 
     float* ring = lds + LP_RING + pair * PC_NSLOT * PC_SLOT;
-    volatile int* prod_p = flags + pair * 4 + 0;
-    volatile int* cons_p = flags + pair * 4 + 1;
-    volatile int* done_p = flags + pair * 4 + 2;
+    // LDS-address-space pointers: through a generic `volatile int*` the polls and counter updates become FLAT instructions, whose
+    // completion is waited for with vmcnt(0) -- i.e. behind every global load and store the wave has in flight
+    typedef __attribute__((address_space(3))) volatile int lds_flag;
+    lds_flag* prod_p = (lds_flag*)(flags + pair * 4 + 0);
+    lds_flag* cons_p = (lds_flag*)(flags + pair * 4 + 1);
+    lds_flag* done_p = (lds_flag*)(flags + pair * 4 + 2);
     float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
 
     // Role-private accumulators: declared here (they feed the common reduction below) but initialised ONLY inside the
@@ -645,13 +702,16 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             }
         }
         int nprod = 0;
+        HP_DECL;
         auto acquire = [&]() -> float* {
+            HP_ACQ0;
             while (true) {
                 const int c = __builtin_amdgcn_readfirstlane(*cons_p);
                 if (nprod - c < PC_NSLOT) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             asm volatile("" ::: "memory");
+            HP_ACQ1;
             return ring + (nprod % PC_NSLOT) * PC_SLOT;
         };
         auto release = [&]() {
@@ -660,68 +720,104 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             if (lane == 0) *prod_p = nprod;
         };
         const int cperm = (li & 3) * 4 + (li >> 2);
-        // per-group inputs are fetched one group ahead (raw loads only; everything derived is recomputed)
-        float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
-        unsigned n_msk = 1;
+        // Per-group inputs are fetched one group ahead (raw loads only).  The group index is wave-uniform, so the sample index and
+        // everything per sample live in scalar registers; optional inputs get a valid dummy address (the building map) and a
+        // select instead of a branch around their load, and the last iteration prefetches a clamped (valid) group: the loop top is
+        // straight-line code -- written with a branch per optional load and the (b, y, x) arithmetic done twice it cost ~2,300
+        // cycles of a ~15,000-cycle group with the matrix pipe idle.
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        int vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+        const bool has_msk = p.mask != nullptr, has_adm = p.admin != nullptr, has_gpc = a.g_popcount != nullptr;
+        const bool has_gpd = a.g_popdense != nullptr, has_gsm = a.g_scale_map != nullptr, has_fbn = a.fuse_feat_bn != 0;
+        const uint8_t* msk_p = has_msk ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
+        const float* adm_p = has_adm ? p.admin : p.building;
+        const float* gpd_p = has_gpd ? a.g_popdense : p.building;
+        const float* gsm_p = has_gsm ? a.g_scale_map : p.building;
+        const unsigned fcs = (unsigned)p.feat.cstride, gcs = (unsigned)a.g_feat.cstride;
+        float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
+        long long n_cen = 0;          // raw: the int64 -> float conversion at the point of USE (inside fetch it is a wait for the loads just issued)
+        unsigned n_msk = 1, n_go = 0;
+        bool n_valid = false;
+        int n_b = 0;
         auto fetch = [&](int gg) {
             const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
             const int q = g * 16 + li;
-            const bool valid = q < HW;
-            const int64_t pix = (int64_t)b * HW + (valid ? q : 0);
-            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-            const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+            n_valid = q < HW;
+            n_b = b;
+            const unsigned qq = n_valid ? (unsigned)q : 0u;
+            const unsigned y = pc_div(qq, p.div_w), x = qq - y * (unsigned)p.W;
+            const float* fb = p.feat.ptr + b * p.feat.bstride;
+            const unsigned fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
+            n_go = (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                n_xv[j] = (a.dbg & 4) ? 0.01f * (float)(lane + j) : fp[(4 * j + lk) * p.feat.cstride];
-                n_fv[j] = ((a.dbg & 4) || !a.fuse_feat_bn) ? 1.f : fp[(4 * lk + j) * p.feat.cstride];
+                n_xv[j] = fb[fo + (unsigned)(4 * j + lk) * fcs];
+                n_fv[j] = fb[fo + (unsigned)(4 * lk + j) * fcs];        // (only used with fuse_feat_bn; the same cache lines as n_xv)
             }
-            if (!(a.dbg & 4)) {
-                n_msk = p.mask ? p.mask[pix] : 1;
-                n_bld = p.building[pix];
-                if (p.admin) n_adm = p.admin[pix];
-                if (a.g_popdense) n_gpd = a.g_popdense[pix];
-                if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
-            }
+            const int64_t pb = (int64_t)b * HW;
+            n_msk = msk_p[pb + qq];
+            n_bld = p.building[pb + qq];
+            n_adm = adm_p[pb + qq];
+            n_gpd = gpd_p[pb + qq];
+            n_gsm = gsm_p[pb + qq];
+            // the two per-sample scalars as well: read at their point of use they were two DEPENDENT, fully exposed memory
+            // round trips at the top of every group
+            // (indexed with an opaque per-lane zero: a provably uniform load result is moved to scalar registers by the compiler
+            // with v_readfirstlane RIGHT HERE, behind a vmcnt(0) wait for everything the prefetch has just issued)
+            if (has_adm) n_cen = p.census[b + vzero];
+            if (has_gpc) n_gpc = a.g_popcount[b + vzero];
         };
+        float pend_o[4] = {0.f, 0.f, 0.f, 0.f};
+        float* pend_p = nullptr;
         const int gstep = gridDim.x * 4;
-        int gg = blockIdx.x * 4 + wave;
+        int gg = blockIdx.x * 4 + wv;
         if (gg < a.total_groups) fetch(gg);
         for (; gg < a.total_groups; gg += gstep) {
-            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
-            const int q = g * 16 + li;
-            const bool valid = q < HW;
-            const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
-            const bool sel = valid && n_msk != 0;
+            const bool valid = n_valid;
+            const bool sel = valid && (!has_msk || n_msk != 0);
+            float* const gp = a.g_feat.ptr + n_b * a.g_feat.bstride + n_go;       // this lane's pixel of the gradient map, channel 0
             float xv[4], fvv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = valid ? n_fv[j] : 1.f; }
+            for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = (valid && has_fbn) ? n_fv[j] : 1.f; }
             float gup = 0.f;
-            if (a.dbg & 4) gup = 1.f;
-            else if (sel) {
-                const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
-                gup = gsc;
-                if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
-                if (a.g_popdense) gup += n_gpd * n_bld;
-                if (a.g_scale_map) gup += n_gsm;
+            {
+                const bool region = !has_adm || n_adm == (float)n_cen;
+                float u = gsc;
+                u += (has_gpc && region) ? n_gpc * n_bld : 0.f;
+                u += has_gpd ? n_gpd * n_bld : 0.f;
+                u += has_gsm ? n_gsm : 0.f;
+                gup = sel ? u : 0.f;
             }
-            if (gg + gstep < a.total_groups) fetch(gg + gstep);       // in flight during this group's MFMA chain
+            {   // the next group's inputs: in flight during this group's MFMA chain
+                const int gn = gg + gstep;
+                fetch(gn < a.total_groups ? gn : a.total_groups - 1);
+            }
+            // the previous group's gradient goes out HERE, behind the prefetch: stored at the end of its own iteration it
+            // sat in front of the next iteration's wait for the prefetched inputs (vmcnt counts loads and stores in one queue)
+            if (pend_p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
+                pend_p = nullptr;
+            }
             // g_feat is written exactly once per element by this kernel (no zero-fill pass in front of it): crop pixels
             // by the producer that owns their group -- zeros when the group is skipped --, the border by the consumers
             auto store_zero = [&]() {
                 if (a.zero_in_kernel && valid) {
-                    float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) op[(4 * lk + r) * a.g_feat.cstride] = 0.f;
+                    for (int r = 0; r < 4; ++r) gp[(unsigned)(4 * lk + r) * gcs] = 0.f;
                 }
             };
             if (!__any(sel)) { store_zero(); continue; }
+            HP_MARK(0);
             f32x4 h1[4], h2[4], h3[4];
             head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
             relu4(h1);
-            head_layer64(lds, LB_A2, LB_B2, lane, lk, h1, h2);
+            head_layer64_pf(lds, LB_A2, LB_B2, lane, lk, h1, h2);
             relu4(h2);
-            head_layer64(lds, LB_A3, LB_B4, lane, lk, h2, h3);
+            head_layer64_pf(lds, LB_A3, LB_B4, lane, lk, h2, h3);
             relu4(h3);
+            HP_MARK(1);
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -746,28 +842,33 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                     g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
                 }
             }
+            HP_MARK(2);
             if (!(a.dbg & 2)) {   // slot kind 0: (G3, H2) -> dW4, db4
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g3);
                 head_store_mat(sl + 64 * SCR_LD, li, lk, h2);
                 release();
             }
-            head_dgrad64(lds, LB_T3, lane, g3, g2);
+            HP_MARK(3);
+            head_dgrad64_pf(lds, LB_T3, lane, g3, g2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+            HP_MARK(4);
             if (!(a.dbg & 2)) {   // slot kind 1: (G2, H1) -> dW2, db2
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g2);
                 head_store_mat(sl + 64 * SCR_LD, li, lk, h1);
                 release();
             }
-            head_dgrad64(lds, LB_T2, lane, g2, g1);
+            HP_MARK(5);
+            head_dgrad64_pf(lds, LB_T2, lane, g2, g1);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+            HP_MARK(6);
             if (!(a.dbg & 2)) {   // slot kind 2: (G1, X) -> dW0, db0
                 float* sl = acquire();
                 head_store_mat(sl, li, lk, g1);
@@ -775,6 +876,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 for (int j = 0; j < 4; ++j) sl[64 * SCR_LD + (4 * j + lk) * SCR_LD + cperm] = xv[j];
                 release();
             }
+            HP_MARK(7);
             f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA dependent latency
 #pragma unroll                                                                       // (40 cyc) exceeds the issue interval (32)
             for (int mb = 0; mb < 4; mb += 2) {
@@ -789,15 +891,20 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
             if (valid) {
-                float* op = a.g_feat.ptr + b * a.g_feat.bstride + (int64_t)(p.py + y) * a.g_feat.rstride + p.px + x;
+                pend_p = gp;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float o = gx[r];
                     if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                    op[(4 * lk + r) * a.g_feat.cstride] = o;
+                    pend_o[r] = o;
                 }
             }
         }
+        if (pend_p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
+        }
+        HP_DUMP;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) *done_p = 1;
     } else {
@@ -2270,6 +2377,19 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         hipLaunchKernelGGL(head_bwd_bf16_coop4_kernel, dim3(nwg), dim3(256), H4_END, st, a);
     }
     else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+#ifdef POPCORN_HEAD_PROF
+    if (use_pc && !p.bf && getenv("POPCORN_HEAD_PROF")) {
+        static long long hp[256 * 16];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_head_prof), sizeof(hp));
+        double tot[10] = {0};
+        for (int w = 0; w < nwg; ++w) for (int k = 0; k < 10; ++k) tot[k] += (double)hp[w * 16 + k];
+        const double ngr = (double)a.total_groups / (nwg * 4);
+        fprintf(stderr, "head_bwd_pc producer phases, cycles per group (fwd, out+g3, slot0, dgrad3, slot1, dgrad2, slot2, gx+store, loop top; of which ring waits):");
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %.0f", tot[k] / nwg / ngr);
+        fprintf(stderr, "\n");
+    }
+#endif
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
     HeadReduceArgs r{};

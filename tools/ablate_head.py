@@ -1,5 +1,5 @@
 """Ablation of the producer/consumer head-backward kernel (B=64, 100x100, all pixels selected).  GPU only.
-POPCORN_HEAD_DBG bits: 1 consumer idle, 2 no hand-off (producer never touches the ring), 4 no per-group global loads."""
+POPCORN_HEAD_DBG bits: 1 consumer idle, 2 no hand-off (producer never touches the ring)."""
 import os, subprocess, sys
 code = r'''
 import sys, os
@@ -27,8 +27,11 @@ e1.record(); torch.cuda.synchronize()
 print("%.1f us" % (e0.elapsed_time(e1) * 100))
 '''
 for tag, env in [("pc full", {}), ("single-role", {"POPCORN_HEAD_BWD_SINGLE_ROLE": "1"}), ("consumer idle", {"POPCORN_HEAD_DBG": "1"}),
-                 ("no hand-off", {"POPCORN_HEAD_DBG": "2"}), ("no loads", {"POPCORN_HEAD_DBG": "4"}),
-                 ("no hand-off, no loads", {"POPCORN_HEAD_DBG": "6"})]:
+                 ("no hand-off", {"POPCORN_HEAD_DBG": "2"})]:
     e = dict(os.environ); e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
+    if "--phases" in sys.argv:       # profiling build (tools/head_phases.sh): the last launch's producer phase cycles
+        ph = [l for l in out.stderr.splitlines() if "producer phases" in l]
+        print(f"{tag:24s}", ph[-1].split("):")[-1] if ph else out.stderr[-300:])
+        continue
     print(f"{tag:24s}", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])

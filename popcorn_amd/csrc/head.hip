@@ -346,36 +346,69 @@ __device__ __forceinline__ void head_dgrad64(const float* lds, int t_off, int la
 // lgkmcnt wait of ~150 cycles per 16 MFMAs) and re-serialises the 4 accumulator chains in places (a dependent MFMA issues
 // 40 cycles after its predecessor, not 32).  Here the fragments of K-block mb+1 are in flight during the 16 MFMAs of block
 // mb, and a scheduling barrier per K-step pins the 4-way accumulator interleave.
-__device__ __forceinline__ void head_mm64_pf(const float* lds, int off, int lane, const f32x4 (&in)[4], f32x4 (&acc)[4]) {
+// hook(step), step = 0..15: called after the 4 MFMAs of every K-step, in front of its scheduling barrier -- the caller's slice of
+// non-matrix work (a piece of a ring-slot write, of the next group's prefetch) that is to execute in the shadow of those MFMAs.
+// pre: the fragments of K-block 0, read by the caller one phase earlier; nx (out): the block-0 fragments of the NEXT contraction
+// (at nx_off, nx_stride K-blocks between its output blocks), read during this one's last block -- no contraction starts with an
+// exposed LDS round trip.
+template <class Hook>
+__device__ __forceinline__ void head_mm64_pf(const float* lds, int off, int lane, const f32x4 (&in)[4], f32x4 (&acc)[4],
+                                             const f32x4 (&pre)[4], int nx_off, int nx_stride, f32x4 (&nx)[4], Hook&& hook) {
     f32x4 a4[2][4];
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo) a4[0][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + 0) * 64 + lane) * 4]);
+    for (int mo = 0; mo < 4; ++mo) a4[0][mo] = pre[mo];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         if (mb < 3) {
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo)
                 a4[(mb + 1) & 1][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + mb + 1) * 64 + lane) * 4]);
+        } else {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) nx[mo] = *reinterpret_cast<const f32x4*>(&lds[nx_off + (mo * nx_stride * 64 + lane) * 4]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo)
                 acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb & 1][mo][r], in[mb][r], acc[mo], 0, 0, 0);
+            hook(mb * 4 + r);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
-__device__ __forceinline__ void head_layer64_pf(const float* lds, int a_off, int b_off, int lane, int lk,
-                                                const f32x4 (&h)[4], f32x4 (&acc)[4]) {
+__device__ __forceinline__ void head_frag0(const float* lds, int off, int stride, int lane, f32x4 (&f)[4]) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) f[mo] = *reinterpret_cast<const f32x4*>(&lds[off + (mo * stride * 64 + lane) * 4]);
+}
+// ReLU in ONE instruction (fmaxf on a value the compiler cannot prove canonical costs a canonicalising v_max x, x in front)
+__device__ __forceinline__ void relu_block(f32x4& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+}
+__device__ __forceinline__ void mask_block(f32x4& g, const f32x4& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = h[r] > 0.f ? g[r] : 0.f;
+}
+// first layer with the four output blocks interleaved (head_layer1 issues the 4 K-steps of a block back to back: dependent)
+__device__ __forceinline__ void head_layer1_il(const float* lds, int a_off, int b_off, int lane, int lk, const float (&xv)[4],
+                                               f32x4 (&h)[4]) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        h[mb] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb + 4 * lk]);
+        a4[mb] = *reinterpret_cast<const f32x4*>(&lds[a_off + (mb * 64 + lane) * 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb][j], xv[j], h[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void head_bias4(const float* lds, int b_off, int lk, f32x4 (&acc)[4]) {
 #pragma unroll
     for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
-    head_mm64_pf(lds, a_off, lane, h, acc);
-}
-__device__ __forceinline__ void head_dgrad64_pf(const float* lds, int t_off, int lane, const f32x4 (&g)[4], f32x4 (&out)[4]) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) out[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    head_mm64_pf(lds, t_off, lane, g, out);
 }
 
 // scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a [64][SCR_LD] matrix whose columns are
@@ -703,12 +736,16 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         }
         int nprod = 0;
         HP_DECL;
-        auto acquire = [&]() -> float* {
+        // c_early: the consumer's counter as read one phase earlier (it only grows: a stale value is merely conservative) -- the
+        // LDS round trip of the poll is then hidden behind that phase instead of sitting in front of every slot
+        auto acquire = [&](int c_early) -> float* {
             HP_ACQ0;
-            while (true) {
-                const int c = __builtin_amdgcn_readfirstlane(*cons_p);
-                if (nprod - c < PC_NSLOT) break;
-                __builtin_amdgcn_s_sleep(2);
+            if (nprod - __builtin_amdgcn_readfirstlane(c_early) >= PC_NSLOT) {
+                while (true) {
+                    const int c = __builtin_amdgcn_readfirstlane(*cons_p);
+                    if (nprod - c < PC_NSLOT) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
             asm volatile("" ::: "memory");
             HP_ACQ1;
@@ -740,37 +777,66 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         unsigned n_msk = 1, n_go = 0;
         bool n_valid = false;
         int n_b = 0;
-        auto fetch = [&](int gg) {
-            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
-            const int q = g * 16 + li;
-            n_valid = q < HW;
-            n_b = b;
-            const unsigned qq = n_valid ? (unsigned)q : 0u;
-            const unsigned y = pc_div(qq, p.div_w), x = qq - y * (unsigned)p.W;
-            const float* fb = p.feat.ptr + b * p.feat.bstride;
-            const unsigned fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
-            n_go = (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                n_xv[j] = fb[fo + (unsigned)(4 * j + lk) * fcs];
-                n_fv[j] = fb[fo + (unsigned)(4 * lk + j) * fcs];        // (only used with fuse_feat_bn; the same cache lines as n_xv)
-            }
-            const int64_t pb = (int64_t)b * HW;
-            n_msk = msk_p[pb + qq];
-            n_bld = p.building[pb + qq];
-            n_adm = adm_p[pb + qq];
-            n_gpd = gpd_p[pb + qq];
-            n_gsm = gsm_p[pb + qq];
-            // the two per-sample scalars as well: read at their point of use they were two DEPENDENT, fully exposed memory
-            // round trips at the top of every group
-            // (indexed with an opaque per-lane zero: a provably uniform load result is moved to scalar registers by the compiler
-            // with v_readfirstlane RIGHT HERE, behind a vmcnt(0) wait for everything the prefetch has just issued)
-            if (has_adm) n_cen = p.census[b + vzero];
-            if (has_gpc) n_gpc = a.g_popcount[b + vzero];
-        };
+        // The prefetch in five stages: inside the group loop they run one per K-step in the shadow of the second layer's MFMAs
+        // (head_mm64_pf's hook); stage 4 also sends the PREVIOUS group's gradient out -- behind the loads: stored at the end of its
+        // own iteration it sat in front of the next iteration's wait for the prefetched inputs (vmcnt counts loads and stores in one
+        // queue).
         float pend_o[4] = {0.f, 0.f, 0.f, 0.f};
         float* pend_p = nullptr;
+        const float* f_fb = nullptr;
+        unsigned f_fo = 0, f_qq = 0;
+        int64_t f_pb = 0;
+        int f_b = 0;
+        auto fetch_stage = [&](int st, int gg) {
+            if (st == 0) {
+                const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+                const int q = g * 16 + li;
+                n_valid = q < HW;
+                n_b = f_b = b;
+                f_qq = n_valid ? (unsigned)q : 0u;
+                const unsigned y = pc_div(f_qq, p.div_w), x = f_qq - y * (unsigned)p.W;
+                f_fb = p.feat.ptr + b * p.feat.bstride;
+                f_fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
+                n_go = (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
+                f_pb = (int64_t)b * HW;
+            } else if (st == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n_xv[j] = f_fb[f_fo + (unsigned)(4 * j + lk) * fcs];
+            } else if (st == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n_fv[j] = f_fb[f_fo + (unsigned)(4 * lk + j) * fcs];   // (only used with fuse_feat_bn; n_xv's cache lines)
+            } else if (st == 3) {
+                n_msk = msk_p[f_pb + f_qq];
+                n_bld = p.building[f_pb + f_qq];
+                n_adm = adm_p[f_pb + f_qq];
+                n_gpd = gpd_p[f_pb + f_qq];
+                n_gsm = gsm_p[f_pb + f_qq];
+            } else if (st == 4) {
+                // the two per-sample scalars as well: read at their point of use they were two DEPENDENT, fully exposed memory
+                // round trips at the top of every group
+                // (indexed with an opaque per-lane zero: a provably uniform load result is moved to scalar registers by the compiler
+                // with v_readfirstlane RIGHT HERE, behind a vmcnt(0) wait for everything the prefetch has just issued)
+                if (has_adm) n_cen = p.census[f_b + vzero];
+                if (has_gpc) n_gpc = a.g_popcount[f_b + vzero];
+                if (pend_p) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
+                    pend_p = nullptr;
+                }
+            }
+        };
+        auto fetch = [&](int gg) {
+#pragma unroll
+            for (int st = 0; st < 5; ++st) fetch_stage(st, gg);
+        };
         const int gstep = gridDim.x * 4;
+        const bool handoff = !(a.dbg & 2);
+        const int sbase = 4 * lk * SCR_LD + cperm;            // this lane's element (block 0, r = 0) of a slot matrix
+        auto put = [&](float* sl, int e, const f32x4 (&G)[4], const f32x4 (&Hm)[4]) {      // element e = 4 * mb + r of both matrices
+            const int o = sbase + (16 * (e >> 2) + (e & 3)) * SCR_LD;
+            sl[o] = G[e >> 2][e & 3];
+            sl[64 * SCR_LD + o] = Hm[e >> 2][e & 3];
+        };
         int gg = blockIdx.x * 4 + wv;
         if (gg < a.total_groups) fetch(gg);
         for (; gg < a.total_groups; gg += gstep) {
@@ -789,17 +855,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 u += has_gsm ? n_gsm : 0.f;
                 gup = sel ? u : 0.f;
             }
-            {   // the next group's inputs: in flight during this group's MFMA chain
-                const int gn = gg + gstep;
-                fetch(gn < a.total_groups ? gn : a.total_groups - 1);
-            }
-            // the previous group's gradient goes out HERE, behind the prefetch: stored at the end of its own iteration it
-            // sat in front of the next iteration's wait for the prefetched inputs (vmcnt counts loads and stores in one queue)
-            if (pend_p) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
-                pend_p = nullptr;
-            }
+            const int gnx = gg + gstep < a.total_groups ? gg + gstep : a.total_groups - 1;   // (clamped: the last prefetch is a dummy)
             // g_feat is written exactly once per element by this kernel (no zero-fill pass in front of it): crop pixels
             // by the producer that owns their group -- zeros when the group is skipped --, the border by the consumers
             auto store_zero = [&]() {
@@ -808,16 +864,26 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                     for (int r = 0; r < 4; ++r) gp[(unsigned)(4 * lk + r) * gcs] = 0.f;
                 }
             };
-            if (!__any(sel)) { store_zero(); continue; }
+            if (!__any(sel)) { fetch(gnx); store_zero(); continue; }
             HP_MARK(0);
-            f32x4 h1[4], h2[4], h3[4];
-            head_layer1(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-            relu4(h1);
-            head_layer64_pf(lds, LB_A2, LB_B2, lane, lk, h1, h2);
-            relu4(h2);
-            head_layer64_pf(lds, LB_A3, LB_B4, lane, lk, h2, h3);
+            // Every contraction gets its first fragments from the phase before it (fa / fb, alternating), and the ReLU / ReLU' of its
+            // input blocks 1-3 happens in the shadow of its own first K-steps (block mb + 1 in step 4 mb): a layer boundary costs the
+            // ReLU of ONE block, not an LDS round trip + 16-32 VALU instructions with the matrix pipe idle.
+            f32x4 h1[4], h2[4], h3[4], fa[4], fb[4];
+            head_frag0(lds, LB_A2, 4, lane, fa);
+            head_layer1_il(lds, LB_A1, LB_B0, lane, lk, xv, h1);
+            head_bias4(lds, LB_B2, lk, h2);
+            relu_block(h1[0]);
+            head_mm64_pf(lds, LB_A2, lane, h1, h2, fa, LB_A3, 4, fb, [&](int st) {
+                if (!(st & 3) && st < 12) relu_block(h1[(st >> 2) + 1]);
+                if ((st & 1) && st < 10) fetch_stage(st >> 1, gnx);
+            });
+            head_bias4(lds, LB_B4, lk, h3);
+            relu_block(h2[0]);
+            head_mm64_pf(lds, LB_A3, lane, h2, h3, fb, LB_T3, 4, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(h2[(st >> 2) + 1]); });
             relu4(h3);
             HP_MARK(1);
+            const int c_early0 = *cons_p;
             float s = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -843,51 +909,52 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 }
             }
             HP_MARK(2);
-            if (!(a.dbg & 2)) {   // slot kind 0: (G3, H2) -> dW4, db4
-                float* sl = acquire();
-                head_store_mat(sl, li, lk, g3);
-                head_store_mat(sl + 64 * SCR_LD, li, lk, h2);
-                release();
-            }
+            // The three hand-offs (slot kind 0: (G3, H2) -> dW4, db4; 1: (G2, H1) -> dW2, db2; 2: (G1, X) -> dW0, db0) are written
+            // one element pair per K-step in the shadow of the NEXT contraction's MFMAs -- as a block in front of it, the 32 scattered
+            // LDS writes + their wait were ~600-1,000 cycles per slot with the matrix pipe idle.
+            float* sl = handoff ? acquire(c_early0) : nullptr;
             HP_MARK(3);
-            head_dgrad64_pf(lds, LB_T3, lane, g3, g2);
+            const int c_early1 = *cons_p;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g2[mb][r] = h2[mb][r] > 0.f ? g2[mb][r] : 0.f;
+            for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            head_mm64_pf(lds, LB_T3, lane, g3, g2, fa, LB_T2, 4, fb, [&](int st) { if (handoff) put(sl, st, g3, h2); });
+            if (handoff) release();
+            mask_block(g2[0], h2[0]);
             HP_MARK(4);
-            if (!(a.dbg & 2)) {   // slot kind 1: (G2, H1) -> dW2, db2
-                float* sl = acquire();
-                head_store_mat(sl, li, lk, g2);
-                head_store_mat(sl + 64 * SCR_LD, li, lk, h1);
-                release();
-            }
+            sl = handoff ? acquire(c_early1) : nullptr;
             HP_MARK(5);
-            head_dgrad64_pf(lds, LB_T2, lane, g2, g1);
+            const int c_early2 = *cons_p;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g1[mb][r] = h1[mb][r] > 0.f ? g1[mb][r] : 0.f;
+            for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            head_mm64_pf(lds, LB_T2, lane, g2, g1, fb, LB_T1, 1, fa, [&](int st) {
+                if (handoff) put(sl, st, g2, h1);
+                if (!(st & 3) && st < 12) mask_block(g2[(st >> 2) + 1], h2[(st >> 2) + 1]);
+            });
+            if (handoff) release();
+            mask_block(g1[0], h1[0]);
+            mask_block(g1[1], h1[1]);
             HP_MARK(6);
-            if (!(a.dbg & 2)) {   // slot kind 2: (G1, X) -> dW0, db0
-                float* sl = acquire();
-                head_store_mat(sl, li, lk, g1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sl[64 * SCR_LD + (4 * j + lk) * SCR_LD + cperm] = xv[j];
-                release();
-            }
+            sl = handoff ? acquire(c_early2) : nullptr;
             HP_MARK(7);
             f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA dependent latency
 #pragma unroll                                                                       // (40 cyc) exceeds the issue interval (32)
             for (int mb = 0; mb < 4; mb += 2) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(&lds[LB_T1 + (mb * 64 + lane) * 4]);
-                const f32x4 u4 = *reinterpret_cast<const f32x4*>(&lds[LB_T1 + ((mb + 1) * 64 + lane) * 4]);
+                const f32x4 t4 = fa[mb], u4 = fa[mb + 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
                     gx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[r], g1[mb + 1][r], gx2, 0, 0, 0);
+                    if (mb == 0 && r < 2) mask_block(g1[2 + r], h1[2 + r]);
+                    if (handoff) {
+                        const int e = (mb >> 1) * 8 + 2 * r;            // 8 steps x 2 elements of G1, the 4 x values in the first 4
+                        sl[sbase + (16 * (e >> 2) + (e & 3)) * SCR_LD] = g1[e >> 2][e & 3];
+                        sl[sbase + (16 * ((e + 1) >> 2) + ((e + 1) & 3)) * SCR_LD] = g1[(e + 1) >> 2][(e + 1) & 3];
+                        if (mb == 0) sl[64 * SCR_LD + (4 * r + lk) * SCR_LD + cperm] = xv[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (handoff) release();
 #pragma unroll
             for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
             if (valid) {

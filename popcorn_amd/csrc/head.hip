@@ -682,7 +682,11 @@ __device__ long long g_head_prof[256 * 16];
 // Hand-off: per pair two LDS counters (produced / consumed) + a done flag, polled with s_sleep; LDS operations of a wave
 // are performed in order, so "data writes, then counter write" needs no fence beyond a compiler barrier.  Slots carry
 // no tag: every processed group emits exactly three slots (layer 3, 2, 1), so slot k is of kind k % 3.
-constexpr int PC_SLOT = 2 * 64 * SCR_LD;                 // G[64][20] + H[64][20]
+constexpr int PC_LKS = 80;                                // floats per (block, lk) row of a slot matrix: 16 lanes x 4 + 16 (the 4 lk rows
+                                                          // of a block start 16 banks apart: conflict-free transposing reads)
+constexpr int PC_MBS = 4 * PC_LKS;                        // per 16-row block
+constexpr int PC_MAT = 4 * PC_MBS;                        // one 64 x 16 matrix (1280 floats)
+constexpr int PC_SLOT = 2 * PC_MAT;                       // G + H
 constexpr int PC_NSLOT = 2;
 constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is shared with the single-role kernel
 constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
@@ -756,7 +760,6 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             ++nprod;
             if (lane == 0) *prod_p = nprod;
         };
-        const int cperm = (li & 3) * 4 + (li >> 2);
         // Per-group inputs are fetched one group ahead (raw loads only).  The group index is wave-uniform, so the sample index and
         // everything per sample live in scalar registers; optional inputs get a valid dummy address (the building map) and a
         // select instead of a branch around their load, and the last iteration prefetches a clamped (valid) group: the loop top is
@@ -831,11 +834,15 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         };
         const int gstep = gridDim.x * 4;
         const bool handoff = !(a.dbg & 2);
-        const int sbase = 4 * lk * SCR_LD + cperm;            // this lane's element (block 0, r = 0) of a slot matrix
-        auto put = [&](float* sl, int e, const f32x4 (&G)[4], const f32x4 (&Hm)[4]) {      // element e = 4 * mb + r of both matrices
-            const int o = sbase + (16 * (e >> 2) + (e & 3)) * SCR_LD;
-            sl[o] = G[e >> 2][e & 3];
-            sl[64 * SCR_LD + o] = Hm[e >> 2][e & 3];
+        // Slot matrices are stored as the producer HOLDS them (D layout: lane (pixel li, lk), register block mb = rows 16 mb + 4 lk
+        // + r): one 16-byte write per block, [mb][lk][PC_LKS] floats with the lane's 4 values at li * 4 -- the consumer does the
+        // transposing reads.  (The first form scattered every element into a [row][pixel] matrix: 32 ds_write_b32 per slot on the
+        // producer, the critical path, where every LDS instruction costs the wave ~30-40 cycles of MFMA issue --
+        // profiles/r3_mfma_peak.json, lds variants at 1 wave per SIMD.)
+        const int sbase = lk * PC_LKS + li * 4;
+        auto put = [&](float* sl, int mb, const f32x4 (&G)[4], const f32x4 (&Hm)[4]) {
+            *reinterpret_cast<f32x4*>(&sl[mb * PC_MBS + sbase]) = G[mb];
+            *reinterpret_cast<f32x4*>(&sl[PC_MAT + mb * PC_MBS + sbase]) = Hm[mb];
         };
         int gg = blockIdx.x * 4 + wv;
         if (gg < a.total_groups) fetch(gg);
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             const int c_early1 = *cons_p;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            head_mm64_pf(lds, LB_T3, lane, g3, g2, fa, LB_T2, 4, fb, [&](int st) { if (handoff) put(sl, st, g3, h2); });
+            head_mm64_pf(lds, LB_T3, lane, g3, g2, fa, LB_T2, 4, fb, [&](int st) { if (handoff && (st & 3) == 1) put(sl, st >> 2, g3, h2); });
             if (handoff) release();
             mask_block(g2[0], h2[0]);
             HP_MARK(4);
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
             head_mm64_pf(lds, LB_T2, lane, g2, g1, fb, LB_T1, 1, fa, [&](int st) {
-                if (handoff) put(sl, st, g2, h1);
+                if (handoff && (st & 3) == 1) put(sl, st >> 2, g2, h1);           // (block mb was masked in step 4 (mb - 1))
                 if (!(st & 3) && st < 12) mask_block(g2[(st >> 2) + 1], h2[(st >> 2) + 1]);
             });
             if (handoff) release();
@@ -945,11 +952,9 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                     gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
                     gx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[r], g1[mb + 1][r], gx2, 0, 0, 0);
                     if (mb == 0 && r < 2) mask_block(g1[2 + r], h1[2 + r]);
-                    if (handoff) {
-                        const int e = (mb >> 1) * 8 + 2 * r;            // 8 steps x 2 elements of G1, the 4 x values in the first 4
-                        sl[sbase + (16 * (e >> 2) + (e & 3)) * SCR_LD] = g1[e >> 2][e & 3];
-                        sl[sbase + (16 * ((e + 1) >> 2) + ((e + 1) & 3)) * SCR_LD] = g1[(e + 1) >> 2][(e + 1) & 3];
-                        if (mb == 0) sl[64 * SCR_LD + (4 * r + lk) * SCR_LD + cperm] = xv[r];
+                    if (handoff) {            // G1 block r in step (0, r) -- blocks 2, 3 are masked in steps (0, 0), (0, 1) --, X in (2, 0)
+                        if (mb == 0) *reinterpret_cast<f32x4*>(&sl[r * PC_MBS + sbase]) = g1[r];
+                        else if (r == 0) *reinterpret_cast<f32x4*>(&sl[PC_MAT + sbase]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1021,13 +1026,20 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         // fetch the (G, H) fragments of the current slot and hand the slot back
         auto take = [&](f32x4 (&af)[4], f32x4 (&bf)[4], bool x_only) {
             asm volatile("" ::: "memory");
+            // transposing reads: fragment (q, ks) = element (row 16 q + li, pixel 4 ks + lk) = register li & 3 of the producer lane
+            // (pixel, lk' = li >> 2), block q; for X (16 channels x 16 pixels, channel 4 j + lk' in register j) the two are swapped.
+            // Lanes hit 16 (li >> 2) + 4 lk + (li & 3) (mod 32) = every bank twice: conflict-free 4-byte reads, paired by the compiler
+            // into ds_read2_b32 (ks, ks + 1 are 16 floats apart).
             const float* gm = ring + (ncons % PC_NSLOT) * PC_SLOT;
-            const float* hm = gm + 64 * SCR_LD;
+            const float* hm = gm + PC_MAT;
+            const int cb = (li >> 2) * PC_LKS + lk * 4 + (li & 3), xb = (li & 3) * PC_LKS + lk * 4 + (li >> 2);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                af[q] = *reinterpret_cast<const f32x4*>(&gm[(16 * q + li) * SCR_LD + 4 * lk]);
-                bf[q] = *reinterpret_cast<const f32x4*>(&hm[(16 * (x_only ? 0 : q) + li) * SCR_LD + 4 * lk]);
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    af[q][ks] = gm[q * PC_MBS + cb + 16 * ks];
+                    bf[q][ks] = x_only ? hm[xb + 16 * ks] : hm[q * PC_MBS + cb + 16 * ks];
+                }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ++ncons;
             if (lane == 0) *cons_p = ncons;          // slot is free again: everything needed is in registers

@@ -137,12 +137,12 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     flops = float(FLOP_HEAD_BWD_PX) * nsel
     issued = float(FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX) * nsel
     achieved = flops / dur / 1e12
-    pmc = _pmc("r2_pmc_head_bwd.json") or _pmc("r1_pmc_head_bwd.json")
+    pmc = _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     kname = ("head_bwd_bf16_coop4_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, the 4 waves of a workgroup share the weight gradients through an LDS exchange + transposing reads, 2 workgroups per CU)" if bf else
              "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
     if bf:
-        pmc = _pmc("r2_pmc_head_bwd_bf16.json")
+        pmc = _pmc("r3_pmc_head_bwd_bf16.json") or _pmc("r2_pmc_head_bwd_bf16.json")
         traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     return {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call",
             "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -194,7 +194,7 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
     nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
-    pmc = _pmc("r2_pmc_conv_8to8_bf16.json" if esz == 2 else "r2_pmc_conv_8to8.json")
+    pmc = _pmc("r3_pmc_conv_8to8_bf16.json" if esz == 2 else "r3_pmc_conv_8to8.json")
     return {"bound": "hbm", "kernel": f"{'conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)' if esz == 2 else 'conv3x3_mfma_kernel<8,8,fwd> (fp32)'} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
             "traffic": pmc["traffic_bytes"] if pmc and B == 64 else None, "launch_us": round(dur * 1e6, 2),

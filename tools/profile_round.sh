@@ -18,7 +18,7 @@ for prec in fp32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_${prec}_$c
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${prec}_$c -o b -- \
-        python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-class-sweep --no-extras --precision $prec > $OUT/pmc_${prec}_$c.log 2>&1
+        python3 bench.py --steps 2 --warmup 1 --repeats 1 --prewarm-seconds 0 --no-graph --no-cpu-baseline --no-class-sweep --no-extras --precision $prec > $OUT/pmc_${prec}_$c.log 2>&1
   done
 done
 # the standalone grouped conv 8->8 @128x128 x4 launch (roofline_conv): the precision goes through exported variables (ABL_PREC) that
@@ -33,3 +33,5 @@ for prec in fp32 bf16; do
   done
 done
 python3 tools/pmc_round_summary.py $TAG
+# only the summaries travel back (gpurun merges at most 64 MiB of gpurun_out/)
+rm -rf $OUT/prof_fp32 $OUT/prof_bf16 $OUT/pmc_fp32_* $OUT/pmc_bf16_* $OUT/pmcc_fp32_* $OUT/pmcc_bf16_*

@@ -12,6 +12,8 @@ all-reduce are single kernels / a single collective.  The static-shape step can 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -27,11 +29,14 @@ HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
 class FusedTrainStep:
     def __init__(self, model, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, gradient_clip=0.01,
                  loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01, lam_weak=100.0,
-                 reducer: FlatReducer | None = None, use_graph=False, raw_norm=None):
+                 reducer: FlatReducer | None = None, use_graph=False, raw_norm=None, graph_cache_max=None):
         """raw_norm = (band6, mean6, std6): how a RAW tile (sample key "raw" instead of "input": (B, Craw, H, W) reflectances /
         backscatter) becomes the model input -- band selection (data/PopulationDataset.py:566-568) + apply_normalize
         (utils/utils.py:105-127); default: the reference's dataset statistics (popcorn_amd.data.stats).  With a raw sample the
-        step's first launch does select + normalise + reflect padding in one pass (pc_select_normalize_pad)."""
+        step's first launch does select + normalise + reflect padding in one pass (pc_select_normalize_pad).
+        graph_cache_max: how many captured steps (one per (tile shape, truncation regime, precision)) stay alive -- each owns a
+        private memory pool with every activation and gradient of its step; default 6 or POPCORN_GRAPH_CACHE_MAX.  A capture that
+        runs out of memory drops ALL cached graphs (and their pools) and is retried once."""
         from .data import stats as _stats
         self.raw_norm = raw_norm or (_stats.BAND6, _stats.MEAN6, _stats.STD6)
         self.model = model
@@ -89,7 +94,8 @@ class FusedTrainStep:
         self.use_graph = use_graph
         self._graphs = None
         self._graph_cache = {}          # key -> captured step; a few recurring shapes (e.g. the smaller last batch of an epoch,
-        self._graph_cache_max = 6       # alternating truncation regimes) replay instead of being captured over and over
+        self._graph_cache_max = max(1, int(graph_cache_max if graph_cache_max is not None      # alternating truncation regimes)
+                                           else os.environ.get("POPCORN_GRAPH_CACHE_MAX", "6")))  # replay instead of being re-captured
         self._static = None
         self._sel_ring, self._sel_next = [], 0          # pinned host slots for the per-step selection grid (H2D without a host sync)
         self.last = {}
@@ -322,7 +328,16 @@ class FusedTrainStep:
                 self._graphs, self.last = self._graph_cache.pop(key)      # (re-inserted below: most recently used last)
             else:
                 with L.precision(self.model.precision):      # the mode is read when a launch is enqueued = captured
-                    self._capture(sample, sel_host, key)
+                    try:
+                        self._capture(sample, sel_host, key)
+                    except torch.OutOfMemoryError:
+                        # every cached step keeps its own pool alive: let them all go and try once more with the memory back
+                        self._graphs = None
+                        self._graph_cache.clear()
+                        self._static = None
+                        torch.cuda.synchronize()
+                        torch.cuda.empty_cache()
+                        self._capture(sample, sel_host, key)
             self._graph_cache[key] = (self._graphs, self.last)
             while len(self._graph_cache) > self._graph_cache_max:
                 self._graph_cache.pop(next(iter(self._graph_cache)))

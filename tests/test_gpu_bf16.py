@@ -704,3 +704,115 @@ def test_bf16_training_tracks_fp32_training_over_200_steps():
     q32, q16 = r["r2_median_last_10_epochs"]["fp32"], r["r2_median_last_10_epochs"]["bf16"]
     assert q32 > 0.9 and q16 > 0.9 and abs(q16 - q32) <= 0.03, r
     assert r["relative_param_distance"] < 0.5, r          # the two runs end closer to each other than either moved from the start
+
+
+# ---- the gradient-truncation regimes, the autograd node on an odd padded geometry and the unfused backward, in bf16 mode --------
+def _bf16_grad_gate(got, g16, g32, where):
+    """The gate of test_bf16_train_step_other_geometries: every tensor within TOL_GRAD_WORST of the bf16 oracle or well inside the
+    band bf16 rounding itself spans (bf16 oracle vs fp32 oracle), and the median over tensors under TOL_GRAD_MEDIAN."""
+    assert set(got) == set(g16), (where, set(got) ^ set(g16))
+    errs = []
+    for n in g16:
+        e, band = rel(got[n].cpu(), g16[n]), rel(g16[n], g32[n])
+        errs.append(e)
+        assert e < max(TOL_GRAD_WORST, 0.75 * band), (where, n, e, band)
+    assert float(np.median(errs)) < TOL_GRAD_MEDIAN, (where, float(np.median(errs)))
+
+
+@pytest.mark.parametrize("flags", [dict(encoder_no_grad=True), dict(encoder_no_grad=True, unet_no_grad=True)])
+def test_bf16_train_step_truncation_regimes(flags):
+    """limit1 / limit2 (run_train.py:191-198) in bf16 mode: with the encoder frozen the first convs of the Up blocks take the
+    separate weight-gradient + data-gradient launches instead of the fused backward, and the transposed convs their
+    weight-gradient-only form (engine.py: backward); with the whole U-Net frozen only the head is differentiated."""
+    from popcorn_amd.train import FusedTrainStep
+    m, sd = _model()
+    s = _sample()
+    torch.manual_seed(3)
+    _, _, g32, _ = O.train_step_grads(sd, dict(s), **flags)
+    with O.bf16_mode():
+        torch.manual_seed(3)
+        l16, out16, g16, _ = O.train_step_grads(sd, dict(s), **flags)
+    m.set_precision("bf16")
+    tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+    p0 = tr.flat_p.clone()
+    torch.manual_seed(3)
+    loss = tr.step({k: v.cuda() for k, v in s.items()}, **flags)
+    torch.cuda.synchronize()
+    assert abs(loss[0].item() - l16.item()) < TOL_LOSS * abs(l16.item())
+    assert rel(tr.last["popcount"].cpu(), out16["popcount"]) < TOL_COUNT
+    _bf16_grad_gate({n: tr.grads[n] for n in g16}, g16, g32, str(flags))
+    # frozen groups: gradient zero, parameters untouched by the step (torch.optim.Adam skips .grad is None)
+    params = dict(m.named_parameters())
+    frozen = [n for n in tr.names if n not in g16]
+    assert frozen
+    for n in frozen:
+        assert float(tr.grads[n].abs().max()) == 0.0, n
+        assert torch.equal(params[n].detach().cpu(), sd[n]), n
+    assert not torch.equal(tr.flat_p, p0)
+
+
+def test_bf16_autograd_node_padding_true_on_an_odd_geometry():
+    """model.forward(padding=True) + loss.backward() through _PopcornFn in bf16 mode on a tile whose padded extent is not a
+    multiple of 4 (90 x 86 -> 118 x 114: 59 x 57 at the second level, odd pooling windows, ragged strips of the fused backward and
+    the max-pool scatter kernels)."""
+    from popcorn_amd.utils.losses import get_loss
+    from popcorn_amd.data.synthetic import make_raw_batch
+    m, sd = _model()
+    batch = make_raw_batch(2, 90, 86, seed=11, region="disc")
+    x = O.select_normalize(batch["raw"])
+    s = {"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}
+
+    def oracle_grads():
+        work = dict(sd)
+        names = O.trainable_names(sd)
+        for n in names:
+            work[n] = sd[n].detach().clone().requires_grad_(True)
+        torch.manual_seed(9)
+        out = O.popcorn_forward(work, dict(s), padding=True, sparse=True)
+        l, _ = O.get_loss(out, s, scale=out["scale"], loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01, tag="weak")
+        (l * 100.0).backward()
+        return l.detach(), out, {n: work[n].grad for n in names if work[n].grad is not None}
+
+    l32, _, g32 = oracle_grads()
+    with O.bf16_mode():
+        l16, out16, g16 = oracle_grads()
+    m.set_precision("bf16")
+    m.train()
+    m.zero_grad()
+    sc = {k: v.cuda() for k, v in s.items()}
+    torch.manual_seed(9)
+    o = m(sc, train=True, padding=True, sparse=True)
+    loss, _ = get_loss(o, sc, scale=o["scale"], loss=["log_l1_loss"], lam=[1.0], scale_regularization=0.01, tag="weak")
+    (loss * 100.0).backward()
+    assert abs(loss.item() - l16.item()) < 2 * TOL_LOSS * max(1.0, abs(l16.item()))
+    assert rel(o["popcount"].detach().cpu(), out16["popcount"].detach()) < 2 * TOL_COUNT
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    _bf16_grad_gate(got, g16, g32, "padding=True 90x86")
+    m.zero_grad()
+
+
+def test_bf16_train_step_with_the_unfused_backward(monkeypatch):
+    """POPCORN_FUSED_CONV_BWD=0 (the A/B switch of engine.py) keeps the separate data-gradient / weight-gradient launches
+    reachable: same gate as the fused step, and both forms agree with each other to bf16 rounding of the gradients."""
+    from popcorn_amd import engine as E
+    from popcorn_amd.train import FusedTrainStep
+    s = _sample()
+    m0, sd = _model()
+    torch.manual_seed(3)
+    _, _, g32, _ = O.train_step_grads(sd, dict(s))
+    with O.bf16_mode():
+        torch.manual_seed(3)
+        l16, _, g16, _ = O.train_step_grads(sd, dict(s))
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "FUSED_CONV_BWD", fused)
+        m, _ = _model()
+        m.set_precision("bf16")
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(3)
+        loss = tr.step({k: v.cuda() for k, v in s.items()})
+        torch.cuda.synchronize()
+        assert abs(loss[0].item() - l16.item()) < TOL_LOSS * abs(l16.item())
+        _bf16_grad_gate({n: tr.grads[n] for n in g16}, g16, g32, f"fused={fused}")
+        res[fused] = {n: tr.grads[n].clone() for n in g16}
+    assert max(rel(res[True][n], res[False][n]) for n in g16) < TOL_GRAD_WORST

@@ -289,3 +289,49 @@ def test_graph_cache_alternating_shapes_and_regimes_equals_eager():
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1])
     assert runs[1][2] == 4                      # four distinct (shape, regime) keys, eight steps
+
+
+def test_graph_cache_is_bounded_and_survives_an_out_of_memory_capture(monkeypatch):
+    """graph_cache_max / POPCORN_GRAPH_CACHE_MAX bound the number of captured steps kept alive (each owns a private memory pool);
+    a capture that raises torch.OutOfMemoryError drops every cached graph and is retried once -- results stay those of eager."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    samples = []
+    for (B, H, W, seed) in [(2, 64, 64, 11), (3, 64, 64, 12), (2, 96, 64, 13)]:
+        b = make_raw_batch(B, H, W, seed=seed, device="cuda", region="disc")
+        samples.append({"input": ops.select_normalize(b["raw"], stats.BAND6, stats.MEAN6, stats.STD6), "admin_mask": b["admin_mask"],
+                        "census_idx": b["census_idx"], "y": b["y"]})
+
+    def trainer(**kw):
+        torch.manual_seed(1600)
+        m = POPCORN(6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        return FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, **kw)
+
+    order = [0, 1, 2, 0, 1, 2, 0]
+    ref = trainer(use_graph=False)
+    torch.manual_seed(21)
+    want = [ref.step(dict(samples[i])).tolist() for i in order]
+    monkeypatch.setenv("POPCORN_GRAPH_CACHE_MAX", "2")
+    tr = trainer(use_graph=True)
+    assert tr._graph_cache_max == 2
+    assert trainer(use_graph=True, graph_cache_max=1)._graph_cache_max == 1
+    orig, calls = tr._capture, [0]
+
+    def flaky(*a, **k):
+        calls[0] += 1
+        if calls[0] == 3:                                   # the third capture "runs out of memory" once
+            raise torch.OutOfMemoryError("synthetic")
+        return orig(*a, **k)
+
+    tr._capture = flaky
+    torch.manual_seed(21)
+    got = []
+    for i in order:
+        got.append(tr.step(dict(samples[i])).tolist())
+        assert len(tr._graph_cache) <= 2
+    torch.cuda.synchronize()
+    assert got == want and torch.equal(tr.flat_p, ref.flat_p)
+    assert calls[0] > 4                                     # evictions force re-captures: bounded memory, not bounded work

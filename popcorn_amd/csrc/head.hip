@@ -141,11 +141,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     if (g_end > p.groups) g_end = p.groups;
     // The inputs of group g + 1 (mask byte, 4 feature values per lane) are loaded while group g runs its MFMA chain: the
     // gather is unconditional (clamped pixel) so that it does not sit behind the selection branch.
+    // (the epilogue's building score and admin id come with the same prefetch: read where they are used they are one more exposed
+    // round trip at the tail of every group)
+    float bld_n = 0.f, adm_n = 0.f;
     auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
         const int q = g * 16 + li;
         const bool valid = q < HW && g < g_end;
         const int qc = valid ? q : 0;
         sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        bld_n = p.building[(int64_t)b * HW + qc];
+        if (p.admin) adm_n = p.admin[(int64_t)b * HW + qc];
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
         const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
 #pragma unroll
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
         const bool sel = sel_n;
+        const float bld = bld_n, adm = adm_n;
         float xv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[j] = xv_n[j];
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
             // NaN-propagating ReLU like torch's (v_max_f32 returns the non-NaN operand): a NaN head output must reach the
             // loss, where the trainer's guard sees it (run_train.py:224-227).  The hidden ReLUs use the plain maximum.
             const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);
-            const float pd = scale * p.building[pix];
+            const float pd = scale * bld;
             if (p.scale_map) p.scale_map[pix] = scale;
             p.popdense[pix] = pd;
-            const bool region = p.admin ? (p.admin[pix] == cid) : true;
+            const bool region = p.admin ? (adm == cid) : true;
             pc_sum += region ? pd : 0.f;
             sc_sum += scale;
         }
@@ -1280,11 +1286,16 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     const int g_begin = (blockIdx.x * 4 + wave) * p.groups_per_wave;
     int g_end = g_begin + p.groups_per_wave;
     if (g_end > p.groups) g_end = p.groups;
+    // (the epilogue's building score and admin id come with the same prefetch: read where they are used they are one more exposed
+    // round trip at the tail of every group)
+    float bld_n = 0.f, adm_n = 0.f;
     auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
         const int q = g * 16 + li;
         const bool valid = q < HW && g < g_end;
         const int qc = valid ? q : 0;
         sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        bld_n = p.building[(int64_t)b * HW + qc];
+        if (p.admin) adm_n = p.admin[(int64_t)b * HW + qc];
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
         // channels-last feature map: the 16 channels of the pixel are contiguous
         const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride +
@@ -1303,6 +1314,7 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
         const bool sel = sel_n;
+        const float bld = bld_n, adm = adm_n;
         const hs16x4 xb = hb_pack4(xv_n[0], xv_n[1], xv_n[2], xv_n[3]);
         fetch(g + 1, sel_n, xv_n);
         float outv = 0.f;
@@ -1335,10 +1347,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
         }
         if (valid && lk == 0) {
             const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);
-            const float pd = scale * p.building[pix];
+            const float pd = scale * bld;
             if (p.scale_map) p.scale_map[pix] = scale;
             p.popdense[pix] = pd;
-            const bool region = p.admin ? (p.admin[pix] == cid) : true;
+            const bool region = p.admin ? (adm == cid) : true;
             pc_sum += region ? pd : 0.f;
             sc_sum += scale;
         }
@@ -1461,7 +1473,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     const int t_offx2 = (lk >> 1) * H4_SLOT + H4_X + (t_r0 + 4) * H4_XROW + 8 * ((li & 3) ^ (((t_r0 + 4) ^ ((t_r0 + 4) >> 2)) & 3));
 
     // per-group inputs, fetched one group ahead
-    float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f;
+    float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
+    long long n_cen = 0;          // the two per-sample scalars ride with the prefetch (raw; converted where used): read at their point of
+                                  // use they are two dependent, fully exposed memory round trips per group (see head_bwd_pc_kernel)
     uint2 n_f4 = make_uint2(0u, 0u);
     unsigned n_msk = 1;
     auto fetch = [&](int gg) {
@@ -1477,9 +1491,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
         n_f4 = *reinterpret_cast<const uint2*>(fp + 4 * lk);          // channels 4*lk .. +3: mask of the fused ReLU backward AND the dW0 operand
         n_msk = p.mask ? p.mask[pix] : 1;
         n_bld = p.building[pix];
-        if (p.admin) n_adm = p.admin[pix];
+        if (p.admin) { n_adm = p.admin[pix]; n_cen = p.census[b]; }
         if (a.g_popdense) n_gpd = a.g_popdense[pix];
         if (a.g_scale_map) n_gsm = a.g_scale_map[pix];
+        if (a.g_popcount) n_gpc = a.g_popcount[b];
     };
     const int gstep = gridDim.x * H4_WAVES;
     const int niter = (a.total_groups + gstep - 1) / gstep;
@@ -1500,9 +1515,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
             const uint2 f4 = valid ? n_f4 : make_uint2(0u, 0u);
             float gup = 0.f;
             if (sel) {
-                const bool region = p.admin ? (n_adm == (float)p.census[b]) : true;
+                const bool region = p.admin ? (n_adm == (float)n_cen) : true;
                 gup = gsc;
-                if (a.g_popcount && region) gup += a.g_popcount[b] * n_bld;
+                if (a.g_popcount && region) gup += n_gpc * n_bld;
                 if (a.g_popdense) gup += n_gpd * n_bld;
                 if (a.g_scale_map) gup += n_gsm;
             }

@@ -446,23 +446,20 @@ def cpu_baseline(torch, sd, seconds):
 
 
 def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
-    """The train step with every batch coming from PINNED HOST memory: a copy stream moves batch i+1 (raw bands, region ids,
-    census ids, targets) into one of two device staging sets while step i computes; the compute stream waits for the copy
-    event, selects + normalises into the graph's static input and frees the staging set.  The reference's loop does the same
-    H2D every step (run_train.py:186, utils/utils.py:22-27), synchronously."""
-    from popcorn_amd import ops
+    """The train step with every batch coming from PINNED HOST memory.  The loader owns TWO static sets of the trainer
+    (`static_buffers(slot=0 / 1)`: raw tile + one packed buffer {admin_mask, y, census_idx}), each captured into its own graph: a copy
+    stream moves batch i+1 straight into the idle set (2 H2D copies, no staging copy, no kernel outside the graph) while the graph of
+    the other set computes step i; two events per set order the two streams.  The reference's loop does the same H2D every step
+    (run_train.py:186, utils/utils.py:22-27), synchronously."""
     from popcorn_amd.data import stats
-    dev = batch["raw"].device
+    B, _, H, W = batch["raw"].shape
     raw = batch["raw"] if band_sel is None else batch["raw"][:, list(band_sel)].contiguous()
-    sel = stats.BAND6 if band_sel is None else tuple(range(6))
-    packed_ok = "_packed" in sample
-    if packed_ok:      # raw bands + ONE packed buffer {admin_mask, y, census_idx} (FusedTrainStep.static_buffers): 2 H2D + 1 device copy
-        host = {"raw": raw.cpu().pin_memory(),
-                "_packed": trainer.pack_small(batch["admin_mask"].cpu(), batch["y"].cpu(), batch["census_idx"].cpu()).pin_memory()}
-    else:
-        host = {"raw": raw.cpu().pin_memory(), "admin_mask": batch["admin_mask"].float().cpu().pin_memory(),
-                "census_idx": batch["census_idx"].cpu().pin_memory(), "y": batch["y"].cpu().pin_memory()}
-    stage = [{k: torch.empty_like(v, device=dev) for k, v in host.items()} for _ in range(2)]
+    keep_norm = trainer.raw_norm
+    if band_sel is not None:             # the host already holds the 6 model bands: the ingest kernel only normalises + pads
+        trainer.raw_norm = (tuple(range(6)), stats.MEAN6, stats.STD6)
+    host = {"raw": raw.cpu().pin_memory(),
+            "_packed": trainer.pack_small(batch["admin_mask"].cpu(), batch["y"].cpu(), batch["census_idx"].cpu()).pin_memory()}
+    sets = [trainer.static_buffers(B, H, W, raw_channels=raw.shape[1], slot=sl) for sl in (0, 1)]
     copied = [torch.cuda.Event() for _ in range(2)]
     consumed = [torch.cuda.Event() for _ in range(2)]
     cstream = torch.cuda.Stream()
@@ -475,7 +472,7 @@ def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
         with torch.cuda.stream(cstream):
             cstream.wait_event(consumed[slot])
             for k, v in host.items():
-                stage[slot][k].copy_(v, non_blocking=True)
+                sets[slot][k].copy_(v, non_blocking=True)
             copied[slot].record(cstream)
 
     def run(n):
@@ -485,17 +482,15 @@ def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
                 feed(i + 1)
             slot = i & 1
             cur.wait_event(copied[slot])
-            ops.select_normalize(stage[slot]["raw"], sel, stats.MEAN6, stats.STD6, out=sample["input"])
-            for k in (("_packed",) if packed_ok else ("admin_mask", "census_idx", "y")):
-                sample[k].copy_(stage[slot][k], non_blocking=True)
+            trainer.step(sets[slot])
             consumed[slot].record(cur)
-            trainer.step(sample)
     run(8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(nsteps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trainer.raw_norm = keep_norm
     nbytes = sum(v.numel() * v.element_size() for v in host.values())
     return {"feed": label, "steps": nsteps, "ms_per_step": round(dt / nsteps * 1e3, 4), "host_bytes_per_step": nbytes,
             "h2d_gbps_sustained": round(nbytes * nsteps / dt / 1e9, 2)}, dt
@@ -558,8 +553,8 @@ def extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, s
     out["h2d"] = {"unit": "patches/s", "precision": args.precision, "legs": legs,
                   "resident_same_block": {"steps": nfeed, "ms_per_step": round(dt_res / nfeed * 1e3, 4),
                                           "value": round(B * world * nfeed / dt_res, 1)},
-                  "note": "whole job, max over ranks; pinned host -> device staging (double-buffered) on a copy stream, "
-                          "compute waits on the copy event; the headline `value` keeps its inputs resident in HBM"}
+                  "note": "whole job, max over ranks; pinned host -> the idle one of two static input sets (one captured graph each) on a "
+                          "copy stream, compute waits on the copy event; the headline `value` keeps its inputs resident in HBM"}
     # restore the resident inputs of the static sample
     sample["admin_mask"].copy_(batch["admin_mask"]); sample["census_idx"].copy_(batch["census_idx"]); sample["y"].copy_(batch["y"])
 

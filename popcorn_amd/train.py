@@ -322,7 +322,9 @@ class FusedTrainStep:
 
     def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
         dkey = "input" if sample.get("input") is not None else "raw"
-        key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision)
+        # "_slot": which of the loader's static sets this is (static_buffers(slot=...)): every set has its own captured graph, so
+        # a double-buffering loader replays graph A on set A while the copy stream fills set B -- no device-to-device copies
+        key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision, sample.get("_slot", 0))
         if self._graphs is None or self._graphs[0] != key:
             if key in self._graph_cache:
                 self._graphs, self.last = self._graph_cache.pop(key)      # (re-inserted below: most recently used last)
@@ -356,23 +358,26 @@ class FusedTrainStep:
             graphs[2].replay()
         return self.loss_out
 
-    def static_buffers(self, B, H, W, C=6, raw_channels=None):
+    def static_buffers(self, B, H, W, C=6, raw_channels=None, slot=0):
         """The device tensors the captured graph reads {input, admin_mask (float ids), census_idx, y}.  A data pipeline
         that writes its batch straight into them (e.g. ``ops.select_normalize(raw, ..., out=buf["input"])``) and passes
         this very dict to ``step`` saves the per-step input copies.  raw_channels: the data tensor is the RAW tile
-        {raw (B, raw_channels, H, W)} instead of the normalised input (the graph then starts with the one-pass ingest)."""
+        {raw (B, raw_channels, H, W)} instead of the normalised input (the graph then starts with the one-pass ingest).
+        slot: independent sets for a double-buffering loader (each is captured into its own graph: H2D copies go straight into the
+        idle set on a copy stream, guarded by two events, and `step(set)` replays that set's graph)."""
         dkey = "input" if raw_channels is None else "raw"
         C = C if raw_channels is None else raw_channels
         if self._static is None:
             self._static = {}
-        cur = self._static.get(dkey)
+        skey = (dkey, C, slot)             # (a new B / H / W replaces the set of that kind: bounded memory with varying tile sizes)
+        cur = self._static.get(skey)
         if cur is None or tuple(cur[dkey].shape) != (B, C, H, W):
             dev = self.device
             # the three small tensors are views of ONE packed byte buffer ("_packed": admin_mask f32 | y f32 | census_idx i64, each
             # 16-byte aligned): a loader that stages a batch elsewhere moves them with a single device copy
             n_am, n_y = B * H * W * 4, -(-B * 4 // 16) * 16
             packed = torch.zeros(n_am + n_y + B * 8, dtype=torch.uint8, device=dev)
-            cur = self._static[dkey] = {dkey: torch.zeros(B, C, H, W, device=dev),
+            cur = self._static[skey] = {dkey: torch.zeros(B, C, H, W, device=dev), "_slot": slot,
                                         "admin_mask": packed[:n_am].view(torch.float32).view(B, H, W),
                                         "y": packed[n_am:n_am + B * 4].view(torch.float32),
                                         "census_idx": packed[n_am + n_y:].view(torch.int64), "_packed": packed}
@@ -390,7 +395,7 @@ class FusedTrainStep:
         return out
 
     def _capture(self, sample, sel_host, key):
-        dkey, _, enc_ng, unet_ng, _ = key
+        dkey, _, enc_ng, unet_ng, _, _ = key
         mine = [d for d in (self._static or {}).values() if all(sample.get(k) is d[k] for k in d)]
         if mine:
             st = dict(mine[0])

@@ -335,3 +335,40 @@ def test_graph_cache_is_bounded_and_survives_an_out_of_memory_capture(monkeypatc
     torch.cuda.synchronize()
     assert got == want and torch.equal(tr.flat_p, ref.flat_p)
     assert calls[0] > 4                                     # evictions force re-captures: bounded memory, not bounded work
+
+
+def test_two_static_sets_with_their_own_graphs_equal_the_single_set_run():
+    """static_buffers(slot=0 / 1): a double-buffering loader alternates between two input sets, each captured into its own graph;
+    losses and parameters equal those of the same batches through one set (and through eager launches), bit for bit."""
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batches = [make_raw_batch(3, 100, 100, seed=40 + i, device="cuda", region="disc") for i in range(4)]
+
+    def trainer(use_graph):
+        torch.manual_seed(1600)
+        m = POPCORN(6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        return FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
+
+    def fill(st, b):
+        st["raw"].copy_(b["raw"]); st["admin_mask"].copy_(b["admin_mask"]); st["census_idx"].copy_(b["census_idx"]); st["y"].copy_(b["y"])
+
+    runs = []
+    for mode in ("eager", "one_set", "two_sets"):
+        tr = trainer(mode != "eager")
+        torch.manual_seed(77)
+        losses = []
+        for i in range(8):
+            b = batches[i % 4]
+            if mode == "eager":
+                s = {"raw": b["raw"], "admin_mask": b["admin_mask"], "census_idx": b["census_idx"], "y": b["y"]}
+            else:
+                s = tr.static_buffers(3, 100, 100, raw_channels=b["raw"].shape[1], slot=(i & 1) if mode == "two_sets" else 0)
+                fill(s, b)
+            losses.append(tr.step(s).tolist())
+        torch.cuda.synchronize()
+        if mode == "two_sets":
+            assert len(tr._graph_cache) == 2
+        runs.append((losses, tr.flat_p.clone()))
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[1][1], runs[2][1])

@@ -21,12 +21,26 @@ copied = [torch.cuda.Event() for _ in range(2)]; consumed = [torch.cuda.Event() 
 cs = torch.cuda.Stream(); cur = torch.cuda.current_stream()
 for e in consumed: e.record(cur)
 COPY = True
+NSPLIT = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # raw tile split over this many copy streams (one SDMA engine each)
+cs2 = [torch.cuda.Stream() for _ in range(NSPLIT - 1)]
+ev2 = [[torch.cuda.Event() for _ in range(NSPLIT - 1)] for _ in range(2)]
 def feed(i):
     s = i & 1
+    B = host["raw"].shape[0]
     with torch.cuda.stream(cs):
         cs.wait_event(consumed[s])
+    if COPY:
+        for j, st_ in enumerate(cs2):
+            with torch.cuda.stream(st_):
+                st_.wait_event(consumed[s])
+                lo, hi = B * (j + 1) // NSPLIT, B * (j + 2) // NSPLIT
+                sets[s]["raw"][lo:hi].copy_(host["raw"][lo:hi], non_blocking=True)
+                ev2[s][j].record(st_)
+    with torch.cuda.stream(cs):
         if COPY:
-            for k, v in host.items(): sets[s][k].copy_(v, non_blocking=True)
+            sets[s]["raw"][:B // NSPLIT].copy_(host["raw"][:B // NSPLIT], non_blocking=True)
+            sets[s]["_packed"].copy_(host["_packed"], non_blocking=True)
+            for e in ev2[s]: cs.wait_event(e)
         copied[s].record(cs)
 def run(n, do_feed=True):
     if do_feed: feed(0)

@@ -72,15 +72,24 @@ class FlatReducer:
         gloo works through the host and cannot)."""
         return self.active and self.backend == "nccl" and not self.capture_failed and os.environ.get("POPCORN_DP_ONE_GRAPH", "1") != "0"
 
+    def _host_path_sync(self, t: torch.Tensor):
+        # gloo moves device tensors through the host and waits for the producing stream itself; with two ranks sharing one GPU
+        # (the functional runs) that wait stalls for 30 - 1,700 ms every few steps (tools/dp_gloo_probe.py: 2-rank step 270 ms
+        # instead of 4 ms).  Draining the stream first -- the collective is a host round trip anyway -- removes the stalls.
+        if self.backend != "nccl" and t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+
     def reduce_stats(self, stats: torch.Tensor):
         """stats: float64[2] {Nsel, sum(scale)} -> global sums (in place)."""
         if self.active:
+            self._host_path_sync(stats)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         return stats
 
     def reduce_grads(self, flat: torch.Tensor):
         """flat fp32 gradient buffer -> sum over ranks (in place).  One collective per step."""
         if self.active:
+            self._host_path_sync(flat)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 

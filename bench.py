@@ -212,6 +212,14 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
     rec, names = [], []
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
+    # calibrate torch.cuda._sleep to ~150 us
+    c0, c1 = ev(), ev()
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    c0.record(); torch.cuda._sleep(2_000_000); c1.record()
+    torch.cuda.synchronize()
+    spin_cycles = int(2_000_000 * 0.150 / max(c0.elapsed_time(c1), 1e-3))
+
     def numel(t):
         return 0 if t is None else t.numel()
 
@@ -222,6 +230,11 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
         orig = getattr(obj, attr)
 
         def fn(*a, **k):
+            # a device-side delay in front of the first event: the host builds the launch (descriptors, ctypes call: 20-40 us)
+            # while the device spins, so that start event, kernel(s) and end event are all queued when the device reaches them
+            # -- without it the device idles between the two events while the host prepares the launch, and a 18 us kernel
+            # reads 42 us
+            torch.cuda._sleep(spin_cycles)
             e0 = ev(); e0.record()
             r = orig(*a, **k)
             e1 = ev(); e1.record()
@@ -382,8 +395,8 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
             "hbm_view": {"achieved_gbps": round(by / us / 1e3, 1), "peak": HBM_PEAK / 1e9, "frac": round(by / us * 1e6 / HBM_PEAK, 4)},
             "by_kind": {k: {"launches": t[3], "us": round(t[0], 1), "tflops": round(t[1] / t[0] / 1e6, 2), "gbps": round(t[2] / t[0] / 1e3, 1)}
                         for k, t in tot.items()},
-            "layers": layers, "note": "eager launches with an event after each (launch gaps of the host loop are inside the "
-                                      "per-launch figure); graph replay of the whole step is what `value` measures"}
+            "layers": layers, "note": "eager launches between two events each, behind a 150 us device-side spin so that the host's launch "
+                                      "preparation is not inside the figure; graph replay of the whole step is what `value` measures"}
 
 
 def _physical_cores():

@@ -124,6 +124,76 @@ __device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
         for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
 }
 
+// The same two contractions for the producer waves of head_bwd_pc_kernel, software-pipelined by hand: with ONE wave of that role
+// per SIMD nothing hides an LDS round trip, and hipcc sinks the fragment reads to just in front of their first use (a
+// lgkmcnt wait of ~150 cycles per 16 MFMAs) and re-serialises the 4 accumulator chains in places (a dependent MFMA issues
+// 40 cycles after its predecessor, not 32).  Here the fragments of K-block mb+1 are in flight during the 16 MFMAs of block
+// mb, and a scheduling barrier per K-step pins the 4-way accumulator interleave.
+// hook(step), step = 0..15: called after the 4 MFMAs of every K-step, in front of its scheduling barrier -- the caller's slice of
+// non-matrix work (a piece of a ring-slot write, of the next group's prefetch) that is to execute in the shadow of those MFMAs.
+// pre: the fragments of K-block 0, read by the caller one phase earlier; nx (out): the block-0 fragments of the NEXT contraction
+// (at nx_off, nx_stride K-blocks between its output blocks), read during this one's last block -- no contraction starts with an
+// exposed LDS round trip.
+template <class Hook>
+__device__ __forceinline__ void head_mm64_pf(const float* lds, int off, int lane, const f32x4 (&in)[4], f32x4 (&acc)[4],
+                                             const f32x4 (&pre)[4], int nx_off, int nx_stride, f32x4 (&nx)[4], Hook&& hook) {
+    f32x4 a4[2][4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) a4[0][mo] = pre[mo];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        if (mb < 3) {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+                a4[(mb + 1) & 1][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + mb + 1) * 64 + lane) * 4]);
+        } else {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) nx[mo] = *reinterpret_cast<const f32x4*>(&lds[nx_off + (mo * nx_stride * 64 + lane) * 4]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+                acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb & 1][mo][r], in[mb][r], acc[mo], 0, 0, 0);
+            hook(mb * 4 + r);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+__device__ __forceinline__ void head_frag0(const float* lds, int off, int stride, int lane, f32x4 (&f)[4]) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) f[mo] = *reinterpret_cast<const f32x4*>(&lds[off + (mo * stride * 64 + lane) * 4]);
+}
+// ReLU in ONE instruction (fmaxf on a value the compiler cannot prove canonical costs a canonicalising v_max x, x in front)
+__device__ __forceinline__ void relu_block(f32x4& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+}
+__device__ __forceinline__ void mask_block(f32x4& g, const f32x4& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = h[r] > 0.f ? g[r] : 0.f;
+}
+// first layer with the four output blocks interleaved (head_layer1 issues the 4 K-steps of a block back to back: dependent)
+__device__ __forceinline__ void head_layer1_il(const float* lds, int a_off, int b_off, int lane, int lk, const float (&xv)[4],
+                                               f32x4 (&h)[4]) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        h[mb] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb + 4 * lk]);
+        a4[mb] = *reinterpret_cast<const f32x4*>(&lds[a_off + (mb * 64 + lane) * 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb][j], xv[j], h[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void head_bias4(const float* lds, int b_off, int lk, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
+}
+
 // fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop4_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -174,12 +244,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         fetch(g + 1, sel_n, xv_n);
         float outv = 0.f;
         if (__any(sel)) {
-            f32x4 h[4], acc[4];
-            head_layer1(lds, L_A1, L_B0, lane, lk, xv, h);
-            relu4(h);
-            head_layer64(lds, L_A2, L_B2, lane, lk, h, acc);
-            relu4(acc);
-            head_layer64(lds, L_A3, L_B4, lane, lk, acc, h);
+            // software-pipelined chain (the helpers of the backward's producer waves): every contraction's first weight fragments are
+            // read one phase ahead, the ReLU of its input blocks 1-3 happens inside its own first K-steps
+            f32x4 h[4], acc[4], h3[4], fa[4], fb[4];
+            head_frag0(lds, L_A2, 4, lane, fa);
+            head_layer1_il(lds, L_A1, L_B0, lane, lk, xv, h);
+            head_bias4(lds, L_B2, lk, acc);
+            relu_block(h[0]);
+            head_mm64_pf(lds, L_A2, lane, h, acc, fa, L_A3, 4, fb, [&](int st) { if (!(st & 3) && st < 12) relu_block(h[(st >> 2) + 1]); });
+            head_bias4(lds, L_B4, lk, h3);
+            relu_block(acc[0]);
+            head_mm64_pf(lds, L_A3, lane, acc, h3, fb, L_W6, 0, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(acc[(st >> 2) + 1]); });
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) h[mb] = h3[mb];
             relu4(h);
             float s = 0.f;
 #pragma unroll
@@ -345,76 +422,6 @@ __device__ __forceinline__ void head_dgrad64(const float* lds, int t_off, int la
             for (int mi = 0; mi < 4; ++mi)
                 out[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mi][r], g[mb][r], out[mi], 0, 0, 0);
     }
-}
-
-// The same two contractions for the producer waves of head_bwd_pc_kernel, software-pipelined by hand: with ONE wave of that role
-// per SIMD nothing hides an LDS round trip, and hipcc sinks the fragment reads to just in front of their first use (a
-// lgkmcnt wait of ~150 cycles per 16 MFMAs) and re-serialises the 4 accumulator chains in places (a dependent MFMA issues
-// 40 cycles after its predecessor, not 32).  Here the fragments of K-block mb+1 are in flight during the 16 MFMAs of block
-// mb, and a scheduling barrier per K-step pins the 4-way accumulator interleave.
-// hook(step), step = 0..15: called after the 4 MFMAs of every K-step, in front of its scheduling barrier -- the caller's slice of
-// non-matrix work (a piece of a ring-slot write, of the next group's prefetch) that is to execute in the shadow of those MFMAs.
-// pre: the fragments of K-block 0, read by the caller one phase earlier; nx (out): the block-0 fragments of the NEXT contraction
-// (at nx_off, nx_stride K-blocks between its output blocks), read during this one's last block -- no contraction starts with an
-// exposed LDS round trip.
-template <class Hook>
-__device__ __forceinline__ void head_mm64_pf(const float* lds, int off, int lane, const f32x4 (&in)[4], f32x4 (&acc)[4],
-                                             const f32x4 (&pre)[4], int nx_off, int nx_stride, f32x4 (&nx)[4], Hook&& hook) {
-    f32x4 a4[2][4];
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) a4[0][mo] = pre[mo];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        if (mb < 3) {
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo)
-                a4[(mb + 1) & 1][mo] = *reinterpret_cast<const f32x4*>(&lds[off + ((mo * 4 + mb + 1) * 64 + lane) * 4]);
-        } else {
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo) nx[mo] = *reinterpret_cast<const f32x4*>(&lds[nx_off + (mo * nx_stride * 64 + lane) * 4]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo)
-                acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb & 1][mo][r], in[mb][r], acc[mo], 0, 0, 0);
-            hook(mb * 4 + r);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-__device__ __forceinline__ void head_frag0(const float* lds, int off, int stride, int lane, f32x4 (&f)[4]) {
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) f[mo] = *reinterpret_cast<const f32x4*>(&lds[off + (mo * stride * 64 + lane) * 4]);
-}
-// ReLU in ONE instruction (fmaxf on a value the compiler cannot prove canonical costs a canonicalising v_max x, x in front)
-__device__ __forceinline__ void relu_block(f32x4& h) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
-}
-__device__ __forceinline__ void mask_block(f32x4& g, const f32x4& h) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) g[r] = h[r] > 0.f ? g[r] : 0.f;
-}
-// first layer with the four output blocks interleaved (head_layer1 issues the 4 K-steps of a block back to back: dependent)
-__device__ __forceinline__ void head_layer1_il(const float* lds, int a_off, int b_off, int lane, int lk, const float (&xv)[4],
-                                               f32x4 (&h)[4]) {
-    f32x4 a4[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        h[mb] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb + 4 * lk]);
-        a4[mb] = *reinterpret_cast<const f32x4*>(&lds[a_off + (mb * 64 + lane) * 4]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mb][j], xv[j], h[mb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-__device__ __forceinline__ void head_bias4(const float* lds, int b_off, int lk, f32x4 (&acc)[4]) {
-#pragma unroll
-    for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
 }
 
 // scatter a D-layout (hidden x pixel) tile into the wave's LDS scratch as a [64][SCR_LD] matrix whose columns are

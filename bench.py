@@ -897,7 +897,12 @@ def main():
                        "global_batch": B * world, "tile": "15x100x100 -> 6x100x100 (128x128 internal)",
                        "parallelism": f"dp{world}", "graph": not args.no_graph,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
-                       "collectives": bool(trainer.reducer.active)},
+                       "collectives": bool(trainer.reducer.active),
+                       "collectives_per_step": 2 if trainer.reducer.active else 0,
+                       # how the captured step holds them: "one" = both inside the step's single HIP graph (RCCL), "split" =
+                       # three graphs with the two collectives launched between them (gloo, or a failed capture)
+                       "dp_graph": (None if (args.no_graph or not trainer.reducer.active or trainer._graphs is None) else
+                                    ("one" if len(trainer._graphs[3]) == 1 else "split"))},
             "timing": f"median of {len(blocks)} blocks of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks; "
                       f"{prewarm_steps} untimed steps ({args.prewarm_seconds} s) + {args.warmup} warm-up steps in front (clock settling, see --prewarm-seconds)",
             "prewarm_steps": prewarm_steps,

@@ -175,14 +175,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // mask is applied when the registers are written to LDS: a predicated load is if-converted into load + select,
     // i.e. an s_waitcnt right behind the load and no overlap with the MFMA phase.
     f32x4 R[NIT];
-    bool rvalid = false;
+    int rvalid = 0;                                       // how many of the segment's 4 pixels are inside the image (0 .. 4)
     auto issue = [&](int ch, int b, int y0, int x0) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
-        rvalid = ok;
+        // a row whose width is not a multiple of 4 ends inside a segment: the tail of that segment is read (the row stride is a
+        // multiple of 4, so the 16 bytes exist) and masked per pixel when it is written to LDS
+        rvalid = ok ? (p.W - xg < 4 ? p.W - xg : 4) : 0;
         if (LD == LD_REFLECT) {
             // first layer: reflect padding + channel gather; handles its own bounds (segments may straddle x = 0 / W)
-            rvalid = l_act;
+            rvalid = l_act ? 4 : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 R[it] = l_act ? pc_fetch_reflect_seg(q.a, b, ch * CHUNK + it, y, xg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -198,11 +200,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         } else if (LD == LD_POOL) {
             const int64_t off = ok ? b * my_bs + (int64_t)(2 * y) * my_rs + 2 * xg : 0;
             const int rs1 = ok ? my_rs : 0;
+            // the second 16-byte piece of the window: beyond the source row when fewer than 3 output pixels of this segment exist
+            // (ragged width) -- it is then masked anyway and reads the first piece's address instead
+            const int o4 = rvalid > 2 ? 4 : 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const act_t* s0 = a_ptr + (ch * CHUNK + it) * a_cstr + off;
-                const f32x4 a0 = pc_ld4(s0), a1 = pc_ld4(s0 + 4);
-                const f32x4 b0 = pc_ld4(s0 + rs1), b1 = pc_ld4(s0 + rs1 + 4);
+                const f32x4 a0 = pc_ld4(s0), a1 = pc_ld4(s0 + o4);
+                const f32x4 b0 = pc_ld4(s0 + rs1), b1 = pc_ld4(s0 + rs1 + o4);
                 f32x4 v;
                 v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1]));
                 v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
@@ -216,8 +221,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
         if (l_act) {
             float* d = wl + l_r * LROW + 4 * l_seg;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-                *reinterpret_cast<f32x4*>(d + it * LCH) = rvalid ? R[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < NIT; ++it) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < rvalid ? R[it][e] : 0.f;
+                *reinterpret_cast<f32x4*>(d + it * LCH) = v;
+            }
         }
     };
     auto load_generic = [&](int ch, int b, int y0, int x0) {
@@ -1330,8 +1339,12 @@ int conv_src_mode(const pc_src& s, int H, int W) {
     if (s.C == 0) return 0;
     const bool al = ((reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0) && (s.rstride % 4 == 0) && (s.cstride % 4 == 0) && (s.bstride % 4 == 0);
     if (!al) return 0;
-    if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W && (W % 4) == 0) return 1;
-    if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && (W % 4) == 0) return 2;
+    // (W % 4 != 0 is fine: the row stride is a multiple of 4, so every 16-byte segment that starts inside a row exists in
+    // memory; the loader masks its tail per pixel.  POOL2 reads source columns 2 xg .. 2 xg + 7 of which only those below 2 W are
+    // used: for rvalid <= 2 the second piece is not read at all, for rvalid == 3 it ends at 2 xg + 7 <= 2 W + 1 < row stride + 4
+    // only if the source row has at least 2 W + 2 floats -- required here.)
+    if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W) return 1;
+    if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && ((W % 4) == 0 || s.rstride >= 2 * W + 2)) return 2;
     return 0;
 }
 
@@ -1351,7 +1364,8 @@ int launch_conv(ConvArgs& p, int nprob, hipStream_t stream) {
     if (g_pc_precision == PC_PREC_BF16) return launch_conv_bf16<CIN, COUT, MODE>(p, nprob, stream);
     // loader choice: all problems of the group must qualify for a staged loader
     bool direct = true, pool = CHUNK >= 8, reflect = true;      // DIRECT also for the 2 / 4-channel first layers (pre-padded input)
-    bool vec = (p.W % 4) == 0;
+    bool vec = true;      // (any width: the vector epilogues only take strips that lie completely inside the image; a ragged last strip
+                          // of a row takes the per-element path)
     // fp32 mode: planar fp32 tensors everywhere
     const uintptr_t amask = 15;                        // a 4-pixel vector access: 16 bytes
     for (int i = 0; i < nprob; ++i) {

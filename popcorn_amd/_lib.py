@@ -149,12 +149,37 @@ def act_dtype():
     return torch.bfloat16 if lib().pc_get_precision() == PC_PREC_BF16 else torch.float32
 
 
+_PAD_ROWS = [False]
+
+
+class padded_rows:
+    """``with padded_rows():`` -- planar fp32 activations whose width is not a multiple of 4 are allocated with their rows padded
+    to one (a (B, C, H, W) view of a (B, C, H, W4) buffer; the pad columns are never read as data).  Every row then starts on a
+    16-byte boundary and the conv kernels keep their aligned staged loaders and vector stores -- e.g. the building extractor's
+    1038- and 519-pixel-wide levels of a 2048 x 2048 inference window (popcorn.py:231-258 pads it by 14), which otherwise take the
+    per-element loader (3.4x slower on those launches).  Used by the inference path (eval.py); training tiles are unaffected."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _PAD_ROWS[0]
+        _PAD_ROWS[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _PAD_ROWS[0] = self.prev
+        return False
+
+
 def empty_act(B, C_, H, W, device, zero=False):
     """Activation / activation-gradient tensor (B, C, H, W) in the layout of the current arithmetic mode: planar fp32, or
     channels-last bf16 (one aligned 16-byte slot per pixel and 8-channel group; include/popcorn_hip.h)."""
     mk = torch.zeros if zero else torch.empty
     if lib().pc_get_precision() == PC_PREC_BF16:
         return mk(B, C_, H, W, device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    if _PAD_ROWS[0] and W % 4:
+        return mk(B, C_, H, (W + 3) // 4 * 4, device=device, dtype=torch.float32)[..., :W]
     return mk(B, C_, H, W, device=device, dtype=torch.float32)
 
 

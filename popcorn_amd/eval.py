@@ -229,7 +229,7 @@ def evaluate_raster(models, raster, patchsize=INFERENCE_PATCH_SIZE, overlap=OVER
         inp = raster(x, y, season, patchsize).contiguous()
         sample = {"input": inp}
         pds, scs = [], []
-        with torch.no_grad():
+        with torch.no_grad(), L.padded_rows():      # (16-byte aligned rows for the levels whose width is not a multiple of 4)
             for j, m in enumerate(models):
                 m.eval()
                 if j > 0 and m.sentinelbuildings and "building_counts" in sample:

@@ -1341,10 +1341,10 @@ int conv_src_mode(const pc_src& s, int H, int W) {
     if (!al) return 0;
     // (W % 4 != 0 is fine: the row stride is a multiple of 4, so every 16-byte segment that starts inside a row exists in
     // memory; the loader masks its tail per pixel.  POOL2 reads source columns 2 xg .. 2 xg + 7 of which only those below 2 W are
-    // used: for rvalid <= 2 the second piece is not read at all, for rvalid == 3 it ends at 2 xg + 7 <= 2 W + 1 < row stride + 4
-    // only if the source row has at least 2 W + 2 floats -- required here.)
+    // used: with 1 or 2 valid pixels in the last segment (W % 4 = 1, 2) the second 16-byte piece is not read at all, with 3
+    // (W % 4 = 3) it ends at column 2 W + 1: the source row must then have at least 2 W + 2 floats.)
     if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W) return 1;
-    if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && ((W % 4) == 0 || s.rstride >= 2 * W + 2)) return 2;
+    if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && ((W % 4) != 3 || s.rstride >= 2 * W + 2)) return 2;
     return 0;
 }
 

@@ -555,15 +555,20 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         if not (COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (h, w) == (2 * z[keys[0]].shape[2], 2 * z[keys[0]].shape[3])):
             return None
         outs = {k: E(c, h, w) for k in keys}
-        if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or w not in (64, 128):
+        # (the composed BACKWARD kernels exist for 64- and 128-wide maps; a forward-only pass takes any geometry the kernel accepts,
+        # e.g. the 2048 / 1024-wide levels of an inference window)
+        if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or (any(saves) and w not in (64, 128)):
             return None
         ws = ops.conv3x3_up_fwd_group([{"skip": skip[k], "z": z[k], "w": ly(k, tag).w, "wt": ly(k, ttag).w, "bt": ly(k, ttag).b,
                                         "bn": ly(k, tag).bn, "out": outs[k], "ws": precomp.get((tag, k))} for k in keys])
         return outs, dict(zip(keys, ws))
 
     # with the composed first conv nobody reads the up-sampled tensors u2 / u1 -- not even the backward pass (up_bwd.hip)
-    compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and W1 in (64, 128)
-    compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and Wp in (64, 128)
+    fwd_only = not any(saves)          # (forward-only passes -- inference windows -- take any width the composed forward kernel accepts)
+    compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and \
+        (W1 in (64, 128) or (fwd_only and W1 % 32 == 0))
+    compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and \
+        (Wp in (64, 128) or (fwd_only and Wp % 32 == 0))
     precomp = {}
     if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
         # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)

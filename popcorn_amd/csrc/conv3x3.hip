@@ -1637,7 +1637,9 @@ extern "C" int64_t pc_conv3x3_up_ws_bytes(int C) { return (int64_t)((C / 8) * 15
 
 extern "C" int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C) {
     if (g_pc_precision != PC_PREC_FP32 || !skip || !z || !out) return 0;
-    if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W & 31)) return 0;
+    // (any even width with 16-byte aligned rows: the low-resolution piece is masked per column, the border bias per pixel, the ragged
+    // last strip of a row is stored by the per-element epilogue)
+    if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W & 1)) return 0;
     if (skip->C != Cs || z->C != C || z->H * 2 != H || z->W * 2 != W || z->mode != PC_SRC_DIRECT || z->oy || z->ox) return 0;
     if (z->dtype != PC_F32 || !pc_planar(*z) || skip->dtype != PC_F32 || !pc_planar(*skip) || out->dtype != PC_F32 || !pc_planar(*out)) return 0;
     if (conv_src_mode(*skip, H, W) != 1) return 0;

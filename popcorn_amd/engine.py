@@ -566,9 +566,9 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     # with the composed first conv nobody reads the up-sampled tensors u2 / u1 -- not even the backward pass (up_bwd.hip)
     fwd_only = not any(saves)          # (forward-only passes -- inference windows -- take any width the composed forward kernel accepts)
     compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and \
-        (W1 in (64, 128) or (fwd_only and W1 % 32 == 0))
+        (W1 in (64, 128) or fwd_only)
     compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and \
-        (Wp in (64, 128) or (fwd_only and Wp % 32 == 0))
+        (Wp in (64, 128) or fwd_only)
     precomp = {}
     if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
         # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)

@@ -213,7 +213,7 @@ def test_unet_backward_fused_level_equals_layerwise(monkeypatch):
         assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6), k
 
 
-@pytest.mark.parametrize("Cs,hw", [(8, (32, 64)), (16, (36, 32)), (8, (128, 128))])
+@pytest.mark.parametrize("Cs,hw", [(8, (32, 64)), (16, (36, 32)), (8, (128, 128)), (8, (44, 60)), (16, (20, 76)), (8, (12, 38))])
 def test_conv3x3_up_fwd_group_vs_convt_then_conv(Cs, hw):
     """pc_conv3x3_up_fwd_group (the first conv of an Up block from the LOW-resolution map: composed 2x2-neighbourhood weights per
     output parity, transposed-conv bias through the in-image taps; no up-sampled tensor) against torch float64
@@ -235,8 +235,15 @@ def test_conv3x3_up_fwd_group_vs_convt_then_conv(Cs, hw):
         refs.append(_ref_layer(torch.cat([skip.double(), u], 1), w, p).float())
         dv = [t.cuda() for t in (skip, z, w, wt, bt)]
         dp = [t.cuda() for t in p]
+        out = torch.full((B, 8, H, W), float("nan"), device="cuda")
+        if W % 4:                  # widths that are not a multiple of 4 need 16-byte aligned rows (L.padded_rows: the inference path)
+            with L.padded_rows():
+                sk = L.empty_act(B, Cs, H, W, "cuda")
+                out = L.empty_act(B, 8, H, W, "cuda")
+            sk.copy_(dv[0]); out.fill_(float("nan"))
+            dv[0] = sk
         pr = {"skip": dv[0], "z": dv[1], "w": dv[2], "wt": dv[3], "bt": dv[4], "bn": L.bn(dp[0], dp[1], dp[2], dp[3], dp[4], 1e-5),
-              "out": torch.full((B, 8, H, W), float("nan"), device="cuda")}
+              "out": out}
         assert ops.conv3x3_up_fwd_ok(pr["skip"], pr["z"], pr["out"])
         keep.append((dv, dp))
         probs.append(pr)

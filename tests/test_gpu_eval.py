@@ -196,3 +196,38 @@ def test_stitcher_and_census_vs_the_references_own_test_target_g12():
             assert abs(float(v) - ref) <= 5e-5 * max(1.0, abs(ref)), (name, k, float(v), ref)
         adj = E.adjust_map_to_census(r["map"].cuda().clone(), bnd, c["census_idx"], c["census_pop"])
         torch.testing.assert_close(adj.cpu(), r["adjusted"], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hw", [(172, 204), (90, 86), (256, 192)])
+def test_inference_forward_with_aligned_rows_and_composed_up_vs_plain_and_oracle(hw, monkeypatch):
+    """The inference path (eval.py) allocates activations with 16-byte aligned rows (L.padded_rows) and takes the composed Up
+    convolution at any even width.  (1) With the composed path switched off, aligned rows only change which LOADER a layer takes,
+    not a single arithmetic operation: bit-identical maps.  (2) With it on (the default) the maps agree to fp32 re-association
+    (<= 2e-5) and with the oracle at the forward bound of this suite.  Geometries whose padded levels are not multiples of 4 / 32
+    (the building extractor pads by 14: 200 x 232 -> 100 x 116 -> 50 x 58, 118 x 114 -> 59 x 57 -> 29 x 28, ...)."""
+    from popcorn_amd import _lib as L
+    from popcorn_amd import engine as E
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    H, W = hw
+    torch.manual_seed(1600)
+    m = POPCORN(6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = O.select_normalize(make_raw_batch(1, H, W, seed=5, region="full")["raw"])
+
+    def run(aligned):
+        with torch.no_grad(), L.padded_rows(aligned):
+            o = m({"input": x.cuda()}, padding=False)
+        return o["popdensemap"].cpu(), o["scale"].cpu()
+
+    monkeypatch.setattr(E, "COMPOSED_UP", False)
+    plain = run(False)
+    rows = run(True)
+    assert torch.equal(plain[0], rows[0]) and torch.equal(plain[1], rows[1])
+    monkeypatch.setattr(E, "COMPOSED_UP", True)
+    comp = run(True)
+    ref = O.popcorn_forward(sd, {"input": x}, padding=False, sparse=False)
+    for got, base, want in ((comp[0], plain[0], ref["popdensemap"]), (comp[1], plain[1], ref["scale"])):
+        scale = max(want.abs().max().item(), 1e-6)
+        assert (got - base).abs().max().item() <= 2e-5 * scale
+        assert (got - want).abs().max().item() <= 1e-4 * scale

@@ -130,7 +130,8 @@ typedef struct pc_conv_fwd_desc {
     /* optional, Cout == 8 only: instead of `out` (may then be NULL) write the single-channel map
      * dot_out[b][0][y][x] = sum_co dot_w[co] * relu(bn(conv))[co] -- the contribution of this layer's 8 feature channels to a
      * following 1x1 convolution (the frozen building extractor's fusion_out_conv, popcorn.py:301: its feature map has no
-     * other consumer, so it is never written).  Same geometry condition as pool_out. */
+     * other consumer, so it is never written).  PC_PREC_FP32: any geometry, planar fp32 dot_out; PC_PREC_BF16: the geometry
+     * condition of pool_out. */
     const float* dot_w; const pc_dst* dot_out;
 } pc_conv_fwd_desc;
 int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);

@@ -664,6 +664,22 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                 const int co = nb * 8 + col;
                 const f32x4 v = pacc[u][nb];
                 if (MODE == MODE_FWD) {
+                    if (EPI == EPI_DOT && q.dot_w) {
+                        // partial strip (ragged width / height): the 1x1 partial logit per element; the 8 lanes `col` of a group hold
+                        // the same pixels, so they are active together and the cross-lane sum is complete
+                        const float wl = q.dot_w[co];
+                        float* dp = q.dot_out.ptr + eb * q.dot_out.bstride + (int64_t)y * q.dot_out.rstride + x;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float o = v[r] * e_scale[nb] + e_shift[nb];
+                            float t = (p.relu ? fmaxf(o, 0.f) : o) * wl;
+                            t += __shfl_xor(t, 1);
+                            t += __shfl_xor(t, 2);
+                            t += __shfl_xor(t, 4);
+                            if (col == 0 && x + r < p.W) dp[r] = t;
+                        }
+                        continue;
+                    }
                     act_t* op = outp + eb * o_bs + co * o_cs + (int64_t)y * o_rs + x;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1470,9 +1486,11 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
         const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
         if (rc) return rc;
         if (d[i].dot_w) {
-            // the partial 1x1 sum replaces the feature map: all strips must take the vector epilogue
-            if (!d[i].dot_out || !d[i].dot_out->ptr || Cin != 8 || Cout != 8 || !relu || d[i].pool_out ||
-                !pool_out_geometry_ok(*d[i].dot_out, H, W))
+            // the partial 1x1 sum replaces the feature map.  bf16 mode: all strips must take the vector epilogue; fp32: any geometry
+            // (partial strips take the per-element form), planar fp32 output
+            const bool dot_geom = d[i].dot_out && (g_pc_precision == PC_PREC_BF16 ? pool_out_geometry_ok(*d[i].dot_out, H, W)
+                                                                                  : (d[i].dot_out->dtype == PC_F32 && pc_planar(*d[i].dot_out)));
+            if (!d[i].dot_out || !d[i].dot_out->ptr || Cin != 8 || Cout != 8 || !relu || d[i].pool_out || !dot_geom)
                 return PC_EINVAL;
             p.pr[i].dot_w = d[i].dot_w;
             p.pr[i].dot_out = *d[i].dot_out;

@@ -474,7 +474,8 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     mk = torch.empty if len(engines[0].streams) == 2 else torch.zeros
     if logit_only is None:
         logit_only = [False] * nE
-    dot_ok = len(engines[0].streams) == 2 and Wp % 32 == 0 and Hp % 4 == 0
+    # (fp32: any geometry -- partial strips take the per-element form of the epilogue; the bf16 kernels' form needs whole strips)
+    dot_ok = len(engines[0].streams) == 2 and (L.act_dtype() == torch.float32 or (Wp % 32 == 0 and Hp % 4 == 0))
     logit_only = [bool(lo) and dot_ok and not saves[e] and feats_list[e] is None and engines[e].fusion_w is not None
                   for e, lo in enumerate(logit_only)]
     feats = [f if f is not None else

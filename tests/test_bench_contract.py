@@ -1,0 +1,50 @@
+"""The driver's bench contract: `python bench.py ...` prints ONE JSON line (the last line of stdout) with the agreed keys, and the
+numbers on it are consistent with each other.  CPU part: the committed line of the final build (profiles/r3_bench_final.json);
+GPU part: a short live run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"}
+
+
+def _check_line(d, extras):
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["unit"] == "patches/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    B = d["config"]["global_batch"]
+    assert abs(d["value"] - B * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]            # value = tiles of one step / its time
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] * 1e12 - r["alg_flop_per_launch"] / (r["launch_us"] * 1e-6)) <= 2e-3 * r["achieved"] * 1e12
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["alg_bytes_per_launch"]
+    if extras:
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        assert d["bf16"]["value"] > d["value"] and d["soak"]["steps"] >= 1000 and len(d["h2d"]["legs"]) == 2
+
+
+def test_committed_final_bench_line_keeps_the_contract():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_final.json")))
+    _check_line(d, extras=True)
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32"
+    assert d["value"] >= 36300.0                          # >= 36.3 k patches/s (step <= 1.76 ms)
+
+
+@pytest.mark.gpu
+def test_live_bench_prints_one_json_line_last():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "2",
+                          "--prewarm-seconds", "0", "--no-extras", "--no-cpu-baseline", "--no-class-sweep"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                            # the JSON line is the LAST line of stdout
+    _check_line(d, extras=False)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1

@@ -145,8 +145,8 @@ int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int
  * through the taps that stay inside the image) are composed from w [8][Cs + C][3][3], wt [C][C][2][2], bt [C] into `ws`
  * (pc_conv3x3_up_ws_bytes(C) bytes) by a small first launch.  The up-sampled tensor is neither written nor read, and its half of
  * the convolution costs 2/3 of the MFMAs on a quarter of the input bytes.  (Cs, C) = (8, 8) or (16, 16), Cout = 8, H % 4 == 0,
- * W % 32 == 0, aligned planar fp32 (pc_conv3x3_up_fwd_ok); otherwise PC_EINVAL and the callers run pc_convt2x2_fwd_group +
- * pc_conv3x3_bn_relu_fwd_group. */
+ * W even, planar fp32 with 16-byte aligned rows (pc_conv3x3_up_fwd_ok); otherwise PC_EINVAL and the callers run
+ * pc_convt2x2_fwd_group + pc_conv3x3_bn_relu_fwd_group.  (The backward below exists for W = 64 and 128.) */
 typedef struct pc_conv_up_fwd_desc {
     const pc_src* skip; const pc_src* z; const float* w; const float* wt; const float* bt; const pc_bn* bn; const pc_dst* out; void* ws;
 } pc_conv_up_fwd_desc;

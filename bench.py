@@ -163,6 +163,24 @@ def _spin_cycles(torch, us=150.0):
     return int(_spin_cycles.per_us * us)
 
 
+class _LocalReducer:
+    """Stand-in for FlatReducer inside the roofline legs: they run on rank 0 only, so no collective may be part of their steps (the
+    timed kernel does not depend on them)."""
+    active, capture_failed, world = False, False, 1
+
+    def reduce_stats(self, t):
+        return t
+
+    def reduce_grads(self, t):
+        return t
+
+    def global_batch(self, b):
+        return b
+
+    def capturable(self):
+        return False
+
+
 def _head_bwd_in_replayed_step(torch, trainer, sample, reps):
     """Median seconds of the head-backward call (pack + kernel + reduce launches) inside replayed train steps: see the caller."""
     from popcorn_amd import ops, _lib as L
@@ -193,16 +211,10 @@ def _head_bwd_in_replayed_step(torch, trainer, sample, reps):
         begin(2)
         return r
 
-    class _Local:
-        active, capture_failed, world = False, False, 1
-        def reduce_stats(self, t): return t
-        def reduce_grads(self, t): return t
-        def global_batch(self, b): return b
-        def capturable(self): return False
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     ops.head_bwd = split
-    trainer.reducer = _Local()
+    trainer.reducer = _LocalReducer()
     try:
         with torch.cuda.stream(side), L.precision(trainer.model.precision):
             try:
@@ -267,17 +279,11 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
         t1.record()
         rec.append((t0, t1))
         return r
-    class _Local:       # this leg runs on rank 0 only: no collective may be part of its steps (the kernel does not depend on them)
-        active, capture_failed, world = False, False, 1
-        def reduce_stats(self, t): return t
-        def reduce_grads(self, t): return t
-        def global_batch(self, b): return b
-        def capturable(self): return False
     saved_graph, saved_reducer = trainer.use_graph, trainer.reducer
     snap = (trainer.flat_p.clone(), trainer.m.clone(), trainer.v.clone(), trainer.step_count.clone())
     ops.head_bwd = timed
     trainer.use_graph = False
-    trainer.reducer = _Local()
+    trainer.reducer = _LocalReducer()
     try:
         for r in range(reps + 2):
             torch.manual_seed(1)

@@ -2150,8 +2150,16 @@ __global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in
     const int x0 = 4 * piece, xs = x0 - left;
     f32x4 v;
     if (xs >= 0 && xs + 3 < W) {
-        const f32x4u t = *reinterpret_cast<const f32x4u*>(src + xs);       // interior: one (unaligned) 16-byte load
-        v = f32x4{t[0], t[1], t[2], t[3]};
+        if (((xs | W) & 1) == 0) {
+            // even pad and even width (14 / 100 for the training tiles): the piece is 8-byte aligned -- two 8-byte loads (the
+            // 4-byte-aligned vector type below is split into four dword loads by the compiler)
+            typedef float f32x2a __attribute__((ext_vector_type(2)));
+            const f32x2a t0 = *reinterpret_cast<const f32x2a*>(src + xs), t1 = *reinterpret_cast<const f32x2a*>(src + xs + 2);
+            v = f32x4{t0[0], t0[1], t1[0], t1[1]};
+        } else {
+            const f32x4u t = *reinterpret_cast<const f32x4u*>(src + xs);   // interior: one (unaligned) 16-byte load
+            v = f32x4{t[0], t[1], t[2], t[3]};
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wp ? src[pc_reflect(xs + e, W)] : 0.f;

@@ -456,7 +456,8 @@ int pc_select_normalize(const float* raw, int Craw, const int* band6, const floa
 
 /* Region totals: sums[id] = sum of pred over pixels with boundary == id, id in [0, num_ids) (other ids, e.g. the -1
  * fill, are ignored); counts[id] (optional) = pixel count.  One pass instead of the per-census-row bbox-crop loop of
- * convert_popmap_to_census (data/PopulationDataset.py:705-712).  fp64 accumulation; pred/boundary 16-byte aligned. */
+ * convert_popmap_to_census (data/PopulationDataset.py:705-712).  fp64 accumulation; pred/boundary: any 4-byte aligned
+ * address (a row band of a larger map): scalar head up to the first 16-byte boundary, 16-byte reads from there. */
 int pc_census_sum(const float* pred, const int32_t* boundary, int64_t n, int num_ids, double* sums, int32_t* counts,
                   void* stream);
 /* Dasymetric adjustment, adjust_map_to_census (PopulationDataset.py:823-852): pred[i] *= pop[id] / float(sums[id]) for

@@ -208,7 +208,14 @@ class precision:
         return False
 
 
+_SYNC_DEBUG = os.environ.get("POPCORN_SYNC_DEBUG") == "1"     # debugging aid: name every enqueued call and drain the device after it
+
+
 def check(code: int, what: str = ""):
+    if _SYNC_DEBUG and code == 0:
+        import sys
+        print(f"[popcorn] {what} enqueued", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if code != 0:
         msg = lib().pc_error_string(int(code)).decode()
         raise PopcornHipError(f"{what}: libpopcorn_hip error {code}: {msg}")

@@ -150,6 +150,20 @@ def normalize_sample(sample, device, transform=None):
     return out
 
 
+def limit_regime(num_pix, limit1, limit2, limit3):
+    """The memory-driven truncation of the backward pass by batch size in pixels (run_train.py:191-198; defaults
+    arguments/train.py:34-36: 9e6 / 9e6 / 13e6): (encoder_no_grad, unet_no_grad, skip the batch).  The limits nest like the
+    reference's ifs: limit2 / limit3 only apply beyond limit1 / limit2."""
+    enc_ng = unet_ng = skip = False
+    if num_pix > limit1:
+        enc_ng = True
+        if num_pix > limit2:
+            unet_ng = True
+            if num_pix > limit3:
+                skip = True
+    return enc_ng, unet_ng, skip
+
+
 class Trainer:
     def __init__(self, args):
         self.args = args
@@ -269,13 +283,9 @@ class Trainer:
             t = torch.tensor([num_pix], device=self.device, dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             num_pix = int(t.item())
-        enc_ng = unet_ng = False                                           # run_train.py:191-198
-        if num_pix > a.limit1:
-            enc_ng = True
-            if num_pix > a.limit2:
-                unet_ng = True
-                if num_pix > a.limit3:
-                    return None
+        enc_ng, unet_ng, skip = limit_regime(num_pix, a.limit1, a.limit2, a.limit3)
+        if skip:
+            return None
         if self.fused is not None:
             # loss_out is one device buffer overwritten by every step: keep a copy for the running log mean
             loss = self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0].clone()

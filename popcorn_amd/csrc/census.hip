@@ -26,10 +26,19 @@ __global__ __launch_bounds__(256) void census_sum_kernel(const float* __restrict
         for (int i = threadIdx.x; i < num_ids; i += 256) { acc[i] = 0.0; cnt[i] = 0; }
         __syncthreads();
     }
-    const int64_t n4 = n >> 2;
+    // any 4-byte aligned band of a larger map (a rank's row band starts at byte r0 * w * 4): a scalar head up to pred's first
+    // 16-byte boundary, 16-byte reads from there (boundary too when it happens to be aligned at the same element), scalar tail
+    int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(pred) & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    const bool b_vec = ((reinterpret_cast<uintptr_t>(boundary + head)) & 15) == 0;
+    const float* pv = pred + head;
+    const int32_t* bv = boundary + head;
+    const int64_t n4 = (n - head) >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(pred + 4 * i);
-        const int4 b = *reinterpret_cast<const int4*>(boundary + 4 * i);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pv + 4 * i);
+        int4 b;
+        if (b_vec) b = *reinterpret_cast<const int4*>(bv + 4 * i);
+        else { b.x = bv[4 * i]; b.y = bv[4 * i + 1]; b.z = bv[4 * i + 2]; b.w = bv[4 * i + 3]; }
         const int ids[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -40,9 +49,10 @@ __global__ __launch_bounds__(256) void census_sum_kernel(const float* __restrict
             }
         }
     }
-    // tail
+    // head + tail
     if (blockIdx.x == 0) {
-        for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+        for (int64_t j = threadIdx.x; j < head + (n - head - 4 * n4); j += 256) {
+            const int64_t i = j < head ? j : head + 4 * n4 + (j - head);
             const int id = boundary[i];
             if ((unsigned)id < (unsigned)num_ids) {
                 if (use_lds) { atomicAdd(&acc[id], (double)pred[i]); atomicAdd(&cnt[id], 1); }
@@ -144,7 +154,7 @@ int stream_grid(int64_t n, int per_thread = 4) {
 extern "C" int pc_census_sum(const float* pred, const int32_t* boundary, int64_t n, int num_ids, double* sums,
                              int32_t* counts, void* stream) {
     if (!pred || !boundary || !sums || num_ids <= 0) return PC_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(pred) & 15) || (reinterpret_cast<uintptr_t>(boundary) & 15)) return PC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(pred) & 3) || (reinterpret_cast<uintptr_t>(boundary) & 3)) return PC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(census_zero_kernel, dim3((num_ids + 255) / 256 > 64 ? 64 : (num_ids + 255) / 256), dim3(256), 0, st, sums, counts, num_ids);
     PC_CHECK_LAUNCH();

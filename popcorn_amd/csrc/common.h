@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include "popcorn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -64,6 +65,20 @@ __device__ __forceinline__ float pc_src_at(const pc_src& s, int64_t i) {
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// One-time launcher setup (hipFuncSetAttribute(MaxDynamicSharedMemorySize), resident-grid probes) is per DEVICE, not per process:
+// the guard is a bit mask over the current device ordinal, set with an atomic OR (a process that launches on a second device
+// repeats the setup there; two host threads racing through it both do the idempotent setup).
+struct pc_once_per_device {
+    std::atomic<uint64_t> done{0};
+    static uint64_t bit() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        return 1ull << (d & 63);
+    }
+    bool need() const { return !(done.load(std::memory_order_acquire) & bit()); }
+    void mark() { done.fetch_or(bit(), std::memory_order_release); }
+};
+
 // Workgroups of 256 threads (one wave per SIMD) that are resident on the whole chip at once for a kernel using `regs`
 // unified VGPR+AGPR registers per lane (512 per SIMD lane, allocated in blocks of 8) and `lds` bytes of LDS (160 KB / CU).
 static inline int pc_resident_workgroups(int regs, size_t lds) {
@@ -84,7 +99,8 @@ static inline int pc_resident_workgroups(int regs, size_t lds) {
 
 // Division by a launch-invariant divisor without the ~40-instruction VALU sequence the compiler emits for a runtime
 // integer divide (there is no hardware integer divide; in the persistent tile loops those sequences were ~1000
-// instructions per stage per wave -- tools/ablate_conv.py).  q = umulhi(n, ceil(2^32 / d)) is exact for n * d < 2^32.
+// instructions per stage per wave -- tools/ablate_conv.py).  q = umulhi(n, ceil(2^32 / d)) is exact for n * d < 2^32; pc_div
+// corrects the estimate beyond that.
 struct pc_fastdiv {
     uint32_t d, m;
 };
@@ -94,7 +110,15 @@ static inline pc_fastdiv pc_make_fastdiv(uint32_t d) {
     f.m = f.d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + f.d - 1) / f.d);
     return f;
 }
-__device__ __forceinline__ uint32_t pc_div(uint32_t n, const pc_fastdiv& f) { return f.d == 1 ? n : __umulhi(n, f.m); }
+// Round 4: m = ceil(2^32 / d) OVER-estimates the quotient by one for some n once n * d reaches 2^32 -- 100 x 100 tiles never get
+// there, a 2 x 2100 x 2150 census region does (group index 564 k / 282 k groups per image -> sample index 2 of 2 = a fault in the head
+// backward).  The estimate is never more than one too large for n < 2^32 (n * (m - 2^32 / d) / 2^32 < 1): one multiply + compare
+// makes the quotient exact for every n, d with n + d < 2^32.
+__device__ __forceinline__ uint32_t pc_div(uint32_t n, const pc_fastdiv& f) {
+    if (f.d == 1) return n;
+    const uint32_t q = __umulhi(n, f.m);
+    return q - (uint32_t)(q * f.d > n);
+}
 
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give every XCD a contiguous slice of the tile
 // space so that neighbouring tiles (which share halo rows and the same weights) hit the same private L2.

@@ -877,7 +877,8 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     const size_t lds = ((size_t)4 * (P2 ? SROWS * (8 * 40 + 32) : CHUNK * CSW) + (N16 ? 16 * (CIN * 9 + 1) : 4 * (COUT * (CIN * 3 + 4) + 16)) +
                         (ZC / 8) * 64 * 28) * sizeof(float);   // wave strips + weight image (+ composed weight image)
     static int resident = 0;               // workgroups of this instantiation that fit on the chip at once
-    if (!resident) {
+    static pc_once_per_device once;
+    if (once.need()) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, LD, EPI, ZC>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -885,6 +886,7 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
         e = hipFuncGetAttributes(&fa, fn);
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, lds);
+        once.mark();
         if (getenv("POPCORN_CONV_DBG"))
             fprintf(stderr, "conv3x3<%d,%d,%d,%d,z%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD, ZC,
                     fa.numRegs, lds, resident);
@@ -1259,7 +1261,8 @@ int launch_conv_cl(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
     const size_t lds = (size_t)4 * BWAVE_F * sizeof(float) + (size_t)4 * COUT * NCHUNK * 24 * sizeof(unsigned short);
     static int resident = 0;
-    if (!resident) {
+    static pc_once_per_device once;
+    if (once.need()) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -1267,6 +1270,7 @@ int launch_conv_cl(ConvArgs& p, int nprob, hipStream_t stream) {
         e = hipFuncGetAttributes(&fa, fn);
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, lds);
+        once.mark();
         if (getenv("POPCORN_CONV_DBG"))
             fprintf(stderr, "conv3x3_cl<%d,%d,%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CIN, COUT, MODE, LD, EPI,
                     fa.numRegs, lds, resident);

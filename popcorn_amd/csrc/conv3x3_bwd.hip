@@ -339,7 +339,8 @@ template <int GC, int XC, bool POOL>
 int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     using Cfg = BwdCfg<GC, XC>;
     static int resident = 0;
-    if (!resident) {
+    static pc_once_per_device once;
+    if (once.need()) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_cl_kernel<GC, XC, POOL>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_B);
         if (e != hipSuccess) return (int)e;
@@ -347,6 +348,7 @@ int launch_bwd(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
         e = hipFuncGetAttributes(&fa, fn);
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, Cfg::LDS_B);
+        once.mark();
         if (getenv("POPCORN_CONV_DBG"))
             fprintf(stderr, "conv3x3_bwd<%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", GC, XC, (int)POOL, fa.numRegs, (size_t)Cfg::LDS_B, resident);
     }
@@ -573,7 +575,8 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_f32_kernel(const BwdArgs p) {
 
 int launch_bwd_f32(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     static int resident = 0;
-    if (!resident) {
+    static pc_once_per_device once;
+    if (once.need()) {
         const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_f32_kernel);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_B);
         if (e != hipSuccess) return (int)e;
@@ -581,6 +584,7 @@ int launch_bwd_f32(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
         e = hipFuncGetAttributes(&fa, fn);
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, F_LDS_B);
+        once.mark();
         if (getenv("POPCORN_CONV_DBG"))
             fprintf(stderr, "conv3x3_bwd_f32: %d regs, %zu B LDS -> %d resident workgroups\n", fa.numRegs, (size_t)F_LDS_B, resident);
     }

@@ -769,16 +769,18 @@ int launch_wgrad_wave(const WgradGroup& g, int n, int kind, int& nwg, int nchunk
     size_t lw_f32 = (size_t)4 * CINC * WIN_CSW * sizeof(float);          // fp32 strips
     if (lw_f32 < lred) lw_f32 = lred;
     const size_t lw_bf = WgradClCfg<CINC, COUT>::LDS_B;                   // channels-last bf16 strips / reduction staging
-    static int resident[5] = {0, 0, 0, 0, 0};    // workgroups of the instantiation that fit on the chip at once
+    static int resident[5] = {0, 0, 0, 0, 0};
+    static pc_once_per_device once[5];    // workgroups of the instantiation that fit on the chip at once
     auto go = [&](auto kern, int slot) -> int {
         const size_t lw = slot >= 3 ? lw_bf : lw_f32;
-        if (!resident[slot]) {
+        if (once[slot].need()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
             if (e != hipSuccess) return (int)e;
             hipFuncAttributes fa;
             e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
             if (e != hipSuccess) return (int)e;
             resident[slot] = pc_resident_workgroups(fa.numRegs, lw);
+            once[slot].mark();
             if (getenv("POPCORN_CONV_DBG"))
                 fprintf(stderr, "wgrad<%d,%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", CINC, COUT, slot, fa.numRegs, lw,
                         resident[slot]);
@@ -837,12 +839,12 @@ int launch_wgrad(WgradArgs& p, int Cin, float* dw, float* db, int accumulate, vo
         if (rc) return rc;
     } else {
         const size_t ldsb = (size_t)Cfg::LDS_FLOATS * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static pc_once_per_device once;
+        if (once.need()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<CINC, COUT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
+            once.mark();
         }
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<CINC, COUT>), dim3(nwg, nchunk), dim3(256), ldsb, stream, p);
         PC_CHECK_LAUNCH();

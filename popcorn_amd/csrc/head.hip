@@ -2284,11 +2284,13 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     // cover its image chunk -- with a fixed 8 groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on
     // 1024 slots, i.e. a second, quarter-full round.
     static int resident = 0;
-    if (!resident) {
+    static pc_once_per_device once;
+    if (once.need()) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
         if (e != hipSuccess) return (int)e;
         resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
+        once.mark();
     }
     int chunks = resident / (B > 0 ? B : 1);                      // chunks per image that fit in one round
     const int max_chunks = (p.groups + 31) / 32;                  // never fewer than 8 groups per wave (workspace bound)
@@ -2451,15 +2453,15 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         const char* dv = getenv("POPCORN_HEAD_DBG");
         a.dbg = dv ? atoi(dv) : 0;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static pc_once_per_device once;
+    if (once.need()) {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
         e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
+        once.mark();
     }
     {
         void* img = head_image_slot(ws, B, H, W, 1);
@@ -2468,8 +2470,8 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         PC_CHECK_LAUNCH();
     }
     if (p.bf) {
-        static bool a4 = false;
-        if (!a4) {
+        static pc_once_per_device once4;
+        if (once4.need()) {
             hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_bf16_coop4_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, H4_END);
             if (e5 != hipSuccess) return (int)e5;
@@ -2478,7 +2480,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, head_bwd_bf16_coop4_kernel, 256, H4_END);
                 fprintf(stderr, "head_bwd_bf16_coop4: %d bytes of LDS -> %d workgroups per CU\n", H4_END, nb);
             }
-            a4 = true;
+            once4.mark();
         }
         nwg = (a.total_groups + H4_WAVES - 1) / H4_WAVES;       // two 4-wave workgroups per CU (2 x 79 KB of LDS)
         if (nwg > 512) nwg = 512;

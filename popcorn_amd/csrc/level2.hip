@@ -500,7 +500,7 @@ __global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) {
-    return p && dtype == PC_F32 && xs <= 1 && aligned16(p) && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
+    return p && dtype == PC_F32 && (xs == 1 || xs == 0) && aligned16(p) && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
 }
 
 }  // namespace
@@ -533,11 +533,11 @@ extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, vo
         p.u2 = nullptr; p.u2_bs = p.u2_cs = 0; p.u2_rs = 0;
         if (s.u2) { p.u2 = s.u2->ptr; p.u2_bs = s.u2->bstride; p.u2_cs = s.u2->cstride; p.u2_rs = s.u2->rstride; }
     }
-    static bool attr = false;
-    if (!attr) {
+    static pc_once_per_device once;
+    if (once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L2_LDS);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        once.mark();
     }
     hipLaunchKernelGGL(level2_fwd_kernel, dim3(B, n), dim3(512), L2_LDS, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();
@@ -573,11 +573,11 @@ extern "C" int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, in
         p.out = s.out->ptr; p.o_bs = s.out->bstride; p.o_cs = s.out->cstride; p.o_rs = s.out->rstride;
         p.ws1 = (float*)s.ws1; p.ws2 = (float*)s.ws2;
     }
-    static bool attr = false;
-    if (!attr) {
+    static pc_once_per_device once;
+    if (once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        once.mark();
     }
     hipLaunchKernelGGL(level2_bwd_kernel, dim3(2 * B, n), dim3(512), B2_LDS, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();

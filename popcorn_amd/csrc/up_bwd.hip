@@ -411,11 +411,11 @@ int launch_up_bwd(const UbArgs& a, int n, int nwg, hipStream_t st) {
     if (scratch > fl) fl = scratch;
     if ((size_t)256 * 16 > fl) fl = 256 * 16;
     const size_t lds = fl * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static pc_once_per_device once;
+    if (once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_bwd_kernel<C, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        once.mark();
     }
     hipLaunchKernelGGL((up_bwd_kernel<C, W>), dim3(nwg, n), dim3(256), lds, st, a);
     PC_CHECK_LAUNCH();

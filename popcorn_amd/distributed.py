@@ -69,8 +69,20 @@ class FlatReducer:
 
     def capturable(self):
         """Collectives of this group can be recorded into a HIP graph (torch's NCCL / RCCL backend supports stream capture;
-        gloo works through the host and cannot)."""
-        return self.active and self.backend == "nccl" and not self.capture_failed and os.environ.get("POPCORN_DP_ONE_GRAPH", "1") != "0"
+        gloo works through the host and cannot).  OPT-IN (POPCORN_DP_ONE_GRAPH=1): the one-graph step has only ever run with one
+        rank (single-GPU test boxes), where the collectives are identities; until a run with >= 2 GPUs has verified it the
+        default is the split form -- three graphs with the two collectives launched eagerly between them (+ ~30 us per step)."""
+        return self.active and self.backend == "nccl" and not self.capture_failed and os.environ.get("POPCORN_DP_ONE_GRAPH", "0") == "1"
+
+    def all_agree(self, ok: bool) -> bool:
+        """True iff ``ok`` holds on EVERY rank (eager MIN all-reduce of a flag): decisions that change the sequence of collectives
+        a rank issues must be taken by all ranks together."""
+        if not self.active:
+            return bool(ok)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
 
     def _host_path_sync(self, t: torch.Tensor):
         # gloo moves device tensors through the host and waits for the producing stream itself; with two ranks sharing one GPU

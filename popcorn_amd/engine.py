@@ -484,6 +484,11 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     E = lambda c, h, w: L.empty_act(B, c, h, w, dev)  # noqa: E731
     streams = engines[0].streams
     assert all([st[0] for st in e.streams] == [st[0] for st in streams] for e in engines)
+    if Xp_all is not None:
+        # the padded input is sliced by engines[0]'s stream table: every engine must read the same channels in the same order
+        order = stream_channel_order(streams)
+        if any(stream_channel_order(e.streams) != order for e in engines) or Xp_all.shape[1] != sum(st[2] for st in streams):
+            raise ValueError(f"Xp_all holds {Xp_all.shape[1]} channels; the engines expect {order} (identical for all engines)")
     keys = [(e, s) for e in range(nE) for s, _, _, _ in streams]
     ly = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
 
@@ -543,12 +548,9 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     a2 = conv("inc2", a1, 8, Hp, Wp, pooled=pa2)
     b1 = down("d1a", a2, pa2, 16, H1, W1)
     b2 = conv("d1b", b1, 16, H1, W1, pooled=pb2)
-    def convt(tag, ins, c, h, w, only=None):
-        """only: the keys that need the up-sampled tensor (the others get None)"""
-        ks = keys if only is None else [k for k in keys if k in only]
-        outs = {k: (E(c, h, w) if k in ks else None) for k in keys}
-        if ks:
-            ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in ks])
+    def convt(tag, ins, c, h, w):
+        outs = {k: E(c, h, w) for k in keys}
+        ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in keys])
         return outs
 
     def up_conv(tag, ttag, skip, z, c, h, w):

@@ -108,8 +108,13 @@ class Stitcher:
                 for p in range(self.acc.shape[0]):
                     plane = self.acc[p]                                # (hp, w) contiguous: chunk r = band r
                     dist.reduce_scatter_tensor(plane[rank * self.hb:(rank + 1) * self.hb], plane, group=reducer.group)
-            else:                                                      # gloo (functional runs): no reduce-scatter on devices
+            else:
+                # gloo (functional runs) has no reduce-scatter on device tensors: all-reduce, then make the result look like one --
+                # the rows of the OTHER ranks' bands are poisoned, so anything that reads a stale row after this call (which the
+                # RCCL branch leaves unsummed) shows up as NaN in the functional tests instead of passing by accident
                 dist.all_reduce(self.acc, group=reducer.group)
+                self.acc[:, :rank * self.hb] = float("nan")
+                self.acc[:, (rank + 1) * self.hb:] = float("nan")
         self.band = (r0, r1)
         return self.band
 
@@ -160,6 +165,7 @@ def census_sums_sharded(st: "Stitcher", boundary, num_ids, reducer: FlatReducer)
     band, then ONE all-reduce of the float64 per-region sums (num_ids * 8 bytes) -- the full map never travels."""
     r0, r1 = st.band if st.band is not None else (0, st.h)
     if r1 > r0:
+        # (a band starts at byte r0 * w * 4 of the plane: any 4-byte alignment -- pc_census_sum takes a scalar head)
         sums = census_sums(st.out[r0:r1], boundary[r0:r1].contiguous().to(torch.int32), num_ids)
     else:
         sums = torch.zeros(num_ids, dtype=torch.float64, device=st.out.device)

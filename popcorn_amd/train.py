@@ -22,6 +22,19 @@ from . import ops
 from .distributed import FlatReducer
 from .model.popcorn import pad_geometry
 
+def _is_oom(exc):
+    """An allocation failure, also when it surfaces as the RuntimeError of a failed ``capture_end`` with the OutOfMemoryError as its
+    context (an exception inside ``with torch.cuda.graph(g)`` leaves through ``__exit__`` -> ``capture_end``, which raises on the
+    invalidated capture and masks the original)."""
+    seen = set()
+    while exc is not None and id(exc) not in seen:
+        seen.add(id(exc))
+        if isinstance(exc, torch.OutOfMemoryError) or "out of memory" in str(exc).lower():
+            return True
+        exc = exc.__cause__ or exc.__context__
+    return False
+
+
 LOSS_INDEX = {"l1_loss": 0, "log_l1_loss": 1, "mse_loss": 2, "log_mse_loss": 3}
 HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
 
@@ -332,11 +345,13 @@ class FusedTrainStep:
                 with L.precision(self.model.precision):      # the mode is read when a launch is enqueued = captured
                     try:
                         self._capture(sample, sel_host, key)
-                    except torch.OutOfMemoryError:
-                        # every cached step keeps its own pool alive: let them all go and try once more with the memory back
+                    except RuntimeError as e:
+                        if not _is_oom(e):
+                            raise
+                        # every cached step keeps its own pool alive: let them all go and try once more with the memory back.  The
+                        # loader-facing static sets are NOT part of those pools and stay (a loader keeps writing into them)
                         self._graphs = None
                         self._graph_cache.clear()
-                        self._static = None
                         torch.cuda.synchronize()
                         torch.cuda.empty_cache()
                         self._capture(sample, sel_host, key)
@@ -420,6 +435,7 @@ class FusedTrainStep:
             # ONE graph for the whole step.  Data parallel on RCCL: the two collectives ({Nsel, sum scale}: 16 bytes; the flat
             # gradient: 157 KB) are captured as nodes of the same graph -- no graph boundary and no eager collective launch
             # between the three sections (POPCORN_DP_ONE_GRAPH=0 or a backend that cannot be captured: the split form below)
+            ok = True
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -429,12 +445,18 @@ class FusedTrainStep:
                     self.reducer.reduce_grads(self.flat_g)
                     self._update(enc_ng, unet_ng)
                 graphs = [g]
-            except Exception:
-                if not self.reducer.active:
+            except RuntimeError as e:
+                # only a failed CAPTURE of the collectives falls back; allocation failures and programming errors propagate
+                if not self.reducer.active or _is_oom(e):
                     raise
                 torch.cuda.synchronize()
-                self.reducer.capture_failed = True
-                graphs = []
+                ok, graphs = False, []
+            if self.reducer.active:
+                # every rank must replay the same structure (one graph with captured collectives vs three graphs with eager
+                # collectives between them issue different collective sequences): agree, and fall back TOGETHER
+                if not self.reducer.all_agree(ok):
+                    self.reducer.capture_failed = True
+                    graphs = []
         if not graphs:
             g0, g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g0):

@@ -28,3 +28,17 @@ def test_synthetic_dataset_and_collate_shapes():
     assert b["S2"].shape == (3, 4, H, W) and b["S1"].shape == (3, 2, H, W) and b["admin_mask"].shape == (3, H, W)
     assert torch.equal(b["census_idx"], torch.tensor([1, 2, 3]))
     assert (b["admin_mask"][0, ds.hw[0][0]:, :] == -1).all()
+
+
+def test_limit_regime_nests_like_the_reference():
+    """run_train.py:191-198 with the defaults of arguments/train.py:34-36 (9e6 / 9e6 / 13e6)."""
+    from popcorn_amd.cli import limit_regime, train_parser
+    a = train_parser().parse_args([])
+    assert (a.limit1, a.limit2, a.limit3, a.weak_batch_size) == (9000000, 9000000, 13000000, 2)
+    L = (a.limit1, a.limit2, a.limit3)
+    assert limit_regime(2 * 2100 * 2140, *L) == (False, False, False)          # 8.988e6 px: everything trains
+    assert limit_regime(9000000, *L) == (False, False, False)                 # strict ">"
+    assert limit_regime(2 * 2100 * 2150, *L) == (True, True, False)            # 9.03e6 px: head only (limit1 == limit2)
+    assert limit_regime(13000001, *L) == (True, True, True)                   # skipped
+    assert limit_regime(500, 100, 1000, 2000) == (True, False, False)         # decoder + head
+    assert limit_regime(5000, 100, 10000, 2000) == (True, False, False)       # limit3 only applies beyond limit2

@@ -162,3 +162,71 @@ def test_two_rank_evaluate_raster_equals_single_process(band):
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)), name
         np.testing.assert_allclose(b[fin], a[fin], rtol=2e-5, atol=2e-6, err_msg=name)
+
+
+def _band_census_rank(rank, world, port, q):
+    """evaluate_raster(gather=False) + census_sums_sharded on a raster with an ODD width and an odd band height: rank 1's band
+    starts at a byte offset that is not a multiple of 16 (pc_census_sum refused it and the other rank then hung in
+    the all-reduce)."""
+    import torch.distributed as dist
+    from popcorn_amd import eval as E
+    from popcorn_amd.distributed import FlatReducer
+    from popcorn_amd.model import POPCORN
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda().eval()
+    g = torch.Generator().manual_seed(11)
+    h, w = 301, 421
+    raster = torch.randn(1, 6, h, w, generator=g).cuda()
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    boundary = ((yy // 43) * 10 + xx // 47).to(torch.int32).cuda()
+    boundary[:3] = -1
+    red = FlatReducer()
+    if world > 1:
+        st = E.evaluate_raster([m], raster, patchsize=128, overlap=16, reducer=red, rank=rank, band_reduce=True, gather=False)
+        r0, r1 = st.band
+        assert (r0 * w) % 4 != 0 or rank == 0
+        # the emulated reduce-scatter poisons the rows of the other ranks' bands: nothing below may read them
+        if rank == 1:
+            assert torch.isnan(st.out[:r0]).all()
+        sums = E.census_sums_sharded(st, boundary, 80, red)
+        band = st.out[r0:r1].clone()
+        maps = st.gather_bands(red)
+        assert torch.equal(maps[0][r0:r1], band)
+    else:
+        maps = E.evaluate_raster([m], raster, patchsize=128, overlap=16, reducer=red, rank=0)
+        sums = E.census_sums(maps[0].contiguous(), boundary, 80)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put([sums.cpu().numpy(), maps[0].cpu().numpy()])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_banded_census_sums_with_odd_width_and_poisoned_foreign_bands():
+    """301 x 421 raster over 2 ranks: bands of 151 rows, rank 1's band starts at element 151 * 421 (odd -> 4-byte aligned only).
+    Region sums from the distributed bands == the single-process sums; the gathered mean map == the single-process map; the
+    reduce-scatter emulation on gloo leaves NaN in every row a rank does not own, so a stale-row read cannot pass."""
+    from tests.test_gpu_dp import _get
+    outs = []
+    for world in (1, 2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_band_census_rank, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs.append(_get(q, procs))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    (s1, m1), (s2, m2) = outs
+    assert np.isfinite(s2).all()
+    np.testing.assert_allclose(s2, s1, rtol=1e-6, atol=1e-6)
+    fin = np.isfinite(m1)
+    assert np.array_equal(fin, np.isfinite(m2))
+    np.testing.assert_allclose(m2[fin], m1[fin], rtol=2e-5, atol=2e-6)

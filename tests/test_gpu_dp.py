@@ -78,7 +78,7 @@ def _run(rank, world, port, use_graph, q):
         for a, b in zip(got, want):
             assert torch.equal(a.nan_to_num(-1.0), b.nan_to_num(-1.0))
         if use_graph:
-            # one graph with both collectives captured as nodes (default on RCCL), or
+            # one graph with both collectives captured as nodes (POPCORN_DP_ONE_GRAPH=1, opt-in until verified on >= 2 GPUs), or
             # forward | stats all-reduce | backward | gradient all-reduce | update as three graphs around two eager collectives
             assert len(tr._graphs[3]) == (3 if split else 1), (len(tr._graphs[3]), tr.reducer.capture_failed)
     if rank == 0:

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra objects of the line: `bf16` (config 4's precision, same process), `soak` (N = 1: one "
                          "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
+    ap.add_argument("--extras-multi", action="store_true",
+                    help="N > 1: also run the `bf16` and `h2d` legs (default: skipped, the multi-GPU run stays under two minutes)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `config3_regions`, `config5`")
     ap.add_argument("--soak-steps", type=int, default=1500)
     ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed steps in front of the W warm-up steps until this much wall time has passed: the part's clocks settle "
@@ -308,17 +311,20 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     flops = float(FLOP_HEAD_BWD_PX) * nsel
     issued = float(FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX) * nsel
     achieved = flops / dur / 1e12
-    pmc = _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
+    pmc = _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
+    rp_us, rp_file = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else "head_bwd_pc_kernel", "bf16" if bf else "fp32")
     kname = ("head_bwd_bf16_coop4_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, the 4 waves of a workgroup share the weight gradients through an LDS exchange + transposing reads, 2 workgroups per CU)" if bf else
              "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
     if bf:
-        pmc = _pmc("r3_pmc_head_bwd_bf16.json") or _pmc("r2_pmc_head_bwd_bf16.json")
+        pmc = _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or _pmc("r2_pmc_head_bwd_bf16.json")
         traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     return {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call",
             "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "launch_us_eager_step": round(dur_eager * 1e6, 2),
+            "rocprof_us": rp_us, "rocprof_file": rp_file,
+            "rocprof_frac": (round(flops / (rp_us * 1e-6) / peak, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
             "timed": ("graph replay of the step split at the call (events around the middle graph)" if dur_graph else
                       "eager steps, events around the call behind a device-side spin"),
             "alg_flop_per_launch": flops, "units_per_launch": nsel,
@@ -368,7 +374,8 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
     nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
-    pmc = _pmc("r3_pmc_conv_8to8_bf16.json" if esz == 2 else "r3_pmc_conv_8to8.json")
+    pmc = (_pmc("r4_pmc_conv_8to8_bf16.json" if esz == 2 else "r4_pmc_conv_8to8.json") or
+           _pmc("r3_pmc_conv_8to8_bf16.json" if esz == 2 else "r3_pmc_conv_8to8.json"))
     return {"bound": "hbm", "kernel": f"{'conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)' if esz == 2 else 'conv3x3_mfma_kernel<8,8,fwd> (fp32)'} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
             "traffic": pmc["traffic_bytes"] if pmc and B == 64 else None, "launch_us": round(dur * 1e6, 2),
@@ -624,6 +631,154 @@ def cpu_baseline(torch, sd, seconds):
             "sample": f"{best['steps']} train steps x B={best['batch']} synthetic 100x100 tiles in {best['seconds']} s (oracle = "
                       f"torch-CPU fp32 restatement; {avail} logical / {phys} physical cores available; best of the legs below)",
             "legs": legs}
+
+
+def _rocprof_avg_us(kernel, precision):
+    """Average duration (us) of `kernel` in the NEWEST tracked rocprofv3 summary of this precision (profiles/r*_<prec>_graph_kernel_stats.csv:
+    `rocprofv3 --kernel-trace --stats` of this very bench command under graph replay), and the file it came from."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{precision}_graph_kernel_stats.csv")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        for row in csv.DictReader(fh):
+            if kernel in row["Name"]:
+                return round(float(row["AverageNs"]) / 1e3, 2), os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
+
+
+def fwd_parity(torch, margs, sd_cpu, batch, dev):
+    """BASELINE's metric, second half ("fwd max-abs-err vs CPU"): the drop-in forward of config[1] -- B tiles of 100 x 100, sparse
+    head over the census regions -- through the HIP path against the CPU oracle on the same tiles, same parameters."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd.model import get_model_kwargs, model_dict
+    torch.manual_seed(1600)
+    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev).eval()
+    model.load_state_dict(sd_cpu)
+    x = O.select_normalize(batch["raw"].cpu())
+    cpu = {"input": x, "admin_mask": batch["admin_mask"].cpu(), "census_idx": batch["census_idx"].cpu()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        torch.manual_seed(11)
+        ref = O.popcorn_forward(sd_cpu, dict(cpu), padding=False, sparse=True)
+        torch.manual_seed(11)
+        out = model({k: v.to(dev) for k, v in cpu.items()}, padding=False, sparse=True)
+    res = {"config": f"B={x.shape[0]} 100x100 vs CPU oracle (drop-in forward, padding=False, sparse=True)", "tolerance": 1e-4}
+    worst_abs = worst_rel = 0.0
+    for key in ("popdensemap", "popcount", "scale"):
+        a, r = out[key].float().cpu(), ref[key].float()
+        if a.shape != r.shape:
+            raise SystemExit(f"fwd_parity: {key} shape {tuple(a.shape)} vs oracle {tuple(r.shape)}")
+        ea = (a - r).abs().max().item()
+        er = ea / max(r.abs().max().item(), 1e-30)
+        res[key] = {"max_abs": ea, "max_rel": er}
+        worst_abs, worst_rel = max(worst_abs, ea), max(worst_rel, er)
+    res["max_abs"], res["max_rel"] = worst_abs, worst_rel
+    res["ok"] = worst_rel <= 1e-4
+    return res
+
+
+FLOP_FWD_PX = 2 * (9040 + 9072 + 9344)        # SURVEY.md 8d per pixel: trainable U-Net + building extractor + head = 54,912 flop
+
+
+def config5_leg(torch, margs, dev, hw=(4096, 5888), passes=3):
+    """BASELINE config 5 on one GPU: sliding 2048 x 2048 windows (overlap 128) over a synthetic raster, ensemble of one, device-resident
+    stitcher (eval.evaluate_raster): windows/s, Mpx/s through the network, fraction of the fp32-matrix peak at 54.9 kflop / px."""
+    from popcorn_amd.eval import evaluate_raster, get_patch_indices
+    from popcorn_amd.model import get_model_kwargs, model_dict
+    torch.manual_seed(1600)
+    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev).eval()
+    raster = torch.randn(1, 6, hw[0], hw[1], device=dev)
+    nwin = get_patch_indices(hw[0], hw[1]).shape[0]
+    times = []
+    for _ in range(passes + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mean, _, _, _ = evaluate_raster([model], raster)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times[1:])
+    px = nwin * 2048 * 2048
+    ok = bool(torch.isfinite(mean).all())
+    del raster, mean
+    torch.cuda.empty_cache()
+    return {"workload": f"{nwin} windows of 2048x2048 (overlap 128) over a {hw[0]}x{hw[1]} synthetic raster, 1 member, fp32, stitched on the device",
+            "windows_per_s": round(nwin / dt, 1), "Mpx_per_s": round(px / dt / 1e6, 1), "ms_per_window": round(dt / nwin * 1e3, 3),
+            "alg_flop_per_px": FLOP_FWD_PX, "tflops": round(px * FLOP_FWD_PX / dt / 1e12, 2),
+            "frac_of_fp32_mfma_peak": round(px * FLOP_FWD_PX / dt / FP32_MATRIX_PEAK, 4), "finite": ok}
+
+
+def _region_alg_flop(B, H, W, nsel, enc_ng, unet_ng):
+    """Algorithmic flop of one train step on B regions of H x W (SURVEY.md 8d per-pixel figures: MACs per pixel of the conv domain --
+    encoder 3,888, decoder 5,152 (both streams), building extractor 9,072 on ITS padded domain, head 9,344 per selected pixel)."""
+    from popcorn_amd.model.popcorn import pad_geometry
+    pt, pb, pl, pr = pad_geometry(H, W, False)
+    pu = B * (H + pt + pb) * (W + pl + pr)                       # the trainable U-Net's conv domain
+    pbe = B * (H + 28) * (W + 28)                                # the frozen extractor pads by 14 on every side (popcorn.py:231-258)
+    enc, dec, be, head = 3888, 5152, 9072, 9344
+    mac = pu * (enc + dec) + pbe * be + nsel * head              # forward
+    mac += 2 * nsel * head                                       # head backward (data + weight gradients)
+    if not unet_ng:
+        mac += pu * 2 * dec                                      # decoder: data + weight gradients
+        if not enc_ng:
+            mac += pu * (2 * enc - 432)                          # encoder: both, minus the data gradient of the two input convs
+        else:
+            mac -= pu * (576 + 288 + 64)                         # no data gradient into the skip tensors / the 32x32-level output
+    return 2.0 * mac
+
+
+def config3_regions_leg(torch, margs, dev, steps=3):
+    """BASELINE config 3 as the reference RUNS it (run_train.py:186-202): weak_batch_size = 2 census regions of variable size, the
+    truncation regime of each batch decided by the real limit1 / limit2 / limit3 defaults, eager launches (no graph for varying
+    shapes).  A seeded list of batch geometries spanning 1e5 .. 9e6 px; Mpx/s over the whole list, algorithmic TFLOP/s."""
+    from popcorn_amd import ops
+    from popcorn_amd.cli import limit_regime, train_parser
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import get_model_kwargs, model_dict
+    from popcorn_amd.train import FusedTrainStep
+    a = train_parser().parse_args([])
+    torch.manual_seed(1600)
+    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
+    tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, reducer=_LocalReducer())
+    shapes = [(230, 220), (517, 389), (700, 640), (1030, 770), (1500, 1400), (2000, 1700), (2100, 2140), (2100, 2150)]
+    rows, tot_px, tot_t, tot_fl = [], 0, 0.0, 0.0
+    torch.cuda.reset_peak_memory_stats()
+    for H, W in shapes:
+        B = a.weak_batch_size
+        enc_ng, unet_ng, skip = limit_regime(B * H * W, a.limit1, a.limit2, a.limit3)
+        batch = make_raw_batch(B, H, W, seed=H * 1000 + W, region="disc")
+        x = ops.select_normalize(batch["raw"].to(dev), stats.BAND6, stats.MEAN6, stats.STD6)
+        smp = {"input": x, "admin_mask": batch["admin_mask"].to(dev), "census_idx": batch["census_idx"].to(dev), "y": batch["y"].to(dev)}
+        torch.manual_seed(3)
+        tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)          # warm-up (allocations, attribute queries)
+        torch.cuda.synchronize()
+        nsel = int(tr.last["mask"].sum().item())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        lv = float(loss[0].item())
+        if not (lv == lv) or abs(lv) == float("inf"):
+            raise SystemExit(f"config3_regions: non-finite loss at {B}x{H}x{W}")
+        fl = _region_alg_flop(B, H, W, nsel, enc_ng, unet_ng)
+        rows.append({"batch": f"{B}x{H}x{W}", "Mpx": round(B * H * W / 1e6, 3), "regime": "head only" if unet_ng else ("decoder + head" if enc_ng else "all"),
+                     "selected_px": nsel, "ms_per_step": round(dt * 1e3, 3), "Mpx_per_s": round(B * H * W / dt / 1e6, 1),
+                     "tflops": round(fl / dt / 1e12, 2)})
+        tot_px += B * H * W; tot_t += dt; tot_fl += fl
+        del smp, x, batch
+        torch.cuda.empty_cache()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    del tr, model
+    torch.cuda.empty_cache()
+    return {"workload": "run_train.py geometry: weak_batch_size=2 census regions, sizes 1e5..9e6 px, regime per batch from the default "
+                        "limit1/2/3 = 9e6/9e6/13e6, eager fused step (fp32), disc-shaped regions inside the crop",
+            "Mpx_per_s": round(tot_px / tot_t / 1e6, 1), "step_tflops": round(tot_fl / tot_t / 1e12, 2),
+            "frac_of_fp32_mfma_peak": round(tot_fl / tot_t / FP32_MATRIX_PEAK, 4), "peak_hbm_gib": round(peak, 2), "batches": rows}
 
 
 def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
@@ -885,9 +1040,19 @@ def main():
         per_rank = [round(own_ms, 4)]
 
     extras = {}
-    if not args.no_extras:
+    if not args.no_extras and (world == 1 or args.extras_multi):
         extras = extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, step, build, run_blocks, timed_block)
 
+    # which devices took part (one entry per rank: "<rank>:<device ordinal>:<bus id>"), gathered through the job's own backend
+    dp = {"ranks_seen": 1, "devices": None, "capture_failed": False}
+    if world > 1:
+        pr = torch.cuda.get_device_properties(dev)
+        mine = f"{rank}:{local_rank}:{getattr(pr, 'pci_bus_id', '?')}"
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        flag = torch.tensor([1 if trainer.reducer.capture_failed else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        dp = {"ranks_seen": len(set(seen)), "devices": seen, "capture_failed": bool(flag.item())}
     if rank == 0:
         tiles = B * world * args.steps
         value = tiles / dt
@@ -905,6 +1070,8 @@ def main():
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "collectives": bool(trainer.reducer.active),
                        "collectives_per_step": 2 if trainer.reducer.active else 0,
+                       "rccl_ranks_seen": dp["ranks_seen"] if (dist.is_initialized() and dist.get_backend() == "nccl") else None,
+                       "ranks_seen": dp["ranks_seen"], "rank_devices": dp["devices"], "dp_capture_failed": dp["capture_failed"],
                        # how the captured step holds them: "one" = both inside the step's single HIP graph (RCCL), "split" =
                        # three graphs with the two collectives launched between them (gloo, or a failed capture)
                        "dp_graph": (None if (args.no_graph or not trainer.reducer.active or trainer._graphs is None) else
@@ -929,6 +1096,14 @@ def main():
         else:
             res["cpu_baseline"] = None
         res.update(extras)
+        if world == 1 and not args.no_config_legs and args.precision == "fp32":
+            # BASELINE's other configurations on the same line: forward parity of config[1] against the CPU oracle (the metric's
+            # second half), config[2] at the reference's real region geometry, config[4]'s sliding windows
+            res["fwd_parity"] = fwd_parity(torch, margs, sd_cpu, batch, dev)
+            del trainer, model
+            torch.cuda.empty_cache()
+            res["config3_regions"] = config3_regions_leg(torch, margs, dev)
+            res["config5"] = config5_leg(torch, margs, dev)
     else:
         res = None
     # RCCL writes its version banner through C stdio, which (stdout not being a terminal) would otherwise be flushed at exit,
@@ -944,6 +1119,8 @@ def main():
             time.sleep(0.5 if rank == 0 else 0.0)        # the other ranks' last flush
     if res is not None:
         print(json.dumps(res), flush=True)
+    if dp["capture_failed"]:
+        sys.exit(3)              # the line above is printed, but a data-parallel graph capture that failed is not a clean run
 
 
 if __name__ == "__main__":

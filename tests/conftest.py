@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Every gradient comparison that passed through the tie adjudication instead of the flat 2e-4 bar (tests/tie_adjudication.py):
+    which test, how many decisions differed, and how far either fp32 side is from the fp64 oracle."""
+    try:
+        from tests.tie_adjudication import ADJUDICATED
+    except Exception:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", f"tie adjudications: {len(ADJUDICATED)} comparison(s) passed through a proven decision flip")
+    for r in ADJUDICATED:
+        tr.write_line(f"  {r['test']}: worst {r['worst']:.2e}, flips {r['flips']}, w_hip {r['w_hip']:.2e}, w_ref {r['w_ref']:.2e}")

@@ -41,10 +41,24 @@ def test_committed_final_bench_line_keeps_the_contract():
 @pytest.mark.gpu
 def test_live_bench_prints_one_json_line_last():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "2",
-                          "--prewarm-seconds", "0", "--no-extras", "--no-cpu-baseline", "--no-class-sweep"],
+                          "--prewarm-seconds", "0", "--no-extras", "--no-cpu-baseline", "--no-class-sweep", "--no-config-legs"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])                            # the JSON line is the LAST line of stdout
     _check_line(d, extras=False)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+
+
+def test_tracked_profiles_belong_to_the_current_kernel_sources():
+    """profiles/r4_*_graph_kernel_stats.csv are the rocprofv3 summaries the judged numbers are checked against (`roofline.rocprof_us`
+    reads them): they must have been collected from THIS tree's kernels.  tools/profile_round.sh stamps every collection with the
+    sha256 of popcorn_amd/csrc + include/ (tools/csrc_hash.py); a kernel change without a fresh profile fails here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+    stamp = json.load(open(os.path.join(ROOT, "profiles", "r4_stamp.json")))
+    digest, files = csrc_hash(ROOT)
+    assert stamp["files"] == files
+    assert stamp["csrc_sha256"] == digest, "kernel sources changed after profiles/r4_* were collected: run tools/profile_round.sh r4 quick on the GPU box and commit the summaries"
+    for prec in ("fp32", "bf16"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", f"r4_{prec}_graph_kernel_stats.csv"))

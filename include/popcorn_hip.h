@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 4
+#define PC_ABI_VERSION 5
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -133,6 +133,11 @@ typedef struct pc_conv_fwd_desc {
      * other consumer, so it is never written).  PC_PREC_FP32: any geometry, planar fp32 dot_out; PC_PREC_BF16: the geometry
      * condition of pool_out. */
     const float* dot_w; const pc_dst* dot_out;
+    /* optional (PC_PREC_BF16, Cin == 8, no second source): w is [Cout][w_cin][3][3] and applies to input channels
+     * [w_ci0, w_ci0 + w_cin) of `a`; the other channels of the 8-channel slot get zero weights.  w_cin == 0: the ordinary full
+     * weight.  Lets the first convolutions of both streams (2 SAR / 4 optical channels, networks.py:130-133) read ONE shared
+     * 8-channel channels-last input (pc_ingest_cl8) with the standard 8 -> 8 kernel, all (network, stream) pairs in one launch. */
+    int32_t w_ci0, w_cin;
 } pc_conv_fwd_desc;
 int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);
 int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,
@@ -295,6 +300,9 @@ typedef struct pc_wgrad_reduce_desc {
     int32_t accumulate;
     int32_t dw_co_stride;   /* conv3x3: elements between output channels of dw (0 = Cin * 9); > Cin * 9 when the entry is one
                                8-channel column block of a wider weight gradient (dw then points at its first column) */
+    int32_t src_cin, src_ci0; /* conv3x3: the partials were computed over src_cin input channels (0 = Cin) of which this entry
+                               writes the Cin channels starting at src_ci0 into dw -- the weight gradient of a first layer whose
+                               input is a channel window of the shared 8-channel input (pc_conv_fwd_desc.w_ci0 / w_cin) */
 } pc_wgrad_reduce_desc;
 int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void* stream);
 
@@ -401,6 +409,13 @@ int pc_reflect_pad_select(const float* in, float* out, int B, int Cin, int nsel,
  * band / mean / std = HOST arrays of nsel <= 8 entries.  Replaces pc_select_normalize followed by pc_reflect_pad_select. */
 int pc_select_normalize_pad(const float* raw, float* out, int B, int Craw, int nsel, const int* band, const float* mean,
                             const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream);
+/* The same ingest for PC_PREC_BF16: out is ONE channels-last bf16 tensor (B, 8, Hp, Wp) -- an aligned 16-byte slot per pixel
+ * holding the nsel <= 8 selected, normalised (mean / stdv may be NULL: input already normalised), reflect-padded channels rounded
+ * to bf16, the remaining channels zero.  Both streams' first convolutions (pc_conv_fwd_desc.w_ci0 / w_cin) and their weight
+ * gradients (pc_wgrad_reduce_desc.src_cin / src_ci0) read this one tensor through the standard 8-channel kernels instead of
+ * running a planar-fp32 reflect loader per consumer. */
+int pc_ingest_cl8(const float* raw, void* out, int B, int Craw, int nsel, const int* band, const float* mean, const float* stdv,
+                  int H, int W, int top, int bottom, int left, int right, void* stream);
 
 /* ---- training-step scalars ------------------------------------------------------------------------- */
 

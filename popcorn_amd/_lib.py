@@ -34,7 +34,8 @@ class PcBn(C.Structure):
 
 class PcConvFwdDesc(C.Structure):
     _fields_ = [("a", C.POINTER(PcSrc)), ("b", C.POINTER(PcSrc)), ("w", C.c_void_p), ("bn", C.POINTER(PcBn)),
-                ("out", C.POINTER(PcDst)), ("pool_out", C.POINTER(PcDst)), ("dot_w", C.c_void_p), ("dot_out", C.POINTER(PcDst))]
+                ("out", C.POINTER(PcDst)), ("pool_out", C.POINTER(PcDst)), ("dot_w", C.c_void_p), ("dot_out", C.POINTER(PcDst)),
+                ("w_ci0", C.c_int32), ("w_cin", C.c_int32)]
 
 
 class PcConvDgradDesc(C.Structure):
@@ -66,7 +67,8 @@ class PcConvtBwdDesc(C.Structure):
 
 class PcWgradReduceDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nwg", C.c_int32), ("Cin", C.c_int32),
-                ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("dw_co_stride", C.c_int32)]
+                ("Cout", C.c_int32), ("kind", C.c_int32), ("accumulate", C.c_int32), ("dw_co_stride", C.c_int32),
+                ("src_cin", C.c_int32), ("src_ci0", C.c_int32)]
 
 
 class PcConvBwdDesc(C.Structure):
@@ -97,7 +99,7 @@ class PcLevel2BwdDesc(C.Structure):
                 ("ws1", C.c_void_p), ("ws2", C.c_void_p)]
 
 
-PC_ABI_VERSION = 4
+PC_ABI_VERSION = 5
 PC_MAX_GROUP = 4
 PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
 

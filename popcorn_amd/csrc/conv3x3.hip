@@ -75,6 +75,8 @@ struct ConvProb {
     // compose_up_kernel (composed 2x2-neighbourhood weights per output parity; bias-through-the-taps table)
     const float* z; int64_t z_bs, z_cs; int z_rs;
     const float* wz; const float* tb;
+    // channels-last bf16, CIN == 8: w is [COUT][w_cin][3][3] over input channels [w_ci0, w_ci0 + w_cin) (w_cin == 0: full weight)
+    int w_ci0, w_cin;
 };
 
 struct ConvArgs {
@@ -1056,7 +1058,13 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
         const int e = tid + k * 256;
         const int ec = e < COUT * CIN * 9 ? e : 0;
         const int tap = ec % 9, ci = (ec / 9) % CIN, co = ec / (9 * CIN);
-        wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+        if (q.w_cin) {       // channel window of a shared 8-channel input (first layers): zero weights outside it
+            const int cw = ci - q.w_ci0;
+            const bool in = (unsigned)cw < (unsigned)q.w_cin;
+            wreg[k] = in ? q.w[(co * q.w_cin + cw) * 9 + tap] : 0.f;
+        } else {
+            wreg[k] = q.w[co * p.w_co_stride + ci * p.w_ci_stride + (p.w_flip ? 8 - tap : tap)];
+        }
     }
     // per-lane epilogue constants for co = nb*8 + 4*(lk&1) + r
     const bool has_bn = MODE == MODE_FWD || q.act != nullptr;
@@ -1489,6 +1497,13 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
     for (int i = 0; i < n; ++i) {
         const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
         if (rc) return rc;
+        if (d[i].w_cin) {
+            if (g_pc_precision != PC_PREC_BF16 || Cin != 8 || d[i].b || d[i].w_ci0 < 0 || d[i].w_cin < 1 || d[i].w_ci0 + d[i].w_cin > 8 ||
+                d[i].a->mode != PC_SRC_DIRECT)
+                return PC_EINVAL;
+            p.pr[i].w_ci0 = d[i].w_ci0;
+            p.pr[i].w_cin = d[i].w_cin;
+        }
         if (d[i].dot_w) {
             // the partial 1x1 sum replaces the feature map.  bf16 mode: all strips must take the vector epilogue; fp32: any geometry
             // (partial strips take the per-element form), planar fp32 output

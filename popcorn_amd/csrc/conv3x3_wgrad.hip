@@ -896,6 +896,7 @@ struct RbEntry {
     const float* partial; float* dw; float* db;
     int nwg, Cin, Cout, kind, accumulate;     // kind 0: conv3x3, 1: convT 2x2 (C = Cin), 2: raw sum of Cin floats
     int dw_co_stride;                         // conv3x3: elements between output channels of dw (0 = Cin * 9)
+    int src_cin, src_ci0;                     // conv3x3: channel window of the partials (pc_wgrad_reduce_desc), src_cin = Cin: all
 };
 struct RbArgs { RbEntry e[RB_MAX]; };
 
@@ -907,12 +908,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int n_w, n_out;
     if (q.kind == 0) {
-        const int CINC = q.Cin < 16 ? q.Cin : 16;
+        const int CINC = q.src_cin < 16 ? q.src_cin : 16;
         const int EC = q.Cout * CINC * 9 + q.Cout;           // compacted partial (WgradCfg::EC)
         n_w = q.Cout * q.Cin * 9;
         n_out = n_w + q.Cout;
         if (o < n_w) {
-            const int tap = o % 9, ci = (o / 9) % q.Cin, co = o / (9 * q.Cin);
+            const int tap = o % 9, ci = (o / 9) % q.Cin + q.src_ci0, co = o / (9 * q.Cin);
             const int chunk = ci / CINC, cil = ci % CINC;
             const int oc = co * (CINC * 9) + cil * 9 + tap;
             const float* base = q.partial + (int64_t)chunk * q.nwg * EC;
@@ -1001,7 +1002,9 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
         for (int i = 0; i < m; ++i) {
             const pc_wgrad_reduce_desc& s = d[base + i];
             if (!s.partial || !s.dw || s.nwg < 1) return PC_EINVAL;
-            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride};
+            const int src_cin = (s.kind == 0 && s.src_cin > 0) ? s.src_cin : s.Cin;
+            if (s.kind == 0 && (s.src_ci0 < 0 || (s.src_cin > 0 && s.src_ci0 + s.Cin > s.src_cin) || (s.src_cin <= 0 && s.src_ci0 != 0))) return PC_EINVAL;
+            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride, src_cin, s.kind == 0 ? s.src_ci0 : 0};
             const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : (s.kind == 2 ? s.Cin : s.Cin * s.Cin * 4 + s.Cin);
             if (n_out > max_out) max_out = n_out;
         }

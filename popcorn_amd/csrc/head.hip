@@ -2178,6 +2178,30 @@ __global__ __launch_bounds__(256) void reflect_pad_select_kernel(const float* in
     }
 }
 
+// PC_PREC_BF16 ingest (pc_ingest_cl8): one thread = one pixel of the padded domain = ONE aligned 16-byte channels-last slot:
+// band select + normalise + reflect padding + stream order + round to bf16; channel slots >= nsel are zero
+template <bool NORM>
+__global__ __launch_bounds__(256) void ingest_cl8_kernel(const float* __restrict__ in, uint4* __restrict__ out, PadSel ps, int Cin, int nsel,
+                                                         int H, int W, int Hp, int Wp, int top, int left, int npix) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int x = i % Wp, r = i / Wp;
+    const int y = r % Hp, b = r / Hp;
+    const int64_t o = (int64_t)pc_reflect(y - top, H) * W + pc_reflect(x - left, W);
+    const int64_t plane = (int64_t)H * W;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+        if (j < nsel) {
+            t = in[((int64_t)b * Cin + ps.sel[j]) * plane + o];
+            if (NORM) t = (t - ps.mean[j]) / ps.stdv[j];
+        }
+        v[j] = t;
+    }
+    out[i] = make_uint4(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]), pc_pack_bf16(v[4], v[5]), pc_pack_bf16(v[6], v[7]));
+}
+
 }  // namespace
 
 static int launch_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, const float* mean, const float* stdv,
@@ -2217,6 +2241,32 @@ extern "C" int pc_select_normalize_pad(const float* raw, float* out, int B, int 
                                        const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream) {
     if (!mean || !stdv) return PC_EINVAL;
     return launch_pad_select(raw, out, B, Craw, nsel, band, mean, stdv, H, W, top, bottom, left, right, stream);
+}
+
+extern "C" int pc_ingest_cl8(const float* raw, void* out, int B, int Craw, int nsel, const int* band, const float* mean, const float* stdv,
+                             int H, int W, int top, int bottom, int left, int right, void* stream) {
+    if (!raw || !out || !band || B < 1 || nsel < 1 || nsel > 8 || top >= H || bottom >= H || left >= W || right >= W || top < 0 ||
+        bottom < 0 || left < 0 || right < 0 || (mean == nullptr) != (stdv == nullptr) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return PC_EINVAL;
+    PadSel ps{};
+    for (int j = 0; j < nsel; ++j) {
+        if (band[j] < 0 || band[j] >= Craw) return PC_EINVAL;
+        ps.sel[j] = band[j];
+        ps.mean[j] = mean ? mean[j] : 0.f;
+        ps.stdv[j] = stdv ? stdv[j] : 1.f;
+    }
+    const int Hp = H + top + bottom, Wp = W + left + right;
+    const int64_t npix = (int64_t)B * Hp * Wp;
+    if (npix > 0x7fffffff) return PC_EINVAL;
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    if (mean)
+        hipLaunchKernelGGL(ingest_cl8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, raw, reinterpret_cast<uint4*>(out), ps, Craw, nsel,
+                           H, W, Hp, Wp, top, left, (int)npix);
+    else
+        hipLaunchKernelGGL(ingest_cl8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, raw, reinterpret_cast<uint4*>(out), ps, Craw, nsel,
+                           H, W, Hp, Wp, top, left, (int)npix);
+    PC_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pc_sparsity_mask_unet(const float* building, const float* admin_mask, const int64_t* census_idx,

@@ -424,7 +424,13 @@ class UNetEngine:
         else:
             wgs("inc2", "a1", G_a2)
             G_a1 = dg("inc2", G_a2, {s: E(8, Hp, Wp) for s in S}, 0, 8, {s: A[s]["a1"] for s in S}, "inc1")
-        for s, chmap, cin, f0 in self.streams:
+        if saved.get("Xp8") is not None:
+            # both streams' first-layer weight gradients in ONE launch of the standard 8-channel kernel over the shared input; the
+            # batched reduce writes each stream's channel window
+            xp8, win = saved["Xp8"]
+            wb.conv3x3_group([{"a": xp8, "g": G_a1[s], "dw": grads[prefix + ly(s, "inc1").wname], "db": grads[prefix + ly(s, "inc1").bname],
+                               "src_window": win[s]} for s in S], 8)
+        for s, chmap, cin, f0 in (self.streams if saved.get("Xp8") is None else ()):
             if saved.get("Xp") is not None:
                 wg(s, "inc1", saved["Xp"][s], G_a1[s])
             else:
@@ -451,10 +457,16 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
 
     Xp_all (fp32 mode): the already padded, normalised, channel-gathered input (B, sum of stream channels in stream order, Hp, Wp)
     as ``ops.select_normalize_pad`` writes it from a raw tile -- X may then be None (nothing reads the unpadded input)."""
+    bf = L.act_dtype() == torch.bfloat16
     if Xp_all is not None:
         L.require_device(Xp_all)
-        if L.act_dtype() != torch.float32 or tuple(Xp_all.shape[2:]) != (Hp, Wp) or Wp % 4 or Xp_all.dtype != torch.float32:
-            raise ValueError("Xp_all needs the fp32 mode and a (B, C, Hp, Wp) fp32 tensor with Wp % 4 == 0")
+        if bf:
+            # bf16 mode: ONE channels-last bf16 tensor (B, 8, Hp, Wp) as ops.ingest_cl8 writes it (stream channels in stream order,
+            # the rest zero)
+            if tuple(Xp_all.shape[1:]) != (8, Hp, Wp) or Xp_all.dtype != torch.bfloat16 or Xp_all.stride(1) != 1 or Xp_all.stride(3) != 8:
+                raise ValueError("bf16 mode: Xp_all must be a channels-last bf16 (B, 8, Hp, Wp) tensor (ops.ingest_cl8)")
+        elif tuple(Xp_all.shape[2:]) != (Hp, Wp) or Wp % 4 or Xp_all.dtype != torch.float32:
+            raise ValueError("Xp_all needs a (B, C, Hp, Wp) fp32 tensor with Wp % 4 == 0 (fp32 mode)")
         B, dev = Xp_all.shape[0], Xp_all.device
     else:
         L.require_device(X)
@@ -487,7 +499,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     if Xp_all is not None:
         # the padded input is sliced by engines[0]'s stream table: every engine must read the same channels in the same order
         order = stream_channel_order(streams)
-        if any(stream_channel_order(e.streams) != order for e in engines) or Xp_all.shape[1] != sum(st[2] for st in streams):
+        if any(stream_channel_order(e.streams) != order for e in engines) or (not bf and Xp_all.shape[1] != sum(st[2] for st in streams)):
             raise ValueError(f"Xp_all holds {Xp_all.shape[1]} channels; the engines expect {order} (identical for all engines)")
     keys = [(e, s) for e in range(nE) for s, _, _, _ in streams]
     ly = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
@@ -522,16 +534,34 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     # gather stay fused in the loaders (bf16 mode rounds the planar fp32 input there; unpadded inference windows need no copy).
     a1 = {}
     Xp = None
+    Xp8 = None             # bf16 mode: (tensor, {stream: (first channel, channels)}) -- every first conv reads a channel window of it
     if Xp_all is None and PADDED_INPUT and L.act_dtype() == torch.float32 and Wp % 4 == 0 and Wp <= 1024 \
             and (Hp, Wp) != tuple(X.shape[2:]) and X.dtype == torch.float32:
         sel = stream_channel_order(streams)
         Xp_all = ops.reflect_pad_select(X, sel, pad_top, Hp - X.shape[2] - pad_top, pad_left, Wp - X.shape[3] - pad_left)
-    if Xp_all is not None:
+    if Xp_all is None and PADDED_INPUT and bf and len(streams) == 2 and len(keys) <= L.PC_MAX_GROUP and Wp <= 1024 \
+            and (Hp, Wp) != tuple(X.shape[2:]) and X.dtype == torch.float32 and X.is_contiguous():
+        # bf16 mode with real padding: the padded, stream-ordered input once as channels-last bf16 (one 16-byte slot per pixel)
+        Xp_all = ops.ingest_cl8(X, stream_channel_order(streams), None, None, pad_top, Hp - X.shape[2] - pad_top, pad_left,
+                                Wp - X.shape[3] - pad_left)
+    if Xp_all is not None and bf:
+        win, off = {}, 0
+        for s, chmap, cin, f0 in streams:
+            win[s] = (off, cin)
+            off += cin
+        Xp8 = (Xp_all, win)
+        if len(keys) > L.PC_MAX_GROUP:
+            raise ValueError("bf16 shared-input first layer: at most PC_MAX_GROUP (network, stream) pairs")
+        for k in keys:
+            a1[k] = E(8, Hp, Wp)
+        ops.conv3x3_fwd_group([{"a": Xp_all, "w": ly(k, "inc1").w, "bn": ly(k, "inc1").bn, "out": a1[k], "w_window": win[k[1]]}
+                               for k in keys])
+    elif Xp_all is not None:
         Xp, off = {}, 0
         for s, chmap, cin, f0 in streams:
             Xp[s] = Xp_all[:, off:off + cin]
             off += cin
-    for s, chmap, cin, f0 in streams:
+    for s, chmap, cin, f0 in (streams if Xp8 is None else ()):
         ks = [k for k in keys if k[1] == s]
         probs = []
         for k in ks:
@@ -639,6 +669,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
                          u1=u1[k], f1=f1[k], o1=o1, o2=o2, pa2=pa2.get(k), pb2=pb2.get(k), ws_up1=ws_up1.get(k), ws_up2=ws_up2.get(k))
         sv["X"] = X
         sv["Xp"] = Xp                       # per stream: the padded, gathered input (fp32 path) or None
+        sv["Xp8"] = Xp8                     # bf16 path: (shared channels-last input, channel window per stream) or None
         sv["geom"] = (pad_top, pad_left, Hp, Wp)
         sv["feats"] = feats[e]
         saved.append(sv)

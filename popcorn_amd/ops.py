@@ -81,6 +81,9 @@ def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0),
             dp = L.dst(pr["pool_out"])
             keep.append(dp)
             descs[i].pool_out = C.pointer(dp)
+        if pr.get("w_window") is not None:       # bf16 mode: w covers input channels [ci0, ci0 + cin) of the shared 8-channel input
+            descs[i].w_ci0, descs[i].w_cin = int(pr["w_window"][0]), int(pr["w_window"][1])
+            assert pr["w"].shape[1] == descs[i].w_cin and Ca + Cb == 8
     L.check(L.lib().pc_conv3x3_bn_relu_fwd_group(n, descs, int(relu), B, H, W, Ca + Cb, Cout, L.stream_ptr()),
             "pc_conv3x3_bn_relu_fwd_group")
 
@@ -530,6 +533,23 @@ def select_normalize_pad(raw, band, mean, std, top, bottom, left, right, out=Non
     return out
 
 
+def ingest_cl8(raw, band, mean, std, top, bottom, left, right, out=None):
+    """PC_PREC_BF16 ingest (pc_ingest_cl8): band selection + (x - mean) / std (mean / std None: already normalised) + reflect padding
+    of a planar fp32 (B, Craw, H, W) tile into ONE channels-last bf16 tensor (B, 8, Hp, Wp): channel j = the j-th selected band,
+    channels >= len(band) zero."""
+    L.require_device(raw)
+    assert raw.is_contiguous() and raw.dtype == torch.float32
+    B, Craw, H, W = raw.shape
+    n = len(band)
+    if out is None:
+        out = torch.empty(B, 8, H + top + bottom, W + left + right, device=raw.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    assert out.stride(1) == 1 and out.stride(3) == 8
+    fa = lambda v: None if v is None else (C.c_float * n)(*[float(t) for t in v])  # noqa: E731
+    L.check(L.lib().pc_ingest_cl8(L.ptr(raw), L.ptr(out), B, Craw, n, (C.c_int * n)(*[int(v) for v in band]), fa(mean), fa(std),
+                                  H, W, top, bottom, left, right, L.stream_ptr()), "pc_ingest_cl8")
+    return out
+
+
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
              g_feat=None, feat_bn=None):
@@ -686,7 +706,12 @@ class WgradBatch:
         L.check(L.lib().pc_conv3x3_wgrad_partial_group(n, descs, B, H, W, Ca + Cb, cout, C.byref(nwg), L.stream_ptr()),
                 "pc_conv3x3_wgrad_partial_group")
         for ws, pr in zip(slots, problems):
-            if cin_total is None:
+            if pr.get("src_window") is not None:
+                # the partials cover all Ca input channels; dw ([cout][cin][3][3]) receives the channels [ci0, ci0 + cin) only
+                ci0, cin = pr["src_window"]
+                assert pr["dw"].shape[1] == cin and ci0 + cin <= Ca + Cb and cin_total is None
+                self.entries.append((ws, pr["dw"], pr["db"], nwg.value, cin, cout, 0, 0, 0, Ca + Cb, ci0))
+            elif cin_total is None:
                 self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0))
             else:
                 self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Ca + Cb, cout, 0, cin_total * 9, 0))
@@ -836,6 +861,8 @@ class WgradBatch:
             d[i].dw_co_stride = ent[7] if len(ent) > 7 else 0
             d[i].db = 0 if db is None else db.data_ptr()
             d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate = nwg, cin, cout, kind, int(self.accumulate)
+            if len(ent) > 9:
+                d[i].src_cin, d[i].src_ci0 = ent[9], ent[10]
         for j, (pp, tot, nwg, part) in enumerate(self.raw_entries):
             i = len(self.entries) + j
             d[i].partial, d[i].dw, d[i].db = pp, tot, 0

@@ -231,6 +231,12 @@ class FusedTrainStep:
                 Xp_all = ops.select_normalize_pad(raw, [band[c] for c in order], [mean[c] for c in order], [std[c] for c in order],
                                                   pt, pb, pl, pr)
                 X = None
+            elif fused and E.PADDED_INPUT and L.act_dtype() == torch.bfloat16 and len(eng_u.streams) == 2 and (pt or pb or pl or pr):
+                # bf16 mode: the same one-launch ingest, written as ONE channels-last bf16 tensor (8-channel slots) that both
+                # networks' first convolutions and the first-layer weight gradients read through the standard 8-channel kernels
+                order = E.stream_channel_order(eng_u.streams)
+                Xp_all = ops.ingest_cl8(raw, [band[c] for c in order], [mean[c] for c in order], [std[c] for c in order], pt, pb, pl, pr)
+                X = None
             else:
                 X = ops.select_normalize(raw, band, mean, std)
         else:

@@ -816,3 +816,69 @@ def test_bf16_train_step_with_the_unfused_backward(monkeypatch):
         _bf16_grad_gate({n: tr.grads[n] for n in g16}, g16, g32, f"fused={fused}")
         res[fused] = {n: tr.grads[n].clone() for n in g16}
     assert max(rel(res[True][n], res[False][n]) for n in g16) < TOL_GRAD_WORST
+
+
+# ---- round 4: shared channels-last input of the first layers (pc_ingest_cl8, weight / gradient channel windows) -----------------
+@pytest.mark.parametrize("shape,pads", [((3, 100, 100), (14, 14, 14, 14)), ((2, 37, 53), (5, 6, 2, 9)), ((1, 64, 48), (0, 0, 8, 8))])
+@pytest.mark.parametrize("norm", [True, False])
+def test_bf16_ingest_cl8_vs_torch(shape, pads, norm):
+    """Band select + normalise + reflect pad + round, as one channels-last bf16 tensor with 8-channel slots: BIT-exact against
+    torch (same fp32 division as pc_select_normalize, same round-to-nearest-even), zero in the unused channel slots."""
+    import torch.nn.functional as F
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    B, H, W = shape
+    top, bottom, left, right = pads
+    g = torch.Generator().manual_seed(7)
+    raw = torch.cat([torch.randint(0, 10000, (B, 13, H, W), generator=g).float(), torch.randn(B, 2, H, W, generator=g) * 4 - 12], 1)
+    order = [4, 5, 2, 1, 0, 3]                                  # model channels in stream order: [VV, VH | B, G, R, NIR]
+    band = [stats.BAND6[c] for c in order]
+    mean = [stats.MEAN6[c] for c in order] if norm else None
+    std = [stats.STD6[c] for c in order] if norm else None
+    out = ops.ingest_cl8(raw.cuda(), band, mean, std, top, bottom, left, right)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (B, 8, H + top + bottom, W + left + right) and out.stride(1) == 1
+    x = raw[:, band]
+    if norm:
+        x = (x - torch.tensor(mean).view(1, 6, 1, 1)) / torch.tensor(std).view(1, 6, 1, 1)
+    ref = F.pad(x, (left, right, top, bottom), mode="reflect").to(torch.bfloat16)
+    assert torch.equal(out[:, :6].cpu(), ref)
+    assert not out[:, 6:].any()
+
+
+@pytest.mark.parametrize("window", [(0, 2), (2, 4), (0, 8), (5, 3)])
+@pytest.mark.parametrize("shape", [(2, 128, 128), (1, 37, 53)])
+def test_bf16_conv_fwd_and_wgrad_with_a_channel_window_of_a_shared_input(window, shape):
+    """pc_conv_fwd_desc.w_ci0 / w_cin and pc_wgrad_reduce_desc.src_cin / src_ci0: a conv whose weight covers a channel window of an
+    8-channel channels-last input == the conv over the sliced input; its weight gradient == the window of the full gradient."""
+    import torch.nn.functional as F
+    from popcorn_amd import ops, _lib as L
+    B, H, W = shape
+    ci0, cin = window
+    x8 = _bf(_mk(B, 8, H, W, seed=70))
+    w = _mk(8, cin, 3, 3, seed=71, scale=0.3)
+    b = _mk(8, seed=72, scale=0.1)
+    gamma, beta, mean, var = _bn(8, 73)
+    wd = _bf(w).double().requires_grad_(True)
+    bias = b.double().clone().requires_grad_(True)
+    y = F.conv2d(x8[:, ci0:ci0 + cin].double(), wd, bias, padding=1)
+    ref = F.relu(F.batch_norm(y, mean.double(), var.double(), gamma.double(), beta.double(), training=False, eps=1e-5)).float()
+    gout = _bf(_mk(B, 8, H, W, seed=74))
+    y.backward(gout.double())
+    with L.precision("bf16"):
+        out = L.empty_act(B, 8, H, W, "cuda")
+        bnd = L.bn(b.cuda(), gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda(), 1e-5)
+        ops.conv3x3_fwd_group([{"a": _dev(x8), "w": w.cuda(), "bn": bnd, "out": out, "w_window": (ci0, cin)}])
+        _close_bf16(out, ref)
+        dw = torch.full((8, cin, 3, 3), float("nan"), device="cuda")
+        db = torch.full((8,), float("nan"), device="cuda")
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.conv3x3_group([{"a": _dev(x8), "g": _dev(gout), "dw": dw, "db": db, "src_window": (ci0, cin)}], 8)
+        wb.finish()
+    # (the weight gradient contracts the UNROUNDED-weight-independent operands x and g: compare with autograd of the sliced conv)
+    sw = wd.grad.abs().max().item()
+    assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * sw
+    assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * max(bias.grad.abs().max().item(), 1.0)
+    with L.precision("fp32"):
+        with pytest.raises(RuntimeError):                      # the window is a bf16-mode feature: refused, not ignored, in fp32 mode
+            ops.conv3x3_fwd_group([{"a": x8.cuda(), "w": w.cuda(), "bn": bnd, "out": torch.empty(B, 8, H, W, device="cuda"),
+                                    "w_window": (ci0, cin)}])

@@ -267,7 +267,9 @@ int pc_convt2x2_bwd_group(int n, const pc_convt_bwd_desc* d, int B, int H, int W
  * One workgroup per (tile, problem) keeps x, c1 and c2 in LDS (a whole map is 64 KB: no halo exists at whole-tile residency);
  * only u2 (B x 16 x 64 x 64) and, when c1 / c2 are given (networks whose backward pass needs them), those two maps go to HBM.
  * Replaces two pc_conv3x3_bn_relu_fwd_group launches and one pc_convt2x2_fwd_group launch.  Geometry: x 16 channels, 32 x 32,
- * planar fp32, 16-byte aligned rows (pc_level2_fwd_ok); anything else returns PC_EINVAL and the callers keep the three launches. */
+ * planar fp32, 16-byte aligned rows (pc_level2_fwd_ok); anything else returns PC_EINVAL and the callers keep the three launches.
+ * PC_PREC_BF16 (level2_cl.hip): the same call on channels-last bf16 tensors (x, c1, c2: 16-channel pixels; u2 B x 16 x 64 x 64) --
+ * the whole tile as the LDS strip image of the channels-last conv kernel, bit-identical to the three launches it replaces. */
 typedef struct pc_level2_fwd_desc {
     const pc_src* x; const float* w1; const pc_bn* bn1; const float* w2; const pc_bn* bn2; const float* wt; const float* bt;
     const pc_dst* c1; const pc_dst* c2;   /* optional (NULL: not written) */

@@ -505,7 +505,12 @@ bool plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) 
 
 }  // namespace
 
+// level2_cl.hip: the channels-last bf16 form of the forward kernel (PC_PREC_BF16)
+bool pc_level2_fwd_cl_ok(const pc_src* x, const pc_dst* u2);
+int pc_level2_fwd_cl_launch(int n, const pc_level2_fwd_desc* d, int B, hipStream_t stream);
+
 extern "C" int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2) {
+    if (g_pc_precision == PC_PREC_BF16) return pc_level2_fwd_cl_ok(x, u2) ? 1 : 0;
     if (g_pc_precision != PC_PREC_FP32 || !x) return 0;
     if (x->C != 16 || x->H != 32 || x->W != 32 || x->mode != PC_SRC_DIRECT || x->oy || x->ox) return 0;
     return plane_ok(x->ptr, x->bstride, x->cstride, x->rstride, x->xstride, x->dtype) &&
@@ -514,6 +519,7 @@ extern "C" int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2) {
 
 extern "C" int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream) {
     if (n < 1 || n > PC_MAX_GROUP || B < 1 || !d) return PC_EINVAL;
+    if (g_pc_precision == PC_PREC_BF16) return pc_level2_fwd_cl_launch(n, d, B, (hipStream_t)stream);
     L2Args a;
     for (int i = 0; i < n; ++i) {
         const pc_level2_fwd_desc& s = d[i];

@@ -609,7 +609,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         wss = ops.conv3x3_up_compose([{"w": ly(k, t).w, "wt": ly(k, tt).w, "bt": ly(k, tt).b} for t, tt, k in lst])
         precomp = {(t, k): w_ for (t, tt, k), w_ in zip(lst, wss)}
     u2 = None
-    if FUSED_LEVEL2 and L.act_dtype() == torch.float32 and pb2 and (H2, W2) == (32, 32):
+    if FUSED_LEVEL2 and pb2 and (H2, W2) == (32, 32):           # (both arithmetic modes: level2.hip / level2_cl.hip)
         # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with
         # the 16 x 32 x 32 maps in LDS; c1 / c2 / u2 go to HBM only for whoever reads them
         u2 = {k: (None if compose2 else E(16, 2 * H2, 2 * W2)) for k in keys}

@@ -206,9 +206,11 @@ def convt2x2_group(problems):
 
 def level2_fwd_ok(x, u2):
     """Does the one-launch 32 x 32 level (pc_level2_fwd_group) take these tensors?  x: (B,16,32,32) pooled map, u2: (B,16,64,64)."""
-    if x is None or x.dim() != 4 or tuple(x.shape[1:]) != (16, 32, 32) or x.dtype != torch.float32 or x.stride(3) != 1:
+    adt = L.act_dtype()                    # fp32 mode: planar fp32; bf16 mode: channels-last bf16 (level2_cl.hip)
+    planar = adt == torch.float32
+    if x is None or x.dim() != 4 or tuple(x.shape[1:]) != (16, 32, 32) or x.dtype != adt or x.stride(3 if planar else 1) != 1:
         return False
-    if u2 is not None and (tuple(u2.shape[1:]) != (16, 64, 64) or u2.dtype != torch.float32 or u2.stride(3) != 1):
+    if u2 is not None and (tuple(u2.shape[1:]) != (16, 64, 64) or u2.dtype != adt or u2.stride(3 if planar else 1) != 1):
         return False
     sx = L.src(x)
     du = L.dst(u2) if u2 is not None else None

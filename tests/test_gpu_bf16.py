@@ -882,3 +882,69 @@ def test_bf16_conv_fwd_and_wgrad_with_a_channel_window_of_a_shared_input(window,
         with pytest.raises(RuntimeError):                      # the window is a bf16-mode feature: refused, not ignored, in fp32 mode
             ops.conv3x3_fwd_group([{"a": x8.cuda(), "w": w.cuda(), "bn": bnd, "out": torch.empty(B, 8, H, W, device="cuda"),
                                     "w_window": (ci0, cin)}])
+
+
+def test_bf16_whole_level_forward_kernel_is_bit_identical_to_the_three_launches(monkeypatch):
+    """level2_cl.hip (down2's DoubleConv + up2's ConvTranspose2d on the 32 x 32 level, one launch, whole tile in LDS) against the
+    layer-by-layer launches: same MFMA instruction order per accumulator and the same rounding points, so c1, c2, u2, everything
+    downstream and the frozen extractor's partial logits are BIT-identical; and the op refuses what it cannot take."""
+    from popcorn_amd import engine as E, ops, _lib as L
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    m.set_precision("bf16")
+    eng_u, eng_b = m.engines()
+    X = torch.randn(3, 6, 100, 100, generator=torch.Generator().manual_seed(2)).cuda()
+    outs, launches = {}, {}
+    orig = ops.level2_fwd_group
+    with L.precision("bf16"):
+        for flag in (True, False):
+            monkeypatch.setattr(E, "FUSED_LEVEL2", flag)
+            n = [0]
+
+            def counted(problems, _n=n):
+                _n[0] += 1
+                return orig(problems)
+            monkeypatch.setattr(ops, "level2_fwd_group", counted)
+            (f_b, f_u), (_, saved) = E.forward_multi([eng_b, eng_u], X, 14, 14, 128, 128, [False, True], logit_only=[True, False])
+            torch.cuda.synchronize()
+            launches[flag] = n[0]
+            outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("c1", "c2", "u2", "e1", "e2")}
+                                                     for s in ("sar_stream", "optical_stream")})
+        assert launches == {True: 1, False: 0}
+        assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+        for s in ("sar_stream", "optical_stream"):
+            for k in ("c1", "c2", "u2", "e1", "e2"):
+                a, b = outs[True][2][s][k], outs[False][2][s][k]
+                assert a.dtype == torch.bfloat16 and a.stride(1) == 1 and torch.equal(a, b), (s, k)
+        assert not ops.level2_fwd_ok(torch.zeros(2, 16, 32, 32, device="cuda"), None)                         # fp32 container
+        assert not ops.level2_fwd_ok(L.empty_act(2, 16, 30, 32, "cuda"), None)
+        assert ops.level2_fwd_ok(L.empty_act(2, 16, 32, 32, "cuda"), L.empty_act(2, 16, 64, 64, "cuda"))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_bf16_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_graph):
+    """bf16 mode: the step fed the RAW 15-band tile (first launch = pc_ingest_cl8: select + normalise + pad + round into the shared
+    channels-last input) against the step fed the normalised input (the same ingest without the normalisation): identical
+    values after rounding, so losses and parameters agree bit for bit."""
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=5, device="cuda", region="disc")
+    x = ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    runs = []
+    for key, data in (("input", x), ("raw", batch["raw"])):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        m.set_precision("bf16")
+        tr = FusedTrainStep(m, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
+        losses = []
+        for step in range(3):
+            torch.manual_seed(50 + step)
+            losses.append(tr.step({key: data, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}).tolist())
+        torch.cuda.synchronize()
+        runs.append((losses, tr.flat_p.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])

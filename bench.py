@@ -886,7 +886,24 @@ def extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, s
         return step()
     sample["admin_mask"].copy_(batch["admin_mask"]); sample["census_idx"].copy_(batch["census_idx"]); sample["y"].copy_(batch["y"])
     dt_res, _, _ = timed_block(resident_step, nfeed)
-    out["h2d"] = {"unit": "patches/s", "precision": args.precision, "legs": legs,
+    # what feeding costs at scale: bytes per step of the DEFAULT feed (the 6 selected bands -- what the reference's loader ships,
+    # data/PopulationDataset.py:566-568 -- fp32) at the resident step rate, per rank and for 8 ranks through one host, next to what one
+    # pinned hipMemcpyAsync stream sustains on this host (256 MB, median of 5)
+    probe = torch.empty(256 * 2 ** 20, dtype=torch.uint8).pin_memory()
+    dprobe = torch.empty_like(probe, device=dev)
+    cp = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dprobe.copy_(probe, non_blocking=True)
+        torch.cuda.synchronize()
+        cp.append(probe.numel() / (time.perf_counter() - t0) / 1e9)
+    pinned_gbps = statistics.median(cp[1:])
+    del probe, dprobe
+    need = legs[0]["host_bytes_per_step"] / (dt_res / nfeed) / 1e9
+    out["h2d"] = {"unit": "patches/s", "precision": args.precision, "legs": legs, "default_feed": legs[0]["feed"],
+                  "h2d_gbps_needed_per_rank": round(need, 2), "h2d_gbps_needed_8_ranks": round(8 * need, 1),
+                  "host_pinned_gbps_measured": round(pinned_gbps, 1),
                   "resident_same_block": {"steps": nfeed, "ms_per_step": round(dt_res / nfeed * 1e3, 4),
                                           "value": round(B * world * nfeed / dt_res, 1)},
                   "note": "whole job, max over ranks; pinned host -> the idle one of two static input sets (one captured graph each) on a "

@@ -368,7 +368,13 @@ int64_t pc_head_ws_bytes(int B, int H, int W);
 int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                 const float* building, const float* admin_mask, const int64_t* census_idx,
                 float* scale_map, float* popdensemap, float* popcount, double* stats,
-                const int32_t* nsel_counts, void* ws, int B, int H, int W, void* stream);
+                const int32_t* nsel_counts, void* ws, int B, int H, int W, int flags, void* stream);
+/* flags of pc_head_fwd / pc_head_bwd.  Both kernels read the head's weights from an LDS image that a small launch assembles in `ws`
+ * per call.  A training step runs pc_head_fwd and pc_head_bwd on the SAME weights and workspace: PC_HEAD_FWD_PACK_BOTH makes the
+ * forward call's pack launch write the backward's image as well, PC_HEAD_BWD_PACKED tells the backward call that it is there (the
+ * caller guarantees: same hw contents, same ws, same B / H / W, same arithmetic mode in between) -- one launch less per step. */
+#define PC_HEAD_FWD_PACK_BOTH 1
+#define PC_HEAD_BWD_PACKED 1
 
 /* backward of pc_head_fwd (the forward chain is recomputed in registers).  Upstream gradients, all optional (NULL):
  *   g_popcount[B]; g_popdense[B][H][W]; g_scale_map[B][H][W] (gradient w.r.t. scale = relu(out), e.g. the scattered
@@ -384,7 +390,7 @@ int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, cons
                 const float* g_popcount, const float* g_popdense, const float* g_scale_map,
                 const float* g_scale_const, float* const* dhw, int accumulate,
                 const pc_dst* g_feat, const pc_bn* feat_bn_sar, const pc_bn* feat_bn_opt,
-                int Hp, int Wp, void* ws, int B, int H, int W, void* stream);
+                int Hp, int Wp, void* ws, int B, int H, int W, int flags, void* stream);
 
 /* ---- compaction of scale[mask] in row-major (b,y,x) order (the boolean-index gather of popcorn.py:173).
  * out must hold B*H*W floats; *n_out (device int32) receives Nsel. */

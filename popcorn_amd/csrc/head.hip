@@ -1729,8 +1729,12 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
 
 // assembles the LDS weight image of the head kernel that follows, once, in global memory (kind 0: fp32 forward, 1: fp32
 // backward, 2: bf16 forward, 3: bf16 backward)
-__global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* img, int kind) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+// blocks 0..7 assemble image `kind` into img; blocks 8..15 (PC_HEAD_FWD_PACK_BOTH: a 16-block launch) the backward's image of the same
+// mode (kind + 1) into img2
+__global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* img, int kind, void* img2) {
+    const int second = blockIdx.x >= 8 ? 1 : 0;
+    const int tid = (blockIdx.x - 8 * second) * blockDim.x + threadIdx.x, nt = 8 * blockDim.x;
+    if (second) { img = img2; kind += 1; }
     if (kind == 0) head_stage_weights(reinterpret_cast<float*>(img), p, tid, nt);
     else if (kind == 1) head_stage_weights_bwd(reinterpret_cast<float*>(img), p, tid, nt);
     else head_stage_weights_bf16(reinterpret_cast<unsigned char*>(img), p, kind == 3, tid, nt);
@@ -2316,7 +2320,7 @@ extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
 extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                            const float* building, const float* admin_mask, const int64_t* census_idx,
                            float* scale_map, float* popdensemap, float* popcount, double* stats,
-                           const int32_t* nsel_counts, void* ws, int B, int H, int W, void* stream) {
+                           const int32_t* nsel_counts, void* ws, int B, int H, int W, int flags, void* stream) {
     if (!feat || !hw || !building || !popdensemap || !popcount || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
     HeadArgs p{};
@@ -2354,7 +2358,8 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
     void* img = head_image_slot(ws, B, H, W, 0);
     p.wimage = img;
-    hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 2 : 0);
+    const bool both = (flags & PC_HEAD_FWD_PACK_BOTH) != 0;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(both ? 16 : 8), dim3(256), 0, st, p, img, p.bf ? 2 : 0, head_image_slot(ws, B, H, W, 1));
     PC_CHECK_LAUNCH();
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
@@ -2452,7 +2457,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
                            const float* g_popcount, const float* g_popdense, const float* g_scale_map,
                            const float* g_scale_const, float* const* dhw, int accumulate,
                            const pc_dst* g_feat, const pc_bn* feat_bn_sar, const pc_bn* feat_bn_opt,
-                           int Hp, int Wp, void* ws, int B, int H, int W, void* stream) {
+                           int Hp, int Wp, void* ws, int B, int H, int W, int flags, void* stream) {
     if (!feat || !hw || !building || !dhw || !g_feat || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
     const bool bfmode = g_pc_precision == PC_PREC_BF16;          // bf16 mode: feat and g_feat are channels-last bf16 tensors
@@ -2516,8 +2521,10 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     {
         void* img = head_image_slot(ws, B, H, W, 1);
         p.wimage = img;
-        hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 3 : 1);
-        PC_CHECK_LAUNCH();
+        if (!(flags & PC_HEAD_BWD_PACKED)) {
+            hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 3 : 1, (void*)nullptr);
+            PC_CHECK_LAUNCH();
+        }
     }
     if (p.bf) {
         static pc_once_per_device once4;

@@ -455,8 +455,11 @@ def _hw_array(head_tensors):
     return arr
 
 
+PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED = 1, 1
+
+
 def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
-             want_scale=True, stats=None, nsel_counts=None):
+             want_scale=True, stats=None, nsel_counts=None, pack_both=False):
     """Sparse/dense head + occupancy product + census reduction.  popcorn.py:161-190.
     head_tensors = [w0,b0,w2,b2,w4,b4,w6,b6].  Returns (scale_map, popdensemap, popcount)."""
     L.require_device(feat, building, *head_tensors)
@@ -470,7 +473,8 @@ def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     hw = _hw_array(head_tensors)
     L.check(L.lib().pc_head_fwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
                                 L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(stats),
-                                L.ptr(nsel_counts), L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_fwd")
+                                L.ptr(nsel_counts), L.ptr(ws), B, H, W, PC_HEAD_FWD_PACK_BOTH if pack_both else 0, L.stream_ptr()),
+            "pc_head_fwd")
     return scale_map, popdense, popcount
 
 
@@ -554,8 +558,9 @@ def ingest_cl8(raw, band, mean, std, top, bottom, left, right, out=None):
 
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
-             g_feat=None, feat_bn=None):
-    """Backward of head_fwd.  Returns (list of 8 head grads, g_feat (B,16,Hp,Wp))."""
+             g_feat=None, feat_bn=None, packed=False):
+    """Backward of head_fwd.  Returns (list of 8 head grads, g_feat (B,16,Hp,Wp)).  pack_both (head_fwd) / packed (here): a training
+    step's forward call assembles the backward's weight image too (same weights, same workspace): one launch less."""
     L.require_device(feat, building, *head_tensors)
     B, _, Hp, Wp = feat.shape
     dev = feat.device
@@ -571,7 +576,7 @@ def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
                                 L.ptr(census_idx), L.ptr(g_popcount), L.ptr(g_popdense), L.ptr(g_scale_map),
                                 L.ptr(g_scale_const), dhw, int(accumulate), C.byref(d),
                                 C.byref(feat_bn[0]) if feat_bn else None, C.byref(feat_bn[1]) if feat_bn else None,
-                                Hp, Wp, L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_bwd")
+                                Hp, Wp, L.ptr(ws), B, H, W, PC_HEAD_BWD_PACKED if packed else 0, L.stream_ptr()), "pc_head_bwd")
     return grads, g_feat
 
 

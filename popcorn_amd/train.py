@@ -256,7 +256,7 @@ class FusedTrainStep:
             feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
                                                      admin_mask=s["admin_mask"], census_idx=s["census_idx"],
-                                                     stats=self.stats, nsel_counts=counts)
+                                                     stats=self.stats, nsel_counts=counts, pack_both=True)
         self._ctx = (feats, saved, building, mask, (pt, pl), (B, H, W))
         self.last = {"popcount": popcount, "popdensemap": popdense, "scale_map": scale_map, "mask": mask}
 
@@ -272,7 +272,7 @@ class FusedTrainStep:
         khgrads, fix = m.head_grad_targets(hgrads)
         _, G = ops.head_bwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask, admin_mask=s["admin_mask"],
                             census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=khgrads,
-                            feat_bn=None if unet_no_grad else eng_u.feat_bn())
+                            feat_bn=None if unet_no_grad else eng_u.feat_bn(), packed=True)
         fix()
         if unet_no_grad:
             self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()

@@ -75,7 +75,6 @@ struct ConvProb {
     // compose_up_kernel (composed 2x2-neighbourhood weights per output parity; bias-through-the-taps table)
     const float* z; int64_t z_bs, z_cs; int z_rs;
     const float* wz; const float* tb;
-    int z_xs;             // channels-last bf16 form (UPC > 0 of conv3x3_cl_kernel): x stride of z; wz = the transposed conv's weight, tb = its bias
     // channels-last bf16, CIN == 8: w is [COUT][w_cin][3][3] over input channels [w_ci0, w_ci0 + w_cin) (w_cin == 0: full weight)
     int w_ci0, w_cin;
 };
@@ -940,20 +939,9 @@ __device__ __forceinline__ u32x4 cl_max8(u32x4 a, u32x4 b) {      // elementwise
     }
     return o;
 }
-// UPC > 0 (forward, LD_DIRECT): the LAST UPC of the CIN input channels are the output of ConvTranspose2d(UPC, UPC, 2, stride 2) over the
-// low-resolution map z (H/2 x W/2, channels-last bf16) -- torch.cat([skip, Up.up(z)]) of networks.py:302-318 -- and are never read from
-// memory: the stage of such a chunk loads the 4 x 18 low-resolution pixels under the strip (8 bytes per lane and row instead of 16-byte
-// pieces of an up-sampled tensor a quarter as dense), runs the transposed conv on the matrix pipe (v_mfma_f32_16x16x16_bf16: M = (x
-// parity b, 8 output channels), N = 16 low-resolution pixels, K = ci; one instruction per strip row + two for the halo columns), rounds
-// to bf16 -- the mode's rounding point of a transposed-conv output -- and writes the strip image the 3x3 taps then read.  Same
-// fragments, K order and rounding as convt2x2_fwd_cl_kernel: bit-identical to the materialised up-sampled map.
-typedef short cl_s4 __attribute__((ext_vector_type(4)));
-template <int CIN, int COUT, int MODE, int LD, int EPI, int UPC = 0>
+template <int CIN, int COUT, int MODE, int LD, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
-    static_assert(UPC == 0 || (MODE == MODE_FWD && LD == LD_DIRECT && (UPC == 8 || UPC == 16) && CIN > UPC), "virtual up-sampled chunks");
     constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
-    constexpr int NREAL = (CIN - UPC) / 8;               // chunks read from memory; chunks NREAL.. are virtual (UPC > 0)
-    constexpr int NVC = UPC / 8;
     constexpr int NB = COUT / 8;
     constexpr int NIT = CIN < 8 ? CIN : 1;               // REFLECT loader: planar fp32 rows, one 16-byte segment per channel
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -980,94 +968,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     f32x4 RF[LD == LD_REFLECT ? NIT : 1];
     unsigned rvalid = 0;
     const int r_r = lane / 10, r_seg = lane - r_r * 10;  // REFLECT: lane = (row, 4-pixel segment of the 40-pixel row)
-    // virtual chunks: A fragments of the transposed conv (lane m = li: x parity b = li >> 3, output channel co8 = li & 7; k-group lk:
-    // ci = 4 lk + e) per virtual chunk and output-row parity a, and the bias of the D rows co8 = 4 (lk & 1) + r
-    cl_s4 up_aw[NVC > 0 ? NVC : 1][2];
-    float up_bias[NVC > 0 ? NVC : 1][4];
-    uint2 RZ[5];
-    unsigned zvalid = 0;
-    const pc_bf16_t* const zptr = reinterpret_cast<const pc_bf16_t*>(q.z);
-    const int Hz = p.H >> 1, Wz = p.W >> 1;
-    if constexpr (UPC > 0) {
-#pragma unroll
-        for (int vc = 0; vc < NVC; ++vc) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ci = 4 * lk + e;
-                    up_aw[vc][a][e] = ci < UPC ? (short)pc_f2bf(q.wz[((ci * UPC + 8 * vc + (li & 7)) * 2 + a) * 2 + (li >> 3)]) : (short)0;
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) up_bias[vc][r] = q.tb ? q.tb[8 * vc + 4 * (lk & 1) + r] : 0.f;
-        }
-    }
-    auto issue_up = [&](int b, int y0, int x0) {
-        // main tile: lane (li = low-resolution column x0 / 2 + li, k-group lk: channels 4 lk .. + 3), rows y0 / 2 - 1 .. + 2;
-        // halo: lanes li < 8 = (row li >> 1, side li & 1): columns x0 / 2 - 1 and x0 / 2 + 16
-        const pc_bf16_t* zb = zptr + b * q.z_bs;
-        const int i0 = (y0 >> 1) - 1, j0 = x0 >> 1;
-        unsigned vm = 0;
-        const bool kok = 4 * lk < UPC;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = i0 + t, j = j0 + li;
-            const bool ok = kok && (unsigned)i < (unsigned)Hz && (unsigned)j < (unsigned)Wz;
-            RZ[t] = *reinterpret_cast<const uint2*>(zb + (ok ? (int64_t)i * q.z_rs + (int64_t)j * q.z_xs + 4 * lk : 0));
-            vm |= (ok ? 1u : 0u) << t;
-        }
-        {
-            const int i = i0 + ((li >> 1) & 3), j = (li & 1) ? j0 + 16 : j0 - 1;
-            const bool ok = kok && li < 8 && (unsigned)i < (unsigned)Hz && (unsigned)j < (unsigned)Wz;
-            RZ[4] = *reinterpret_cast<const uint2*>(zb + (ok ? (int64_t)i * q.z_rs + (int64_t)j * q.z_xs + 4 * lk : 0));
-            vm |= (ok ? 1u : 0u) << 4;
-        }
-        zvalid = vm;
-    };
-    auto commit_up = [&](int vc, int y0, int x0) {
-        auto frag = [&](int t) {
-            const uint2 v = ((zvalid >> t) & 1u) ? RZ[t] : make_uint2(0u, 0u);
-            cl_s4 f;
-            f[0] = (short)(v.x & 0xffffu); f[1] = (short)(v.x >> 16); f[2] = (short)(v.y & 0xffffu); f[3] = (short)(v.y >> 16);
-            return f;
-        };
-        const int bpar = lk >> 1, half = lk & 1;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const cl_s4 bv = frag(t);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int r = 2 * t + a - 1;                       // strip row (0 .. 5) of up-sampled row 2 (i0 + t) + a
-                if (r < 0 || r > 5) continue;
-                f32x4 acc = f32x4{up_bias[vc][0], up_bias[vc][1], up_bias[vc][2], up_bias[vc][3]};
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(up_aw[vc][a], bv, acc, 0, 0, 0);
-                const int Y = y0 - 1 + r, X = x0 + 2 * li + bpar;
-                const bool ok = (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
-                const uint2 pk = ok ? make_uint2(pc_pack_bf16(acc[0], acc[1]), pc_pack_bf16(acc[2], acc[3])) : make_uint2(0u, 0u);
-                reinterpret_cast<uint2*>(wl + r * BSLOTS + (COL0 - 1) + 1 + 2 * li + bpar)[half] = pk;
-            }
-        }
-        {
-            // halo columns X = x0 - 1 (low-resolution column j0 - 1, parity 1) and X = x0 + 32 (column j0 + 16, parity 0)
-            const cl_s4 bv = frag(4);
-            const int t = (li >> 1) & 3, side = li & 1;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                f32x4 acc = f32x4{up_bias[vc][0], up_bias[vc][1], up_bias[vc][2], up_bias[vc][3]};
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(up_aw[vc][a], bv, acc, 0, 0, 0);
-                const int r = 2 * t + a - 1;
-                const int Y = y0 - 1 + r, X = side ? x0 + 32 : x0 - 1;
-                const bool ok = (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
-                const uint2 pk = ok ? make_uint2(pc_pack_bf16(acc[0], acc[1]), pc_pack_bf16(acc[2], acc[3])) : make_uint2(0u, 0u);
-                if (li < 8 && bpar == 1 - side && r >= 0 && r <= 5)
-                    reinterpret_cast<uint2*>(wl + r * BSLOTS + (COL0 - 1) + (side ? 33 : 0))[half] = pk;
-            }
-        }
-    };
     auto issue = [&](int ch, int b, int y0, int x0) {
-        if constexpr (UPC > 0) {
-            if (ch >= NREAL) { issue_up(b, y0, x0); return; }
-        }
         if constexpr (LD == LD_REFLECT) {
             rvalid = lane < 60 ? 1u : 0u;
 #pragma unroll
@@ -1101,10 +1002,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
             rvalid = vm;
         }
     };
-    auto commit = [&](int ch, int cy0, int cx0) {
-        if constexpr (UPC > 0) {
-            if (ch >= NREAL) { commit_up(ch - NREAL, cy0, cx0); return; }
-        }
+    auto commit = [&]() {
         if constexpr (LD == LD_REFLECT) {
             // planar fp32 model input: round + pack here (the one operand no producer has rounded); channel slots >= CIN are zero
             if (lane < 60) {
@@ -1321,7 +1219,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     f32x4 acc[4][NB];
     for (int stage = 0; stage < nstages; ++stage) {
         const int ch = stage % NCHUNK;
-        if (!(p.dbg & 1)) commit(ch, y0, x0);
+        if (!(p.dbg & 1)) commit();
         int nb_ = b, ny0 = y0, nx0 = x0;
         if (stage + 1 < nstages) {
             if ((stage + 1) % NCHUNK == 0) strip_coords(stage + 1, nb_, ny0, nx0);
@@ -1366,14 +1264,14 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     if (have_prev && !(p.dbg & 4)) epilogue();
 }
 
-template <int CIN, int COUT, int MODE, int LD, int EPI, int UPC = 0>
+template <int CIN, int COUT, int MODE, int LD, int EPI>
 int launch_conv_cl(ConvArgs& p, int nprob, hipStream_t stream) {
     constexpr int NCHUNK = CIN <= 8 ? 1 : CIN / 8;
     const size_t lds = (size_t)4 * BWAVE_F * sizeof(float) + (size_t)4 * COUT * NCHUNK * 24 * sizeof(unsigned short);
     static int resident = 0;
     static pc_once_per_device once;
     if (once.need()) {
-        const void* fn = reinterpret_cast<const void*>(&conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI, UPC>);
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipFuncAttributes fa;
@@ -1390,7 +1288,7 @@ int launch_conv_cl(ConvArgs& p, int nprob, hipStream_t stream) {
     int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
     const int rounds = (p.ntiles + grid - 1) / grid;
     grid = (p.ntiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL((conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI, UPC>), dim3(grid, nprob), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_cl_kernel<CIN, COUT, MODE, LD, EPI>), dim3(grid, nprob), dim3(256), lds, stream, p);
     PC_CHECK_LAUNCH();
     return 0;
 }
@@ -1775,15 +1673,7 @@ __global__ __launch_bounds__(256) void compose_up_kernel(const ComposeArgs a) {
 extern "C" int64_t pc_conv3x3_up_ws_bytes(int C) { return (int64_t)((C / 8) * 1536 + 72 + 2048) * sizeof(float); }
 
 extern "C" int pc_conv3x3_up_fwd_ok(const pc_src* skip, const pc_src* z, const pc_dst* out, int H, int W, int Cs, int C) {
-    if (!skip || !z || !out) return 0;
-    if (g_pc_precision == PC_PREC_BF16) {
-        // channels-last bf16 form (conv3x3_cl_kernel<..., UPC>): the transposed conv runs inside the loader of the up-sampled chunks
-        if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 1) || (W & 1)) return 0;
-        if (skip->C != Cs || z->C != C || z->H * 2 != H || z->W * 2 != W || z->mode != PC_SRC_DIRECT || z->oy || z->ox) return 0;
-        if (skip->mode != PC_SRC_DIRECT || skip->oy || skip->ox || skip->H != H || skip->W != W) return 0;
-        return pc_cl_ok(*skip) && skip->xstride >= Cs && pc_cl_ok(*z) && z->xstride >= C && pc_cl_ok(*out);
-    }
-    if (g_pc_precision != PC_PREC_FP32) return 0;
+    if (g_pc_precision != PC_PREC_FP32 || !skip || !z || !out) return 0;
     // (any even width with 16-byte aligned rows: the low-resolution piece is masked per column, the border bias per pixel, the ragged
     // last strip of a row is stored by the per-element epilogue)
     if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W & 1)) return 0;
@@ -1815,36 +1705,6 @@ extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int 
     const bool precomposed = (relu & PC_UP_PRECOMPOSED) != 0;
     relu &= 1;
     ConvArgs p{};
-    if (g_pc_precision == PC_PREC_BF16) {
-        // no composition and no workspace: the up-sampled chunks are produced by the loader (bit-identical to the materialised map)
-        for (int i = 0; i < n; ++i) {
-            if (!d[i].skip || !d[i].z || !d[i].w || !d[i].wt || !d[i].bn || !d[i].out ||
-                !pc_conv3x3_up_fwd_ok(d[i].skip, d[i].z, d[i].out, H, W, Cs, C))
-                return PC_EINVAL;
-            ConvProb& q = p.pr[i];
-            q.a = *d[i].skip;
-            q.w = d[i].w;
-            q.bn = *d[i].bn;
-            q.out = *d[i].out;
-            q.z = d[i].z->ptr; q.z_bs = d[i].z->bstride; q.z_rs = d[i].z->rstride; q.z_xs = d[i].z->xstride;
-            q.wz = d[i].wt;
-            q.tb = d[i].bt;
-        }
-        p.w_co_stride = (Cs + C) * 9;
-        p.w_ci_stride = 9;
-        p.relu = relu;
-        p.B = B; p.H = H; p.W = W;
-        p.tiles_x = (p.W + TW - 1) / TW;
-        p.tiles_y = (p.H + TH - 1) / TH;
-        p.ntiles = p.B * p.tiles_x * p.tiles_y;
-        if (p.ntiles <= 0) return 0;
-        p.div_tx = pc_make_fastdiv(p.tiles_x);
-        p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
-        p.dbg = g_conv_dbg;
-        p.ts = g_conv_ts;
-        if (Cs == 8) return launch_conv_cl<16, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 8>(p, n, (hipStream_t)stream);
-        return launch_conv_cl<32, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 16>(p, n, (hipStream_t)stream);
-    }
     ComposeArgs ca{};
     for (int i = 0; i < n; ++i) {
         if (!d[i].skip || !d[i].z || !d[i].w || !d[i].wt || !d[i].bn || !d[i].out || !d[i].ws ||

@@ -585,18 +585,9 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
 
     def up_conv(tag, ttag, skip, z, c, h, w):
         """first conv of an Up block straight from the low-resolution map z (composed weights): (outs, workspaces), or None"""
-        if not (COMPOSED_UP and FUSED_CONV_BWD and (h, w) == (2 * z[keys[0]].shape[2], 2 * z[keys[0]].shape[3])):
+        if not (COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (h, w) == (2 * z[keys[0]].shape[2], 2 * z[keys[0]].shape[3])):
             return None
         outs = {k: E(c, h, w) for k in keys}
-        if bf:
-            # bf16 mode: the transposed conv runs inside the conv kernel's loader (bit-identical to the materialised map, any
-            # exactly-2x geometry); no workspace.  The BACKWARD still contracts the up-sampled map (weight gradient of the conv's
-            # up-sampled columns), so the callers materialise it for saved networks -- the frozen extractor never needs it.
-            if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys):
-                return None
-            ops.conv3x3_up_fwd_group([{"skip": skip[k], "z": z[k], "w": ly(k, tag).w, "wt": ly(k, ttag).w, "bt": ly(k, ttag).b,
-                                       "bn": ly(k, tag).bn, "out": outs[k]} for k in keys])
-            return outs, {}
         # (the composed BACKWARD kernels exist for 64- and 128-wide maps; a forward-only pass takes any geometry the kernel accepts,
         # e.g. the 2048 / 1024-wide levels of an inference window)
         if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or (any(saves) and w not in (64, 128)):
@@ -611,20 +602,6 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         (W1 in (64, 128) or fwd_only)
     compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and \
         (Wp in (64, 128) or fwd_only)
-    # bf16 mode: the up-sampled maps are produced inside the conv loaders (up_conv); only SAVED networks still get them from the
-    # transposed-conv launches, for their backward pass
-    virt2 = COMPOSED_UP and FUSED_CONV_BWD and bf and (H1, W1) == (2 * H2, 2 * W2)
-    virt1 = COMPOSED_UP and FUSED_CONV_BWD and bf and (Hp, Wp) == (2 * H1, 2 * W1)
-    skeys = [k for k in keys if saves[k[0]]]
-
-    def convt_saved(tag, ins, c, h, w):
-        """the up-sampled map of the SAVED networks only (bf16 mode, for their backward); None for the others"""
-        outs = {k: None for k in keys}
-        if skeys:
-            for k in skeys:
-                outs[k] = E(c, h, w)
-            ops.convt2x2_group([{"x": ins[k], "w": ly(k, tag).w, "bias": ly(k, tag).b, "out": outs[k]} for k in skeys])
-        return outs
     precomp = {}
     if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
         # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)
@@ -635,10 +612,10 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     if FUSED_LEVEL2 and pb2 and (H2, W2) == (32, 32):           # (both arithmetic modes: level2.hip / level2_cl.hip)
         # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with
         # the 16 x 32 x 32 maps in LDS; c1 / c2 / u2 go to HBM only for whoever reads them
-        u2 = {k: (None if (compose2 or (virt2 and not saves[k[0]])) else E(16, 2 * H2, 2 * W2)) for k in keys}
+        u2 = {k: (None if compose2 else E(16, 2 * H2, 2 * W2)) for k in keys}
         if all(ops.level2_fwd_ok(pb2[k], u2[k]) for k in keys):
             c1 = {k: (E(16, H2, W2) if saves[k[0]] else None) for k in keys}
-            c2 = {k: (E(16, H2, W2) if (saves[k[0]] or compose2 or virt2) else None) for k in keys}
+            c2 = {k: (E(16, H2, W2) if (saves[k[0]] or compose2) else None) for k in keys}
             ops.level2_fwd_group([{"x": pb2[k], "w1": ly(k, "d2a").w, "bn1": ly(k, "d2a").bn, "w2": ly(k, "d2b").w,
                                    "bn2": ly(k, "d2b").bn, "wt": ly(k, "up2t").w, "bt": ly(k, "up2t").b, "c1": c1[k], "c2": c2[k],
                                    "u2": u2[k]} for k in keys])
@@ -649,7 +626,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         c2 = conv("d2b", c1, 16, H2, W2)
         u2 = {k: None for k in keys}
     o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
-    r = up_conv("up2a", "up2t", b2, c2, 8, H1, W1) if (compose2 or virt2) else None
+    r = up_conv("up2a", "up2t", b2, c2, 8, H1, W1) if compose2 else None
     ws_up2 = {}
     if r is None:
         if any(u2[k] is None for k in keys):
@@ -657,18 +634,16 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
     else:
         e1, ws_up2 = r
-        if virt2 and any(u2[k] is None for k in skeys):       # (the whole-level kernel wrote the saved networks' u2 already)
-            u2 = convt_saved("up2t", c2, 16, 2 * H2, 2 * W2)
     e2 = conv("up2b", e1, 8, H1, W1)
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
-    r = up_conv("up1a", "up1t", a2, e2, 8, Hp, Wp) if (compose1 or virt1) else None
+    r = up_conv("up1a", "up1t", a2, e2, 8, Hp, Wp) if compose1 else None
     ws_up1 = {}
     if r is None:
         u1 = convt("up1t", e2, 8, 2 * H1, 2 * W1)
         f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
     else:
         f1, ws_up1 = r
-        u1 = convt_saved("up1t", e2, 8, 2 * H1, 2 * W1) if virt1 else {k: None for k in keys}
+        u1 = {k: None for k in keys}
     f0s = {s: f0 for s, _, _, f0 in streams}
     probs = []
     for k in keys:

@@ -220,11 +220,9 @@ def level2_fwd_ok(x, u2):
 def conv3x3_up_fwd_ok(skip, z, out):
     """Does pc_conv3x3_up_fwd_group (first conv of an Up block computed from the LOW-resolution map, no up-sampled tensor) take
     these tensors?  skip (B,Cs,H,W), z (B,C,H/2,W/2), out (B,8,H,W)."""
-    adt = L.act_dtype()                    # fp32 mode: planar fp32 (composed weights); bf16 mode: channels-last bf16 (transposed conv in the loader)
-    if skip is None or z is None or skip.dtype != adt or z.dtype != adt or out.dtype != adt:
+    if skip is None or z is None or skip.dtype != torch.float32 or z.dtype != torch.float32 or out.dtype != torch.float32:
         return False
-    ax = 3 if adt == torch.float32 else 1
-    if skip.stride(ax) != 1 or z.stride(ax) != 1 or out.stride(ax) != 1:
+    if skip.stride(3) != 1 or z.stride(3) != 1 or out.stride(3) != 1:
         return False
     B, Cs, H, W = skip.shape
     ss, sz, do = L.src(skip), L.src(z), L.dst(out)
@@ -261,21 +259,20 @@ def conv3x3_up_fwd_group(problems, relu=True):
     B, Cs, H, W = skip0.shape
     Cz = z0.shape[1]
     nbytes = int(L.lib().pc_conv3x3_up_ws_bytes(Cz))
-    bf = L.act_dtype() == torch.bfloat16      # bf16 mode: no composition, no workspace (the loader runs the transposed conv)
-    pre = (not bf) and all(pr.get("ws") is not None for pr in problems)
+    pre = all(pr.get("ws") is not None for pr in problems)
     keep, slots = [], []
     descs = (L.PcConvUpFwdDesc * n)()
     for i, pr in enumerate(problems):
         # composed operand images of this call (forward stages, bias table, the backward's data-gradient image): a fresh tensor
         # per problem -- the backward pass of a saved network reads it again (under graph capture it lives in the graph's pool)
-        slots.append(None if bf else (pr["ws"] if pre else torch.empty(nbytes, dtype=torch.uint8, device=skip0.device)))
+        slots.append(pr["ws"] if pre else torch.empty(nbytes, dtype=torch.uint8, device=skip0.device))
         ss, sz, do = L.src(pr["skip"]), L.src(pr["z"]), L.dst(pr["out"])
         keep += [ss, sz, do]
         descs[i].skip, descs[i].z, descs[i].out = C.pointer(ss), C.pointer(sz), C.pointer(do)
         descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
         descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
         descs[i].bn = C.pointer(pr["bn"])
-        descs[i].ws = None if bf else slots[i].data_ptr()
+        descs[i].ws = slots[i].data_ptr()
     L.check(L.lib().pc_conv3x3_up_fwd_group(n, descs, int(relu) | (2 if pre else 0), B, H, W, Cs, Cz, L.stream_ptr()),
             "pc_conv3x3_up_fwd_group")
     return slots

@@ -948,45 +948,3 @@ def test_bf16_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_gr
         runs.append((losses, tr.flat_p.clone()))
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1])
-
-
-@pytest.mark.parametrize("hw", [(100, 100), (72, 40), (36, 52)])
-def test_bf16_up_sampled_chunks_from_the_loader_are_bit_identical_to_the_materialised_map(monkeypatch, hw):
-    """conv3x3_cl_kernel<..., UPC>: the first conv of an Up block computes its up-sampled input chunks inside the loader (transposed
-    conv on the matrix pipe from the low-resolution map, same fragments / K order / rounding point as convt2x2_fwd_cl_kernel) instead
-    of reading a materialised tensor: features, logits and every saved activation are BIT-identical with the switch off; the frozen
-    network no longer launches a transposed conv at all, the saved network keeps its up-sampled maps for the backward pass."""
-    from popcorn_amd import engine as E, ops, _lib as L
-    from popcorn_amd.model import POPCORN
-    from popcorn_amd.model.popcorn import pad_geometry
-    torch.manual_seed(1600)
-    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
-    m.set_precision("bf16")
-    eng_u, eng_b = m.engines()
-    H, W = hw
-    X = torch.randn(2, 6, H, W, generator=torch.Generator().manual_seed(3)).cuda()
-    pt, pb, pl, pr = pad_geometry(H, W, True)
-    Hp, Wp = H + pt + pb, W + pl + pr
-    outs, nconvt = {}, {}
-    orig = ops.convt2x2_group
-    with L.precision("bf16"):
-        for flag in (True, False):
-            monkeypatch.setattr(E, "COMPOSED_UP", flag)
-            cnt = [0]
-
-            def counted(problems, _c=cnt):
-                _c[0] += len(problems)
-                return orig(problems)
-            monkeypatch.setattr(ops, "convt2x2_group", counted)
-            (f_b, f_u), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, Hp, Wp, [False, True], logit_only=[True, False])
-            torch.cuda.synchronize()
-            nconvt[flag] = cnt[0]
-            outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("u1", "u2", "e1", "e2", "f1")}
-                                                     for s in ("sar_stream", "optical_stream")})
-    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
-    for s in ("sar_stream", "optical_stream"):
-        for k in ("u1", "u2", "e1", "e2", "f1"):
-            assert torch.equal(outs[True][2][s][k], outs[False][2][s][k]), (s, k)
-    # switch off: both transposed convs for 4 (network, stream) problems; on: for the 2 saved problems only (up2's comes out of the
-    # whole-level kernel when the second level is 32 x 32)
-    assert nconvt[False] in (8, 4) and nconvt[True] in (4, 2) and nconvt[True] * 2 == nconvt[False], nconvt

@@ -149,3 +149,34 @@ def test_properties_at_the_reference_limits(H, W, expect):
 def _encoder_keys():
     from popcorn_amd import engine as E
     return [E.CONVS[t][0] for t in E.ENCODER]
+
+
+def test_bf16_mode_at_the_reference_limit_size():
+    """PC_PREC_BF16 on a B = 2 batch at 8.99e6 px (everything trains): finite, bit-deterministic, every trainable group moves.  (No
+    oracle at this size: the bf16 restatement is a CPU evaluation with explicit casts; parity of the mode is pinned at small sizes in
+    tests/test_gpu_bf16.py.)"""
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    dev = _batch(2, 2100, 2140)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        m.set_precision("bf16")
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        p0 = tr.flat_p.clone()
+        torch.cuda.reset_peak_memory_stats()
+        torch.manual_seed(3)
+        loss = tr.step(dict(dev))
+        torch.cuda.synchronize()
+        runs.append((loss.tolist(), tr.flat_g.clone(), tr.flat_p.clone()))
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"\n[regions] bf16 2x2100x2140: loss {runs[0][0][0]:.6f}, peak HBM {peak:.2f} GiB")
+    assert torch.isfinite(runs[0][1]).all() and torch.isfinite(runs[0][2]).all()
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    off, table = 0, dict(tr.model.named_parameters())
+    for n in tr.names:
+        k = table[n].numel()
+        if n.endswith(".weight"):
+            assert not torch.equal(runs[0][2][off:off + k], p0[off:off + k]), n
+        off += k

@@ -789,13 +789,21 @@ def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
     (run_train.py:186, utils/utils.py:22-27), synchronously."""
     from popcorn_amd.data import stats
     B, _, H, W = batch["raw"].shape
-    raw = batch["raw"] if band_sel is None else batch["raw"][:, list(band_sel)].contiguous()
     keep_norm = trainer.raw_norm
-    if band_sel is not None:             # the host already holds the 6 model bands: the ingest kernel only normalises + pads
+    packed = trainer.pack_small(batch["admin_mask"].cpu(), batch["y"].cpu(), batch["census_idx"].cpu()).pin_memory()
+    if band_sel == "split":
+        # what a loader reads from disk: the 4 selected S2 bands as the GeoTIFF's uint16 digital numbers + the 2 S1 bands as fp32
+        b6 = list(stats.BAND6)
         trainer.raw_norm = (tuple(range(6)), stats.MEAN6, stats.STD6)
-    host = {"raw": raw.cpu().pin_memory(),
-            "_packed": trainer.pack_small(batch["admin_mask"].cpu(), batch["y"].cpu(), batch["census_idx"].cpu()).pin_memory()}
-    sets = [trainer.static_buffers(B, H, W, raw_channels=raw.shape[1], slot=sl) for sl in (0, 1)]
+        host = {"raw_s2": batch["raw"][:, b6[:4]].round().to(torch.int32).cpu().to(torch.uint16).contiguous().pin_memory(),
+                "raw_s1": batch["raw"][:, b6[4:]].contiguous().cpu().pin_memory(), "_packed": packed}
+        sets = [trainer.static_buffers(B, H, W, split=True, slot=sl) for sl in (0, 1)]
+    else:
+        raw = batch["raw"] if band_sel is None else batch["raw"][:, list(band_sel)].contiguous()
+        if band_sel is not None:             # the host already holds the 6 model bands: the ingest kernel only normalises + pads
+            trainer.raw_norm = (tuple(range(6)), stats.MEAN6, stats.STD6)
+        host = {"raw": raw.cpu().pin_memory(), "_packed": packed}
+        sets = [trainer.static_buffers(B, H, W, raw_channels=raw.shape[1], slot=sl) for sl in (0, 1)]
     copied = [torch.cuda.Event() for _ in range(2)]
     consumed = [torch.cuda.Event() for _ in range(2)]
     cstream = torch.cuda.Stream()
@@ -870,7 +878,9 @@ def extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, s
     # ---- h2d: the headline precision, fed from pinned host memory
     from popcorn_amd.data import stats
     legs = []
-    for band_sel, label in ((stats.BAND6, "6 pre-selected bands (240 KB / tile)"), (None, "15-band tile (600 KB / tile), band select on the device")):
+    for band_sel, label in ((stats.BAND6, "6 pre-selected bands, fp32 (240 KB / tile)"),
+                            ("split", "6 pre-selected bands, S2 as uint16 digital numbers + S1 fp32 (160 KB / tile)"),
+                            (None, "15-band tile (600 KB / tile), band select on the device")):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

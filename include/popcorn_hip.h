@@ -424,6 +424,13 @@ int pc_select_normalize_pad(const float* raw, float* out, int B, int Craw, int n
  * running a planar-fp32 reflect loader per consumer. */
 int pc_ingest_cl8(const float* raw, void* out, int B, int Craw, int nsel, const int* band, const float* mean, const float* stdv,
                   int H, int W, int top, int bottom, int left, int right, void* stream);
+/* Either ingest from the TWO tensors a loader ships per sample (data/PopulationDataset.py:566-600: the Sentinel-2 GeoTIFF bands and the
+ * Sentinel-1 bands, separately): s2 (B, C2, H, W) UINT16 digital numbers (reflectance x 10,000: 0 .. ~10,000 -- the file's own type, two
+ * thirds of the host-to-device bytes of an fp32 tile) and s1 (B, C1, H, W) fp32 backscatter.  band[j] indexes the concatenation
+ * [s2 | s1]; the uint16 -> fp32 conversion is exact, so the result equals the fp32-fed ingest bit for bit.  cl8 = 0: planar fp32
+ * out (B, nsel, Hp, Wp) as pc_select_normalize_pad writes it; cl8 = 1: the channels-last bf16 slot tensor of pc_ingest_cl8. */
+int pc_ingest_split(const uint16_t* s2, int C2, const float* s1, int C1, void* out, int cl8, int B, int nsel, const int* band,
+                    const float* mean, const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream);
 
 /* ---- training-step scalars ------------------------------------------------------------------------- */
 

@@ -2206,6 +2206,39 @@ __global__ __launch_bounds__(256) void ingest_cl8_kernel(const float* __restrict
     out[i] = make_uint4(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]), pc_pack_bf16(v[4], v[5]), pc_pack_bf16(v[6], v[7]));
 }
 
+// the same ingest from the two tensors a loader ships (pc_ingest_split): S2 reflectances as UINT16 digital numbers (planar, C2 bands) and
+// S1 backscatter as fp32 (planar, C1 bands); channel index sel[j] < C2 -> s2, else s1[sel[j] - C2].  One thread = one pixel of the padded
+// domain, all nsel channels: the planar fp32 form writes nsel coalesced words, the channels-last bf16 form one 16-byte slot.
+template <bool CL8>
+__global__ __launch_bounds__(256) void ingest_split_kernel(const uint16_t* __restrict__ s2, const float* __restrict__ s1, void* __restrict__ out, PadSel ps,
+                                                           int C2, int C1, int nsel, int H, int W, int Hp, int Wp, int top, int left, int npix) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int x = i % Wp, r = i / Wp;
+    const int y = r % Hp, b = r / Hp;
+    const int64_t o = (int64_t)pc_reflect(y - top, H) * W + pc_reflect(x - left, W);
+    const int64_t plane = (int64_t)H * W;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+        if (j < nsel) {
+            const int c = ps.sel[j];
+            t = c < C2 ? (float)s2[((int64_t)b * C2 + c) * plane + o] : s1[((int64_t)b * C1 + (c - C2)) * plane + o];
+            t = (t - ps.mean[j]) / ps.stdv[j];
+        }
+        v[j] = t;
+    }
+    if (CL8) {
+        reinterpret_cast<uint4*>(out)[i] = make_uint4(pc_pack_bf16(v[0], v[1]), pc_pack_bf16(v[2], v[3]), pc_pack_bf16(v[4], v[5]), pc_pack_bf16(v[6], v[7]));
+    } else {
+        float* op = reinterpret_cast<float*>(out) + (int64_t)b * nsel * Hp * Wp + (int64_t)y * Wp + x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nsel) op[(int64_t)j * Hp * Wp] = v[j];
+    }
+}
+
 }  // namespace
 
 static int launch_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, const float* mean, const float* stdv,
@@ -2269,6 +2302,32 @@ extern "C" int pc_ingest_cl8(const float* raw, void* out, int B, int Craw, int n
     else
         hipLaunchKernelGGL(ingest_cl8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, raw, reinterpret_cast<uint4*>(out), ps, Craw, nsel,
                            H, W, Hp, Wp, top, left, (int)npix);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_ingest_split(const uint16_t* s2, int C2, const float* s1, int C1, void* out, int cl8, int B, int nsel, const int* band,
+                               const float* mean, const float* stdv, int H, int W, int top, int bottom, int left, int right, void* stream) {
+    if (!s2 || !s1 || !out || !band || !mean || !stdv || B < 1 || C2 < 1 || C1 < 1 || nsel < 1 || nsel > 8 || top >= H || bottom >= H ||
+        left >= W || right >= W || top < 0 || bottom < 0 || left < 0 || right < 0 || (reinterpret_cast<uintptr_t>(out) & 15))
+        return PC_EINVAL;
+    PadSel ps{};
+    for (int j = 0; j < nsel; ++j) {
+        if (band[j] < 0 || band[j] >= C2 + C1) return PC_EINVAL;
+        ps.sel[j] = band[j];
+        ps.mean[j] = mean[j];
+        ps.stdv[j] = stdv[j];
+    }
+    const int Hp = H + top + bottom, Wp = W + left + right;
+    const int64_t npix = (int64_t)B * Hp * Wp;
+    if (npix > 0x7fffffff) return PC_EINVAL;
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    if (cl8)
+        hipLaunchKernelGGL(ingest_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, s2, s1, out, ps, C2, C1, nsel, H, W, Hp, Wp, top,
+                           left, (int)npix);
+    else
+        hipLaunchKernelGGL(ingest_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s2, s1, out, ps, C2, C1, nsel, H, W, Hp, Wp, top,
+                           left, (int)npix);
     PC_CHECK_LAUNCH();
     return 0;
 }

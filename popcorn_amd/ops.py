@@ -556,6 +556,30 @@ def ingest_cl8(raw, band, mean, std, top, bottom, left, right, out=None):
     return out
 
 
+def ingest_split(s2_u16, s1, band, mean, std, top, bottom, left, right, cl8=None):
+    """pc_ingest_split: the one-pass ingest (band select + normalise + reflect padding + stream order) from the two tensors a loader
+    ships -- s2_u16 (B, C2, H, W) uint16 reflectance digital numbers, s1 (B, C1, H, W) fp32 -- into the padded model input of the
+    current arithmetic mode (cl8 None): planar fp32 (B, n, Hp, Wp) or the channels-last bf16 slot tensor (B, 8, Hp, Wp).  band indexes
+    [s2 | s1]."""
+    L.require_device(s2_u16, s1)
+    assert s2_u16.dtype == torch.uint16 and s1.dtype == torch.float32 and s2_u16.is_contiguous() and s1.is_contiguous()
+    B, C2, H, W = s2_u16.shape
+    C1 = s1.shape[1]
+    assert tuple(s1.shape) == (B, C1, H, W)
+    n = len(band)
+    if cl8 is None:
+        cl8 = L.act_dtype() == torch.bfloat16
+    Hp, Wp = H + top + bottom, W + left + right
+    if cl8:
+        out = torch.empty(B, 8, Hp, Wp, device=s1.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    else:
+        out = torch.empty(B, n, Hp, Wp, device=s1.device, dtype=torch.float32)
+    fa = lambda v: (C.c_float * n)(*[float(t) for t in v])  # noqa: E731
+    L.check(L.lib().pc_ingest_split(L.ptr(s2_u16), C2, L.ptr(s1), C1, L.ptr(out), int(bool(cl8)), B, n, (C.c_int * n)(*[int(v) for v in band]),
+                                    fa(mean), fa(std), H, W, top, bottom, left, right, L.stream_ptr()), "pc_ingest_split")
+    return out
+
+
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
              g_feat=None, feat_bn=None, packed=False):

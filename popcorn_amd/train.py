@@ -35,6 +35,18 @@ def _is_oom(exc):
     return False
 
 
+def data_keys(sample):
+    """The keys of a sample that carry the image: the normalised model input, the raw fp32 tile, or the loader's pair {uint16 S2
+    digital numbers, fp32 S1} (ingested by pc_ingest_split)."""
+    if sample.get("input") is not None:
+        return ("input",)
+    if sample.get("raw") is not None:
+        return ("raw",)
+    if sample.get("raw_s2") is not None:
+        return ("raw_s2", "raw_s1")
+    raise KeyError("sample needs 'input', 'raw' or 'raw_s2' + 'raw_s1'")
+
+
 LOSS_INDEX = {"l1_loss": 0, "log_l1_loss": 1, "mse_loss": 2, "log_mse_loss": 3}
 HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
 
@@ -217,13 +229,28 @@ class FusedTrainStep:
     # ---- the three stream-ordered sections -------------------------------------------------------------------------
     def _forward(self, s, sel, encoder_no_grad, unet_no_grad):
         m = self.model
-        raw = s.get("raw") if s.get("input") is None else None
-        B, _, H, W = (raw if raw is not None else s["input"]).shape
+        dk = data_keys(s)
+        raw = s.get("raw") if dk == ("raw",) else None
+        B, _, H, W = s[dk[0]].shape
         eng_u, eng_b = m.engines()
         pt, pb, pl, pr = pad_geometry(H, W, False)
         fused = (pt, pb, pl, pr) == (m.p, m.p, m.p, m.p)      # e.g. 100x100 tiles: both networks see the same 128x128 domain
         Xp_all = None
-        if raw is not None:
+        if dk == ("raw_s2", "raw_s1"):
+            # the loader's own tensors: S2 as uint16 digital numbers [R, G, B, NIR] (two thirds of the PCIe bytes of fp32), S1 fp32
+            # [VV, VH]; their concatenation IS the model's channel order, so band index = model channel
+            _, mean, std = self.raw_norm
+            s2, s1 = s["raw_s2"], s["raw_s1"]
+            if s2.shape[1] != 4 or s1.shape[1] != 2:
+                raise ValueError("raw_s2 / raw_s1: the 4 selected S2 bands [R, G, B, NIR] as uint16 and the 2 S1 bands [VV, VH] as fp32")
+            bf16 = L.act_dtype() == torch.bfloat16
+            if fused and E.PADDED_INPUT and len(eng_u.streams) == 2 and (pt or pb or pl or pr) and (bf16 or (W + pl + pr) % 4 == 0):
+                order = E.stream_channel_order(eng_u.streams)
+                Xp_all = ops.ingest_split(s2, s1, order, [mean[c] for c in order], [std[c] for c in order], pt, pb, pl, pr)
+                X = None
+            else:
+                X = ops.select_normalize(torch.cat([s2.to(torch.float32), s1], 1).contiguous(), tuple(range(6)), mean, std)
+        elif raw is not None:
             band, mean, std = self.raw_norm
             if fused and E.PADDED_INPUT and L.act_dtype() == torch.float32 and (W + pl + pr) % 4 == 0 and len(eng_u.streams) == 2:
                 # raw tile -> padded, normalised, stream-ordered input in ONE launch; the unpadded input is never written
@@ -323,7 +350,7 @@ class FusedTrainStep:
     def step(self, sample, encoder_no_grad=False, unet_no_grad=False):
         """One optimisation step on ``sample`` = {input (B,6,H,W) normalised -- or raw (B,Craw,H,W), see ``raw_norm`` --,
         admin_mask, census_idx, y}.  Returns the device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
-        dkey = "input" if sample.get("input") is not None else "raw"
+        dkey = data_keys(sample)[0]
         B, _, H, W = sample[dkey].shape
         sel_host = self._draw_selection(H, W)
         if not self.use_graph:
@@ -340,7 +367,8 @@ class FusedTrainStep:
         return self._graph_step(sample, sel_host, encoder_no_grad, unet_no_grad)
 
     def _graph_step(self, sample, sel_host, encoder_no_grad, unet_no_grad):
-        dkey = "input" if sample.get("input") is not None else "raw"
+        dks = data_keys(sample)
+        dkey = dks[0]
         # "_slot": which of the loader's static sets this is (static_buffers(slot=...)): every set has its own captured graph, so
         # a double-buffering loader replays graph A on set A while the copy stream fills set B -- no device-to-device copies
         key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision, sample.get("_slot", 0))
@@ -365,7 +393,7 @@ class FusedTrainStep:
             while len(self._graph_cache) > self._graph_cache_max:
                 self._graph_cache.pop(next(iter(self._graph_cache)))
         _, st, sel, graphs = self._graphs
-        for k in (dkey, "admin_mask", "census_idx", "y"):
+        for k in dks + ("admin_mask", "census_idx", "y"):
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
                 st[k].copy_(sample[k], non_blocking=True)
         self._sel_to_device(sel_host, sel)
@@ -379,15 +407,15 @@ class FusedTrainStep:
             graphs[2].replay()
         return self.loss_out
 
-    def static_buffers(self, B, H, W, C=6, raw_channels=None, slot=0):
+    def static_buffers(self, B, H, W, C=6, raw_channels=None, slot=0, split=False):
         """The device tensors the captured graph reads {input, admin_mask (float ids), census_idx, y}.  A data pipeline
         that writes its batch straight into them (e.g. ``ops.select_normalize(raw, ..., out=buf["input"])``) and passes
         this very dict to ``step`` saves the per-step input copies.  raw_channels: the data tensor is the RAW tile
         {raw (B, raw_channels, H, W)} instead of the normalised input (the graph then starts with the one-pass ingest).
         slot: independent sets for a double-buffering loader (each is captured into its own graph: H2D copies go straight into the
         idle set on a copy stream, guarded by two events, and `step(set)` replays that set's graph)."""
-        dkey = "input" if raw_channels is None else "raw"
-        C = C if raw_channels is None else raw_channels
+        dkey = "raw_s2" if split else ("input" if raw_channels is None else "raw")      # split: {raw_s2 uint16 (B,4,H,W), raw_s1 (B,2,H,W)}
+        C = 4 if split else (C if raw_channels is None else raw_channels)
         if self._static is None:
             self._static = {}
         skey = (dkey, C, slot)             # (a new B / H / W replaces the set of that kind: bounded memory with varying tile sizes)
@@ -398,7 +426,9 @@ class FusedTrainStep:
             # 16-byte aligned): a loader that stages a batch elsewhere moves them with a single device copy
             n_am, n_y = B * H * W * 4, -(-B * 4 // 16) * 16
             packed = torch.zeros(n_am + n_y + B * 8, dtype=torch.uint8, device=dev)
-            cur = self._static[skey] = {dkey: torch.zeros(B, C, H, W, device=dev), "_slot": slot,
+            data = {"raw_s2": torch.zeros(B, 4, H, W, device=dev, dtype=torch.uint16), "raw_s1": torch.zeros(B, 2, H, W, device=dev)} if split \
+                else {dkey: torch.zeros(B, C, H, W, device=dev)}
+            cur = self._static[skey] = {**data, "_slot": slot,
                                         "admin_mask": packed[:n_am].view(torch.float32).view(B, H, W),
                                         "y": packed[n_am:n_am + B * 4].view(torch.float32),
                                         "census_idx": packed[n_am + n_y:].view(torch.int64), "_packed": packed}
@@ -421,7 +451,7 @@ class FusedTrainStep:
         if mine:
             st = dict(mine[0])
         else:
-            st = {k: sample[k].detach().clone().contiguous() for k in (dkey, "admin_mask", "census_idx", "y")}
+            st = {k: sample[k].detach().clone().contiguous() for k in data_keys(sample) + ("admin_mask", "census_idx", "y")}
             st["admin_mask"] = st["admin_mask"].float()
         sel = sel_host.to(self.device)
         # warm-up on a side stream (first-launch attribute calls, workspace allocation), state restored afterwards

@@ -28,7 +28,7 @@ def _check_line(d, extras):
     if extras:
         c = d["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-        assert d["bf16"]["value"] > d["value"] and d["soak"]["steps"] >= 1000 and len(d["h2d"]["legs"]) == 2
+        assert d["bf16"]["value"] > d["value"] and d["soak"]["steps"] >= 1000 and len(d["h2d"]["legs"]) >= 2
 
 
 def test_committed_final_bench_line_keeps_the_contract():

@@ -306,3 +306,55 @@ def test_conv3x3_up_bwd_group_vs_autograd(Cs, hw):
         for name, got, ref in (("gz", pr["gz"], rgz), ("dw", pr["dw"][:, Cs:], rdw), ("dwt", pr["dwt"], rdwt), ("dbt", pr["dbt"], rdbt)):
             err = (got.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
             assert err < 5e-5, (name, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_from_the_loaders_uint16_s2_and_fp32_s1_equals_the_step_from_raw_tiles(precision, use_graph):
+    """pc_ingest_split: the step fed {raw_s2: uint16 digital numbers of the 4 selected S2 bands, raw_s1: fp32 S1} -- what a loader reads
+    from disk, two thirds of the host-to-device bytes of fp32 -- against the step fed the fp32 15-band tile: the uint16 -> fp32 conversion
+    is exact, so losses and parameters agree bit for bit over three steps (both arithmetic modes, eager and replayed)."""
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=5, device="cuda", region="disc")
+    b6 = list(stats.BAND6)
+    s2 = batch["raw"][:, b6[:4]].to(torch.int32).cpu().to(torch.uint16).cuda().contiguous()
+    s1 = batch["raw"][:, b6[4:]].contiguous()
+    assert torch.equal(s2.cpu().to(torch.int32).float().cuda(), batch["raw"][:, b6[:4]])           # the synthetic S2 values are integers
+    runs = []
+    for data in ({"raw": batch["raw"]}, {"raw_s2": s2, "raw_s1": s1}):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        m.set_precision(precision)
+        tr = FusedTrainStep(m, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01, use_graph=use_graph)
+        losses = []
+        for step in range(3):
+            torch.manual_seed(50 + step)
+            losses.append(tr.step({**data, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}).tolist())
+        torch.cuda.synchronize()
+        runs.append((losses, tr.flat_p.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_ingest_split_on_an_unfused_geometry_falls_back_to_the_two_step_form():
+    """A tile whose padding differs between the two networks (64 x 48: no shared padded domain) takes the convert + select_normalize
+    path; same result as the fp32-fed step."""
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(2, 64, 48, seed=6, device="cuda", region="disc")
+    b6 = list(stats.BAND6)
+    s2 = batch["raw"][:, b6[:4]].to(torch.int32).cpu().to(torch.uint16).cuda().contiguous()
+    s1 = batch["raw"][:, b6[4:]].contiguous()
+    out = []
+    for data in ({"raw": batch["raw"]}, {"raw_s2": s2, "raw_s1": s1}):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        tr = FusedTrainStep(m, lr=1e-3, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(9)
+        out.append((tr.step({**data, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}).tolist(), tr.flat_p.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])

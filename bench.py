@@ -795,8 +795,8 @@ def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
         # what a loader reads from disk: the 4 selected S2 bands as the GeoTIFF's uint16 digital numbers + the 2 S1 bands as fp32
         b6 = list(stats.BAND6)
         trainer.raw_norm = (tuple(range(6)), stats.MEAN6, stats.STD6)
-        host = {"raw_s2": batch["raw"][:, b6[:4]].round().to(torch.int32).cpu().to(torch.uint16).contiguous().pin_memory(),
-                "raw_s1": batch["raw"][:, b6[4:]].contiguous().cpu().pin_memory(), "_packed": packed}
+        host = {"_rawpacked": trainer.pack_split(batch["raw"][:, b6[:4]].round().to(torch.int32).cpu().to(torch.uint16).contiguous(),
+                                                 batch["raw"][:, b6[4:]].contiguous().cpu()).pin_memory(), "_packed": packed}
         sets = [trainer.static_buffers(B, H, W, split=True, slot=sl) for sl in (0, 1)]
     else:
         raw = batch["raw"] if band_sel is None else batch["raw"][:, list(band_sel)].contiguous()

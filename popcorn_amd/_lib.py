@@ -230,37 +230,66 @@ def require_device(*tensors):
                                   % t.device)
 
 
+_STREAM = [None]
+
+
+class stream_scope:
+    """``with stream_scope():`` -- resolve torch's current stream ONCE for every launch enqueued inside the block.  An eager train step
+    on a small census region is bound by the host (40+ launches, each of which asked torch for the current stream: ~8 us a call, a
+    quarter of the step's enqueue time, tools/host_time_eager.py); the stream cannot change inside the blocks that use this (one
+    section of a step, on the stream it was entered on).  Re-entrant; the outermost scope decides."""
+
+    def __enter__(self):
+        self.owner = _STREAM[0] is None
+        if self.owner:
+            _STREAM[0] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.owner:
+            _STREAM[0] = None
+        return False
+
+
 def stream_ptr() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM[0] if _STREAM[0] is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ptr(t) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=(0, 1, 2, 3)) -> PcSrc:
+_CHMAP0 = (0, 1, 2, 3)
+
+
+def src(t: torch.Tensor, C_=None, mode=PC_SRC_DIRECT, oy=0, ox=0, chmap=_CHMAP0) -> PcSrc:
     """Descriptor of a (B, C, H, W) fp32 or bf16 tensor, planar (unit x stride) or channels-last (unit channel stride);
     strides in elements."""
-    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and (t.stride(3) == 1 or t.stride(1) == 1)
+    st, sh, dt = t.stride(), t.shape, t.dtype
+    assert dt in (torch.float32, torch.bfloat16) and len(sh) == 4 and (st[3] == 1 or st[1] == 1)
     s = PcSrc()
-    s.xstride = t.stride(3)
-    s.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
+    s.xstride = st[3]
+    s.dtype = PC_BF16_T if dt == torch.bfloat16 else PC_F32_T
     s.ptr = t.data_ptr()
-    s.C = t.shape[1] if C_ is None else C_
-    s.H, s.W = t.shape[2], t.shape[3]
-    s.bstride, s.cstride, s.rstride = t.stride(0), t.stride(1), t.stride(2)
+    s.C = sh[1] if C_ is None else C_
+    s.H, s.W = sh[2], sh[3]
+    s.bstride, s.cstride, s.rstride = st[0], st[1], st[2]
     s.mode, s.oy, s.ox = mode, oy, ox
-    s.chmap[:] = list(chmap)
+    if chmap != _CHMAP0:
+        s.chmap[:] = list(chmap)
+    else:
+        s.chmap[1], s.chmap[2], s.chmap[3] = 1, 2, 3
     return s
 
 
 def dst(t: torch.Tensor) -> PcDst:
-    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and (t.stride(3) == 1 or t.stride(1) == 1)
+    st, dt = t.stride(), t.dtype
+    assert dt in (torch.float32, torch.bfloat16) and len(st) == 4 and (st[3] == 1 or st[1] == 1)
     d = PcDst()
-    d.xstride = t.stride(3)
-    d.dtype = PC_BF16_T if t.dtype == torch.bfloat16 else PC_F32_T
+    d.xstride = st[3]
+    d.dtype = PC_BF16_T if dt == torch.bfloat16 else PC_F32_T
     d.ptr = t.data_ptr()
-    d.bstride, d.cstride, d.rstride = t.stride(0), t.stride(1), t.stride(2)
+    d.bstride, d.cstride, d.rstride = st[0], st[1], st[2]
     return d
 
 

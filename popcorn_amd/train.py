@@ -357,7 +357,7 @@ class FusedTrainStep:
             s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items() if not k.startswith("_")}
             s["admin_mask"] = s["admin_mask"].float()
             sel = self._sel_to_device(sel_host)
-            with L.precision(self.model.precision):
+            with L.precision(self.model.precision), L.stream_scope():      # (one stream lookup for the step's ~40 launches)
                 self._forward(s, sel, encoder_no_grad, unet_no_grad)
                 self.reducer.reduce_stats(self.stats)
                 self._backward(s, encoder_no_grad, unet_no_grad)
@@ -426,13 +426,28 @@ class FusedTrainStep:
             # 16-byte aligned): a loader that stages a batch elsewhere moves them with a single device copy
             n_am, n_y = B * H * W * 4, -(-B * 4 // 16) * 16
             packed = torch.zeros(n_am + n_y + B * 8, dtype=torch.uint8, device=dev)
-            data = {"raw_s2": torch.zeros(B, 4, H, W, device=dev, dtype=torch.uint16), "raw_s1": torch.zeros(B, 2, H, W, device=dev)} if split \
-                else {dkey: torch.zeros(B, C, H, W, device=dev)}
+            if split:
+                # both tensors are views of ONE byte buffer ("_rawpacked": uint16 S2 | fp32 S1, 16-byte aligned): one H2D copy per batch
+                n2 = -(-B * 4 * H * W * 2 // 16) * 16
+                rp = torch.zeros(n2 + B * 2 * H * W * 4, dtype=torch.uint8, device=dev)
+                data = {"raw_s2": rp[:B * 4 * H * W * 2].view(torch.uint16).view(B, 4, H, W),
+                        "raw_s1": rp[n2:].view(torch.float32).view(B, 2, H, W), "_rawpacked": rp}
+            else:
+                data = {dkey: torch.zeros(B, C, H, W, device=dev)}
             cur = self._static[skey] = {**data, "_slot": slot,
                                         "admin_mask": packed[:n_am].view(torch.float32).view(B, H, W),
                                         "y": packed[n_am:n_am + B * 4].view(torch.float32),
                                         "census_idx": packed[n_am + n_y:].view(torch.int64), "_packed": packed}
         return cur
+
+    @staticmethod
+    def pack_split(s2_u16, s1):
+        """Host-side counterpart of the ``_rawpacked`` layout of ``static_buffers(split=True)`` (one byte tensor)."""
+        n2 = -(-s2_u16.numel() * 2 // 16) * 16
+        out = torch.zeros(n2 + s1.numel() * 4, dtype=torch.uint8)
+        out[:s2_u16.numel() * 2].view(torch.uint16).copy_(s2_u16.reshape(-1))
+        out[n2:].view(torch.float32).copy_(s1.float().reshape(-1))
+        return out
 
     @staticmethod
     def pack_small(admin_mask, y, census_idx):

@@ -1,0 +1,45 @@
+"""Host-side cost of an EAGER FusedTrainStep.step on a small census-region batch (the reference's variable-size regions cannot replay a
+captured graph): wall time per step vs device time, and the cProfile top of the enqueue path.
+
+    python tools/host_time_eager.py [B H W]
+"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import torch                                                         # noqa: E402
+from popcorn_amd import ops                                          # noqa: E402
+from popcorn_amd.data import stats                                   # noqa: E402
+from popcorn_amd.data.synthetic import make_raw_batch                # noqa: E402
+from popcorn_amd.model import POPCORN                                # noqa: E402
+from popcorn_amd.train import FusedTrainStep                         # noqa: E402
+
+B, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (2, 230, 220)
+torch.manual_seed(1600)
+m = POPCORN(6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+b = make_raw_batch(B, H, W, seed=1, device="cuda", region="disc")
+x = ops.select_normalize(b["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+smp = {"input": x, "admin_mask": b["admin_mask"], "census_idx": b["census_idx"], "y": b["y"]}
+for _ in range(5):
+    tr.step(dict(smp))
+torch.cuda.synchronize()
+n = 50
+t0 = time.perf_counter()
+for _ in range(n):
+    tr.step(dict(smp))
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+print("eager %dx%dx%d: enqueue %.3f ms/step, complete %.3f ms/step" % (B, H, W, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(n):
+    tr.step(dict(smp))
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -741,6 +741,7 @@ def config3_regions_leg(torch, margs, dev, steps=3):
     from popcorn_amd.model import get_model_kwargs, model_dict
     from popcorn_amd.train import FusedTrainStep
     a = train_parser().parse_args([])
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))      # host glue = tiny CPU ops (the trainer's setting, cli.py); the CPU legs left it wide
     torch.manual_seed(1600)
     model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
     tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, reducer=_LocalReducer())

@@ -2501,7 +2501,11 @@ extern "C" int pc_compact_masked(const float* src, const uint8_t* mask, float* o
     hipStream_t st = (hipStream_t)stream;
     const int nblocks = (int)((n + CBLK - 1) / CBLK);
     int32_t* bc = reinterpret_cast<int32_t*>(ws);
-    if (nblocks == 0) return (int)hipMemsetAsync(n_out, 0, sizeof(int32_t), st);
+    if (nblocks == 0) {           // (a kernel, not a memset node: see zero_fill_kernel)
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t*>(n_out), 1);
+        PC_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(256), 0, st, mask, bc, n);
     PC_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nblocks, n_out);

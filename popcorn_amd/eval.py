@@ -86,6 +86,28 @@ class Stitcher:
         if x1 > x0 and y1 > y0:
             self.count[x0:x1, y0:y1] += M
 
+    def add_counts_only(self, windows, M, ps, overlap=OVERLAP):
+        """The visit counts of MANY windows other ranks computed, in one pass: a 2-D difference array (4 scatter-adds per window, one
+        ``index_put_``) and two prefix sums over the raster instead of one slice-add per window from the host loop.  windows: iterable of
+        (row origin, column origin)."""
+        ws = [(int(x), int(y)) for x, y in windows]
+        if not ws:
+            return
+        dev = self.count.device
+        xy = torch.tensor(ws, dtype=torch.int64, device=dev)
+        x0 = (xy[:, 0] + overlap).clamp(max=self.h)
+        x1 = (xy[:, 0] + ps - overlap).clamp(max=self.h)
+        y0 = (xy[:, 1] + overlap).clamp(max=self.w)
+        y1 = (xy[:, 1] + ps - overlap).clamp(max=self.w)
+        keep = (x1 > x0) & (y1 > y0)
+        x0, x1, y0, y1 = x0[keep], x1[keep], y0[keep], y1[keep]
+        diff = torch.zeros(self.h + 1, self.w + 1, dtype=torch.int32, device=dev)
+        m = torch.full((x0.numel(),), int(M), dtype=torch.int32, device=dev)
+        for xs, ys, sgn in ((x0, y0, 1), (x0, y1, -1), (x1, y0, -1), (x1, y1, 1)):
+            diff.index_put_((xs, ys), m * sgn, accumulate=True)
+        cnt = diff.cumsum(0, dtype=torch.int32).cumsum(1, dtype=torch.int32)[:self.h, :self.w]
+        self.count += cnt.to(self.count.dtype)
+
     def all_reduce(self, reducer: FlatReducer):
         """Multi-GPU, simple form: sum the full accumulators on every rank (interiors of regular windows are disjoint, the
         bottom/right catch-up windows overlap them -- the count map handles both)."""
@@ -226,11 +248,12 @@ def evaluate_raster(models, raster, patchsize=INFERENCE_PATCH_SIZE, overlap=OVER
     st = Stitcher(h, w, dev, world=reducer.world)
     idx = get_patch_indices(h, w, patchsize, overlap, fourseasons)
     mine = set(shard_indices(idx.shape[0], rank, reducer.world))
+    if band_reduce and reducer.world > 1:
+        # the visit count needs no collective: the windows of the OTHER ranks enter this rank's count map analytically, all at once
+        st.add_counts_only([(int(idx[i][0]), int(idx[i][1])) for i in range(idx.shape[0]) if i not in mine], len(models), patchsize, overlap)
     for i in range(idx.shape[0]):
         x, y, season = (int(v) for v in idx[i])
         if i not in mine:
-            if band_reduce and reducer.world > 1:
-                st.add_count_only(x, y, len(models), patchsize, overlap)      # the visit count needs no collective
             continue
         inp = raster(x, y, season, patchsize).contiguous()
         sample = {"input": inp}

@@ -42,3 +42,22 @@ def test_limit_regime_nests_like_the_reference():
     assert limit_regime(13000001, *L) == (True, True, True)                   # skipped
     assert limit_regime(500, 100, 1000, 2000) == (True, False, False)         # decoder + head
     assert limit_regime(5000, 100, 10000, 2000) == (True, False, False)       # limit3 only applies beyond limit2
+
+
+def test_every_tool_script_still_compiles():
+    """tools/*.py are measurement scaffolding that DESIGN.md cites; nothing runs them on the CPU box, but each must at least parse
+    against the current tree (a renamed op breaks them silently otherwise: the names they import from popcorn_amd are checked too)."""
+    import ast
+    import glob
+    import importlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(files) >= 30
+    for f in files:
+        tree = ast.parse(open(f).read(), filename=f)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("popcorn_amd") and node.level == 0:
+                mod = importlib.import_module(node.module)
+                for alias in node.names:
+                    assert hasattr(mod, alias.name) or importlib.util.find_spec(node.module + "." + alias.name) is not None, (f, node.module, alias.name)

@@ -231,3 +231,19 @@ def test_inference_forward_with_aligned_rows_and_composed_up_vs_plain_and_oracle
         scale = max(want.abs().max().item(), 1e-6)
         assert (got - base).abs().max().item() <= 2e-5 * scale
         assert (got - want).abs().max().item() <= 1e-4 * scale
+
+
+def test_batched_visit_counts_equal_the_per_window_form():
+    """Stitcher.add_counts_only (difference array + two prefix sums for all foreign windows at once) == add_count_only per window,
+    including windows that stick out of the raster and windows with an empty interior."""
+    from popcorn_amd import eval as E
+    h, w, ps, ov = 301, 421, 128, 16
+    idx = E.get_patch_indices(h, w, ps, ov, fourseasons=True)
+    wins = [(int(r[0]), int(r[1])) for r in idx] + [(290, 410), (0, 400), (h - 20, 0)]
+    a = E.Stitcher(h, w, "cuda")
+    b = E.Stitcher(h, w, "cuda")
+    for x, y in wins:
+        a.add_count_only(x, y, 3, ps, ov)
+    b.add_counts_only(wins, 3, ps, ov)
+    assert a.count.dtype == b.count.dtype == torch.int16
+    assert torch.equal(a.count, b.count) and int(a.count.max()) > 3

@@ -10,10 +10,11 @@ from popcorn_amd.model import POPCORN
 from popcorn_amd.train import FusedTrainStep
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 special = [(2, 100, 100), (1, 36, 68), (2, 64, 64), (1, 98, 98), (2, 50, 82)]
+LO, HI = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (40, 120)      # side range of the random geometries
 worst = 0.0
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
-    B, H, W = special[it] if it < len(special) else (rnd.randint(1, 3), rnd.randint(40, 120), rnd.randint(40, 120))
+    B, H, W = special[it] if (it < len(special) and len(sys.argv) <= 3) else (rnd.randint(1, 3), rnd.randint(LO, HI), rnd.randint(LO, HI))
     torch.manual_seed(1600)
     model = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

@@ -13,7 +13,7 @@ for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   rm -rf gpurun_out/pmck_$i
   timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/pmck_$i -o k -- \
-      python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-extras --no-class-sweep "$@" > gpurun_out/pmck_$i.log 2>&1
+      python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-graph --no-cpu-baseline --no-extras --no-class-sweep --no-config-legs --prewarm-seconds 0 "$@" > gpurun_out/pmck_$i.log 2>&1
 done
 python3 - "$K" <<'PY'
 import collections, csv, glob, sys

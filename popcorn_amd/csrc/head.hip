@@ -1912,65 +1912,36 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     if (vec4) {
         // four consecutive pixels of a row per thread: 16-byte accesses (the feature read is 4-byte aligned only: the crop
         // offset px is arbitrary), a quarter of the dependent iterations of the scalar loop
-        // TWO items per iteration, all loads of both issued before anything is consumed (round 4: one block per CU and one item per
-        // dependent iteration left the kernel at 17.6 us for 11 MB -- pure load latency)
-        const unsigned n4 = (unsigned)(n >> 2), w4 = (unsigned)a.W >> 2, nth = gridDim.x * blockDim.x;
-        const int nlog = a.feat.C < 2 ? a.feat.C : 2;          // channels read in the unrolled form (the two partial logits); more: below
-        for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * nth) {
-            f32x4u fv[2][2];
-            f32x4 adm[2];
-            float cid[2];
-            unsigned csel[2];
-            bool rs[2], live[2];
-            int xs[2], ys[2], bs[2];
+        const unsigned n4 = (unsigned)(n >> 2), w4 = (unsigned)a.W >> 2;
+        for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+            const unsigned row = i4 / w4;
+            const int x = (int)(i4 - row * w4) * 4, y = (int)(row % (unsigned)a.H), b = (int)(row / (unsigned)a.H);
+            const float* fp = a.feat.ptr + b * a.feat.bstride + (int64_t)(a.py + y) * a.feat.rstride + a.px + x;
+            f32x4 s = f32x4{bv, bv, bv, bv};
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned i4 = i0 + k * nth;
-                live[k] = i4 < n4;
-                const unsigned j4 = live[k] ? i4 : i0;
-                const unsigned row = j4 / w4;
-                xs[k] = (int)(j4 - row * w4) * 4; ys[k] = (int)(row % (unsigned)a.H); bs[k] = (int)(row / (unsigned)a.H);
-                const float* fp = a.feat.ptr + bs[k] * a.feat.bstride + (int64_t)(a.py + ys[k]) * a.feat.rstride + a.px + xs[k];
-                fv[k][0] = *reinterpret_cast<const f32x4u*>(fp);
-                fv[k][1] = *reinterpret_cast<const f32x4u*>(fp + (nlog > 1 ? a.feat.cstride : 0));
-                adm[k] = *reinterpret_cast<const f32x4*>(a.admin + 4 * (int64_t)j4);
-                cid[k] = (float)a.census[bs[k]];
-                rs[k] = a.rowsel[ys[k]] != 0;
-                csel[k] = *reinterpret_cast<const unsigned*>(a.colsel + xs[k]);        // (x is a multiple of 4: 4 selection bytes)
+            for (int c = 0; c < 16; ++c)
+                if (c < a.feat.C) {
+                    const f32x4u f = *reinterpret_cast<const f32x4u*>(fp + c * a.feat.cstride);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = fmaf(f[e], wv[c], s[e]);
+                }
+            const f32x4 adm = *reinterpret_cast<const f32x4*>(a.admin + 4 * (int64_t)i4);
+            const float cid = (float)a.census[b];
+            const bool rs = a.rowsel[y] != 0;
+            f32x4 bld;
+            unsigned mbits = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bld[e] = 1.f / (1.f + expf(-s[e]));
+                const bool region = adm[e] == cid;
+                const bool base = a.occ ? (bld[e] > 0.f) : true;
+                const bool m = region && (base || (rs && a.colsel[x + e]));
+                mbits |= (m ? 1u : 0u) << (8 * e);
+                nsel += m;
+                nreg += region;
             }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (!live[k]) continue;
-                const unsigned i4 = i0 + k * nth;
-                f32x4 s = f32x4{bv, bv, bv, bv};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[e] = fmaf(fv[k][0][e], wv[0], s[e]);
-                    if (nlog > 1) s[e] = fmaf(fv[k][1][e], wv[1], s[e]);
-                }
-                if (a.feat.C > 2) {                            // a full feature map (single-stream variants): the remaining channels
-                    const float* fp = a.feat.ptr + bs[k] * a.feat.bstride + (int64_t)(a.py + ys[k]) * a.feat.rstride + a.px + xs[k];
-                    for (int c = 2; c < a.feat.C; ++c) {
-                        const f32x4u f = *reinterpret_cast<const f32x4u*>(fp + c * a.feat.cstride);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[e] = fmaf(f[e], wv[c], s[e]);
-                    }
-                }
-                f32x4 bld;
-                unsigned mbits = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bld[e] = 1.f / (1.f + expf(-s[e]));
-                    const bool region = adm[k][e] == cid[k];
-                    const bool base = a.occ ? (bld[e] > 0.f) : true;
-                    const bool m = region && (base || (rs[k] && ((csel[k] >> (8 * e)) & 0xffu)));
-                    mbits |= (m ? 1u : 0u) << (8 * e);
-                    nsel += m;
-                    nreg += region;
-                }
-                *reinterpret_cast<f32x4*>(a.out.ptr + bs[k] * a.out.bstride + (int64_t)ys[k] * a.out.rstride + xs[k]) = bld;
-                *reinterpret_cast<unsigned*>(a.mask + 4 * (int64_t)i4) = mbits;
-            }
+            *reinterpret_cast<f32x4*>(a.out.ptr + b * a.out.bstride + (int64_t)y * a.out.rstride + x) = bld;
+            *reinterpret_cast<unsigned*>(a.mask + 4 * (int64_t)i4) = mbits;
         }
     } else
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n; i += gridDim.x * blockDim.x) {
@@ -1997,30 +1968,17 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
     __syncthreads();
     if (threadIdx.x == 0) {
         const int s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        // integer counts: order-independent, exact.  Every block leaves its pair in ITS OWN slot (plain stores) and takes a ticket: ONE
-        // device-scope atomic per block -- atomics on one address retire at ~13 ns each and all blocks finish together (2048 blocks x 3
-        // atomics took 80 us; 256 x 2, the round-3 form, ~7 us of this 17 us kernel)
-        a.scratch[4 + 2 * blockIdx.x] = (unsigned)s0;
-        a.scratch[5 + 2 * blockIdx.x] = (unsigned)s1;
+        // integer counts: order-independent, exact.  ONE 64-bit atomic per block {nsel | nregion << 32}: device-scope
+        // atomics on one address retire at ~13 ns each (2048 blocks x 3 atomics took 80 us)
+        if (s0 | s1) atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), (unsigned long long)(unsigned)s0 | ((unsigned long long)(unsigned)s1 << 32));
         __threadfence();
         last = atomicAdd(&a.scratch[2], 1u) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!last) return;
     __threadfence();
-    {
-        // the last block sums the slots (fixed order)
-        unsigned t0 = 0, t1 = 0;
-        for (unsigned k = threadIdx.x; k < gridDim.x; k += blockDim.x) {
-            t0 += __hip_atomic_load(&a.scratch[4 + 2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (device-scope: past this CU's L1)
-            t1 += __hip_atomic_load(&a.scratch[5 + 2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_down(t0, off); t1 += __shfl_down(t1, off); }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = (int)t0; red[1][threadIdx.x >> 6] = (int)t1; }
-        __syncthreads();
-    }
-    const unsigned tot_sel = (unsigned)(red[0][0] + red[0][1] + red[0][2] + red[0][3]), tot_reg = (unsigned)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), 0ull);
+    const unsigned tot_sel = (unsigned)tot, tot_reg = (unsigned)(tot >> 32);
     __syncthreads();                       // every thread of this block has read the totals before counts[0] is fixed up
     if (tot_sel == 0) {
         // an empty selection falls back to the region mask (popcorn.py:374-375)
@@ -2034,7 +1992,7 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
         a.counts[1] = (int32_t)tot_reg;
         // this block is the last one alive: leave the accumulator and the ticket at zero for the next call (which is ordered
         // behind this kernel on the stream), instead of a zeroing launch in front of every call
-        a.scratch[2] = 0u;                 // (the slots are overwritten by every call)
+        a.scratch[0] = 0u; a.scratch[1] = 0u; a.scratch[2] = 0u;
         __threadfence();
     }
 }
@@ -2491,13 +2449,12 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     if (!feat || !w || !bias || !building_out || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !counts ||
         feat->C < 1 || feat->C > 16)
         return PC_EINVAL;
-    constexpr int SM_MAX_BLOCKS = 512;
-    static unsigned* scratch = nullptr;     // {-, -, ticket, -, per-block {nsel, nregion} slots}: the ticket is zero between calls (the
+    static unsigned* scratch = nullptr;     // {acc nsel, acc nregion, ticket, -}: device-scope atomics only; zero between calls (the
                                             // kernel's last block resets it), zeroed once here
     if (!scratch) {
-        hipError_t e = hipMalloc(&scratch, (4 + 2 * SM_MAX_BLOCKS) * sizeof(unsigned));
+        hipError_t e = hipMalloc(&scratch, 4 * sizeof(unsigned));
         if (e != hipSuccess) return (int)e;
-        e = hipMemset(scratch, 0, (4 + 2 * SM_MAX_BLOCKS) * sizeof(unsigned));
+        e = hipMemset(scratch, 0, 4 * sizeof(unsigned));
         if (e != hipSuccess) return (int)e;
         e = hipDeviceSynchronize();            // the first kernel may run on a non-blocking stream
         if (e != hipSuccess) return (int)e;
@@ -2508,7 +2465,7 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     a.B = B; a.H = H; a.W = W; a.py = py; a.px = px; a.bf = g_pc_precision == PC_PREC_BF16;
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
-    if (grid > SM_MAX_BLOCKS) grid = SM_MAX_BLOCKS;     // two blocks per CU (one ticket atomic each: the serial part)
+    if (grid > 256) grid = 256;            // one block per CU: the per-block atomics are the serial part
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(score_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();

@@ -62,3 +62,24 @@ def test_tracked_profiles_belong_to_the_current_kernel_sources():
     assert stamp["csrc_sha256"] == digest, "kernel sources changed after profiles/r4_* were collected: run tools/profile_round.sh r4 quick on the GPU box and commit the summaries"
     for prec in ("fp32", "bf16"):
         assert os.path.exists(os.path.join(ROOT, "profiles", f"r4_{prec}_graph_kernel_stats.csv"))
+
+
+@pytest.mark.gpu
+def test_live_two_rank_bench_line_on_one_gpu_through_gloo():
+    """`bench.py --gpus 2` (the launcher path the driver's scaling runs take: child torch.distributed.run, barrier-bracketed blocks, MAX
+    over ranks, the data-parallel fields) as a functional run on the one GPU of the test box (POPCORN_DIST_BACKEND=gloo: both ranks share
+    the device, collectives through the host; the split-graph step).  Checks the contract of the N > 1 line, not its speed."""
+    env = dict(os.environ, POPCORN_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
+                          "--prewarm-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert REQUIRED <= set(d)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["global_batch"] == 128 and c["parallelism"] == "dp2" and c["backend"] == "gloo"
+    assert c["collectives"] is True and c["collectives_per_step"] == 2 and c["dp_graph"] == "split" and c["ranks_seen"] == 2
+    assert c["dp_capture_failed"] is False and len(d["per_rank_ms_per_step"]) == 2
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
+    assert "bf16" not in d and "h2d" not in d and "soak" not in d          # N > 1: the extra legs are skipped (run stays short)
+    assert d["cpu_baseline"] is None and "config3_regions" not in d

@@ -70,6 +70,8 @@ def train_parser():
     p.add_argument("-mws", "--max_weak_samples", type=int, default=None)
     # build-specific
     p.add_argument("--synthetic_regions", type=int, default=64, help="size of the synthetic weaksup dataset")
+    p.add_argument("--synthetic_hw_range", type=int, nargs=2, default=[64, 144],
+                   help="side range (pixels) of the synthetic census-region crops; the reference's regions reach ~3000 px sides (limit1 = 9e6 px per batch)")
     p.add_argument("--fixed_hw", type=int, nargs=2, default=None, help="fixed crop size (enables HIP-graph replay)")
     p.add_argument("--torch_optimizer", action="store_true",
                    help="reference recipe through torch autograd + torch.optim.Adam instead of the fused HIP step")
@@ -180,7 +182,8 @@ class Trainer:
             raise SystemExit("--torch_optimizer is the single-process reference recipe: it has no gradient all-reduce; "
                              "data-parallel runs use the fused step (drop the flag)")
         seed_all(args.seed)
-        ds = SyntheticWeaksupDataset(args.synthetic_regions, seed=args.seed, fixed_hw=args.fixed_hw)
+        ds = SyntheticWeaksupDataset(args.synthetic_regions, min_hw=args.synthetic_hw_range[0], max_hw=args.synthetic_hw_range[1],
+                                     seed=args.seed, fixed_hw=args.fixed_hw)
         self.sampler = None
         if self.world > 1:
             self.sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
@@ -190,7 +193,8 @@ class Trainer:
                                                   collate_fn=Population_Dataset_collate_fn, drop_last=True)
         # weak validation set (run_train.py:410-414: a second Population_Dataset in weaksup mode, batch size -wvb)
         self.val_loader = torch.utils.data.DataLoader(
-            SyntheticWeaksupDataset(args.synthetic_val_regions, seed=args.seed + 77, fixed_hw=args.fixed_hw),
+            SyntheticWeaksupDataset(args.synthetic_val_regions, min_hw=args.synthetic_hw_range[0], max_hw=args.synthetic_hw_range[1],
+                                    seed=args.seed + 77, fixed_hw=args.fixed_hw),
             batch_size=args.weak_val_batch_size, shuffle=False, collate_fn=Population_Dataset_collate_fn, drop_last=False)
         self._test_raster = None
         self.model = model_dict[args.model](**get_model_kwargs(args, args.model)).to(self.device)   # same seed: same init on every rank

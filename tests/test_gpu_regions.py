@@ -180,3 +180,30 @@ def test_bf16_mode_at_the_reference_limit_size():
         if n.endswith(".weight"):
             assert not torch.equal(runs[0][2][off:off + k], p0[off:off + k]), n
         off += k
+
+
+def test_trainer_loop_on_variable_size_regions_through_all_limit_regimes(tmp_path):
+    """run_train.py:146-269 end to end on variable-size synthetic census regions of 150-700 px sides (B = 2, collate pads to the larger
+    crop, augmentations on): with limits of 2e5 / 4e5 / 7e5 px the epoch's batches fall into all four cases of run_train.py:191-198
+    (everything trains / encoder frozen / head only / skipped); the loss stays finite, the steps are eager (no graph for varying
+    shapes) and a second trainer from the same seed reproduces the first one's parameters bit for bit."""
+    from popcorn_amd.cli import Trainer, limit_regime, train_parser
+    argv = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-4 --synthetic_regions 24 -wb 2 "
+            f"--save_dir {tmp_path} -lt 100 -val 100 -e 1 --synthetic_hw_range 150 700 -lim1 200000 -lim2 400000 -lim3 700000 --save-model no").split()
+    params = []
+    for rep in range(2):
+        t = Trainer(train_parser().parse_args(argv))
+        if rep == 0:
+            cases = set()
+            for sample in t.loader:
+                n = sample["S2"].shape[0] * sample["S2"].shape[2] * sample["S2"].shape[3]
+                cases.add(limit_regime(n, 200000, 400000, 700000))
+            assert cases == {(False, False, False), (True, False, False), (True, True, False), (True, True, True)}, cases
+            t = Trainer(train_parser().parse_args(argv))          # (the loader's shuffle order was consumed above)
+        assert t.fused is not None and t.fused.use_graph is False
+        t.train()
+        torch.cuda.synchronize()
+        params.append(t.fused.flat_p.clone())
+        assert torch.isfinite(params[-1]).all()
+        assert int(t.fused.step_count[2].item()) > int(t.fused.step_count[0].item()) > 0       # head stepped more often than the encoder
+    assert torch.equal(params[0], params[1])

@@ -76,7 +76,7 @@ PADDED_INPUT = os.environ.get("POPCORN_PADDED_INPUT", "1") != "0"
 
 
 class _Layer:
-    __slots__ = ("w", "b", "bn", "bn_nobias", "wname", "bname", "_keep")
+    __slots__ = ("w", "b", "bn", "bn_nobias", "wname", "bname", "_keep", "_slices")
 
     def __init__(self, T, conv_key, bn_key):
         self.wname, self.bname = conv_key + ".weight", conv_key + ".bias"
@@ -89,6 +89,16 @@ class _Layer:
         else:
             self.bn = self.bn_nobias = None
             self._keep = ()
+        self._slices = {}
+
+    def bn_slice(self, c0, n):
+        """The ReLU / BN factor descriptor (no conv bias) of channels [c0, c0 + n) of this layer's output -- for launches that take one
+        8-channel column block of it as a problem of its own."""
+        key = (c0, n)
+        if key not in self._slices:
+            g, be, m, v = self._keep
+            self._slices[key] = L.bn(None, g[c0:c0 + n], be[c0:c0 + n], m[c0:c0 + n], v[c0:c0 + n], BN_EPS)
+        return self._slices[key]
 
 
 class UNetEngine:
@@ -348,11 +358,33 @@ class UNetEngine:
         G_c2 = {}
         if composed2:
             # skip column block (16 channels @ H1 x W1): weight gradient into the first 16 input columns, data gradient masked by d1b
-            wb.conv3x3_group([{"a": A[s]["b2"], "g": G_e1[s], "dw": grads[prefix + ly(s, "up2a").wname],
-                               "db": grads[prefix + ly(s, "up2a").bname]} for s in S], ly(S[0], "up2a").w.shape[0], cin_total=32)
-            if not encoder_no_grad:
-                G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+            def f32_ok(g, x):
+                if x.shape[2:] != g.shape[2:] or g.shape[3] % 4:
+                    return False
+                return all(t.stride(3) == 1 and t.stride(2) % 4 == 0 and t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+                           for t in (g, x))
+            if FUSED_CONV_BWD and not bf and not encoder_no_grad and 2 * len(S) <= L.PC_MAX_GROUP and \
+                    all(f32_ok(G_e1[s], A[s]["b2"]) for s in S):
+                # ... as ONE launch of the fused 8 <-> 8 backward kernel (round 4): the two 8-channel halves of the 16-channel skip tensor
+                # are two problems per stream over the same gradient (it comes out of L2 once), each writing its half of the data
+                # gradient and its column block of the weight gradient -- instead of a 16 -> 8 weight-gradient launch + an 8 -> 16
+                # data-gradient launch over the same two tensors
+                G_b2 = {s: E(16, H1, W1) for s in S}
+                probs = []
+                for s in S:
+                    lay = ly(s, "up2a")
+                    for i in (0, 1):
+                        probs.append({"g": G_e1[s], "x": A[s]["b2"][:, 8 * i:8 * i + 8], "w": lay.w, "out": G_b2[s][:, 8 * i:8 * i + 8],
+                                      "dw": grads[prefix + lay.wname], "db": grads[prefix + lay.bname] if i == 0 else None,
+                                      "x_bn": ly(s, "d1b").bn_slice(8 * i, 8), "c0_add": 8 * i})
+                wb.conv3x3_bwd_group(probs, 32, 0)
                 G_c2 = {s: E(16, H2, W2) for s in S}
+            else:
+                wb.conv3x3_group([{"a": A[s]["b2"], "g": G_e1[s], "dw": grads[prefix + ly(s, "up2a").wname],
+                                   "db": grads[prefix + ly(s, "up2a").bname]} for s in S], ly(S[0], "up2a").w.shape[0], cin_total=32)
+                if not encoder_no_grad:
+                    G_b2 = dg("up2a", G_e1, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b2"] for s in S}, "d1b")
+                    G_c2 = {s: E(16, H2, W2) for s in S}
             up_bwd("up2t", "up2a", G_e1, "c2", "d2b", "ws_up2", None if encoder_no_grad else G_c2)
         else:
             if fuse and not encoder_no_grad:

@@ -179,7 +179,8 @@ def empty_act(B, C_, H, W, device, zero=False):
     channels-last bf16 (one aligned 16-byte slot per pixel and 8-channel group; include/popcorn_hip.h)."""
     mk = torch.zeros if zero else torch.empty
     if lib().pc_get_precision() == PC_PREC_BF16:
-        return mk(B, C_, H, W, device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        t = torch.empty(B, C_, H, W, device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        return t.zero_() if zero else t          # (torch.zeros takes no memory_format)
     if _PAD_ROWS[0] and W % 4:
         return mk(B, C_, H, (W + 3) // 4 * 4, device=device, dtype=torch.float32)[..., :W]
     return mk(B, C_, H, W, device=device, dtype=torch.float32)

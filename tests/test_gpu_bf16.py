@@ -948,3 +948,31 @@ def test_bf16_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_gr
         runs.append((losses, tr.flat_p.clone()))
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("ic", [2, 4])
+def test_bf16_single_modality_train_step_vs_bf16_oracle(ic):
+    """S1-only / S2-only variants (popcorn.py:48-54,136-145) in bf16 mode: one stream runs, the other 8 feature channels are a ZERO
+    channels-last tensor (round 4: that allocation used torch.zeros with a memory_format argument and raised -- the combination had never
+    been run).  Loss, popcount and the 32 gradients against the bf16 oracle, same gates as the dual-stream model."""
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    g = np.load(os.path.join(G, "g8_single_modality.npz"))
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=ic, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    s = {k: torch.from_numpy(g[f"ic{ic}/{k}"]) for k in ("input", "admin_mask", "census_idx", "y")}
+    torch.manual_seed(5)
+    _, _, g32, _ = O.train_step_grads(sd, dict(s))
+    with O.bf16_mode():
+        torch.manual_seed(5)
+        l16, out16, g16, _ = O.train_step_grads(sd, dict(s))
+    m.set_precision("bf16")
+    tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+    torch.manual_seed(5)
+    loss = tr.step({k: v.cuda() for k, v in s.items()})
+    torch.cuda.synchronize()
+    assert abs(loss[0].item() - l16.item()) < TOL_LOSS * abs(l16.item())
+    assert rel(tr.last["popcount"].cpu(), out16["popcount"]) < TOL_COUNT
+    assert len(g16) == 32
+    _bf16_grad_gate({n: tr.grads[n] for n in g16}, g16, g32, f"ic{ic}")

@@ -110,7 +110,9 @@ class FusedTrainStep:
         for lo, la in zip(loss, lam):
             if lo in LOSS_INDEX:
                 self.lam4[LOSS_INDEX[lo]] += la
-        self.sreg, self.lam_weak = scale_regularization, lam_weak
+        # popcorn.py:177-181 + utils/losses.py:63-76: without the occupancy model forward() returns scale = None and get_loss adds NO
+        # scale regulariser, whatever --scale_regularization says (round 4: the fused step used to add it)
+        self.sreg, self.lam_weak = (scale_regularization if model.occupancymodel else 0.0), lam_weak
         self.reducer = reducer or FlatReducer()
         self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
         self.loss_out = torch.zeros(2, device=dev, dtype=torch.float32)
@@ -268,7 +270,16 @@ class FusedTrainStep:
                 X = ops.select_normalize(raw, band, mean, std)
         else:
             X = s["input"]
-        if fused:
+        # popcorn.py:113-114: the building score comes from the frozen extractor unless the model was built with sentinelbuildings =
+        # False AND the sample brings its own "building_counts" (a dataset that ships a building layer)
+        given = (not m.sentinelbuildings) and s.get("building_counts") is not None
+        if given:
+            building = s["building_counts"].contiguous().float()
+            if tuple(building.shape) != (B, 1, H, W):
+                raise ValueError(f"building_counts must be (B, 1, H, W) = {(B, 1, H, W)}, got {tuple(building.shape)}")
+            mask, counts = ops.sparsity_mask(building, s["admin_mask"], s["census_idx"], sel[:H], sel[H:], m.occupancymodel)
+            (feats,), (saved,) = E.forward_multi([eng_u], X, pt, pl, H + pt + pb, W + pl + pr, [not unet_no_grad], Xp_all=Xp_all)
+        elif fused:
             (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
                                                        [False, not unet_no_grad], logit_only=[True, False], Xp_all=Xp_all)
             building, mask, counts = eng_b.score_and_mask(f_b, H, W, pt, pl, s["admin_mask"], s["census_idx"], sel[:H],
@@ -279,7 +290,7 @@ class FusedTrainStep:
         s["building_counts"] = building
         if not m.occupancymodel:
             building = torch.ones_like(building)
-        if not fused:
+        if not fused and not given:
             feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
                                                      admin_mask=s["admin_mask"], census_idx=s["census_idx"],
@@ -371,7 +382,8 @@ class FusedTrainStep:
         dkey = dks[0]
         # "_slot": which of the loader's static sets this is (static_buffers(slot=...)): every set has its own captured graph, so
         # a double-buffering loader replays graph A on set A while the copy stream fills set B -- no device-to-device copies
-        key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision, sample.get("_slot", 0))
+        key = (dkey, tuple(sample[dkey].shape), encoder_no_grad, unet_no_grad, self.model.precision, sample.get("_slot", 0),
+               (not self.model.sentinelbuildings) and sample.get("building_counts") is not None)
         if self._graphs is None or self._graphs[0] != key:
             if key in self._graph_cache:
                 self._graphs, self.last = self._graph_cache.pop(key)      # (re-inserted below: most recently used last)
@@ -393,7 +405,8 @@ class FusedTrainStep:
             while len(self._graph_cache) > self._graph_cache_max:
                 self._graph_cache.pop(next(iter(self._graph_cache)))
         _, st, sel, graphs = self._graphs
-        for k in dks + ("admin_mask", "census_idx", "y"):
+        extra = ("building_counts",) if key[-1] else ()          # (an input only for sentinelbuildings = False models fed a building layer)
+        for k in dks + ("admin_mask", "census_idx", "y") + extra:
             if sample[k] is not st[k]:            # a loader that fills static_buffers() in place skips the copy
                 st[k].copy_(sample[k], non_blocking=True)
         self._sel_to_device(sel_host, sel)
@@ -461,12 +474,14 @@ class FusedTrainStep:
         return out
 
     def _capture(self, sample, sel_host, key):
-        dkey, _, enc_ng, unet_ng, _, _ = key
+        dkey, _, enc_ng, unet_ng = key[:4]
         mine = [d for d in (self._static or {}).values() if all(sample.get(k) is d[k] for k in d)]
         if mine:
             st = dict(mine[0])
         else:
             st = {k: sample[k].detach().clone().contiguous() for k in data_keys(sample) + ("admin_mask", "census_idx", "y")}
+            if not self.model.sentinelbuildings and sample.get("building_counts") is not None:
+                st["building_counts"] = sample["building_counts"].detach().clone().contiguous().float()     # an INPUT of this model (see _forward)
             st["admin_mask"] = st["admin_mask"].float()
         sel = sel_host.to(self.device)
         # warm-up on a side stream (first-launch attribute calls, workspace allocation), state restored afterwards

@@ -373,3 +373,46 @@ def test_trainer_validation_test_loops_guards_and_checkpoint_interop(tmp_path):
         t5.model.head[6].bias.fill_(float("nan"))
     with pytest.raises(Exception, match="NaN/Inf"):
         t5.train()
+
+
+@pytest.mark.parametrize("occ,senb", [(False, True), (False, False), (True, False)])
+def test_fused_step_without_occupancy_model_or_with_its_own_building_layer_vs_oracle(occ, senb):
+    """The non-default model variants in TRAINING (popcorn.py:113-114,177-181; utils/losses.py:63-76): occupancymodel = False (popdensemap
+    = relu(out), scale = None -> NO scale regulariser in the loss whatever the flag says: the fused step used to add it, found by
+    tools/sweep_train_variants.py) and sentinelbuildings = False with a building layer in the sample (used instead of the frozen
+    extractor's score: the fused step used to ignore it).  Loss and all gradients against the oracle."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=occ, pretrained=True, biasinit=0.9407, sentinelbuildings=senb).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = make_raw_batch(3, 100, 100, seed=3, region="disc")
+    cpu = {"input": O.select_normalize(b["raw"]), "admin_mask": b["admin_mask"], "census_idx": b["census_idx"], "y": b["y"]}
+    if not senb:
+        cpu["building_counts"] = torch.rand(3, 1, 100, 100, generator=torch.Generator().manual_seed(4))
+    for use_graph in (False, True):
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, scale_regularization=0.01, use_graph=use_graph)
+        torch.manual_seed(5)
+        loss = tr.step({k: v.cuda() for k, v in cpu.items()}).clone()
+        torch.cuda.synchronize()
+        names = O.trainable_names(sd)
+        wsd = dict(sd)
+        for nm in names:
+            wsd[nm] = sd[nm].detach().clone().requires_grad_(True)
+        work = {k: v.clone() for k, v in cpu.items()}
+        torch.manual_seed(5)
+        out = O.popcorn_forward(wsd, work, padding=False, sparse=True, occupancymodel=occ, sentinelbuildings=senb)
+        rl, _ = O.get_loss(out, work, scale=out["scale"], loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01, tag="weak")
+        (rl * 100.0).backward()
+        assert abs(loss[0].item() - rl.item()) < 1e-5 * max(1.0, abs(rl.item())), (use_graph, loss, rl)
+        if not occ:
+            assert loss[1].item() == 0.0                                                    # no regulariser term
+        for nm in names:
+            g = wsd[nm].grad
+            assert g is not None
+            e = (tr.grads[nm].cpu() - g).abs().max().item()
+            assert e <= 2e-4 * max(g.abs().max().item(), 1e-3), (use_graph, nm, e)
+        m.load_state_dict(sd)
+        tr.sync_from_model()

@@ -138,6 +138,12 @@ typedef struct pc_conv_fwd_desc {
      * weight.  Lets the first convolutions of both streams (2 SAR / 4 optical channels, networks.py:130-133) read ONE shared
      * 8-channel channels-last input (pc_ingest_cl8) with the standard 8 -> 8 kernel, all (network, stream) pairs in one launch. */
     int32_t w_ci0, w_cin;
+    /* optional (PC_PREC_BF16, 8 -> 8 layers, ReLU, no second source / pooled / dot output): the ConvTranspose2d(8, 8, 2, stride 2) of the
+     * Up block that consumes this layer's output (networks.py:302-306: weight upt_w [8][8][2][2], bias upt_b) runs in this launch's
+     * epilogue and writes upt_out (B x 8 x 2H x 2W, channels-last bf16): the rounded output of a lane IS the matrix operand of the
+     * transposed conv, so the separate launch and its read of `out` disappear (`out` is still written for the backward pass).  All
+     * problems of a launch or none. */
+    const float* upt_w; const float* upt_b; const pc_dst* upt_out;
 } pc_conv_fwd_desc;
 int pc_conv3x3_pool_out_ok(const pc_dst* out, int H, int W);
 int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, int relu, int B, int H, int W, int Cin, int Cout,

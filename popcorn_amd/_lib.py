@@ -35,7 +35,7 @@ class PcBn(C.Structure):
 class PcConvFwdDesc(C.Structure):
     _fields_ = [("a", C.POINTER(PcSrc)), ("b", C.POINTER(PcSrc)), ("w", C.c_void_p), ("bn", C.POINTER(PcBn)),
                 ("out", C.POINTER(PcDst)), ("pool_out", C.POINTER(PcDst)), ("dot_w", C.c_void_p), ("dot_out", C.POINTER(PcDst)),
-                ("w_ci0", C.c_int32), ("w_cin", C.c_int32)]
+                ("w_ci0", C.c_int32), ("w_cin", C.c_int32), ("upt_w", C.c_void_p), ("upt_b", C.c_void_p), ("upt_out", C.POINTER(PcDst))]
 
 
 class PcConvDgradDesc(C.Structure):

@@ -77,6 +77,10 @@ struct ConvProb {
     const float* wz; const float* tb;
     // channels-last bf16, CIN == 8: w is [COUT][w_cin][3][3] over input channels [w_ci0, w_ci0 + w_cin) (w_cin == 0: full weight)
     int w_ci0, w_cin;
+    // EPI_UPT: the ConvTranspose2d(8, 8, 2, stride 2) that consumes this layer's output (Up.up, networks.py:302-306), applied in the
+    // epilogue: upt_out = (B, 8, 2H, 2W) channels-last bf16
+    const float* upt_w; const float* upt_b;
+    pc_dst upt_out;
 };
 
 struct ConvArgs {
@@ -112,7 +116,7 @@ constexpr int CSW = SROWS * RS;          // channel stride inside a wave's LDS r
 // EPI: extra work of the forward vector epilogue, as separate instantiations so that the other shapes keep their register
 // count.  EPI_POOL: also write the 2x2-max-pooled output (ConvProb::pool_out).  EPI_DOT: problems with ConvProb::dot_w
 // write the 1x1-conv partial sum over their 8 channels instead of the feature map (ConvProb::dot_out).
-enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3 };   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
+enum { EPI_NONE = 0, EPI_POOL = 1, EPI_DOT = 2, EPI_POOLBWD = 3, EPI_UPT = 4 };   // EPI_UPT (channels-last bf16, 8 -> 8 forward): also the ConvTranspose2d that follows   // EPI_POOLBWD: DGRAD with the MaxPool2d(2) backward scatter
 template <int CIN, int COUT, int MODE, int LD, int EPI, int ZC = 0>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     constexpr int CHUNK = CIN < 8 ? CIN : 8;       // 8 channels per LDS stage: 36 KB per workgroup, 4 workgroups per CU
@@ -1091,6 +1095,26 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
             for (int r = 0; r < 4; ++r) dotw[r] = pc_bf16r(q.dot_w[c4 + r]);
         }
     }
+    // EPI_UPT: A fragments of the transposed conv for the two rows of a pair.  The epilogue's packed output of a lane IS the B
+    // fragment of v_mfma_f32_16x16x16_bf16 (N = pixel li, k-group lk = 4 channels): lanes lk = 0, 1 hold row s = 0 of the pair, lanes
+    // lk = 2, 3 row s = 1 -- so the weights of row s sit in the k-groups 2 s, 2 s + 1 of A and the other two k-groups are zero
+    // (M = (x parity b = li >> 3, output channel li & 7); one instruction per (row s, output-row parity a))
+    typedef short upt_s4 __attribute__((ext_vector_type(4)));
+    upt_s4 upt_aw[2][2];
+    float upt_bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_UPT) {
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = 4 * (lk & 1) + e;
+                    upt_aw[sr][a][e] = (lk >> 1) == sr ? (short)pc_f2bf(q.upt_w[((ci * 8 + (li & 7)) * 2 + a) * 2 + (li >> 3)]) : (short)0;
+                }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) upt_bias[r] = q.upt_b ? q.upt_b[c4 + r] : 0.f;
+    }
     for (int e = tid; e < 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
     __syncthreads();
 #pragma unroll
@@ -1148,7 +1172,28 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                         for (int r = 0; r < 4; ++r) dsum += v[r] * dotw[r];
                         continue;
                     }
-                    if (ok) pc_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
+                    if (ok && (EPI != EPI_UPT || outp)) pc_st4(outp + eb * o_bs + (int64_t)y * o_rs + (int64_t)x * o_xs + nb * 8 + c4, v);
+                    if constexpr (EPI == EPI_UPT) {
+                        // the transposed conv of this unit's two rows: D[(b, co)][pixel] -> up-sampled pixel (2 y_s + a, 2 x + b)
+                        upt_s4 bv;
+                        {
+                            const unsigned p0 = pc_pack_bf16(v[0], v[1]), p1 = pc_pack_bf16(v[2], v[3]);
+                            bv[0] = (short)(p0 & 0xffffu); bv[1] = (short)(p0 >> 16); bv[2] = (short)(p1 & 0xffffu); bv[3] = (short)(p1 >> 16);
+                        }
+                        pc_bf16_t* const uo = reinterpret_cast<pc_bf16_t*>(q.upt_out.ptr) + eb * q.upt_out.bstride;
+                        const int u_rs = q.upt_out.rstride, u_xs = q.upt_out.xstride;
+#pragma unroll
+                        for (int sr = 0; sr < 2; ++sr) {
+                            const int ys = ey0 + 2 * (u >> 1) + sr;
+                            const bool oks = ys < p.H && x < p.W;
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) {
+                                f32x4 ua = f32x4{upt_bias[0], upt_bias[1], upt_bias[2], upt_bias[3]};
+                                ua = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(upt_aw[sr][a], bv, ua, 0, 0, 0);
+                                if (oks) pc_st4(uo + (int64_t)(2 * ys + a) * u_rs + (int64_t)(2 * x + (lk >> 1)) * u_xs + c4, ua);
+                            }
+                        }
+                    }
                     if (EPI == EPI_POOL && q.pool_out.ptr) {
                         // MaxPool2d(2) (full strips only, pc_conv3x3_pool_out_ok): x pair = lane ^ 1 (DPP quad permute), row pair =
                         // lane ^ 32 (v_permlane32_swap: both halves' values in every lane) -- no trip through the LDS crossbar
@@ -1304,6 +1349,14 @@ int launch_conv_cl_epi(ConvArgs& p, int nprob, hipStream_t stream) {
         bool dot = false;
         for (int i = 0; i < nprob; ++i) dot = dot || p.pr[i].dot_w != nullptr;
         if (dot) return launch_conv_cl<CIN, COUT, MODE, LD, EPI_DOT>(p, nprob, stream);
+    }
+    if constexpr (MODE == MODE_FWD && CIN == 8 && COUT == 8 && LD == LD_DIRECT) {
+        int nupt = 0;
+        for (int i = 0; i < nprob; ++i) nupt += p.pr[i].upt_w != nullptr;
+        if (nupt) {
+            if (nupt != nprob) return PC_EINVAL;            // all problems of the launch or none
+            return launch_conv_cl<CIN, COUT, MODE, LD, EPI_UPT>(p, nprob, stream);
+        }
     }
     if constexpr (MODE == MODE_DGRAD) {
         if (p.pool) return launch_conv_cl<CIN, COUT, MODE, LD, EPI_POOLBWD>(p, nprob, stream);
@@ -1497,6 +1550,15 @@ extern "C" int pc_conv3x3_bn_relu_fwd_group(int n, const pc_conv_fwd_desc* d, in
     for (int i = 0; i < n; ++i) {
         const int rc = fill_fwd(p.pr[i], d[i].a, d[i].b, d[i].w, d[i].bn, d[i].out, Cin);
         if (rc) return rc;
+        if (d[i].upt_w) {
+            // the transposed conv of the Up block that follows, in this launch's epilogue (channels-last bf16, 8 -> 8 layers)
+            if (g_pc_precision != PC_PREC_BF16 || Cin != 8 || Cout != 8 || !relu || d[i].b || d[i].pool_out || d[i].dot_w || !d[i].upt_out ||
+                !d[i].upt_out->ptr || !pc_cl_ok(*d[i].upt_out) || d[i].upt_out->xstride < 8 || d[i].a->mode != PC_SRC_DIRECT)
+                return PC_EINVAL;
+            p.pr[i].upt_w = d[i].upt_w;
+            p.pr[i].upt_b = d[i].upt_b;
+            p.pr[i].upt_out = *d[i].upt_out;
+        }
         if (d[i].w_cin) {
             if (g_pc_precision != PC_PREC_BF16 || Cin != 8 || d[i].b || d[i].w_ci0 < 0 || d[i].w_cin < 1 || d[i].w_ci0 + d[i].w_cin > 8 ||
                 d[i].a->mode != PC_SRC_DIRECT)

@@ -71,6 +71,8 @@ FUSED_LEVEL2 = os.environ.get("POPCORN_FUSED_LEVEL2", "1") != "0"
 # fp32: the first conv of an Up block reads the LOW-resolution map through composed (transposed conv o conv) weights instead of an
 # up-sampled tensor (POPCORN_COMPOSED_UP=0: transposed-conv launch + two-source conv)
 COMPOSED_UP = os.environ.get("POPCORN_COMPOSED_UP", "1") != "0"
+# bf16: up1's transposed conv in the epilogue of up2's second conv (POPCORN_FUSED_UPT=0: separate launch; A/B switch)
+FUSED_UPT = os.environ.get("POPCORN_FUSED_UPT", "1") != "0"
 # fp32: padded + channel-gathered input materialised once per forward pass (POPCORN_PADDED_INPUT=0: reflect loaders; A/B switch)
 PADDED_INPUT = os.environ.get("POPCORN_PADDED_INPUT", "1") != "0"
 
@@ -666,12 +668,21 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         e1 = conv("up2a", b2, 8, H1, W1, bs=u2, b_offset=o2)
     else:
         e1, ws_up2 = r
-    e2 = conv("up2b", e1, 8, H1, W1)
+    u1_fused = None
+    if bf and FUSED_UPT and (Hp, Wp) == (2 * H1, 2 * W1):
+        # bf16 mode: up1's transposed conv in the epilogue of the conv that produces its input (one launch instead of two; e2 is still
+        # written for the backward pass)
+        e2 = {k: E(8, H1, W1) for k in keys}
+        u1_fused = {k: E(8, 2 * H1, 2 * W1) for k in keys}
+        ops.conv3x3_fwd_group([{"a": e1[k], "w": ly(k, "up2b").w, "bn": ly(k, "up2b").bn, "out": e2[k], "upt_w": ly(k, "up1t").w,
+                                "upt_b": ly(k, "up1t").b, "upt_out": u1_fused[k]} for k in keys])
+    else:
+        e2 = conv("up2b", e1, 8, H1, W1)
     o1 = ((Hp - 2 * H1) // 2, (Wp - 2 * W1) // 2)
     r = up_conv("up1a", "up1t", a2, e2, 8, Hp, Wp) if compose1 else None
     ws_up1 = {}
     if r is None:
-        u1 = convt("up1t", e2, 8, 2 * H1, 2 * W1)
+        u1 = u1_fused if u1_fused is not None else convt("up1t", e2, 8, 2 * H1, 2 * W1)
         f1 = conv("up1a", a2, 8, Hp, Wp, bs=u1, b_offset=o1)
     else:
         f1, ws_up1 = r

@@ -81,6 +81,11 @@ def conv3x3_fwd_group(problems, relu=True, a_mode=L.PC_SRC_DIRECT, a_pad=(0, 0),
             dp = L.dst(pr["pool_out"])
             keep.append(dp)
             descs[i].pool_out = C.pointer(dp)
+        if pr.get("upt_out") is not None:        # bf16 mode, 8 -> 8: the transposed conv that follows, in this launch's epilogue
+            du = L.dst(pr["upt_out"])
+            keep.append(du)
+            descs[i].upt_w, descs[i].upt_out = pr["upt_w"].data_ptr(), C.pointer(du)
+            descs[i].upt_b = pr["upt_b"].data_ptr() if pr.get("upt_b") is not None else None
         if pr.get("w_window") is not None:       # bf16 mode: w covers input channels [ci0, ci0 + cin) of the shared 8-channel input
             descs[i].w_ci0, descs[i].w_cin = int(pr["w_window"][0]), int(pr["w_window"][1])
             assert pr["w"].shape[1] == descs[i].w_cin and Ca + Cb == 8

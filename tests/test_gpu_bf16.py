@@ -976,3 +976,42 @@ def test_bf16_single_modality_train_step_vs_bf16_oracle(ic):
     assert rel(tr.last["popcount"].cpu(), out16["popcount"]) < TOL_COUNT
     assert len(g16) == 32
     _bf16_grad_gate({n: tr.grads[n] for n in g16}, g16, g32, f"ic{ic}")
+
+
+@pytest.mark.parametrize("hw", [(100, 100), (72, 40), (37, 53)])
+def test_bf16_transposed_conv_in_the_conv_epilogue_is_bit_identical(monkeypatch, hw):
+    """EPI_UPT: up1's ConvTranspose2d runs in the epilogue of the conv that produces its input (the lane's rounded output is the MFMA
+    operand): u1, e2, f1, the features and the frozen extractor's logits are BIT-identical to the two-launch form, at exact-2x and ragged
+    geometries, and the 8-channel transposed-conv launch is gone."""
+    from popcorn_amd import engine as E, ops, _lib as L
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.model.popcorn import pad_geometry
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    m.set_precision("bf16")
+    eng_u, eng_b = m.engines()
+    H, W = hw
+    X = torch.randn(2, 6, H, W, generator=torch.Generator().manual_seed(3)).cuda()
+    pt, pb, pl, pr = pad_geometry(H, W, True)
+    Hp, Wp = H + pt + pb, W + pl + pr
+    outs, n8 = {}, {}
+    orig = ops.convt2x2_group
+    with L.precision("bf16"):
+        for flag in (True, False):
+            monkeypatch.setattr(E, "FUSED_UPT", flag)
+            cnt = [0]
+
+            def counted(problems, _c=cnt):
+                _c[0] += sum(1 for pr_ in problems if pr_["x"].shape[1] == 8)
+                return orig(problems)
+            monkeypatch.setattr(ops, "convt2x2_group", counted)
+            (f_b, f_u), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, Hp, Wp, [False, True], logit_only=[True, False])
+            torch.cuda.synchronize()
+            n8[flag] = cnt[0]
+            outs[flag] = (f_b.clone(), f_u.clone(), {s: {k: saved[s][k].clone() for k in ("u1", "e2", "f1")} for s in ("sar_stream", "optical_stream")})
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for s in ("sar_stream", "optical_stream"):
+        for k in ("u1", "e2", "f1"):
+            assert torch.equal(outs[True][2][s][k], outs[False][2][s][k]), (s, k)
+    exact2x = (Hp // 2) * 2 == Hp and (Wp // 2) * 2 == Wp
+    assert n8[False] == 4 and n8[True] == (0 if exact2x else 4), (n8, exact2x)

@@ -381,6 +381,14 @@ int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, cons
  * caller guarantees: same hw contents, same ws, same B / H / W, same arithmetic mode in between) -- one launch less per step. */
 #define PC_HEAD_FWD_PACK_BOTH 1
 #define PC_HEAD_BWD_PACKED 1
+/* PC_HEAD_FWD_DEFER_REDUCE: pc_head_fwd leaves popcount / stats unreduced (its last, single-block launch is skipped);
+ * pc_head_popcount_loss(ws, ...) -- same ws, B, H, W -- then finishes popcount[B] and stats[2] AND computes the loss forward + backward
+ * of pc_loss_fwd_bwd in one single-block launch (a single-process training step: one launch less; a data-parallel step all-reduces
+ * the stats between the two and keeps the separate calls). */
+#define PC_HEAD_FWD_DEFER_REDUCE 2
+int pc_head_popcount_loss(void* ws, int B, int H, int W, const int32_t* nsel_counts, const float* y, const float* lam4,
+                          float scale_regularization, float lam_weak, float inv_B, float* popcount, double* stats,
+                          float* loss_out, float* g_popcount, float* g_scale_const, void* stream);
 
 /* backward of pc_head_fwd (the forward chain is recomputed in registers).  Upstream gradients, all optional (NULL):
  *   g_popcount[B]; g_popdense[B][H][W]; g_scale_map[B][H][W] (gradient w.r.t. scale = relu(out), e.g. the scattered

@@ -187,3 +187,41 @@ __device__ __forceinline__ f32x4 pc_fetch_reflect_seg(const pc_src& s, int b, in
     }
     return v;
 }
+
+// ---- loss forward + backward for one block of 256 threads (train_ops.hip: pc_loss_fwd_bwd; head.hip: pc_head_popcount_loss) ------------
+// loss = sum_k lam[k] * L_k(popcount, y) + sreg * sum(scale) / Nsel, with L_k in {l1, log_l1, mse, log_mse} taken as a mean over the GLOBAL
+// batch (inv_B = 1 / (world * B)); outputs d(lam_weak * loss) / d popcount[b] and the constant d(lam_weak * loss) / d scale on selected pixels.
+struct pc_loss_args {
+    const float* y;
+    float lam[4]; float sreg, lam_weak, inv_B; int B;
+    float* loss_out;        // [2]: {optimisation loss (local part of the batch mean + regulariser), regulariser}
+    float* g_popcount; float* g_scale_const;
+};
+__device__ __forceinline__ void pc_loss_block(const pc_loss_args& a, const float* popcount, const double* stats, double* red /* [256] shared */) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+        const float pc = popcount[b], y = a.y[b];
+        const float d = pc - y;
+        const float lp = logf(pc + 1.f), ly = logf(y + 1.f);
+        const float dl = lp - ly;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float sgl = dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f);
+        const float l = a.lam[0] * fabsf(d) + a.lam[1] * fabsf(dl) + a.lam[2] * d * d + a.lam[3] * dl * dl;
+        const float g = a.lam[0] * sg + a.lam[1] * sgl / (pc + 1.f) + a.lam[2] * 2.f * d + a.lam[3] * 2.f * dl / (pc + 1.f);
+        a.g_popcount[b] = a.lam_weak * a.inv_B * g;
+        acc += (double)l;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nsel = stats ? stats[0] : 0.0, ssum = stats ? stats[1] : 0.0;
+        const double reg = (a.sreg > 0.f && nsel > 0.0) ? (double)a.sreg * ssum / nsel : 0.0;
+        a.loss_out[0] = (float)(red[0] * (double)a.inv_B + reg);
+        a.loss_out[1] = (float)reg;
+        *a.g_scale_const = (a.sreg > 0.f && nsel > 0.0) ? (float)((double)a.lam_weak * (double)a.sreg / nsel) : 0.f;
+    }
+}

@@ -2376,6 +2376,31 @@ extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
     return (int64_t)B * nchunk * 2 * sizeof(float) + 512 * 12288 * (int64_t)sizeof(float);
 }
 
+// One round of workgroups: every workgroup stages the 36 KB of weights, so the launch holds exactly the workgroups that are resident at
+// once (B images x chunks-per-image <= resident) and each wave walks enough 16-pixel groups to cover its image chunk -- with a fixed 8
+// groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on 1024 slots, i.e. a second, quarter-full round.
+static int head_fwd_chunks(int B, int H, int W, int* groups_per_wave, int* nchunk) {
+    static int resident = 0;
+    static pc_once_per_device once;
+    if (once.need()) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
+        once.mark();
+    }
+    const int groups = (H * W + 15) / 16;
+    int chunks = resident / (B > 0 ? B : 1);                      // chunks per image that fit in one round
+    const int max_chunks = (groups + 31) / 32;                    // never fewer than 8 groups per wave (workspace bound)
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    int gpw = (groups + 4 * chunks - 1) / (4 * chunks);
+    if (gpw < 8) gpw = 8;
+    *groups_per_wave = gpw;
+    *nchunk = (groups + 4 * gpw - 1) / (4 * gpw);
+    return 0;
+}
+
 extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                            const float* building, const float* admin_mask, const int64_t* census_idx,
                            float* scale_map, float* popdensemap, float* popcount, double* stats,
@@ -2392,26 +2417,10 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     p.groups = (H * W + 15) / 16;
     p.div_w = pc_make_fastdiv(W);
     p.div_groups = pc_make_fastdiv(p.groups);
-    // One round of workgroups: every workgroup stages the 36 KB of weights, so the launch holds exactly the workgroups
-    // that are resident at once (B images x chunks-per-image <= resident) and each wave walks enough 16-pixel groups to
-    // cover its image chunk -- with a fixed 8 groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on
-    // 1024 slots, i.e. a second, quarter-full round.
-    static int resident = 0;
-    static pc_once_per_device once;
-    if (once.need()) {
-        hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
-        if (e != hipSuccess) return (int)e;
-        resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
-        once.mark();
+    {
+        const int rc = head_fwd_chunks(B, H, W, &p.groups_per_wave, &p.nchunk);
+        if (rc) return rc;
     }
-    int chunks = resident / (B > 0 ? B : 1);                      // chunks per image that fit in one round
-    const int max_chunks = (p.groups + 31) / 32;                  // never fewer than 8 groups per wave (workspace bound)
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
-    p.groups_per_wave = (p.groups + 4 * chunks - 1) / (4 * chunks);
-    if (p.groups_per_wave < 8) p.groups_per_wave = 8;
-    p.nchunk = (p.groups + 4 * p.groups_per_wave - 1) / (4 * p.groups_per_wave);
     hipStream_t st = (hipStream_t)stream;
     // bf16 mode: the feature map is a channels-last bf16 tensor (16 contiguous channels per pixel); fp32 mode: planar fp32
     if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
@@ -2423,8 +2432,61 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
+    if (flags & PC_HEAD_FWD_DEFER_REDUCE) return 0;               // pc_head_popcount_loss finishes popcount / stats (and the loss)
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
                        p.nchunk, stats, nsel_counts, (double)B * H * W);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+// popcount / stats reduction of pc_head_fwd(PC_HEAD_FWD_DEFER_REDUCE) AND the loss forward + backward (pc_loss_fwd_bwd) in ONE
+// single-block launch: the two 4.7 us launches of a single-process training step (a data-parallel step all-reduces the stats in between
+// and keeps them apart)
+__global__ __launch_bounds__(256) void head_popcount_loss_kernel(const float* partial, int nchunk, const int32_t* nsel_counts, double dense_count,
+                                                                 float* popcount, double* stats, pc_loss_args a) {
+    __shared__ double red[256];
+    __shared__ double s_stats[2];
+    double sc = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+        float t = 0.f, u = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            t += partial[((int64_t)b * nchunk + c) * 2];
+            u += partial[((int64_t)b * nchunk + c) * 2 + 1];
+        }
+        popcount[b] = t;
+        sc += (double)u;
+    }
+    // the same summation order as head_popcount_reduce_kernel's single 64-thread block would be a different one: this kernel's own
+    // fixed order (thread-strided partial sums, then a tree) -- deterministic, and the value only enters the regulariser
+    red[threadIdx.x] = sc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s_stats[0] = nsel_counts ? (double)nsel_counts[0] : dense_count;
+        s_stats[1] = red[0];
+        if (stats) { stats[0] = s_stats[0]; stats[1] = s_stats[1]; }
+    }
+    __syncthreads();
+    pc_loss_block(a, popcount, s_stats, red);
+}
+
+extern "C" int pc_head_popcount_loss(void* ws, int B, int H, int W, const int32_t* nsel_counts, const float* y, const float* lam4,
+                                     float scale_regularization, float lam_weak, float inv_B, float* popcount, double* stats,
+                                     float* loss_out, float* g_popcount, float* g_scale_const, void* stream) {
+    if (!ws || !y || !lam4 || !popcount || !loss_out || !g_popcount || !g_scale_const || B < 1) return PC_EINVAL;
+    int gpw = 0, nchunk = 0;
+    const int rc = head_fwd_chunks(B, H, W, &gpw, &nchunk);
+    if (rc) return rc;
+    pc_loss_args a{};
+    a.y = y;
+    for (int i = 0; i < 4; ++i) a.lam[i] = lam4[i];
+    a.sreg = scale_regularization; a.lam_weak = lam_weak; a.inv_B = inv_B; a.B = B;
+    a.loss_out = loss_out; a.g_popcount = g_popcount; a.g_scale_const = g_scale_const;
+    hipLaunchKernelGGL(head_popcount_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(ws), nchunk,
+                       nsel_counts, (double)B * H * W, popcount, stats, a);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -13,41 +13,9 @@ namespace {
 // a mean over the GLOBAL batch (inv_B = 1 / (world * B)), so that summing every rank's gradient reproduces the
 // single-process gradient exactly.  Outputs d(lam_weak * loss)/d popcount[b] and the constant
 // d(lam_weak * loss)/d scale on selected pixels.
-struct LossArgs {
-    const float* popcount; const float* y; const double* stats;
-    float lam[4]; float sreg, lam_weak, inv_B; int B;
-    float* loss_out;        // [2]: {optimisation loss (local part of the batch mean + regulariser), regulariser}
-    float* g_popcount; float* g_scale_const;
-};
-
-__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const pc_loss_args a, const float* popcount, const double* stats) {
     __shared__ double red[256];
-    double acc = 0.0;
-    for (int b = threadIdx.x; b < a.B; b += 256) {
-        const float pc = a.popcount[b], y = a.y[b];
-        const float d = pc - y;
-        const float lp = logf(pc + 1.f), ly = logf(y + 1.f);
-        const float dl = lp - ly;
-        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        const float sgl = dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f);
-        const float l = a.lam[0] * fabsf(d) + a.lam[1] * fabsf(dl) + a.lam[2] * d * d + a.lam[3] * dl * dl;
-        const float g = a.lam[0] * sg + a.lam[1] * sgl / (pc + 1.f) + a.lam[2] * 2.f * d + a.lam[3] * 2.f * dl / (pc + 1.f);
-        a.g_popcount[b] = a.lam_weak * a.inv_B * g;
-        acc += (double)l;
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double nsel = a.stats ? a.stats[0] : 0.0, ssum = a.stats ? a.stats[1] : 0.0;
-        const double reg = (a.sreg > 0.f && nsel > 0.0) ? (double)a.sreg * ssum / nsel : 0.0;
-        a.loss_out[0] = (float)(red[0] * (double)a.inv_B + reg);
-        a.loss_out[1] = (float)reg;
-        *a.g_scale_const = (a.sreg > 0.f && nsel > 0.0) ? (float)((double)a.lam_weak * (double)a.sreg / nsel) : 0.f;
-    }
+    pc_loss_block(a, popcount, stats, red);
 }
 
 // ---- gradient norm (deterministic two-level tree over a flat buffer) ---------------------------------------------------
@@ -222,12 +190,12 @@ extern "C" int pc_loss_fwd_bwd(const float* popcount, const float* y, const doub
                                float scale_regularization, float lam_weak, float inv_B, int B,
                                float* loss_out, float* g_popcount, float* g_scale_const, void* stream) {
     if (!popcount || !y || !lam4 || !loss_out || !g_popcount || !g_scale_const) return PC_EINVAL;
-    LossArgs a{};
-    a.popcount = popcount; a.y = y; a.stats = stats;
+    pc_loss_args a{};
+    a.y = y;
     for (int i = 0; i < 4; ++i) a.lam[i] = lam4[i];
     a.sreg = scale_regularization; a.lam_weak = lam_weak; a.inv_B = inv_B; a.B = B;
     a.loss_out = loss_out; a.g_popcount = g_popcount; a.g_scale_const = g_scale_const;
-    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, popcount, stats);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -460,11 +460,11 @@ def _hw_array(head_tensors):
     return arr
 
 
-PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED = 1, 1
+PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED, PC_HEAD_FWD_DEFER_REDUCE = 1, 1, 2
 
 
 def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
-             want_scale=True, stats=None, nsel_counts=None, pack_both=False):
+             want_scale=True, stats=None, nsel_counts=None, pack_both=False, defer_reduce=False):
     """Sparse/dense head + occupancy product + census reduction.  popcorn.py:161-190.
     head_tensors = [w0,b0,w2,b2,w4,b4,w6,b6].  Returns (scale_map, popdensemap, popcount)."""
     L.require_device(feat, building, *head_tensors)
@@ -478,7 +478,8 @@ def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     hw = _hw_array(head_tensors)
     L.check(L.lib().pc_head_fwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
                                 L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(stats),
-                                L.ptr(nsel_counts), L.ptr(ws), B, H, W, PC_HEAD_FWD_PACK_BOTH if pack_both else 0, L.stream_ptr()),
+                                L.ptr(nsel_counts), L.ptr(ws), B, H, W,
+                                (PC_HEAD_FWD_PACK_BOTH if pack_both else 0) | (PC_HEAD_FWD_DEFER_REDUCE if defer_reduce else 0), L.stream_ptr()),
             "pc_head_fwd")
     return scale_map, popdense, popcount
 
@@ -628,6 +629,18 @@ def loss_fwd_bwd(popcount, y, stats, lam4, scale_regularization, lam_weak, inv_B
                                     C.c_float(scale_regularization), C.c_float(lam_weak), C.c_float(inv_B),
                                     popcount.numel(), L.ptr(loss_out), L.ptr(g_popcount), L.ptr(g_scale_const),
                                     L.stream_ptr()), "pc_loss_fwd_bwd")
+
+
+def head_popcount_loss(B, H, W, nsel_counts, y, lam4, scale_regularization, lam_weak, inv_B, popcount, stats, loss_out, g_popcount,
+                       g_scale_const):
+    """Finishes a ``head_fwd(..., defer_reduce=True)`` call -- popcount[B] and stats {Nsel, sum scale} from the per-chunk partials in the
+    head workspace -- and computes the loss forward + backward (``loss_fwd_bwd``) in the same single-block launch."""
+    L.require_device(y, popcount)
+    ws = _workspace(L.lib().pc_head_ws_bytes(B, H, W), y.device)
+    L.check(L.lib().pc_head_popcount_loss(L.ptr(ws), B, H, W, L.ptr(nsel_counts), L.ptr(y), (C.c_float * 4)(*lam4),
+                                          C.c_float(scale_regularization), C.c_float(lam_weak), C.c_float(inv_B), L.ptr(popcount),
+                                          L.ptr(stats), L.ptr(loss_out), L.ptr(g_popcount), L.ptr(g_scale_const), L.stream_ptr()),
+            "pc_head_popcount_loss")
 
 
 def grad_norm(flat, norm_out):

@@ -294,17 +294,23 @@ class FusedTrainStep:
             feats, saved = eng_u.forward(X, pt, pl, H + pt + pb, W + pl + pr, save=not unet_no_grad)
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
                                                      admin_mask=s["admin_mask"], census_idx=s["census_idx"],
-                                                     stats=self.stats, nsel_counts=counts, pack_both=True)
-        self._ctx = (feats, saved, building, mask, (pt, pl), (B, H, W))
+                                                     stats=self.stats, nsel_counts=counts, pack_both=True,
+                                                     defer_reduce=not self.reducer.active)
+        # (single process: popcount / stats are finished by the loss launch of _backward; data parallel: here, for the stats all-reduce)
+        self._ctx = (feats, saved, building, mask, (pt, pl), (B, H, W), counts)
         self.last = {"popcount": popcount, "popdensemap": popdense, "scale_map": scale_map, "mask": mask}
 
     def _backward(self, s, encoder_no_grad, unet_no_grad):
         m = self.model
-        feats, saved, building, mask, (pt, pl), (B, H, W) = self._ctx
+        feats, saved, building, mask, (pt, pl), (B, H, W), counts = self._ctx
         g_pc = torch.empty(B, device=self.device, dtype=torch.float32)
         inv_B = 1.0 / self.reducer.global_batch(B)
-        ops.loss_fwd_bwd(self.last["popcount"], s["y"], self.stats, self.lam4, self.sreg, self.lam_weak, inv_B,
-                         self.loss_out, g_pc, self.g_scale_const)
+        if self.reducer.active:
+            ops.loss_fwd_bwd(self.last["popcount"], s["y"], self.stats, self.lam4, self.sreg, self.lam_weak, inv_B,
+                             self.loss_out, g_pc, self.g_scale_const)
+        else:
+            ops.head_popcount_loss(B, H, W, counts, s["y"], self.lam4, self.sreg, self.lam_weak, inv_B, self.last["popcount"], self.stats,
+                                   self.loss_out, g_pc, self.g_scale_const)
         eng_u = m.engines()[0]
         hgrads = [self.grads[n_] for n_ in self.names[-8:]]
         khgrads, fix = m.head_grad_targets(hgrads)

@@ -386,11 +386,6 @@ int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, cons
  * of pc_loss_fwd_bwd in one single-block launch (a single-process training step: one launch less; a data-parallel step all-reduces
  * the stats between the two and keeps the separate calls). */
 #define PC_HEAD_FWD_DEFER_REDUCE 2
-/* PC_HEAD_FWD_PACKED: both weight images are already in ws (pc_head_pack on the same hw / ws / B / H / W / arithmetic mode): pc_head_fwd
- * skips its pack launch.  pc_head_pack depends on the weights only, so a captured training step runs it (and the composition of the
- * Up-block weights) on a side branch of its graph, beside the first layers. */
-#define PC_HEAD_FWD_PACKED 4
-int pc_head_pack(const float* const* hw, void* ws, int B, int H, int W, void* stream);
 int pc_head_popcount_loss(void* ws, int B, int H, int W, const int32_t* nsel_counts, const float* y, const float* lam4,
                           float scale_regularization, float lam_weak, float inv_B, float* popcount, double* stats,
                           float* loss_out, float* g_popcount, float* g_scale_const, void* stream);

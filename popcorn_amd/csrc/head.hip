@@ -2426,30 +2426,15 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     if (p.bf ? !(pc_cl_ok(*feat) && feat->xstride >= 16) : !(feat->dtype == PC_F32 && pc_planar(*feat))) return PC_EINVAL;
     void* img = head_image_slot(ws, B, H, W, 0);
     p.wimage = img;
-    if (!(flags & PC_HEAD_FWD_PACKED)) {
-        const bool both = (flags & PC_HEAD_FWD_PACK_BOTH) != 0;
-        hipLaunchKernelGGL(head_pack_kernel, dim3(both ? 16 : 8), dim3(256), 0, st, p, img, p.bf ? 2 : 0, head_image_slot(ws, B, H, W, 1));
-        PC_CHECK_LAUNCH();
-    }
+    const bool both = (flags & PC_HEAD_FWD_PACK_BOTH) != 0;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(both ? 16 : 8), dim3(256), 0, st, p, img, p.bf ? 2 : 0, head_image_slot(ws, B, H, W, 1));
+    PC_CHECK_LAUNCH();
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     if (flags & PC_HEAD_FWD_DEFER_REDUCE) return 0;               // pc_head_popcount_loss finishes popcount / stats (and the loss)
     hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
                        p.nchunk, stats, nsel_counts, (double)B * H * W);
-    PC_CHECK_LAUNCH();
-    return 0;
-}
-
-// the pack launch of pc_head_fwd / pc_head_bwd on its own (both images of the current arithmetic mode): it depends on the weights only,
-// so a training step can run it on a side branch of its graph, off the critical path
-extern "C" int pc_head_pack(const float* const* hw, void* ws, int B, int H, int W, void* stream) {
-    if (!hw || !ws) return PC_EINVAL;
-    HeadArgs p{};
-    p.w0 = hw[0]; p.b0 = hw[1]; p.w2 = hw[2]; p.b2 = hw[3]; p.w4 = hw[4]; p.b4 = hw[5]; p.w6 = hw[6]; p.b6 = hw[7];
-    p.bf = g_pc_precision == PC_PREC_BF16;
-    hipLaunchKernelGGL(head_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, head_image_slot(ws, B, H, W, 0), p.bf ? 2 : 0,
-                       head_image_slot(ws, B, H, W, 1));
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -477,26 +477,7 @@ def stream_channel_order(streams):
     return [c for _, chmap, cin, _ in streams for c in chmap[:cin]]
 
 
-def up_compose_problems(engines, saves, Hp, Wp):
-    """The composed-Up operand images forward_multi would build for this geometry (fp32 mode, both levels composed): the problem list for
-    ops.conv3x3_up_compose and the keys its results belong to -- or None.  They depend on the WEIGHTS only, so a captured training step
-    launches the composition on a side branch of its graph (train.py) and hands the result in (``precomp``)."""
-    if L.act_dtype() != torch.float32 or not (COMPOSED_UP and FUSED_CONV_BWD):
-        return None
-    H1, W1 = Hp // 2, Wp // 2
-    H2, W2 = H1 // 2, W1 // 2
-    fwd_only = not any(saves)
-    c2 = (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and (W1 in (64, 128) or fwd_only)
-    c1 = (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and (Wp in (64, 128) or fwd_only)
-    keys = [(e, s) for e in range(len(engines)) for s, _, _, _ in engines[0].streams]
-    if not (c1 and c2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP):
-        return None
-    lst = [("up2a", "up2t", k) for k in keys] + [("up1a", "up1t", k) for k in keys]
-    lyr = lambda k, t: engines[k[0]].layers[(k[1], t)]  # noqa: E731
-    return lst, [{"w": lyr(k, t).w, "wt": lyr(k, tt).w, "bt": lyr(k, tt).b} for t, tt, k in lst]
-
-
-def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None, logit_only=None, Xp_all=None, precomp=None, join=None):
+def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None, logit_only=None, Xp_all=None):
     """Forward of several DualStreamUNets (e.g. the frozen building extractor and the trainable U-Net) on the same
     input and geometry, layer by layer, with ONE launch per layer for all (network, stream) pairs: 4x fewer
     launches than per-stream execution and 4x more workgroups per launch on the 32x32 layers.
@@ -509,9 +490,7 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     16-channel map when the geometry does not qualify.
 
     Xp_all (fp32 mode): the already padded, normalised, channel-gathered input (B, sum of stream channels in stream order, Hp, Wp)
-    as ``ops.select_normalize_pad`` writes it from a raw tile -- X may then be None (nothing reads the unpadded input).
-    precomp / join: composed-Up operand images launched by the caller on a side branch (``up_compose_problems``) and the callable that
-    joins that branch; called once, right before the first launch that reads them."""
+    as ``ops.select_normalize_pad`` writes it from a raw tile -- X may then be None (nothing reads the unpadded input)."""
     bf = L.act_dtype() == torch.bfloat16
     if Xp_all is not None:
         L.require_device(Xp_all)
@@ -657,13 +636,12 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         (W1 in (64, 128) or fwd_only)
     compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and \
         (Wp in (64, 128) or fwd_only)
-    if precomp is None:
-        precomp = {}
-        if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
-            # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)
-            lst = [("up2a", "up2t", k) for k in keys] + [("up1a", "up1t", k) for k in keys]
-            wss = ops.conv3x3_up_compose([{"w": ly(k, t).w, "wt": ly(k, tt).w, "bt": ly(k, tt).b} for t, tt, k in lst])
-            precomp = {(t, k): w_ for (t, tt, k), w_ in zip(lst, wss)}
+    precomp = {}
+    if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
+        # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)
+        lst = [("up2a", "up2t", k) for k in keys] + [("up1a", "up1t", k) for k in keys]
+        wss = ops.conv3x3_up_compose([{"w": ly(k, t).w, "wt": ly(k, tt).w, "bt": ly(k, tt).b} for t, tt, k in lst])
+        precomp = {(t, k): w_ for (t, tt, k), w_ in zip(lst, wss)}
     u2 = None
     if FUSED_LEVEL2 and pb2 and (H2, W2) == (32, 32):           # (both arithmetic modes: level2.hip / level2_cl.hip)
         # whole-tile residency: one workgroup per (tile, network-stream) runs down2's two convs and up2's transposed conv with
@@ -682,8 +660,6 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         c2 = conv("d2b", c1, 16, H2, W2)
         u2 = {k: None for k in keys}
     o2 = ((H1 - 2 * H2) // 2, (W1 - 2 * W2) // 2)
-    if join is not None:
-        join()                      # the side branch that produced ``precomp`` (and whatever else the caller put on it) meets here
     r = up_conv("up2a", "up2t", b2, c2, 8, H1, W1) if compose2 else None
     ws_up2 = {}
     if r is None:

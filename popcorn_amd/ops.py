@@ -234,24 +234,18 @@ def conv3x3_up_fwd_ok(skip, z, out):
     return bool(L.lib().pc_conv3x3_up_fwd_ok(C.byref(ss), C.byref(sz), C.byref(do), H, W, Cs, z.shape[1]))
 
 
-def conv3x3_up_compose_slots(problems):
-    """The workspace tensors conv3x3_up_compose fills (one per problem), allocated on the CURRENT stream."""
-    dev = problems[0]["w"].device
-    return [torch.empty(int(L.lib().pc_conv3x3_up_ws_bytes(pr["wt"].shape[0])), dtype=torch.uint8, device=dev) for pr in problems]
-
-
-def conv3x3_up_compose(problems, slots=None):
+def conv3x3_up_compose(problems):
     """Composed operand images for a list (<= 8) of Up-block convolutions {w, wt, bt} (any mix of the 8 + 8 and 16 + 16 channel
-    shapes) in ONE launch.  Returns one workspace tensor per problem (pass it as ``ws`` to conv3x3_up_fwd_group).  slots: tensors from
-    conv3x3_up_compose_slots (a caller that launches this on a side stream allocates them on its main stream first)."""
+    shapes) in ONE launch.  Returns one workspace tensor per problem (pass it as ``ws`` to conv3x3_up_fwd_group)."""
     n = len(problems)
     assert 1 <= n <= 2 * L.PC_MAX_GROUP
+    dev = problems[0]["w"].device
     descs = (L.PcConvUpFwdDesc * n)()
-    cs, cz = (C.c_int * n)(), (C.c_int * n)()
-    slots = slots if slots is not None else conv3x3_up_compose_slots(problems)
+    cs, cz, slots = (C.c_int * n)(), (C.c_int * n)(), []
     for i, pr in enumerate(problems):
         Cz = pr["wt"].shape[0]
         cs[i], cz[i] = pr["w"].shape[1] - Cz, Cz
+        slots.append(torch.empty(int(L.lib().pc_conv3x3_up_ws_bytes(Cz)), dtype=torch.uint8, device=dev))
         descs[i].w, descs[i].wt = pr["w"].data_ptr(), pr["wt"].data_ptr()
         descs[i].bt = pr["bt"].data_ptr() if pr.get("bt") is not None else None
         descs[i].ws = slots[i].data_ptr()
@@ -466,11 +460,11 @@ def _hw_array(head_tensors):
     return arr
 
 
-PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED, PC_HEAD_FWD_DEFER_REDUCE, PC_HEAD_FWD_PACKED = 1, 1, 2, 4
+PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED, PC_HEAD_FWD_DEFER_REDUCE = 1, 1, 2
 
 
 def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
-             want_scale=True, stats=None, nsel_counts=None, pack_both=False, defer_reduce=False, packed=False):
+             want_scale=True, stats=None, nsel_counts=None, pack_both=False, defer_reduce=False):
     """Sparse/dense head + occupancy product + census reduction.  popcorn.py:161-190.
     head_tensors = [w0,b0,w2,b2,w4,b4,w6,b6].  Returns (scale_map, popdensemap, popcount)."""
     L.require_device(feat, building, *head_tensors)
@@ -485,8 +479,7 @@ def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
     L.check(L.lib().pc_head_fwd(C.byref(sf), py, px, hw, L.ptr(mask), L.ptr(building), L.ptr(admin_mask),
                                 L.ptr(census_idx), L.ptr(scale_map), L.ptr(popdense), L.ptr(popcount), L.ptr(stats),
                                 L.ptr(nsel_counts), L.ptr(ws), B, H, W,
-                                (PC_HEAD_FWD_PACK_BOTH if pack_both else 0) | (PC_HEAD_FWD_DEFER_REDUCE if defer_reduce else 0) |
-                                (PC_HEAD_FWD_PACKED if packed else 0), L.stream_ptr()),
+                                (PC_HEAD_FWD_PACK_BOTH if pack_both else 0) | (PC_HEAD_FWD_DEFER_REDUCE if defer_reduce else 0), L.stream_ptr()),
             "pc_head_fwd")
     return scale_map, popdense, popcount
 
@@ -636,13 +629,6 @@ def loss_fwd_bwd(popcount, y, stats, lam4, scale_regularization, lam_weak, inv_B
                                     C.c_float(scale_regularization), C.c_float(lam_weak), C.c_float(inv_B),
                                     popcount.numel(), L.ptr(loss_out), L.ptr(g_popcount), L.ptr(g_scale_const),
                                     L.stream_ptr()), "pc_loss_fwd_bwd")
-
-
-def head_pack(head_tensors, B, H, W, device):
-    """Both weight images of the head kernels (forward + backward, current arithmetic mode) into the head workspace: the launch
-    ``head_fwd(..., packed=True)`` / ``head_bwd(..., packed=True)`` then skip.  Depends on the weights only."""
-    ws = _workspace(L.lib().pc_head_ws_bytes(B, H, W), device)
-    L.check(L.lib().pc_head_pack(_hw_array(head_tensors), L.ptr(ws), B, H, W, L.stream_ptr()), "pc_head_pack")
 
 
 def head_popcount_loss(B, H, W, nsel_counts, y, lam4, scale_regularization, lam_weak, inv_B, popcount, stats, loss_out, g_popcount,

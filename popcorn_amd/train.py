@@ -47,9 +47,6 @@ def data_keys(sample):
     raise KeyError("sample needs 'input', 'raw' or 'raw_s2' + 'raw_s1'")
 
 
-# captured steps: head weight images + Up-weight composition on a side branch of the graph (POPCORN_SIDE_PROLOGUE=0: in line; A/B switch)
-SIDE_PROLOGUE = os.environ.get("POPCORN_SIDE_PROLOGUE", "1") != "0"
-
 LOSS_INDEX = {"l1_loss": 0, "log_l1_loss": 1, "mse_loss": 2, "log_mse_loss": 3}
 HEAD_NO_DECAY = ("head.6.weight", "head.6.bias")        # run_train.py:82
 
@@ -127,7 +124,6 @@ class FusedTrainStep:
         self._graph_cache_max = max(1, int(graph_cache_max if graph_cache_max is not None      # alternating truncation regimes)
                                            else os.environ.get("POPCORN_GRAPH_CACHE_MAX", "6")))  # replay instead of being re-captured
         self._static = None
-        self._side = None               # side stream of the captured step's weight-only prologue branch
         self._sel_ring, self._sel_next = [], 0          # pinned host slots for the per-step selection grid (H2D without a host sync)
         self.last = {}
 
@@ -236,7 +232,6 @@ class FusedTrainStep:
     def _forward(self, s, sel, encoder_no_grad, unet_no_grad):
         m = self.model
         dk = data_keys(s)
-        packed = False                                         # (the head's weight images were assembled on the side branch)
         raw = s.get("raw") if dk == ("raw",) else None
         B, _, H, W = s[dk[0]].shape
         eng_u, eng_b = m.engines()
@@ -285,28 +280,8 @@ class FusedTrainStep:
             mask, counts = ops.sparsity_mask(building, s["admin_mask"], s["census_idx"], sel[:H], sel[H:], m.occupancymodel)
             (feats,), (saved,) = E.forward_multi([eng_u], X, pt, pl, H + pt + pb, W + pl + pr, [not unet_no_grad], Xp_all=Xp_all)
         elif fused:
-            # Weight-only prologue work -- the head's two weight images, the composition of the Up-block weights (fp32) -- on a SIDE
-            # BRANCH of the captured graph, beside the ingest and the first layers instead of in front of their consumers (under capture
-            # only: in eager mode the extra stream events cost more host time than the two small launches)
-            precomp = join = None
-            if SIDE_PROLOGUE and torch.cuda.is_current_stream_capturing():
-                cur = torch.cuda.current_stream()
-                if self._side is None:
-                    self._side = torch.cuda.Stream()
-                cp = E.up_compose_problems([eng_b, eng_u], [False, not unet_no_grad], H + pt + pb, W + pl + pr)
-                slots = ops.conv3x3_up_compose_slots(cp[1]) if cp is not None else None        # (allocated on the main stream)
-                ops._workspace(L.lib().pc_head_ws_bytes(B, H, W), self.device)
-                self._side.wait_stream(cur)
-                with torch.cuda.stream(self._side):
-                    ops.head_pack(m.head_tensors(), B, H, W, self.device)
-                    if cp is not None:
-                        ops.conv3x3_up_compose(cp[1], slots=slots)
-                        precomp = {(t, k): w_ for (t, tt, k), w_ in zip(cp[0], slots)}
-                packed = True
-                join = lambda: cur.wait_stream(self._side)  # noqa: E731
             (f_b, feats), (_, saved) = E.forward_multi([eng_b, eng_u], X, pt, pl, H + pt + pb, W + pl + pr,
-                                                       [False, not unet_no_grad], logit_only=[True, False], Xp_all=Xp_all,
-                                                       precomp=precomp, join=join)
+                                                       [False, not unet_no_grad], logit_only=[True, False], Xp_all=Xp_all)
             building, mask, counts = eng_b.score_and_mask(f_b, H, W, pt, pl, s["admin_mask"], s["census_idx"], sel[:H],
                                                           sel[H:], m.occupancymodel)
         else:
@@ -320,7 +295,7 @@ class FusedTrainStep:
         scale_map, popdense, popcount = ops.head_fwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask,
                                                      admin_mask=s["admin_mask"], census_idx=s["census_idx"],
                                                      stats=self.stats, nsel_counts=counts, pack_both=True,
-                                                     defer_reduce=not self.reducer.active, packed=packed)
+                                                     defer_reduce=not self.reducer.active)
         # (single process: popcount / stats are finished by the loss launch of _backward; data parallel: here, for the stats all-reduce)
         self._ctx = (feats, saved, building, mask, (pt, pl), (B, H, W), counts)
         self.last = {"popcount": popcount, "popdensemap": popdense, "scale_map": scale_map, "mask": mask}

@@ -32,10 +32,21 @@ def _check_line(d, extras):
 
 
 def test_committed_final_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_final.json")))
     _check_line(d, extras=True)
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32"
     assert d["value"] >= 36300.0                          # >= 36.3 k patches/s (step <= 1.76 ms)
+    # round 4: the metric's second half and the other configurations ride on the same line
+    fp = d["fwd_parity"]
+    assert fp["ok"] is True and fp["max_rel"] <= 1e-4 and {"popdensemap", "popcount", "scale"} <= set(fp)
+    assert d["config5"]["windows_per_s"] > 0 and d["config5"]["finite"] is True
+    c3 = d["config3_regions"]
+    assert len(c3["batches"]) >= 6 and max(b["Mpx"] for b in c3["batches"]) > 9.0 and {"all", "head only"} <= {b["regime"] for b in c3["batches"]}
+    r = d["roofline"]
+    assert r["rocprof_us"] and r["rocprof_file"].startswith("r") and abs(r["rocprof_frac"] - r["alg_flop_per_launch"] / (r["rocprof_us"] * 1e-6) / 157.3e12) < 2e-3
+    assert d["h2d"]["h2d_gbps_needed_8_ranks"] > 0 and d["h2d"]["host_pinned_gbps_measured"] > 0 and len(d["h2d"]["legs"]) == 3
+    b = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_final_bf16.json")))
+    assert b["dtype"].startswith("bf16") and b["value"] > 1.9 * d["value"]
 
 
 @pytest.mark.gpu

@@ -11,13 +11,18 @@ s1 = b["raw"][:, b6[4:]].contiguous()
 raw6 = b["raw"][:, b6].contiguous()
 order = [4, 5, 2, 1, 0, 3]
 mean = [stats.MEAN6[c] for c in order]; std = [stats.STD6[c] for c in order]
-def t(fn, n=200):
-    for _ in range(10): fn()
+def t(fn, n=50):
+    """device time per launch: n launches back to back inside one replayed graph (eager calls are host-bound at ~12 us)"""
+    for _ in range(3): fn()
     torch.cuda.synchronize()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n): fn()
+    torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
+    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 print("select_normalize_pad 15-band", t(lambda: ops.select_normalize_pad(b["raw"], [stats.BAND6[c] for c in order], mean, std, 14, 14, 14, 14)))
 print("select_normalize_pad 6-band", t(lambda: ops.select_normalize_pad(raw6, order, mean, std, 14, 14, 14, 14)))

@@ -166,8 +166,11 @@ __device__ __forceinline__ void head_frag0(const float* lds, int off, int stride
 }
 // ReLU in ONE instruction (fmaxf on a value the compiler cannot prove canonical costs a canonicalising v_max x, x in front)
 __device__ __forceinline__ void relu_block(f32x4& h) {
+    // as a signed-integer maximum with 0 (the order of non-negative floats is the order of their bit patterns; anything with the sign
+    // bit, -0 included, is a negative integer): fmaxf() -- and v_med3(x, 0, inf), which hipcc folds back into it -- costs a
+    // canonicalising v_max x, x in front of the v_max.  +NaN passes through (the reference's ReLU propagates NaN as well).
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+    for (int r = 0; r < 4; ++r) h[r] = __int_as_float(max(__float_as_int(h[r]), 0));
 }
 __device__ __forceinline__ void mask_block(f32x4& g, const f32x4& h) {
 #pragma unroll
@@ -194,6 +197,19 @@ __device__ __forceinline__ void head_bias4(const float* lds, int b_off, int lk, 
     for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
 }
 
+// v + v of lane ^ 16 (lane ^ 32) in every lane, on the VALU: v_permlane16_swap exchanges the odd 16-lane rows of its first operand
+// with the even rows of its second (v_permlane32_swap: the upper half with the lower half), so with both operands = v the two results
+// hold the partner pair of every row.  (__shfl_xor is a ds_bpermute: an LDS round trip, twice in a row on the producer's critical path.)
+__device__ __forceinline__ float xor16_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop4_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -232,6 +248,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     bool sel_n = false;
     float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
     if (g_begin < g_end) fetch(g_begin, sel_n, xv_n);
+    f32x4 w6f[4];                  // the last layer's row and bias stay in registers (as in the backward's producer waves)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lds[L_W6 + 16 * mb + 4 * lk]);
+    const float b6v = lds[L_W6 + 64];
     for (int g = g_begin; g < g_end; ++g) {
         const int q = g * 16 + li;
         const bool valid = q < HW;
@@ -256,18 +276,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
             relu_block(acc[0]);
             head_mm64_pf(lds, L_A3, lane, acc, h3, fb, L_W6, 0, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(acc[(st >> 2) + 1]); });
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) h[mb] = h3[mb];
-            relu4(h);
+            for (int mb = 0; mb < 4; ++mb) relu_block(h3[mb]);
             float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[L_W6 + 16 * mb + 4 * lk]);
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(w[r], h[mb][r], s);
-            }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            outv = sel ? s + lds[L_W6 + 64] : 0.f;
+                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
+            s = xor16_sum(s);
+            s = xor32_sum(s);
+            outv = sel ? s + b6v : 0.f;
         }
         if (valid && lk == 0) {
             // NaN-propagating ReLU like torch's (v_max_f32 returns the non-NaN operand): a NaN head output must reach the
@@ -705,6 +722,8 @@ constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is sha
 constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
 constexpr int LP_END = LP_FLAGS + 16;
 
+template <int DBG>        // ablation builds (tools/ablate_head.py): 1 consumer idle, 2 no hand-off; 0 = the product kernel (as run-time flags the
+                          // two switches put a branch around every ring write of the producer: 14 extra basic blocks in its group loop)
 __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const HeadArgs& p = a.f;
@@ -846,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             for (int st = 0; st < 5; ++st) fetch_stage(st, gg);
         };
         const int gstep = gridDim.x * 4;
-        const bool handoff = !(a.dbg & 2);
+        constexpr bool handoff = !(DBG & 2);
         // Slot matrices are stored as the producer HOLDS them (D layout: lane (pixel li, lk), register block mb = rows 16 mb + 4 lk
         // + r): one 16-byte write per block, [mb][lk][PC_LKS] floats with the lane's 4 values at li * 4 -- the consumer does the
         // transposing reads.  (The first form scattered every element into a [row][pixel] matrix: 32 ds_write_b32 per slot on the
@@ -857,6 +876,16 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             *reinterpret_cast<f32x4*>(&sl[mb * PC_MBS + sbase]) = G[mb];
             *reinterpret_cast<f32x4*>(&sl[PC_MAT + mb * PC_MBS + sbase]) = Hm[mb];
         };
+        // the last layer's row (this lane's 16 hidden units) and bias stay in registers: read at their point of use they are 9 LDS round
+        // trips per group in a stretch with no matrix instruction to hide them
+        f32x4 w6f[4], a1f[4], b0f[4];         // (and the first layer's fragments + bias: the group loop started with their round trip)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            w6f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+            a1f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_A1 + (mb * 64 + lane) * 4]);
+            b0f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_B0 + 16 * mb + 4 * lk]);
+        }
+        const float b6v = lds[LB_W6 + 64];
         int gg = blockIdx.x * 4 + wv;
         if (gg < a.total_groups) fetch(gg);
         for (; gg < a.total_groups; gg += gstep) {
@@ -891,43 +920,47 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             // ReLU of ONE block, not an LDS round trip + 16-32 VALU instructions with the matrix pipe idle.
             f32x4 h1[4], h2[4], h3[4], fa[4], fb[4];
             head_frag0(lds, LB_A2, 4, lane, fa);
-            head_layer1_il(lds, LB_A1, LB_B0, lane, lk, xv, h1);
-            head_bias4(lds, LB_B2, lk, h2);
+            head_bias4(lds, LB_B2, lk, h2);          // (in flight during the first layer: the scheduling barriers below keep it up here)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) h1[mb] = b0f[mb];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) h1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[mb][j], xv[j], h1[mb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             relu_block(h1[0]);
             head_mm64_pf(lds, LB_A2, lane, h1, h2, fa, LB_A3, 4, fb, [&](int st) {
                 if (!(st & 3) && st < 12) relu_block(h1[(st >> 2) + 1]);
                 if ((st & 1) && st < 10) fetch_stage(st >> 1, gnx);
+                if (st == 12) head_bias4(lds, LB_B4, lk, h3);
             });
-            head_bias4(lds, LB_B4, lk, h3);
             relu_block(h2[0]);
             head_mm64_pf(lds, LB_A3, lane, h2, h3, fb, LB_T3, 4, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(h2[(st >> 2) + 1]); });
-            relu4(h3);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) relu_block(h3[mb]);
             HP_MARK(1);
             const int c_early0 = *cons_p;
             float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
-            }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const float outv = s + lds[LB_W6 + 64];
+                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
+            s = xor16_sum(s);
+            s = xor32_sum(s);
+            const float outv = s + b6v;
             const float gout = (sel && outv > 0.f) ? gup : 0.f;
             if (!__any(gout != 0.f)) { store_zero(); continue; }
 
             f32x4 g3[4], g2[4], g1[4];
             if (lk == 0) db6 += gout;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                    g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                    g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
                 }
-            }
             HP_MARK(2);
             // The three hand-offs (slot kind 0: (G3, H2) -> dW4, db4; 1: (G2, H1) -> dW2, db2; 2: (G1, X) -> dW0, db0) are written
             // one element pair per K-step in the shadow of the NEXT contraction's MFMAs -- as a block in front of it, the 32 scattered
@@ -1061,7 +1094,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
         while (wait_slot()) {
             f32x4 af[4], bf[4];
             take(af, bf, false);                                             // (G3, H2) -> dW4, db4
-            if (a.dbg & 1) { wait_slot(); take(af, bf, false); wait_slot(); take(af, bf, true); continue; }
+            if (DBG & 1) { wait_slot(); take(af, bf, false); wait_slot(); take(af, bf, true); continue; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) dbs[2][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
 #pragma unroll
@@ -2638,9 +2671,11 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_pc_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
-        if (e2 != hipSuccess) return (int)e2;
+        for (const void* f : {reinterpret_cast<const void*>(&head_bwd_pc_kernel<0>), reinterpret_cast<const void*>(&head_bwd_pc_kernel<1>),
+                              reinterpret_cast<const void*>(&head_bwd_pc_kernel<2>)}) {
+            e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
+            if (e2 != hipSuccess) return (int)e2;
+        }
         once.mark();
     }
     {
@@ -2669,20 +2704,24 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         if (nwg < 1) nwg = 1;
         hipLaunchKernelGGL(head_bwd_bf16_coop4_kernel, dim3(nwg), dim3(256), H4_END, st, a);
     }
-    else if (use_pc) hipLaunchKernelGGL(head_bwd_pc_kernel, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+    else if (use_pc) {
+        if (a.dbg == 1) hipLaunchKernelGGL(head_bwd_pc_kernel<1>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+        else if (a.dbg == 2) hipLaunchKernelGGL(head_bwd_pc_kernel<2>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+        else hipLaunchKernelGGL(head_bwd_pc_kernel<0>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
 #ifdef POPCORN_HEAD_PROF
-    if (use_pc && !p.bf && getenv("POPCORN_HEAD_PROF")) {
-        static long long hp[256 * 16];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_head_prof), sizeof(hp));
-        double tot[10] = {0};
-        for (int w = 0; w < nwg; ++w) for (int k = 0; k < 10; ++k) tot[k] += (double)hp[w * 16 + k];
-        const double ngr = (double)a.total_groups / (nwg * 4);
-        fprintf(stderr, "head_bwd_pc producer phases, cycles per group (fwd, out+g3, slot0, dgrad3, slot1, dgrad2, slot2, gx+store, loop top; of which ring waits):");
-        for (int k = 0; k < 10; ++k) fprintf(stderr, " %.0f", tot[k] / nwg / ngr);
-        fprintf(stderr, "\n");
-    }
+        if (getenv("POPCORN_HEAD_PROF")) {
+            static long long hp[256 * 16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_head_prof), sizeof(hp));
+            double tot[10] = {0};
+            for (int w = 0; w < nwg; ++w) for (int k = 0; k < 10; ++k) tot[k] += (double)hp[w * 16 + k];
+            const double ngr = (double)a.total_groups / (nwg * 4);
+            fprintf(stderr, "head_bwd_pc producer phases, cycles per group (fwd, out+g3, slot0, dgrad3, slot1, dgrad2, slot2, gx+store, loop top; of which ring waits):");
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %.0f", tot[k] / nwg / ngr);
+            fprintf(stderr, "\n");
+        }
 #endif
+    }
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
     HeadReduceArgs r{};

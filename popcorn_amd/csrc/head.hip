@@ -1290,10 +1290,10 @@ __device__ __forceinline__ void hb_layer64(const unsigned char* lds, int a_off, 
     }
 }
 
-// ReLU of an MFMA result in ONE instruction: fmaxf() on a value the compiler cannot prove canonical costs a second v_max (x, x)
-// in front; v_med3_f32(x, 0, +inf) needs none.  (Not inline asm: the compiler does not place the MFMA-result hazard wait in front
-// of an asm statement -- measured: non-deterministic losses.)
-__device__ __forceinline__ float hb_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// ReLU of an MFMA result in ONE instruction: the signed-integer maximum with 0 (see relu_block; fmaxf() -- and v_med3(x, 0, inf),
+// which hipcc folds back into it -- costs a canonicalising v_max x, x in front).  (Not inline asm: the compiler does not place
+// the MFMA-result hazard wait in front of an asm statement -- measured: non-deterministic losses.)
+__device__ __forceinline__ float hb_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ void hb_relu4(f32x4 (&h)[4]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -1319,6 +1319,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    f32x4 w6f[4];                  // the last layer's (rounded) row and bias stay in registers
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+    const float b6v = lf[256];
     const int b = blockIdx.y;
     const int HW = p.H * p.W;
     const float cid = p.census ? (float)p.census[b] : 0.f;
@@ -1376,14 +1380,12 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
             hb_relu_round(h);
             float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(w[r], h[mb][r], s);
-            }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            outv = sel ? s + lf[256] : 0.f;
+                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h[mb][r], s);
+            s = xor16_sum(s);
+            s = xor32_sum(s);
+            outv = sel ? s + b6v : 0.f;
         }
         if (valid && lk == 0) {
             const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);
@@ -1449,6 +1451,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     __syncthreads();
     const float* lf = reinterpret_cast<const float*>(ldsb + HB_F32);
     float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
+    f32x4 w6f[4];                  // the last layer's (rounded) row and bias stay in registers
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+    const float b6v = lf[256];
     const int HW = p.H * p.W;
 
     if (a.zero_in_kernel) {
@@ -1596,14 +1602,12 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 }
                 float s = 0.f;
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+                for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(w[r], h3[mb][r], s);
-                }
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                const float outv = s + lf[256];
+                    for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
+                s = xor16_sum(s);
+                s = xor32_sum(s);
+                const float outv = s + b6v;
                 gout = (sel && outv > 0.f) ? gup : 0.f;
                 active = __any(gout != 0.f);
             }
@@ -1614,14 +1618,12 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 {
                     f32x4 g3[4];
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+                    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                            g3[mb][r] = h3[mb][r] > 0.f ? w[r] * gout : 0.f;
+                            g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
                         }
-                    }
                     gb3[0] = hb_pack8(g3[0], g3[1]); gb3[1] = hb_pack8(g3[2], g3[3]);
                 }
                 {

@@ -188,6 +188,40 @@ __device__ __forceinline__ f32x4 pc_fetch_reflect_seg(const pc_src& s, int b, in
     return v;
 }
 
+// ---- cross-lane exchanges on the VALU -----------------------------------------------------------------------------------------------
+// hipcc lowers EVERY __shfl_xor to ds_bpermute_b32 -- a trip through the LDS crossbar with its own lgkmcnt wait (192 of them per strip
+// pair in the fp32 1x1-dot epilogue) -- although lane ^ 1, ^ 2, ^ 8 are DPP controls (quad_perm, row_ror:8) and lane ^ 16 / ^ 32 are
+// gfx950's v_permlane16_swap / v_permlane32_swap.  All lanes of the 16-lane row (of the wave, for the swaps) must be active.
+template <int CTRL>
+__device__ __forceinline__ float pc_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float pc_lane_xor1(float x) { return pc_dpp<0xB1>(x); }      // quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float pc_lane_xor2(float x) { return pc_dpp<0x4E>(x); }      // quad_perm [2, 3, 0, 1]
+__device__ __forceinline__ float pc_lane_xor8(float x) { return pc_dpp<0x128>(x); }     // row_ror:8
+// sum over the 8 lanes that share lane >> 3, in every lane, in the association order of the xor-1, -2, -4 butterfly (after the two quad
+// steps the four lanes of a quad hold the same bits, so the mirror image within the half row IS the lane ^ 4 partner's value)
+__device__ __forceinline__ float pc_sum8(float x) {
+    x += pc_lane_xor1(x);
+    x += pc_lane_xor2(x);
+    x += pc_dpp<0x141>(x);                                                              // row_half_mirror
+    return x;
+}
+// v + v of lane ^ 16 (lane ^ 32) in every lane: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows
+// of its second (v_permlane32_swap: the upper half with the lower half), so with both operands = v the two results hold the partner
+// pair of every row
+__device__ __forceinline__ float pc_xor16_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pc_xor32_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+
 // ---- loss forward + backward for one block of 256 threads (train_ops.hip: pc_loss_fwd_bwd; head.hip: pc_head_popcount_loss) ------------
 // loss = sum_k lam[k] * L_k(popcount, y) + sreg * sum(scale) / Nsel, with L_k in {l1, log_l1, mse, log_mse} taken as a mean over the GLOBAL
 // batch (inv_B = 1 / (world * B)); outputs d(lam_weak * loss) / d popcount[b] and the constant d(lam_weak * loss) / d scale on selected pixels.

@@ -634,11 +634,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                         f32x4 t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float x = v[r] * wl;
-                            x += __shfl_xor(x, 1);
-                            x += __shfl_xor(x, 2);
-                            x += __shfl_xor(x, 4);
-                            t[r] = x;
+                            t[r] = pc_sum8(__fmul_rn(v[r], wl));      // (rounded product: as `v * wl + dpp(..)` the first step contracts into an fma)
                         }
                         if (col == 0)
                             *reinterpret_cast<f32x4*>(q.dot_out.ptr + eb * q.dot_out.bstride +
@@ -649,8 +645,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
                     if (EPI == EPI_POOL && MODE == MODE_FWD && q.pool_out.ptr) {
                         // MaxPool2d(2): the x pairs are in the lane, the row pair (s_row 0 / 1) sits 8 lanes apart
                         float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
-                        m0 = fmaxf(m0, __shfl_xor(m0, 8));
-                        m1 = fmaxf(m1, __shfl_xor(m1, 8));
+                        m0 = fmaxf(m0, pc_lane_xor8(m0));
+                        m1 = fmaxf(m1, pc_lane_xor8(m1));
                         if (s_row == 0) {
                             act_t* pp = reinterpret_cast<act_t*>(q.pool_out.ptr) + eb * q.pool_out.bstride + (nb * 8 + col) * q.pool_out.cstride +
                                         (int64_t)((ey0 >> 1) + (u >> 1)) * q.pool_out.rstride + (ex0 >> 1) + (xu(u) >> 1);
@@ -678,10 +674,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float o = v[r] * e_scale[nb] + e_shift[nb];
-                            float t = (p.relu ? fmaxf(o, 0.f) : o) * wl;
-                            t += __shfl_xor(t, 1);
-                            t += __shfl_xor(t, 2);
-                            t += __shfl_xor(t, 4);
+                            float t = __fmul_rn(p.relu ? fmaxf(o, 0.f) : o, wl);
+                            t = pc_sum8(t);
                             if (col == 0 && x + r < p.W) dp[r] = t;
                         }
                         continue;
@@ -1210,7 +1204,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
                     }
                 }
                 if (EPI == EPI_DOT && q.dot_w) {
-                    dsum += __shfl_xor(dsum, 16);          // the other four channels of the pixel
+                    dsum = pc_xor16_sum(dsum);             // the other four channels of the pixel
                     if ((lk & 1) == 0 && ok)
                         q.dot_out.ptr[eb * q.dot_out.bstride + (int64_t)y * q.dot_out.rstride + x] = dsum;
                 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
             const f32x4 mine = acc[nb];
             f32x4 other;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(mine[r], 1);
+            for (int r = 0; r < 4; ++r) other[r] = pc_lane_xor1(mine[r]);
             // bb = 0 writes x = 2*jb + {0,1,2,3} (pixels r = 0,1); bb = 1 writes x = 2*jb + {4,5,6,7} (pixels r = 2,3)
             const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
             const int jb = j0 + 4 * lk;

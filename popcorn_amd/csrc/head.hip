@@ -197,19 +197,6 @@ __device__ __forceinline__ void head_bias4(const float* lds, int b_off, int lk, 
     for (int mb2 = 0; mb2 < 4; ++mb2) acc[mb2] = *reinterpret_cast<const f32x4*>(&lds[b_off + 16 * mb2 + 4 * lk]);
 }
 
-// v + v of lane ^ 16 (lane ^ 32) in every lane, on the VALU: v_permlane16_swap exchanges the odd 16-lane rows of its first operand
-// with the even rows of its second (v_permlane32_swap: the upper half with the lower half), so with both operands = v the two results
-// hold the partner pair of every row.  (__shfl_xor is a ds_bpermute: an LDS round trip, twice in a row on the producer's critical path.)
-__device__ __forceinline__ float xor16_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor32_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 // fp32 kernels; PC_PREC_BF16 has its own (head_fwd_bf16_kernel / head_bwd_bf16_coop4_kernel below, channels-last bf16 feature map)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -282,8 +269,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
-            s = xor16_sum(s);
-            s = xor32_sum(s);
+            s = pc_xor16_sum(s);
+            s = pc_xor32_sum(s);
             outv = sel ? s + b6v : 0.f;
         }
         if (valid && lk == 0) {
@@ -946,8 +933,8 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
-            s = xor16_sum(s);
-            s = xor32_sum(s);
+            s = pc_xor16_sum(s);
+            s = pc_xor32_sum(s);
             const float outv = s + b6v;
             const float gout = (sel && outv > 0.f) ? gup : 0.f;
             if (!__any(gout != 0.f)) { store_zero(); continue; }
@@ -1383,8 +1370,8 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h[mb][r], s);
-            s = xor16_sum(s);
-            s = xor32_sum(s);
+            s = pc_xor16_sum(s);
+            s = pc_xor32_sum(s);
             outv = sel ? s + b6v : 0.f;
         }
         if (valid && lk == 0) {
@@ -1605,8 +1592,8 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
-                s = xor16_sum(s);
-                s = xor32_sum(s);
+                s = pc_xor16_sum(s);
+                s = pc_xor32_sum(s);
                 const float outv = s + b6v;
                 gout = (sel && outv > 0.f) ? gup : 0.f;
                 active = __any(gout != 0.f);

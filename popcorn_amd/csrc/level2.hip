@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void level2_fwd_kernel(const L2Args args) {
                 const f32x4 mine = acc[nb];
                 f32x4 other;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) other[e] = __shfl_xor(mine[e], 1);
+                for (int e = 0; e < 4; ++e) other[e] = pc_lane_xor1(mine[e]);
                 const f32x4 v = bb == 0 ? f32x4{mine[0], other[0], mine[1], other[1]} : f32x4{other[2], mine[2], other[3], mine[3]};
                 const int jb = 16 * h + 4 * lk;
                 *reinterpret_cast<f32x4*>(q.u2 + b * q.u2_bs + co * q.u2_cs + (int64_t)(2 * i + a) * q.u2_rs + 2 * jb + 4 * bb) = v;
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(512) void level2_bwd_kernel(const B2Args args) {
         // the 8 waves' sums -> ONE partial per workgroup, in a fixed order (deterministic): waves 4..7 park theirs in the scratch
         // slots, waves 0..3 add them and park the result, then all threads add the four slots and write the partial
         // (D[co = 4 lk + e][ci = li] of tap t sits at slot[(t * 64 + lane) * 4 + e]; bias sums of lanes lk == 0 at slot[2304 + co])
-        dbs += __shfl_xor(dbs, 16);
-        dbs += __shfl_xor(dbs, 32);
+        dbs = pc_xor16_sum(dbs);
+        dbs = pc_xor32_sum(dbs);
         float* const scr = lds + 2 * B2_BUF;
         constexpr int SLOT = 9 * 64 * 4 + 16;
         float* const mine = scr + (wave & 3) * SLOT;

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 5
+#define PC_ABI_VERSION 6
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -304,7 +304,10 @@ typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */
     int32_t nwg, Cin, Cout; /* convT: Cin = Cout = C */
-    int32_t kind;           /* 0: conv3x3, 1: convT 2x2, 2: raw sum of Cin floats per partial into dw (pc_conv3x3_up_bwd_partial_group) */
+    int32_t kind;           /* 0: conv3x3, 1: convT 2x2, 2: raw sum of Cin floats per partial into dw (pc_conv3x3_up_bwd_partial_group),
+                               3: the sparse head's partials (pc_head_bwd with PC_HEAD_BWD_DEFER_REDUCE; partial / nwg from
+                               pc_head_bwd_partials): dw = HOST array of the head's 8 gradient tensors (device pointers in the order of
+                               pc_head_bwd's dhw, NULL = skip), db / Cin / Cout unused; at most one such entry per call */
     int32_t accumulate;
     int32_t dw_co_stride;   /* conv3x3: elements between output channels of dw (0 = Cin * 9); > Cin * 9 when the entry is one
                                8-channel column block of a wider weight gradient (dw then points at its first column) */
@@ -386,6 +389,11 @@ int pc_head_fwd(const pc_src* feat, int py, int px, const float* const* hw, cons
  * of pc_loss_fwd_bwd in one single-block launch (a single-process training step: one launch less; a data-parallel step all-reduces
  * the stats between the two and keeps the separate calls). */
 #define PC_HEAD_FWD_DEFER_REDUCE 2
+/* PC_HEAD_BWD_DEFER_REDUCE: pc_head_bwd leaves its per-workgroup weight-gradient partials in ws unreduced (its last launch is
+ * skipped; g_feat is complete); the caller finishes them with an entry of kind 3 in the pc_wgrad_reduce_batch call of the same
+ * backward pass -- partial / nwg from pc_head_bwd_partials(ws, B, H, W) (same ws, B, H, W, same arithmetic mode) -- one launch less. */
+#define PC_HEAD_BWD_DEFER_REDUCE 2
+int pc_head_bwd_partials(void* ws, int B, int H, int W, const float** partial, int* nwg);
 int pc_head_popcount_loss(void* ws, int B, int H, int W, const int32_t* nsel_counts, const float* y, const float* lam4,
                           float scale_regularization, float lam_weak, float inv_B, float* popcount, double* stats,
                           float* loss_out, float* g_popcount, float* g_scale_const, void* stream);

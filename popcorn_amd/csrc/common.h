@@ -188,6 +188,29 @@ __device__ __forceinline__ f32x4 pc_fetch_reflect_seg(const pc_src& s, int b, in
     return v;
 }
 
+// ---- workgroup partials of the head backward (head.hip) -----------------------------------------------------------------------------
+// [nwg][PC_PE_TOTAL] floats; the weight blocks are MFMA D fragments (written as the accumulators are held).  Shared with
+// conv3x3_wgrad.hip: the batched reduction of a backward pass can finish them in the same launch (pc_wgrad_reduce_desc kind 3).
+constexpr int PC_PE_W4 = 0, PC_PE_W2 = 4096, PC_PE_W0 = 8192, PC_PE_W6 = 9216, PC_PE_B0 = 9280, PC_PE_B2 = 9344, PC_PE_B4 = 9408, PC_PE_B6 = 9472;
+constexpr int PC_PE_TOTAL = 9480;
+// element e of a partial -> (gradient tensor t in the order {w0, b0, w2, b2, w4, b4, w6, b6}, index within it); t = -1: padding
+__device__ __forceinline__ void pc_head_partial_target(int e, int& t, int& idx) {
+    t = -1; idx = 0;
+    if (e < PC_PE_W0) {                   // dW4 / dW2: D[(mb, nb) block][lane = (m >> 2) * 16 + n][reg = m & 3]
+        const int e2 = e & 4095, l = e2 >> 2, blk = l >> 6, lane = l & 63;
+        t = e < PC_PE_W2 ? 4 : 2;
+        idx = (16 * (blk >> 2) + 4 * (lane >> 4) + (e2 & 3)) * 64 + 16 * (blk & 3) + (lane & 15);
+    } else if (e < PC_PE_W6) {            // dW0: block mb, 16 feature columns
+        const int e2 = e - PC_PE_W0, l = e2 >> 2, lane = l & 63;
+        t = 0;
+        idx = (16 * (l >> 6) + 4 * (lane >> 4) + (e2 & 3)) * 16 + (lane & 15);
+    } else if (e < PC_PE_B0) { t = 6; idx = e - PC_PE_W6; }
+    else if (e < PC_PE_B2) { t = 1; idx = e - PC_PE_B0; }
+    else if (e < PC_PE_B4) { t = 3; idx = e - PC_PE_B2; }
+    else if (e < PC_PE_B6) { t = 5; idx = e - PC_PE_B4; }
+    else if (e == PC_PE_B6) { t = 7; idx = 0; }
+}
+
 // ---- cross-lane exchanges on the VALU -----------------------------------------------------------------------------------------------
 // hipcc lowers EVERY __shfl_xor to ds_bpermute_b32 -- a trip through the LDS crossbar with its own lgkmcnt wait (192 of them per strip
 // pair in the fp32 1x1-dot epilogue) -- although lane ^ 1, ^ 2, ^ 8 are DPP controls (quad_perm, row_ror:8) and lane ^ 16 / ^ 32 are

@@ -898,15 +898,56 @@ struct RbEntry {
     int dw_co_stride;                         // conv3x3: elements between output channels of dw (0 = Cin * 9)
     int src_cin, src_ci0;                     // conv3x3: channel window of the partials (pc_wgrad_reduce_desc), src_cin = Cin: all
 };
-struct RbArgs { RbEntry e[RB_MAX]; };
+// blk0: first workgroup of every entry (prefix sums of ceil(outputs / 16)): a flat grid -- as (max outputs / 16) x entries, two
+// thirds of the workgroups of a step's list had nothing to do.  head: the 8 gradient tensors of the sparse head (kind 3, at most one
+// such entry per launch)
+struct RbArgs { RbEntry e[RB_MAX]; int blk0[RB_MAX + 1]; int n; float* head[8]; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a) {
-    const RbEntry& q = a.e[blockIdx.y];
+    int ei = 0;
+    while (ei + 1 < a.n && (int)blockIdx.x >= a.blk0[ei + 1]) ++ei;
+    const RbEntry& q = a.e[ei];
+    const int bx = (int)blockIdx.x - a.blk0[ei];
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const int slice = tid >> 4, o = blockIdx.x * 16 + (tid & 15);
+    const int slice = tid >> 4, o = bx * 16 + (tid & 15);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int n_w, n_out;
+    if (q.kind == 3) {
+        // the head backward's workgroup partials (head.hip, common.h: pc_head_partial_target): 16 consecutive elements x 16 slices of
+        // the partial list; the output index is the inverse of the MFMA fragment layout
+        n_w = n_out = PC_PE_TOTAL;
+        if (o < n_out) {
+            int w = slice;
+            for (; w + 48 < q.nwg; w += 64) {
+                const float* q0 = q.partial + (int64_t)w * PC_PE_TOTAL + o;
+                s0 += q0[0];
+                s1 += q0[(int64_t)16 * PC_PE_TOTAL];
+                s2 += q0[(int64_t)32 * PC_PE_TOTAL];
+                s3 += q0[(int64_t)48 * PC_PE_TOTAL];
+            }
+            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * PC_PE_TOTAL + o];
+        }
+        red[tid] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (tid < 16 && o < n_out) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
+            int t, idx;
+            pc_head_partial_target(o, t, idx);
+            if (t >= 0 && a.head[t]) {
+                float* d = a.head[t] + idx;
+                *d = q.accumulate ? *d + tot : tot;
+            }
+        }
+        // structural zeros: the second (unused) output row of the last layer -- weight elements 64..127 and bias element 1
+        if (bx == 0 && !q.accumulate) {
+            if (tid >= 64 && tid < 128 && a.head[6]) a.head[6][tid] = 0.f;
+            if (tid == 128 && a.head[7]) a.head[7][1] = 0.f;
+        }
+        return;
+    }
     if (q.kind == 0) {
         const int CINC = q.src_cin < 16 ? q.src_cin : 16;
         const int EC = q.Cout * CINC * 9 + q.Cout;           // compacted partial (WgradCfg::EC)
@@ -998,17 +1039,30 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
     for (int base = 0; base < n; base += RB_MAX) {
         RbArgs a{};
         const int m = n - base < RB_MAX ? n - base : RB_MAX;
-        int max_out = 0;
+        bool have_head = false;
+        a.n = m;
+        a.blk0[0] = 0;
         for (int i = 0; i < m; ++i) {
             const pc_wgrad_reduce_desc& s = d[base + i];
             if (!s.partial || !s.dw || s.nwg < 1) return PC_EINVAL;
-            const int src_cin = (s.kind == 0 && s.src_cin > 0) ? s.src_cin : s.Cin;
-            if (s.kind == 0 && (s.src_ci0 < 0 || (s.src_cin > 0 && s.src_ci0 + s.Cin > s.src_cin) || (s.src_cin <= 0 && s.src_ci0 != 0))) return PC_EINVAL;
-            a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride, src_cin, s.kind == 0 ? s.src_ci0 : 0};
-            const int n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : (s.kind == 2 ? s.Cin : s.Cin * s.Cin * 4 + s.Cin);
-            if (n_out > max_out) max_out = n_out;
+            int n_out;
+            if (s.kind == 3) {
+                // dw: HOST array of the head's 8 gradient tensors (device pointers, NULL = skip), order of pc_head_bwd's dhw
+                if (have_head) return PC_EINVAL;
+                have_head = true;
+                float* const* hp = reinterpret_cast<float* const*>(s.dw);
+                for (int t = 0; t < 8; ++t) a.head[t] = hp[t];
+                a.e[i] = RbEntry{s.partial, nullptr, nullptr, s.nwg, 0, 0, 3, s.accumulate, 0, 0, 0};
+                n_out = PC_PE_TOTAL;
+            } else {
+                const int src_cin = (s.kind == 0 && s.src_cin > 0) ? s.src_cin : s.Cin;
+                if (s.kind == 0 && (s.src_ci0 < 0 || (s.src_cin > 0 && s.src_ci0 + s.Cin > s.src_cin) || (s.src_cin <= 0 && s.src_ci0 != 0))) return PC_EINVAL;
+                a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride, src_cin, s.kind == 0 ? s.src_ci0 : 0};
+                n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : (s.kind == 2 ? s.Cin : s.Cin * s.Cin * 4 + s.Cin);
+            }
+            a.blk0[i + 1] = a.blk0[i] + (n_out + 15) / 16;
         }
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((max_out + 15) / 16, m), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(a.blk0[m]), dim3(256), 0, st, a);
         PC_CHECK_LAUNCH();
     }
     return 0;

@@ -383,9 +383,10 @@ __device__ __forceinline__ void head_stage_weights_bwd(float* lds, const HeadArg
     if (tid == 0) lds[LB_W6 + 64] = p.b6[0];
 }
 
-// workgroup partial layout
-constexpr int PE_W4 = 0, PE_W2 = 4096, PE_W0 = 8192, PE_W6 = 9216, PE_B0 = 9280, PE_B2 = 9344, PE_B4 = 9408, PE_B6 = 9472;
-constexpr int PE_TOTAL = 9480;
+// workgroup partial layout (common.h: the batched reduction of conv3x3_wgrad.hip can finish these partials too)
+constexpr int PE_W4 = PC_PE_W4, PE_W2 = PC_PE_W2, PE_W0 = PC_PE_W0, PE_W6 = PC_PE_W6, PE_B0 = PC_PE_B0, PE_B2 = PC_PE_B2, PE_B4 = PC_PE_B4,
+              PE_B6 = PC_PE_B6;
+constexpr int PE_TOTAL = PC_PE_TOTAL;
 
 struct HeadBwdArgs {
     HeadArgs f;
@@ -1787,20 +1788,8 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const HeadReduceAr
     __shared__ float red[256];
     const int tid = threadIdx.x, slice = tid >> 5;
     const int e = blockIdx.x * 32 + (tid & 31);
-    int t = -1, idx = 0;               // tensor id, index within the tensor
-    if (e < PE_W0) {                   // dW4 / dW2: D[(mb, nb) block][lane = (m >> 2) * 16 + n][reg = m & 3]
-        const int e2 = e & 4095, l = e2 >> 2, blk = l >> 6, lane = l & 63;
-        t = e < PE_W2 ? 4 : 2;
-        idx = (16 * (blk >> 2) + 4 * (lane >> 4) + (e2 & 3)) * 64 + 16 * (blk & 3) + (lane & 15);
-    } else if (e < PE_W6) {            // dW0: block mb, 16 feature columns
-        const int e2 = e - PE_W0, l = e2 >> 2, lane = l & 63;
-        t = 0;
-        idx = (16 * (l >> 6) + 4 * (lane >> 4) + (e2 & 3)) * 16 + (lane & 15);
-    } else if (e < PE_B0) { t = 6; idx = e - PE_W6; }
-    else if (e < PE_B2) { t = 1; idx = e - PE_B0; }
-    else if (e < PE_B4) { t = 3; idx = e - PE_B2; }
-    else if (e < PE_B6) { t = 5; idx = e - PE_B4; }
-    else if (e == PE_B6) { t = 7; idx = 0; }
+    int t, idx;                        // tensor id, index within the tensor
+    pc_head_partial_target(e, t, idx);
     float s = 0.f;
     if (t >= 0) {
 #pragma unroll 8
@@ -2599,6 +2588,26 @@ extern "C" int pc_compact_masked(const float* src, const uint8_t* mask, float* o
     return 0;
 }
 
+// workgroup partials of the backward call: behind the forward's partials in ws; one per workgroup of the kernel the mode launches
+// (fp32: one 8-wave workgroup per CU, 4 groups in flight each; bf16: two 4-wave workgroups per CU, 2 x 79 KB of LDS)
+static void head_bwd_partial_geometry(void* ws, int B, int H, int W, bool bf, float** partial, int* nwg) {
+    const int groups = (H * W + 15) / 16, total_groups = B * groups;
+    const int64_t nchunk = (groups + 31) / 32 + 1;
+    *partial = reinterpret_cast<float*>(ws) + B * nchunk * 2;
+    const int per = bf ? H4_WAVES : 4, cap = bf ? 512 : 256;
+    int n = (total_groups + per - 1) / per;
+    if (n > cap) n = cap;
+    if (n < 1) n = 1;
+    *nwg = n;
+}
+extern "C" int pc_head_bwd_partials(void* ws, int B, int H, int W, const float** partial, int* nwg) {
+    if (!ws || !partial || !nwg || B < 1 || H < 1 || W < 1) return PC_EINVAL;
+    float* pp;
+    head_bwd_partial_geometry(ws, B, H, W, g_pc_precision == PC_PREC_BF16, &pp, nwg);
+    *partial = pp;
+    return 0;
+}
+
 extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* const* hw, const uint8_t* mask,
                            const float* building, const float* admin_mask, const int64_t* census_idx,
                            const float* g_popcount, const float* g_popdense, const float* g_scale_map,
@@ -2645,12 +2654,8 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     a.g_feat = *g_feat;
     if (feat_bn_sar && feat_bn_opt) { a.fbn[0] = *feat_bn_sar; a.fbn[1] = *feat_bn_opt; a.fuse_feat_bn = 1; }
     a.total_groups = B * p.groups;
-    // fwd partials live at the start of ws; the backward partials follow
-    const int64_t nchunk = (p.groups + 31) / 32 + 1;
-    a.partial = reinterpret_cast<float*>(ws) + B * nchunk * 2;
-    int nwg = (a.total_groups + 3) / 4;
-    if (nwg > 256) nwg = 256;
-    if (nwg < 1) nwg = 1;
+    int nwg;
+    head_bwd_partial_geometry(ws, B, H, W, p.bf, &a.partial, &nwg);
     {
         const char* dv = getenv("POPCORN_HEAD_DBG");
         a.dbg = dv ? atoi(dv) : 0;
@@ -2688,9 +2693,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
             }
             once4.mark();
         }
-        nwg = (a.total_groups + H4_WAVES - 1) / H4_WAVES;       // two 4-wave workgroups per CU (2 x 79 KB of LDS)
-        if (nwg > 512) nwg = 512;
-        if (nwg < 1) nwg = 1;
         hipLaunchKernelGGL(head_bwd_bf16_coop4_kernel, dim3(nwg), dim3(256), H4_END, st, a);
     }
     else if (use_pc) {
@@ -2713,6 +2715,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     }
     else hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), LB_END * sizeof(float), st, a);
     PC_CHECK_LAUNCH();
+    if (flags & PC_HEAD_BWD_DEFER_REDUCE) return 0;      // the caller's batched reduction finishes the partials (pc_head_bwd_partials)
     HeadReduceArgs r{};
     r.partial = a.partial; r.nwg = nwg; r.accumulate = accumulate;
     for (int i = 0; i < 8; ++i) r.dhw[i] = dhw[i];

@@ -181,10 +181,11 @@ class UNetEngine:
                 self.layers[("optical_stream", "up1b")].bn_nobias if "optical_stream" in names else plain)
 
     # ----------------------------------------------------------------------------------------------- backward
-    def backward(self, saved, G, grads, accumulate=False, encoder_no_grad=False, prefix=""):
+    def backward(self, saved, G, grads, accumulate=False, encoder_no_grad=False, prefix="", head_reduce=None):
         """G: (B,16,Hp,Wp) gradient w.r.t. the conv outputs of the two up1b layers (i.e. already multiplied by
         relu-mask * bn-scale -- the head-backward epilogue does that).  Writes dW/db into ``grads[prefix+name]``
-        (= or += per ``accumulate``).  encoder_no_grad: networks.py:124-132 semantics.
+        (= or += per ``accumulate``).  encoder_no_grad: networks.py:124-132 semantics.  head_reduce: the ``ops.HeadPartials`` of the
+        pass's ``head_bwd(defer_reduce=True)`` -- finished by this pass's batched reduction launch.
         Data-gradient launches are grouped over the two streams (same shapes); weight-gradient launches are per
         stream (each owns its partial-sum workspace)."""
         X = saved["X"]                     # None when the forward pass was fed the padded input directly (Xp_all)
@@ -202,6 +203,8 @@ class UNetEngine:
         # gradient branch on a second stream next to the data-gradient chain was measured three times and lost every time
         # (both branches are bound by the same memory pipe).
         wb = ops.WgradBatch(dev, accumulate)
+        if head_reduce is not None:
+            wb.head_reduce(head_reduce)
 
         def on_side(fn):
             fn()

@@ -460,7 +460,7 @@ def _hw_array(head_tensors):
     return arr
 
 
-PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED, PC_HEAD_FWD_DEFER_REDUCE = 1, 1, 2
+PC_HEAD_FWD_PACK_BOTH, PC_HEAD_BWD_PACKED, PC_HEAD_FWD_DEFER_REDUCE, PC_HEAD_BWD_DEFER_REDUCE = 1, 1, 2, 2
 
 
 def head_fwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
@@ -588,9 +588,11 @@ def ingest_split(s2_u16, s1, band, mean, std, top, bottom, left, right, cl8=None
 
 def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=None, census_idx=None,
              g_popcount=None, g_popdense=None, g_scale_map=None, g_scale_const=None, grads=None, accumulate=False,
-             g_feat=None, feat_bn=None, packed=False):
+             g_feat=None, feat_bn=None, packed=False, defer_reduce=False):
     """Backward of head_fwd.  Returns (list of 8 head grads, g_feat (B,16,Hp,Wp)).  pack_both (head_fwd) / packed (here): a training
-    step's forward call assembles the backward's weight image too (same weights, same workspace): one launch less."""
+    step's forward call assembles the backward's weight image too (same weights, same workspace): one launch less.  defer_reduce:
+    the weight gradients stay per-workgroup partials; returns (HeadPartials, g_feat) instead -- hand the first to the
+    ``WgradBatch`` of the same backward pass (``head_reduce``), whose batched reduction writes ``grads``: one launch less."""
     L.require_device(feat, building, *head_tensors)
     B, _, Hp, Wp = feat.shape
     dev = feat.device
@@ -606,8 +608,22 @@ def head_bwd(feat, py, px, H, W, head_tensors, building, mask=None, admin_mask=N
                                 L.ptr(census_idx), L.ptr(g_popcount), L.ptr(g_popdense), L.ptr(g_scale_map),
                                 L.ptr(g_scale_const), dhw, int(accumulate), C.byref(d),
                                 C.byref(feat_bn[0]) if feat_bn else None, C.byref(feat_bn[1]) if feat_bn else None,
-                                Hp, Wp, L.ptr(ws), B, H, W, PC_HEAD_BWD_PACKED if packed else 0, L.stream_ptr()), "pc_head_bwd")
+                                Hp, Wp, L.ptr(ws), B, H, W,
+                                (PC_HEAD_BWD_PACKED if packed else 0) | (PC_HEAD_BWD_DEFER_REDUCE if defer_reduce else 0),
+                                L.stream_ptr()), "pc_head_bwd")
+    if defer_reduce:
+        pp, nwg = C.c_void_p(0), C.c_int(0)
+        L.check(L.lib().pc_head_bwd_partials(L.ptr(ws), B, H, W, C.byref(pp), C.byref(nwg)), "pc_head_bwd_partials")
+        return HeadPartials(pp.value, nwg.value, list(grads), bool(accumulate)), g_feat
     return grads, g_feat
+
+
+class HeadPartials:
+    """The unreduced weight-gradient partials of a ``head_bwd(defer_reduce=True)`` call: (device pointer, workgroups, the 8 gradient
+    tensors they are to be summed into -- None = skip --, accumulate)."""
+
+    def __init__(self, ptr_, nwg, grads, accumulate):
+        self.ptr, self.nwg, self.grads, self.accumulate = ptr_, nwg, grads, accumulate
 
 
 def select_normalize(raw, band6, mean6, std6, out=None):
@@ -699,6 +715,7 @@ class WgradBatch:
         self.entries = []
         self.raw_entries = []           # (partials ptr, total ptr, nwg, floats): raw sums (kind 2)
         self.chains = []                # composed Up blocks: chain-rule launches that follow the reduction
+        self.head = None                # HeadPartials of the pass's head_bwd(defer_reduce=True): finished by the same launch
         self.slot_bytes = int(max(L.lib().pc_conv3x3_wgrad_ws_bytes(32, 8), L.lib().pc_convt2x2_wgrad_ws_bytes(16)))
         self.slot = 0
 
@@ -898,11 +915,21 @@ class WgradBatch:
         for ws, pr in zip(slices, problems):
             self.entries.append((ws, pr["dw"], pr["db"], nwg.value, Cc, Cc, 1))
 
+    def head_reduce(self, hp):
+        assert self.head is None and isinstance(hp, HeadPartials)
+        self.head = hp
+
     def finish(self):
-        n = len(self.entries) + len(self.raw_entries)
+        n = len(self.entries) + len(self.raw_entries) + (1 if self.head is not None else 0)
         if n == 0:
             return
         d = (L.PcWgradReduceDesc * n)()
+        if self.head is not None:       # (kind 3: dw = HOST array of the 8 gradient tensors)
+            hp, self.head = self.head, None
+            dhw = (C.c_void_p * 8)(*[0 if t is None else t.data_ptr() for t in hp.grads])
+            i = n - 1
+            d[i].partial, d[i].dw, d[i].db = hp.ptr, C.cast(dhw, C.c_void_p).value, 0
+            d[i].nwg, d[i].Cin, d[i].Cout, d[i].kind, d[i].accumulate, d[i].dw_co_stride = hp.nwg, 0, 0, 3, int(hp.accumulate), 0
         for i, ent in enumerate(self.entries):
             ws, dw, db, nwg, cin, cout, kind = ent[:7]
             d[i].partial = ws

@@ -22,6 +22,10 @@ from . import ops
 from .distributed import FlatReducer
 from .model.popcorn import pad_geometry
 
+# A/B switch: 0 = the head backward reduces its own weight-gradient partials (one launch more per step) instead of handing them to the
+# U-Net backward's batched reduction
+DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
+
 def _is_oom(exc):
     """An allocation failure, also when it surfaces as the RuntimeError of a failed ``capture_end`` with the OutOfMemoryError as its
     context (an exception inside ``with torch.cuda.graph(g)`` leaves through ``__exit__`` -> ``capture_end``, which raises on the
@@ -314,16 +318,18 @@ class FusedTrainStep:
         eng_u = m.engines()[0]
         hgrads = [self.grads[n_] for n_ in self.names[-8:]]
         khgrads, fix = m.head_grad_targets(hgrads)
-        _, G = ops.head_bwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask, admin_mask=s["admin_mask"],
-                            census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=khgrads,
-                            feat_bn=None if unet_no_grad else eng_u.feat_bn(), packed=True)
-        fix()
+        # the head's weight-gradient partials are finished by the U-Net backward's batched reduction launch when there is one
+        hp, G = ops.head_bwd(feats, pt, pl, H, W, m.head_tensors(), building, mask=mask, admin_mask=s["admin_mask"],
+                             census_idx=s["census_idx"], g_popcount=g_pc, g_scale_const=self.g_scale_const, grads=khgrads,
+                             feat_bn=None if unet_no_grad else eng_u.feat_bn(), packed=True, defer_reduce=DEFER_HEAD_REDUCE and not unet_no_grad)
         if unet_no_grad:
             self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()
         else:
             if encoder_no_grad:
                 self.flat_g[: self.n - sum(g.numel() for g in hgrads)].zero_()
-            eng_u.backward(saved, G, self.grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.")
+            eng_u.backward(saved, G, self.grads, accumulate=False, encoder_no_grad=encoder_no_grad, prefix="unetmodel.",
+                           head_reduce=hp if isinstance(hp, ops.HeadPartials) else None)
+        fix()                    # (single modality: the padded first-layer gradient -> the parameter's shape; after the reduction)
         self._ctx = None
 
     def _update(self, encoder_no_grad=False, unet_no_grad=False):

@@ -227,6 +227,31 @@ def test_head_bwd_vs_oracle_autograd(sparse, shape):
                                    g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
                                    g_scale_const=torch.tensor([g_const], device="cuda"))
     assert all(torch.equal(a, b) for a, b in zip(grads, grads2)) and torch.equal(g_feat, g_feat2)
+    # deferred reduction (PC_HEAD_BWD_DEFER_REDUCE + kind 3 of pc_wgrad_reduce_batch: the trainer's path): same sums up to the
+    # association order of the partial list; = and += forms; a skipped tensor (NULL) stays untouched
+    for acc in (False, True):
+        tgt = [torch.full_like(t, 0.25) for t in ht]
+        tgt[3] = None
+        hp, g_feat3 = ops.head_bwd(feat.detach().cuda(), py, px, H, W, ht, building.cuda(),
+                                   mask=mask.to(torch.uint8).cuda() if sparse else None,
+                                   admin_mask=admin.cuda(), census_idx=census.cuda(), g_popcount=g_pc.cuda(),
+                                   g_popdense=g_pd.cuda(), g_scale_map=g_sm.cuda(),
+                                   g_scale_const=torch.tensor([g_const], device="cuda"), grads=tgt, accumulate=acc, defer_reduce=True)
+        assert isinstance(hp, ops.HeadPartials) and torch.equal(g_feat3, g_feat)
+        assert all(torch.all(t == 0.25) for t in tgt if t is not None)          # nothing written yet
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.head_reduce(hp)
+        wb.finish()
+        for i, (a, b) in enumerate(zip(tgt, grads)):
+            if a is None:
+                continue
+            want = b + 0.25 if acc else b
+            if i in (6, 7) and acc:
+                want = want.clone()                     # (+= leaves the structurally-zero second row alone)
+                want.view(-1)[want.numel() // 2:] = 0.25
+            torch.testing.assert_close(a, want, rtol=1e-5, atol=3e-6 * max(1.0, b.abs().max().item()), msg=lambda m, i=i: f"tensor {i}: {m}")
+        if not acc:
+            assert torch.all(tgt[6][1] == 0) and tgt[7][1].item() == 0.0
 
 
 @pytest.mark.parametrize("case", ["regions", "empty_selection", "no_occupancy"])

@@ -1,4 +1,5 @@
-"""sha256 over the kernel sources (popcorn_amd/csrc/*.hip, *.h, include/popcorn_hip.h): the stamp that ties the tracked rocprofv3
+"""sha256 over the kernel sources (popcorn_amd/csrc/*.hip, *.h, its Makefile -- the per-file compiler flags are part of the build --,
+include/popcorn_hip.h): the stamp that ties the tracked rocprofv3
 summaries in profiles/ to the build they were collected from (tools/profile_round.sh writes it, tests/test_bench_contract.py checks it)."""
 import glob
 import hashlib
@@ -11,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def csrc_hash(root=ROOT):
     files = sorted(glob.glob(os.path.join(root, "popcorn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "popcorn_amd", "csrc", "*.h")) +
-                   [os.path.join(root, "include", "popcorn_hip.h")])
+                   [os.path.join(root, "popcorn_amd", "csrc", "Makefile"), os.path.join(root, "include", "popcorn_hip.h")])
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.relpath(f, root).encode())

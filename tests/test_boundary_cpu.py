@@ -139,3 +139,17 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(L.PcConvFwdDesc) == lib.pc_sizeof(3)
     assert ctypes.sizeof(L.PcAdamGroups) == lib.pc_sizeof(4)
     assert ctypes.sizeof(L.PcLevel2FwdDesc) == lib.pc_sizeof(5)
+
+
+def test_graft_entry_build_passes_on_the_current_tree():
+    """`__graft_entry__.build()` is the driver's "does it build" check: make (a no-op when the in-tree library is current), import,
+    ABI assertion.  (Round 4 bumped the ABI twice; the assertion inside build() must follow the binding.)"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        g = importlib.import_module("__graft_entry__")
+        g.build()
+    finally:
+        sys.path.remove(root)

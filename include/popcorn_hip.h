@@ -300,6 +300,10 @@ int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const 
 int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream);
 /* debug: 16 x int64 buffer receiving wall-clock (100 MHz) phase stamps of workgroup (0, 0) of pc_level2_bwd_group (NULL = off) */
 void pc_debug_level2_ts(void* buf);
+/* test hook: the cross-lane helpers the kernels use instead of __shfl_xor (= ds_bpermute_b32), applied to one 64-lane wave of floats.
+ * out[384]: [0,64) sum over the 8 lanes sharing lane >> 3 in the association order of the xor-1, -2, -4 butterfly; [64,128) max(x, x of
+ * lane ^ 8); [128,192) x + x of lane ^ 16; [192,256) x + x of lane ^ 32; [256,320) x of lane ^ 1; [320,384) x of lane ^ 2 */
+int pc_debug_lane_ops(const float* in, float* out, void* stream);
 typedef struct pc_wgrad_reduce_desc {
     const float* partial;   /* ws of the deferred call */
     float* dw; float* db;   /* outputs ([Cout][Cin][3][3] / [Cin][Cout][2][2]; db may be NULL) */

@@ -42,3 +42,21 @@ extern "C" int pc_sizeof(int which) {
         default: return -1;
     }
 }
+
+// ---- test hook: the cross-lane helpers of common.h (DPP / v_permlane swaps instead of ds_bpermute) on one wave ----------------------
+__global__ __launch_bounds__(64) void lane_ops_kernel(const float* in, float* out) {
+    const int l = threadIdx.x;
+    const float x = in[l];
+    out[l] = pc_sum8(x);
+    out[64 + l] = fmaxf(x, pc_lane_xor8(x));
+    out[128 + l] = pc_xor16_sum(x);
+    out[192 + l] = pc_xor32_sum(x);
+    out[256 + l] = pc_lane_xor1(x);
+    out[320 + l] = pc_lane_xor2(x);
+}
+extern "C" int pc_debug_lane_ops(const float* in, float* out, void* stream) {
+    if (!in || !out) return PC_EINVAL;
+    hipLaunchKernelGGL(lane_ops_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    PC_CHECK_LAUNCH();
+    return 0;
+}

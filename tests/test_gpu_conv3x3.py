@@ -1,6 +1,7 @@
 """Kernel parity: HIP conv3x3 (+BN+ReLU, fused pool / concat / reflect loaders, dgrad epilogues) vs stock
 PyTorch-CPU fp32 ops (the oracle's building blocks).  Tolerance: 1e-5 abs on O(1) activations (fp32 MFMA is an
 exact fp32 fma chain; only the summation order differs from oneDNN)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -336,3 +337,27 @@ def test_conv_backward_fused_both_concat_blocks_in_one_launch():
     torch.testing.assert_close(o_up.cpu().double(), xd.grad[:, 8:], rtol=1e-5, atol=2e-5)
     assert (dw.cpu().double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
     assert (db.cpu().double() - bias.grad).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_cross_lane_helpers_are_bit_identical_to_the_shuffle_butterflies():
+    """common.h: pc_sum8 / pc_lane_xor* / pc_xor16_sum / pc_xor32_sum (DPP controls and gfx950's v_permlane swaps) replaced every
+    __shfl_xor (= ds_bpermute_b32, an LDS round trip) of the epilogues: same values, same association order, bit for bit."""
+    import ctypes as C
+    from popcorn_amd import _lib as L
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        x = (rng.standard_normal(64) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+        xin = torch.from_numpy(x).cuda()
+        out = torch.empty(384, device="cuda")
+        L.check(L.lib().pc_debug_lane_ops(L.ptr(xin), L.ptr(out), L.stream_ptr()), "pc_debug_lane_ops")
+        o = out.cpu().numpy()
+        lane = np.arange(64)
+        s = x.copy()
+        for k in (1, 2, 4):
+            s = (s + s[lane ^ k]).astype(np.float32)
+        assert np.array_equal(o[0:64].view(np.uint32), s.view(np.uint32)), trial
+        assert np.array_equal(o[64:128], np.maximum(x, x[lane ^ 8]))
+        assert np.array_equal(o[128:192].view(np.uint32), (x + x[lane ^ 16]).astype(np.float32).view(np.uint32))
+        assert np.array_equal(o[192:256].view(np.uint32), (x + x[lane ^ 32]).astype(np.float32).view(np.uint32))
+        assert np.array_equal(o[256:320], x[lane ^ 1]) and np.array_equal(o[320:384], x[lane ^ 2])

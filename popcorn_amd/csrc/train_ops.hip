@@ -104,46 +104,74 @@ __global__ void adam_step_inc_kernel(int32_t* step, int ngroups, int active_mask
 // in L2; all workgroups add in the same order, so they all get the same bits), then updates its 256 elements; the
 // workgroup that finishes last advances the step counter (every workgroup has read it by then).  Replaces the
 // single-workgroup norm kernel + the update + the one-thread counter kernel (3 dependent launches at the end of a step).
-__global__ __launch_bounds__(256) void adam_clip_fused_kernel(const AdamArgs a, float* norm_out, unsigned* ticket) {
-    __shared__ double red[256];
+constexpr int ADAM_NT = 1024;
+__global__ __launch_bounds__(ADAM_NT) void adam_clip_fused_kernel(const AdamArgs a, float* norm_out, unsigned* ticket) {
+    // 39 k parameters: the kernel is a chain of memory round trips, not work.  1024-thread workgroups (every workgroup reads the
+    // whole gradient for the norm: 10 16-byte loads per thread in two batches instead of 39 in five, and 39 workgroups re-read it
+    // instead of 154); the thread's own parameter / state / gradient element and the per-group bias corrections (two double pow()
+    // on three threads) are in flight UNDER the norm phase instead of behind it; one barrier instead of an 8-step tree.
+    __shared__ double wred[ADAM_NT / 64];
     __shared__ float sh[PC_ADAM_GROUPS][2];
     const int tid = threadIdx.x;
+    const int i = blockIdx.x * ADAM_NT + tid;
+    int grp = 0;
+    bool act = i < a.n;
+    if (act && a.grp.nseg) {
+        grp = adam_group_of(a, i);
+        act = (a.grp.active_mask >> grp) & 1;                 // grad is None: parameter and state untouched
+    }
+    const int ic = act ? i : 0;
+    const float g0 = a.g[ic], p0 = a.p[ic], m0 = a.m[ic], v0 = a.v[ic];
+    adam_group_constants(a, sh, tid);
     float coef = 1.f;
     if (a.max_norm > 0.f) {
-        // 8 independent 16-byte loads in flight per thread (a plain loop is one dependent L2 round trip per iteration:
-        // 39 of them, 20 us)
         double acc = 0.0;
         const int n4 = a.n >> 2;
         const f32x4* g4 = reinterpret_cast<const f32x4*>(a.g);
-        int i = tid;
-        for (; i + 7 * 256 < n4; i += 8 * 256) {
+        int k = tid;
+        for (; k + 7 * ADAM_NT < n4; k += 8 * ADAM_NT) {
             f32x4 g[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g[u] = g4[i + u * 256];
+            for (int u = 0; u < 8; ++u) g[u] = g4[k + u * ADAM_NT];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 acc += ((double)g[u][0] * g[u][0] + (double)g[u][1] * g[u][1]) + ((double)g[u][2] * g[u][2] + (double)g[u][3] * g[u][3]);
         }
-        for (; i < n4; i += 256) {
-            const f32x4 g = g4[i];
-            acc += ((double)g[0] * g[0] + (double)g[1] * g[1]) + ((double)g[2] * g[2] + (double)g[3] * g[3]);
+        {
+            f32x4 g[8];                                          // the tail batch: still all loads first
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = k + u * ADAM_NT < n4 ? g4[k + u * ADAM_NT] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc += ((double)g[u][0] * g[u][0] + (double)g[u][1] * g[u][1]) + ((double)g[u][2] * g[u][2] + (double)g[u][3] * g[u][3]);
         }
-        for (int j = 4 * n4 + tid; j < a.n; j += 256) acc += (double)a.g[j] * a.g[j];
-        red[tid] = acc;
+        for (int j = 4 * n4 + tid; j < a.n; j += ADAM_NT) acc += (double)a.g[j] * a.g[j];
+        // wave total in every lane (xor butterfly: the partner sums are commutative pairs, all lanes hold the same bits), then the
+        // 16 wave totals in fixed order -- every workgroup computes the identical norm
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if ((tid & 63) == 0) wred[tid >> 6] = acc;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        const float norm = (float)sqrt(red[0]);
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < ADAM_NT / 64; ++w) tot += wred[w];
+        const float norm = (float)sqrt(tot);
         if (blockIdx.x == 0 && tid == 0 && norm_out) *norm_out = norm;
         coef = a.max_norm / (norm + 1e-6f);
         coef = coef > 1.f ? 1.f : coef;
+    } else {
+        __syncthreads();
     }
-    adam_group_constants(a, sh, tid);
-    __syncthreads();
-    const int i = blockIdx.x * 256 + tid;
-    if (i < a.n) adam_update_one(a, i, coef, sh);
+    if (act) {
+        float g = g0 * coef;
+        if (i < a.n_decay && a.wd != 0.f) g = fmaf(a.wd, p0, g);
+        const float m = a.beta1 * m0 + (1.f - a.beta1) * g;
+        const float v = a.beta2 * v0 + (1.f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / sh[grp][1] + a.eps;
+        a.p[i] = p0 - sh[grp][0] * (m / denom);
+    }
     __syncthreads();
     if (tid == 0) {
         __threadfence();
@@ -255,7 +283,7 @@ extern "C" int pc_adam_clip_step_fused(float* p, const float* g, float* m, float
     if (int rc = fill_groups(a, groups, n)) return rc;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_decay = n_decay; a.hyper = hyper_dev; a.wd = weight_decay;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.norm = nullptr; a.step = step_dev;
-    hipLaunchKernelGGL(adam_clip_fused_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, norm_out_dev, ticket);
+    hipLaunchKernelGGL(adam_clip_fused_kernel, dim3((n + ADAM_NT - 1) / ADAM_NT), dim3(ADAM_NT), 0, (hipStream_t)stream, a, norm_out_dev, ticket);
     PC_CHECK_LAUNCH();
     return 0;
 }

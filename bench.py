@@ -342,6 +342,7 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     of this chip (18 flop / compulsory byte): algorithmic bytes against the HBM peak and algorithmic flops against the
     fp32-matrix peak."""
     from popcorn_amd import ops, _lib as L
+    from popcorn_amd.train import _capturing
     adt = L.act_dtype()
     esz = 2 if adt == torch.bfloat16 else 4
     peak = BF16_MATRIX_PEAK if esz == 2 else FP32_MATRIX_PEAK
@@ -359,7 +360,7 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     g = torch.cuda.CUDAGraph()
     cap = torch.cuda.Stream()
     with torch.cuda.stream(cap):
-        with torch.cuda.graph(g, stream=cap):
+        with _capturing(g, stream=cap):         # (cyclic GC off during the capture: popcorn_amd/train.py)
             for _ in range(reps):
                 for s in sets:
                     ops.conv3x3_fwd_group(s)

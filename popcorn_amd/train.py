@@ -12,6 +12,8 @@ all-reduce are single kernels / a single collective.  The static-shape step can 
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import os
 
 import torch
@@ -25,6 +27,23 @@ from .model.popcorn import pad_geometry
 # A/B switch: 0 = the head backward reduces its own weight-gradient partials (one launch more per step) instead of handing them to the
 # U-Net backward's batched reduction
 DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
+
+@contextlib.contextmanager
+def _capturing(g, **kw):
+    """``torch.cuda.graph(g, **kw)`` with Python's cyclic garbage collector switched off for the duration of the capture.
+    ``torch.cuda.graph.__enter__`` collects once before the capture begins; a collection that the ~40 launches' Python allocations
+    trigger DURING it can finalise an older captured graph / its pool that sat in a reference cycle (an evicted cache entry, an
+    exception's traceback) -- destroying a graph while a capture is open aborts the process (observed: `Fatal Python error: Aborted`
+    with the main thread `Garbage-collecting` inside ``_backward`` of a re-capture after an out-of-memory retry)."""
+    was = gc.isenabled()
+    with torch.cuda.graph(g, **kw):
+        gc.disable()
+        try:
+            yield
+        finally:
+            if was:
+                gc.enable()
+
 
 def _is_oom(exc):
     """An allocation failure, also when it surfaces as the RuntimeError of a failed ``capture_end`` with the OutOfMemoryError as its
@@ -516,7 +535,7 @@ class FusedTrainStep:
             ok = True
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capturing(g):
                     self._forward(st, sel, enc_ng, unet_ng)
                     self.reducer.reduce_stats(self.stats)
                     self._backward(st, enc_ng, unet_ng)
@@ -537,12 +556,12 @@ class FusedTrainStep:
                     graphs = []
         if not graphs:
             g0, g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g0):
+            with _capturing(g0):
                 self._forward(st, sel, enc_ng, unet_ng)
             pool = g0.pool()
-            with torch.cuda.graph(g1, pool=pool):
+            with _capturing(g1, pool=pool):
                 self._backward(st, enc_ng, unet_ng)
-            with torch.cuda.graph(g2, pool=pool):
+            with _capturing(g2, pool=pool):
                 self._update(enc_ng, unet_ng)
             graphs = [g0, g1, g2]
         self._graphs = (key, st, sel, graphs)

@@ -32,9 +32,12 @@ DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
 def _capturing(g, **kw):
     """``torch.cuda.graph(g, **kw)`` with Python's cyclic garbage collector switched off for the duration of the capture.
     ``torch.cuda.graph.__enter__`` collects once before the capture begins; a collection that the ~40 launches' Python allocations
-    trigger DURING it can finalise an older captured graph / its pool that sat in a reference cycle (an evicted cache entry, an
-    exception's traceback) -- destroying a graph while a capture is open aborts the process (observed: `Fatal Python error: Aborted`
-    with the main thread `Garbage-collecting` inside ``_backward`` of a re-capture after an out-of-memory retry)."""
+    trigger DURING it runs arbitrary finalisers of whatever became unreachable earlier in the process with a capture open -- and
+    anything in them that synchronises, frees or touches another context (CUDA-IPC handles of tensors shared with worker processes,
+    process-group objects, ...) is illegal then.  Observed once, deterministically for one state of the test suite: `Fatal Python
+    error: Aborted` with the main thread `Garbage-collecting` inside ``_backward`` of a re-capture, after the multi-process tests
+    had run in the same interpreter.  (Destroying an older captured step in the middle of a capture is NOT the trigger:
+    tools/diag_gc_graph_destroy.py.)  Finalisers simply run after the capture instead."""
     was = gc.isenabled()
     with torch.cuda.graph(g, **kw):
         gc.disable()

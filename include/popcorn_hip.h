@@ -22,11 +22,13 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 6
+#define PC_ABI_VERSION 7
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
 #define PC_ENOGPU (-2)     /* no HIP device */
+#define PC_ENOMEM (-3)     /* pc_train_step: the arena is too small (pc_step_io.arena_needed says how much it takes) */
+#define PC_ENOTSUP (-4)    /* pc_train_step: a variant the native executor does not cover (the caller keeps the per-launch path) */
 
 /* ---- tensor descriptors ------------------------------------------------------------------------- */
 
@@ -84,7 +86,7 @@ int pc_abi_version(void);
 int pc_device_count(void);
 const char* pc_error_string(int code);
 /* sizeof of the ABI structs as compiled: 0 = pc_src, 1 = pc_dst, 2 = pc_bn, 3 = pc_conv_fwd_desc, 4 = pc_adam_groups,
-   5 = pc_level2_fwd_desc (lets a binding verify its struct layout) */
+   5 = pc_level2_fwd_desc, 6 = pc_step_plan, 7 = pc_step_io (lets a binding verify its struct layout) */
 int pc_sizeof(int which);
 
 /* ---- arithmetic mode -----------------------------------------------------------------------------------
@@ -507,6 +509,75 @@ int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n,
  * raw: B x Craw x H x W; out: B x 6 x H x W; band6/mean6/std6: host arrays of 6. */
 int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,
                         float* out, int B, int H, int W, void* stream);
+
+/* ---- native executor of ONE training step: the body of the reference's inner loop (run_train.py:186-238) as one call -----------
+ *   forward(train, padding=False, sparse=True) (popcorn.py:100-193) -> get_loss (utils/losses.py:49-76) -> x lam_weak -> backward
+ *   -> clip_grad_norm_ -> Adam step -> zero_grad
+ * for ANY batch geometry (B, H, W) and truncation regime (encoder_no_grad / unet_no_grad: run_train.py:191-198): the reference
+ * trains on weak_batch_size = 2 census regions of varying size (arguments/train.py:16,34-36), which cannot replay a captured HIP
+ * graph -- and launching the step's ~45 kernels one ctypes call at a time costs more host time than a small region's kernels take
+ * (tools/host_time_eager.py).  pc_train_step computes the geometry of both networks (the trainable U-Net on the add_padding domain,
+ * popcorn.py:231-258; the frozen building extractor on its own 14-pixel reflect-padded domain, popcorn.py:279-322), carves every
+ * activation / gradient / workspace out of ONE caller-provided arena (bump allocation, rows padded to 16 bytes so that every conv
+ * launch takes the aligned staged loaders whatever the region's width), fills the descriptors and issues all launches from C++.
+ * The plan (parameter pointers, BN descriptors, optimiser constants) is built once per trainer (pc_step_create); a step passes only
+ * its batch.  PC_PREC_FP32, dual-stream (S1 + S2) models whose building score comes from the frozen extractor; anything else
+ * returns PC_ENOTSUP and the caller keeps the per-launch path (same kernels, launched through the entry points above).
+ * Conv layer order of the arrays below: inc.conv.0, inc.conv.3, down1.conv.0, down1.conv.3, down2.conv.0, down2.conv.3,
+ * up2.conv.0, up2.conv.3, up1.conv.0, up1.conv.3 (networks.py:121-151,253-320); transposed convs: up2.up, up1.up. */
+#define PC_STEP_CONVS 10
+typedef struct pc_step_stream {
+    const float* w[PC_STEP_CONVS];      /* conv weights [Cout][Cin][3][3] */
+    pc_bn bn[PC_STEP_CONVS];            /* conv bias + BatchNorm2d(eval) of the layer */
+    const float* wt[2]; const float* bt[2];      /* ConvTranspose2d weights [C][C][2][2] and biases */
+    float* dw[PC_STEP_CONVS]; float* db[PC_STEP_CONVS]; float* dwt[2]; float* dbt[2];   /* gradient targets (trainable network only) */
+    int32_t chan[4];                    /* model-input channel of conv channel c ([R,G,B,NIR,VV,VH]: SAR 4,5; optical 2,1,0,3) */
+    int32_t cin, feat_c0;               /* 2 / 4 input channels; first channel of this stream in the 16-channel feature map */
+} pc_step_stream;
+typedef struct pc_step_net { pc_step_stream s[2]; const float* fusion_w; const float* fusion_b; } pc_step_net;
+typedef struct pc_step_plan {
+    pc_step_net unet, extractor;        /* model.unetmodel (trainable), model.building_extractor (frozen) */
+    const float* head_w[8]; float* head_dw[8];     /* {w0,b0,w2,b2,w4,b4,w6,b6} and their gradients */
+    float* flat_p; float* flat_g; float* adam_m; float* adam_v;     /* flat parameter / gradient / moment buffers (n floats) */
+    int32_t n, n_decay, n_head, occupancymodel;
+    const float* hyper_dev; int32_t* step_dev; float* norm_dev; double* stats_dev; float* loss_dev; float* g_scale_const_dev;
+    pc_adam_groups groups;              /* segments of the flat buffer; active_mask is set per step from the regime */
+    float weight_decay, beta1, beta2, eps, max_norm, scale_regularization, lam_weak;
+    float lam4[4];
+    int32_t extractor_pad;              /* 14 (popcorn.py:46) */
+    int32_t band[8]; float mean[8]; float stdv[8];      /* raw-tile ingest: model channel c = (raw band band[c] - mean[c]) / stdv[c] */
+} pc_step_plan;
+enum pc_step_data { PC_DATA_INPUT = 0,   /* data = normalised model input (B, 6, H, W) fp32 */
+                    PC_DATA_RAW = 1,     /* data = raw tile (B, craw, H, W) fp32 (data/PopulationDataset.py:566-568 + utils/utils.py:105-127 fused) */
+                    PC_DATA_SPLIT = 2 }; /* data = uint16 S2 digital numbers (B, 4, H, W), data2 = fp32 S1 (B, 2, H, W) */
+#define PC_STEP_FWD 1      /* ingest .. head forward (+ popcount / stats unless the loss launch finishes them) */
+#define PC_STEP_BWD 2      /* loss, head backward, U-Net backward into flat_g */
+#define PC_STEP_UPD 4      /* clip + Adam */
+typedef struct pc_step_io {
+    int32_t B, H, W, data_kind;
+    const void* data; const void* data2; int32_t craw, dp;          /* dp != 0: data parallel -- the caller all-reduces stats_dev between the
+                                                                       FWD and BWD phases and flat_g between BWD and UPD */
+    const float* admin_mask; const int64_t* census_idx; const float* y; const uint8_t* sel;     /* sel: H row flags then W column flags */
+    int32_t encoder_no_grad, unet_no_grad; float inv_B; int32_t _pad;
+    void* arena; int64_t arena_bytes;       /* device scratch, 256-byte aligned; contents are undefined between steps */
+    /* results */
+    int64_t arena_needed;                   /* bytes this geometry takes (always set; PC_ENOMEM when arena_bytes is smaller) */
+    int64_t off_popcount, off_popdense, off_scale, off_mask, off_building;   /* byte offsets of the step's outputs inside the arena:
+                                               popcount f32[B], popdensemap f32[B][H][W], scale map f32[B][H][W], mask u8[B][H][W],
+                                               building score f32[B][1][H][W] -- valid until the next call */
+    int32_t launches, _pad2;                /* kernels enqueued by the call */
+} pc_step_io;
+void* pc_step_create(const pc_step_plan* plan);
+void pc_step_destroy(void* handle);
+int pc_train_step(void* handle, pc_step_io* io, int phases, void* stream);
+
+/* pc_reflect_pad_select / pc_select_normalize_pad / pc_ingest_split (planar form) for rows of any width and an output whose rows are
+ * out_rstride >= Wp floats apart (planes of Hp * out_rstride): kind as enum pc_step_data; mean == NULL: no normalisation. */
+int pc_ingest_pad_strided(int kind, const void* data, const void* data2, int Cin, float* out, int out_rstride, int B, int nsel,
+                          const int* sel, const float* mean, const float* stdv, int H, int W, int top, int bottom, int left, int right,
+                          void* stream);
+/* p[0 .. n) = 0 by a kernel (zero fills inside a captured step must not be memset nodes: DESIGN.md); p 16-byte aligned */
+int pc_zero_fill(float* p, int64_t n, void* stream);
 
 /* ---- census aggregation + sliding-window stitching ----------------------- */
 

@@ -99,14 +99,51 @@ class PcLevel2BwdDesc(C.Structure):
                 ("ws1", C.c_void_p), ("ws2", C.c_void_p)]
 
 
-PC_ABI_VERSION = 6
+PC_ABI_VERSION = 7
 PC_MAX_GROUP = 4
 PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
+PC_EINVAL, PC_ENOGPU, PC_ENOMEM, PC_ENOTSUP = -1, -2, -3, -4
 
 
 class PcAdamGroups(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("seg_end", C.c_int32 * PC_ADAM_MAX_SEG), ("seg_group", C.c_int32 * PC_ADAM_MAX_SEG),
                 ("active_mask", C.c_int32)]
+
+
+# ---- native step executor (pc_train_step) ------------------------------------------------------------------------------------------
+PC_STEP_CONVS = 10
+PC_DATA_INPUT, PC_DATA_RAW, PC_DATA_SPLIT = 0, 1, 2
+PC_STEP_FWD, PC_STEP_BWD, PC_STEP_UPD = 1, 2, 4
+
+
+class PcStepStream(C.Structure):
+    _fields_ = [("w", C.c_void_p * PC_STEP_CONVS), ("bn", PcBn * PC_STEP_CONVS), ("wt", C.c_void_p * 2), ("bt", C.c_void_p * 2),
+                ("dw", C.c_void_p * PC_STEP_CONVS), ("db", C.c_void_p * PC_STEP_CONVS), ("dwt", C.c_void_p * 2), ("dbt", C.c_void_p * 2),
+                ("chan", C.c_int32 * 4), ("cin", C.c_int32), ("feat_c0", C.c_int32)]
+
+
+class PcStepNet(C.Structure):
+    _fields_ = [("s", PcStepStream * 2), ("fusion_w", C.c_void_p), ("fusion_b", C.c_void_p)]
+
+
+class PcStepPlan(C.Structure):
+    _fields_ = [("unet", PcStepNet), ("extractor", PcStepNet), ("head_w", C.c_void_p * 8), ("head_dw", C.c_void_p * 8),
+                ("flat_p", C.c_void_p), ("flat_g", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("n", C.c_int32), ("n_decay", C.c_int32), ("n_head", C.c_int32), ("occupancymodel", C.c_int32),
+                ("hyper_dev", C.c_void_p), ("step_dev", C.c_void_p), ("norm_dev", C.c_void_p), ("stats_dev", C.c_void_p),
+                ("loss_dev", C.c_void_p), ("g_scale_const_dev", C.c_void_p), ("groups", PcAdamGroups),
+                ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float),
+                ("scale_regularization", C.c_float), ("lam_weak", C.c_float), ("lam4", C.c_float * 4), ("extractor_pad", C.c_int32),
+                ("band", C.c_int32 * 8), ("mean", C.c_float * 8), ("stdv", C.c_float * 8)]
+
+
+class PcStepIo(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("data_kind", C.c_int32), ("data", C.c_void_p), ("data2", C.c_void_p),
+                ("craw", C.c_int32), ("dp", C.c_int32), ("admin_mask", C.c_void_p), ("census_idx", C.c_void_p), ("y", C.c_void_p),
+                ("sel", C.c_void_p), ("encoder_no_grad", C.c_int32), ("unet_no_grad", C.c_int32), ("inv_B", C.c_float), ("_pad", C.c_int32),
+                ("arena", C.c_void_p), ("arena_bytes", C.c_int64), ("arena_needed", C.c_int64), ("off_popcount", C.c_int64),
+                ("off_popdense", C.c_int64), ("off_scale", C.c_int64), ("off_mask", C.c_int64), ("off_building", C.c_int64),
+                ("launches", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class PopcornHipError(RuntimeError):
@@ -127,13 +164,18 @@ def lib():
         cand = C.CDLL(LIB_PATH)
         # the .so is a build artefact (git-ignored): refuse a stale one instead of handing it descriptors of another layout
         ver = cand.pc_abi_version() if hasattr(cand, "pc_abi_version") else -1
-        sizes = [cand.pc_sizeof(i) for i in range(6)] if hasattr(cand, "pc_sizeof") else []
-        want = [C.sizeof(t) for t in (PcSrc, PcDst, PcBn, PcConvFwdDesc, PcAdamGroups, PcLevel2FwdDesc)]
+        sizes = [cand.pc_sizeof(i) for i in range(8)] if hasattr(cand, "pc_sizeof") else []
+        want = [C.sizeof(t) for t in (PcSrc, PcDst, PcBn, PcConvFwdDesc, PcAdamGroups, PcLevel2FwdDesc, PcStepPlan, PcStepIo)]
         if ver != PC_ABI_VERSION or sizes != want:
             raise PopcornHipError(f"{LIB_PATH} is stale: ABI version {ver} (binding: {PC_ABI_VERSION}), struct sizes {sizes} "
                                   f"(binding: {want}); rebuild it with `make -C popcorn_amd/csrc`")
         _lib = cand
         _lib.pc_error_string.restype = C.c_char_p
+        _lib.pc_step_create.restype = C.c_void_p
+        _lib.pc_step_create.argtypes = [C.POINTER(PcStepPlan)]
+        _lib.pc_step_destroy.restype = None
+        _lib.pc_step_destroy.argtypes = [C.c_void_p]
+        _lib.pc_train_step.argtypes = [C.c_void_p, C.POINTER(PcStepIo), C.c_int, C.c_void_p]
         for name in ("pc_conv3x3_wgrad_ws_bytes", "pc_convt2x2_wgrad_ws_bytes", "pc_head_ws_bytes",
                      "pc_compact_ws_bytes", "pc_unet_ws_bytes", "pc_level2_bwd_ws_bytes", "pc_conv3x3_up_ws_bytes", "pc_conv3x3_up_bwd_ws_bytes"):
             if hasattr(_lib, name):

@@ -25,12 +25,14 @@ extern "C" const char* pc_error_string(int code) {
         case 0: return "ok";
         case PC_EINVAL: return "invalid argument / unsupported shape";
         case PC_ENOGPU: return "no HIP device";
+        case PC_ENOMEM: return "pc_train_step: arena too small (pc_step_io.arena_needed)";
+        case PC_ENOTSUP: return "pc_train_step: variant not covered by the native executor";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
 
 // sizeof() of the ABI structs as the compiler laid them out: 0 = pc_src, 1 = pc_dst, 2 = pc_bn,
-// 3 = pc_conv_fwd_desc, 4 = pc_adam_groups, 5 = pc_level2_fwd_desc (binding self-check)
+// 3 = pc_conv_fwd_desc, 4 = pc_adam_groups, 5 = pc_level2_fwd_desc, 6 = pc_step_plan, 7 = pc_step_io (binding self-check)
 extern "C" int pc_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(pc_src);
@@ -39,6 +41,8 @@ extern "C" int pc_sizeof(int which) {
         case 3: return (int)sizeof(pc_conv_fwd_desc);
         case 4: return (int)sizeof(pc_adam_groups);
         case 5: return (int)sizeof(pc_level2_fwd_desc);
+        case 6: return (int)sizeof(pc_step_plan);
+        case 7: return (int)sizeof(pc_step_io);
         default: return -1;
     }
 }

@@ -2250,6 +2250,49 @@ __global__ __launch_bounds__(256) void ingest_split_kernel(const uint16_t* __res
     }
 }
 
+
+// pc_ingest_pad_strided: the three ingests above for rows of ANY width and an output whose rows are `rs` >= Wp floats apart (the native
+// step executor's arena pads rows to 16 bytes): one thread = one 16-byte piece of an output row.  KIND 0: planar fp32 source (model input or
+// raw tile), 2: uint16 S2 + fp32 S1 (channel index sel < C2 -> s2).  Same arithmetic as the kernels above ((x - mean) / std), so the same bits.
+template <int KIND, bool NORM>
+__global__ __launch_bounds__(256) void ingest_pad_strided_kernel(const void* __restrict__ data, const void* __restrict__ data2, float* __restrict__ out, PadSel ps,
+                                                                 int Cin, int C2, int nsel, int H, int W, int Hp, int Wp, int rs, int top, int left,
+                                                                 int64_t npieces, int wq) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npieces) return;
+    const int64_t row = i / wq;
+    const int piece = (int)(i - row * wq);
+    const int pl = (int)(row / Hp), y = (int)(row - (int64_t)pl * Hp);
+    const int b = pl / nsel, j = pl - b * nsel;
+    const int ys = pc_reflect(y - top, H);
+    const int x0 = 4 * piece, xs = x0 - left;
+    const int c = ps.sel[j];
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (KIND == 2 && c < C2) {
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(data) + ((int64_t)(b * C2 + c) * H + ys) * W;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < Wp) v[e] = (float)src[pc_reflect(xs + e, W)];
+    } else {
+        const float* src = KIND == 2 ? reinterpret_cast<const float*>(data2) + ((int64_t)(b * (Cin - C2) + (c - C2)) * H + ys) * W
+                                     : reinterpret_cast<const float*>(data) + ((int64_t)(b * Cin + c) * H + ys) * W;
+        if (xs >= 0 && xs + 3 < W) {
+            const f32x4u t = *reinterpret_cast<const f32x4u*>(src + xs);
+            v = f32x4{t[0], t[1], t[2], t[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < Wp) v[e] = src[pc_reflect(xs + e, W)];
+        }
+    }
+    if (NORM) {
+        const float mu = ps.mean[j], sd = ps.stdv[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wp ? (v[e] - mu) / sd : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + ((int64_t)pl * Hp + y) * rs + x0) = v;      // (rs % 4 == 0: the pad columns of the row get zeros)
+}
+
 }  // namespace
 
 static int launch_pad_select(const float* in, float* out, int B, int Cin, int nsel, const int* sel, const float* mean, const float* stdv,
@@ -2339,6 +2382,55 @@ extern "C" int pc_ingest_split(const uint16_t* s2, int C2, const float* s1, int 
     else
         hipLaunchKernelGGL(ingest_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s2, s1, out, ps, C2, C1, nsel, H, W, Hp, Wp, top,
                            left, (int)npix);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_ingest_pad_strided(int kind, const void* data, const void* data2, int Cin, float* out, int out_rstride, int B, int nsel,
+                                     const int* sel, const float* mean, const float* stdv, int H, int W, int top, int bottom, int left, int right,
+                                     void* stream) {
+    if (!data || !out || !sel || B < 1 || nsel < 1 || nsel > 8 || top >= H || bottom >= H || left >= W || right >= W || top < 0 || bottom < 0 ||
+        left < 0 || right < 0 || (mean == nullptr) != (stdv == nullptr) || (kind == PC_DATA_SPLIT && (!data2 || !mean)) ||
+        (kind != PC_DATA_INPUT && kind != PC_DATA_RAW && kind != PC_DATA_SPLIT))
+        return PC_EINVAL;
+    const int Hp = H + top + bottom, Wp = W + left + right;
+    if (out_rstride < Wp || (out_rstride & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return PC_EINVAL;
+    const int C2 = kind == PC_DATA_SPLIT ? 4 : 0;
+    const int Ctot = kind == PC_DATA_SPLIT ? 6 : Cin;
+    PadSel ps{};
+    for (int j = 0; j < nsel; ++j) {
+        if (sel[j] < 0 || sel[j] >= Ctot) return PC_EINVAL;
+        ps.sel[j] = sel[j];
+        ps.mean[j] = mean ? mean[j] : 0.f;
+        ps.stdv[j] = stdv ? stdv[j] : 1.f;
+    }
+    const int wq = (Wp + 3) >> 2;
+    const int64_t npieces = (int64_t)B * nsel * Hp * wq;
+    const int64_t nblk = (npieces + 255) / 256;
+    if (nblk > 0x7fffffff) return PC_EINVAL;
+    const dim3 grid((unsigned)nblk);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == PC_DATA_SPLIT)
+        hipLaunchKernelGGL((ingest_pad_strided_kernel<2, true>), grid, dim3(256), 0, st, data, data2, out, ps, 6, C2, nsel, H, W, Hp, Wp, out_rstride, top,
+                           left, npieces, wq);
+    else if (mean)
+        hipLaunchKernelGGL((ingest_pad_strided_kernel<0, true>), grid, dim3(256), 0, st, data, data2, out, ps, Cin, 0, nsel, H, W, Hp, Wp, out_rstride, top,
+                           left, npieces, wq);
+    else
+        hipLaunchKernelGGL((ingest_pad_strided_kernel<0, false>), grid, dim3(256), 0, st, data, data2, out, ps, Cin, 0, nsel, H, W, Hp, Wp, out_rstride, top,
+                           left, npieces, wq);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+// zero fill by a kernel (not a memset node: see zero_fill_kernel); p 16-byte aligned
+extern "C" int pc_zero_fill(float* p, int64_t n, void* stream) {
+    if (!p || n < 0 || (reinterpret_cast<uintptr_t>(p) & 15)) return PC_EINVAL;
+    if (n == 0) return 0;
+    const int64_t n4 = n / 4, rem = n - 4 * n4;
+    int grid = (int)((n4 + 255) / 256);
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, n4, rem);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -13,6 +13,7 @@ all-reduce are single kernels / a single collective.  The static-shape step can 
 from __future__ import annotations
 
 import contextlib
+import ctypes as C
 import gc
 import os
 
@@ -27,6 +28,47 @@ from .model.popcorn import pad_geometry
 # A/B switch: 0 = the head backward reduces its own weight-gradient partials (one launch more per step) instead of handing them to the
 # U-Net backward's batched reduction
 DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
+
+# Eager steps (no captured graph: the reference's variable-size census regions, run_train.py:186-202) go through the native executor --
+# ONE C-ABI call per step (pc_train_step: geometry, arena, descriptors and all launches in C++) instead of ~45 ctypes calls.
+# POPCORN_NATIVE_STEP=0: the per-launch Python engine (same kernels; A/B switch and the bit-equality reference of the tests)
+NATIVE_STEP = os.environ.get("POPCORN_NATIVE_STEP", "1") != "0"
+_LAYER_TAGS = ("inc1", "inc2", "d1a", "d1b", "d2a", "d2b", "up2a", "up2b", "up1a", "up1b")      # pc_step_stream's layer order
+_CONVT_TAGS = ("up2t", "up1t")
+
+
+class _ArenaOutputs:
+    """The outputs of a native step -- views into the step's arena, built on first access (``popcount``, ``popdensemap``, ``scale_map``,
+    ``mask``, ``building_counts``).  Valid until the trainer's next step (the arena is reused), like the static outputs of a replayed graph."""
+
+    def __init__(self, arena, io):
+        B, H, W = io.B, io.H, io.W
+        self._arena = arena
+        self._spec = {"popcount": (io.off_popcount, torch.float32, (B,)), "popdensemap": (io.off_popdense, torch.float32, (B, H, W)),
+                      "scale_map": (io.off_scale, torch.float32, (B, H, W)), "mask": (io.off_mask, torch.uint8, (B, H, W)),
+                      "building_counts": (io.off_building, torch.float32, (B, 1, H, W))}
+        self._views = {}
+
+    def __getitem__(self, k):
+        v = self._views.get(k)
+        if v is None:
+            off, dt, shape = self._spec[k]
+            n = 1
+            for d in shape:
+                n *= d
+            nbytes = n * (4 if dt == torch.float32 else 1)
+            v = self._views[k] = self._arena[off:off + nbytes].view(dt).view(shape)
+        return v
+
+    def __contains__(self, k):
+        return k in self._spec
+
+    def get(self, k, default=None):
+        return self[k] if k in self._spec else default
+
+    def keys(self):
+        return self._spec.keys()
+
 
 @contextlib.contextmanager
 def _capturing(g, **kw):
@@ -152,6 +194,17 @@ class FusedTrainStep:
         self._static = None
         self._sel_ring, self._sel_next = [], 0          # pinned host slots for the per-step selection grid (H2D without a host sync)
         self.last = {}
+        self._native = None             # (handle, plan, the engine objects it was built from) of pc_train_step
+        self._arena = None
+        self.native_steps = 0           # eager steps that went through pc_train_step (tests / tools read it)
+
+    def __del__(self):
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            try:
+                L.lib().pc_step_destroy(nat[0])
+            except Exception:
+                pass
 
     # ------------------------------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -253,6 +306,129 @@ class FusedTrainStep:
         table = dict(self.model.named_parameters())
         for n_ in self.names:
             table[n_].grad = self.grads[n_]
+
+    # ---- native executor (one C-ABI call per eager step) ------------------------------------------------------------
+    def _native_ok(self, sample):
+        """Which steps pc_train_step covers (include/popcorn_hip.h): fp32, dual-stream models whose building score comes from the frozen
+        extractor, with the occupancy product.  Everything else keeps the per-launch engine (same kernels)."""
+        m = self.model
+        if not NATIVE_STEP or m.precision != "fp32" or not (m.S1 and m.S2) or not m.occupancymodel:
+            return False
+        if (not m.sentinelbuildings) and sample.get("building_counts") is not None:
+            return False
+        return True
+
+    def _native_handle(self):
+        m = self.model
+        engs = m.engines()
+        if self._native is not None and self._native[2] is engs:
+            return self._native[0]
+        if self._native is not None:
+            L.lib().pc_step_destroy(self._native[0])
+            self._native = None
+        eng_u, eng_b = engs
+        plan = L.PcStepPlan()
+        keep = []
+
+        def fill(net, eng, prefix):
+            for si, (sname, chmap, cin, f0) in enumerate(eng.streams):
+                st = net.s[si]
+                for li, tag in enumerate(_LAYER_TAGS):
+                    lay = eng.layers[(sname, tag)]
+                    st.w[li] = lay.w.data_ptr()
+                    st.bn[li] = lay.bn
+                    if prefix is not None:
+                        st.dw[li] = self.grads[prefix + lay.wname].data_ptr()
+                        st.db[li] = self.grads[prefix + lay.bname].data_ptr()
+                    keep.append(lay)
+                for ti, tag in enumerate(_CONVT_TAGS):
+                    lay = eng.layers[(sname, tag)]
+                    st.wt[ti], st.bt[ti] = lay.w.data_ptr(), lay.b.data_ptr()
+                    if prefix is not None:
+                        st.dwt[ti] = self.grads[prefix + lay.wname].data_ptr()
+                        st.dbt[ti] = self.grads[prefix + lay.bname].data_ptr()
+                    keep.append(lay)
+                for c in range(4):
+                    st.chan[c] = chmap[c]
+                st.cin, st.feat_c0 = cin, f0
+            net.fusion_w = eng.fusion_w.data_ptr()
+            net.fusion_b = eng.fusion_b.data_ptr()
+
+        fill(plan.unet, eng_u, "unetmodel.")
+        fill(plan.extractor, eng_b, None)
+        ht = m.head_tensors()
+        hg = [self.grads[n_] for n_ in self.names[-8:]]
+        for i in range(8):
+            plan.head_w[i], plan.head_dw[i] = ht[i].data_ptr(), hg[i].data_ptr()
+        plan.flat_p, plan.flat_g, plan.adam_m, plan.adam_v = (t.data_ptr() for t in (self.flat_p, self.flat_g, self.m, self.v))
+        plan.n, plan.n_decay, plan.n_head = self.n, self.n_decay, sum(g.numel() for g in hg)
+        plan.occupancymodel = int(bool(m.occupancymodel))
+        plan.hyper_dev, plan.step_dev, plan.norm_dev = self.hyper.data_ptr(), self.step_count.data_ptr(), self.norm.data_ptr()
+        plan.stats_dev, plan.loss_dev, plan.g_scale_const_dev = self.stats.data_ptr(), self.loss_out.data_ptr(), self.g_scale_const.data_ptr()
+        plan.groups = ops.adam_groups(self.segments, {0, 1, 2})
+        plan.weight_decay, plan.beta1, plan.beta2, plan.eps = self.wd, self.betas[0], self.betas[1], self.eps
+        plan.max_norm, plan.scale_regularization, plan.lam_weak = (self.clip or 0.0), self.sreg, self.lam_weak
+        for i in range(4):
+            plan.lam4[i] = self.lam4[i]
+        plan.extractor_pad = m.p
+        band, mean, std = self.raw_norm
+        for c in range(6):
+            plan.band[c], plan.mean[c], plan.stdv[c] = int(band[c]), float(mean[c]), float(std[c])
+        h = L.lib().pc_step_create(C.byref(plan))
+        if not h:
+            raise L.PopcornHipError("pc_step_create failed")
+        self._native = (h, plan, engs, keep, ht, hg)
+        return h
+
+    def _native_io(self, s, sel, encoder_no_grad, unet_no_grad):
+        dk = data_keys(s)
+        B, _, H, W = s[dk[0]].shape
+        io = L.PcStepIo()
+        io.B, io.H, io.W = B, H, W
+        if dk == ("raw_s2", "raw_s1"):
+            if s["raw_s2"].shape[1] != 4 or s["raw_s1"].shape[1] != 2 or s["raw_s2"].dtype != torch.uint16:
+                raise ValueError("raw_s2 / raw_s1: the 4 selected S2 bands [R, G, B, NIR] as uint16 and the 2 S1 bands [VV, VH] as fp32")
+            io.data_kind, io.data, io.data2 = L.PC_DATA_SPLIT, s["raw_s2"].data_ptr(), s["raw_s1"].data_ptr()
+        elif dk == ("raw",):
+            io.data_kind, io.data, io.craw = L.PC_DATA_RAW, s["raw"].data_ptr(), s["raw"].shape[1]
+        else:
+            if s["input"].shape[1] != 6 or s["input"].dtype != torch.float32:
+                raise ValueError("input must be a (B, 6, H, W) fp32 tensor")
+            io.data_kind, io.data = L.PC_DATA_INPUT, s["input"].data_ptr()
+        io.admin_mask, io.census_idx, io.y, io.sel = s["admin_mask"].data_ptr(), s["census_idx"].data_ptr(), s["y"].data_ptr(), sel.data_ptr()
+        io.encoder_no_grad, io.unet_no_grad = int(bool(encoder_no_grad)), int(bool(unet_no_grad))
+        io.inv_B = 1.0 / self.reducer.global_batch(B)
+        io.dp = int(bool(self.reducer.active))
+        return io
+
+    def _native_call(self, h, io, phases, stream):
+        lib = L.lib()
+        for _ in range(2):
+            if self._arena is not None:
+                io.arena, io.arena_bytes = self._arena.data_ptr(), self._arena.numel()
+            rc = lib.pc_train_step(h, C.byref(io), phases, stream)
+            if rc != L.PC_ENOMEM:
+                break
+            # the arena grows to what this geometry takes (+ 1/8: the next region is a little larger more often than not); the old one is
+            # released to torch's stream-ordered allocator, so work still in flight on it finishes first
+            self._arena = None
+            self._arena = torch.empty(int(io.arena_needed * 9 // 8), dtype=torch.uint8, device=self.device)
+        L.check(rc, "pc_train_step")
+
+    def _native_step(self, s, sel, encoder_no_grad, unet_no_grad):
+        h = self._native_handle()
+        io = self._native_io(s, sel, encoder_no_grad, unet_no_grad)
+        stream = L.stream_ptr()
+        if not self.reducer.active:
+            self._native_call(h, io, L.PC_STEP_FWD | L.PC_STEP_BWD | L.PC_STEP_UPD, stream)
+        else:
+            self._native_call(h, io, L.PC_STEP_FWD, stream)
+            self.reducer.reduce_stats(self.stats)
+            self._native_call(h, io, L.PC_STEP_BWD, stream)
+            self.reducer.reduce_grads(self.flat_g)
+            self._native_call(h, io, L.PC_STEP_UPD, stream)
+        self.last = _ArenaOutputs(self._arena, io)
+        self.native_steps += 1
 
     # ---- the three stream-ordered sections -------------------------------------------------------------------------
     def _forward(self, s, sel, encoder_no_grad, unet_no_grad):
@@ -403,6 +579,9 @@ class FusedTrainStep:
             s["admin_mask"] = s["admin_mask"].float()
             sel = self._sel_to_device(sel_host)
             with L.precision(self.model.precision), L.stream_scope():      # (one stream lookup for the step's ~40 launches)
+                if self._native_ok(s):
+                    self._native_step(s, sel, encoder_no_grad, unet_no_grad)
+                    return self.loss_out
                 self._forward(s, sel, encoder_no_grad, unet_no_grad)
                 self.reducer.reduce_stats(self.stats)
                 self._backward(s, encoder_no_grad, unet_no_grad)

@@ -1,0 +1,182 @@
+"""The native step executor (pc_train_step, include/popcorn_hip.h): ONE C-ABI call per eager training step instead of ~45 ctypes
+launches -- the reference's inner loop (run_train.py:186-238) at its real geometry (weak_batch_size = 2 census regions of varying size,
+arguments/train.py:16,34-36).
+
+  * bit-equality with the per-launch Python engine (same kernels, same arithmetic: only the host side differs) over region geometries,
+    the three truncation regimes and the three input forms, two consecutive steps each (loss, every gradient, every parameter, Adam
+    state, outputs);
+  * the entry point called DIRECTLY through ctypes (plan + io structs, no trainer logic in between) against the CPU oracle's loss,
+    popcount and 56 gradients;
+  * arena growth / reuse across changing geometries, and the data-parallel phase split (FWD | BWD | UPD as three calls)."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from oracle import popcorn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REGIMES = {"all": (False, False), "limit1": (True, False), "limit2": (True, True)}
+
+
+def _fresh(native):
+    from popcorn_amd import train as T
+    from popcorn_amd.model import POPCORN
+    torch.manual_seed(1600)
+    m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+    tr = T.FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+    tr._force_native = native
+    return tr
+
+
+def _step(tr, smp, flags):
+    from popcorn_amd import train as T
+    prev = T.NATIVE_STEP
+    T.NATIVE_STEP = tr._force_native
+    try:
+        return tr.step(dict(smp), encoder_no_grad=flags[0], unet_no_grad=flags[1])
+    finally:
+        T.NATIVE_STEP = prev
+
+
+def _batch(B, H, W, kind="input", region="disc"):
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    batch = make_raw_batch(B, H, W, seed=H * 1000 + W, region=region)
+    small = {"admin_mask": batch["admin_mask"].cuda(), "census_idx": batch["census_idx"].cuda(), "y": batch["y"].cuda()}
+    raw = batch["raw"].cuda()
+    if kind == "raw":
+        return {"raw": raw, **small}
+    if kind == "split":
+        sel = raw[:, list(stats.BAND6)]
+        s2 = sel[:, :4].round().clamp(0, 65535)
+        return {"raw_s2": s2.to(torch.int32).cpu().to(torch.uint16).cuda().contiguous(), "raw_s1": sel[:, 4:6].contiguous(), **small}
+    return {"input": ops.select_normalize(raw, stats.BAND6, stats.MEAN6, stats.STD6), **small}
+
+
+GEOMS = [(2, 64, 48), (2, 100, 100), (1, 131, 77), (2, 230, 220), (3, 96, 160), (2, 257, 130)]
+
+
+@pytest.mark.parametrize("regime", list(REGIMES))
+@pytest.mark.parametrize("B,H,W", GEOMS)
+def test_native_step_is_bit_equal_to_the_per_launch_engine(B, H, W, regime):
+    flags = REGIMES[regime]
+    smp = _batch(B, H, W)
+    res = []
+    for native in (True, False):
+        tr = _fresh(native)
+        out = []
+        for it in range(2):
+            torch.manual_seed(3 + it)
+            loss = _step(tr, smp, flags)
+            torch.cuda.synchronize()
+            out.append((loss.clone(), tr.flat_g.clone(), tr.flat_p.clone(), tr.m.clone(), tr.v.clone(), tr.step_count.clone(),
+                        tr.last["popcount"].clone(), tr.last["popdensemap"].clone(), tr.last["scale_map"].clone(), tr.last["mask"].clone()))
+        assert tr.native_steps == (2 if native else 0)
+        res.append(out)
+    names = ("loss", "flat_g", "flat_p", "m", "v", "step", "popcount", "popdensemap", "scale_map", "mask")
+    for it in range(2):
+        for n, a, b in zip(names, res[0][it], res[1][it]):
+            if n in ("popdensemap", "scale_map"):
+                # outside the selection the per-launch path leaves torch.empty memory; compare where the mask selects
+                msk = res[1][it][-1].bool()
+                assert torch.equal(a[msk], b[msk]), (n, it)
+            else:
+                assert torch.equal(a, b), (n, it, (a.float() - b.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["raw", "split"])
+@pytest.mark.parametrize("B,H,W", [(2, 100, 100), (2, 150, 90)])
+def test_native_step_input_forms_are_bit_equal_to_the_per_launch_engine(B, H, W, kind):
+    smp = _batch(B, H, W, kind)
+    res = []
+    for native in (True, False):
+        tr = _fresh(native)
+        torch.manual_seed(3)
+        loss = _step(tr, smp, (False, False))
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.flat_g.clone(), tr.flat_p.clone(), tr.last["popcount"].clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_pc_train_step_through_ctypes_vs_the_oracles_56_gradients():
+    """The C entry point itself: plan + io structs filled here, one call with PC_STEP_FWD | PC_STEP_BWD (no optimiser step), checked against
+    the CPU oracle's loss, popcount and all 56 gradients at 2e-4."""
+    from popcorn_amd import _lib as L
+    B, H, W = 2, 181, 139
+    smp = _batch(B, H, W)
+    tr = _fresh(True)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    p0 = tr.flat_p.clone()
+    torch.manual_seed(3)
+    sel = tr._draw_selection(H, W).cuda()
+    h = tr._native_handle()
+    io = tr._native_io({k: v.contiguous() for k, v in smp.items()}, sel, False, False)
+    lib = L.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.pc_train_step(h, C.byref(io), L.PC_STEP_FWD | L.PC_STEP_BWD, stream)
+    assert rc == L.PC_ENOMEM and io.arena_needed > 0                     # no arena yet: the call reports what the geometry takes
+    arena = torch.empty(io.arena_needed, dtype=torch.uint8, device="cuda")
+    io.arena, io.arena_bytes = arena.data_ptr(), arena.numel()
+    rc = lib.pc_train_step(h, C.byref(io), L.PC_STEP_FWD | L.PC_STEP_BWD, stream)
+    assert rc == 0, lib.pc_error_string(rc)
+    torch.cuda.synchronize()
+    assert 20 <= io.launches <= 80
+    assert torch.equal(tr.flat_p, p0)                                    # no PC_STEP_UPD: parameters untouched
+    cpu = {k: v.cpu() for k, v in smp.items()}
+    torch.manual_seed(3)
+    ref_loss, ref_out, ref_grads, _ = O.train_step_grads(sd, cpu)
+    popcount = arena[io.off_popcount:io.off_popcount + 4 * B].view(torch.float32)
+    assert torch.allclose(popcount.cpu(), ref_out["popcount"], rtol=1e-4, atol=1e-3)
+    assert abs(tr.loss_out[0].item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    assert len(ref_grads) == 56
+    worst = 0.0
+    for n, r in ref_grads.items():
+        e = ((tr.grads[n].cpu() - r).abs().max() / max(r.abs().max().item(), 1e-3)).item()
+        worst = max(worst, e)
+        assert e < 2e-4, (n, e)
+    print(f"\n[native] pc_train_step 2x{H}x{W}: {io.launches} launches, arena {io.arena_needed / 2**20:.1f} MiB, worst gradient error {worst:.2e}")
+    mask = arena[io.off_mask:io.off_mask + B * H * W].view(B, H, W)
+    assert int(mask.sum().item()) == int(ref_out["scale"].numel())          # Nsel: the index path is exact
+
+
+def test_native_arena_grows_and_is_reused_across_geometries():
+    tr = _fresh(True)
+    sizes = []
+    for (B, H, W) in [(2, 64, 48), (2, 230, 220), (2, 64, 48), (1, 300, 200), (2, 230, 220)]:
+        smp = _batch(B, H, W)
+        torch.manual_seed(3)
+        loss = _step(tr, smp, (False, False))
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).all()
+        sizes.append(tr._arena.numel())
+        assert tuple(tr.last["popdensemap"].shape) == (B, H, W) and tr.last["mask"].dtype == torch.uint8
+    assert sizes[1] > sizes[0] and sizes[2] == sizes[1] and sizes[4] == sizes[3] >= sizes[1]       # grows, never shrinks
+    assert tr.native_steps == 5
+
+
+def test_native_phases_split_like_a_data_parallel_step_equal_the_single_call():
+    """FWD | BWD | UPD as three calls with the (identity) collectives of a forced single-rank reducer in between = the one-call step."""
+    from popcorn_amd import _lib as L
+    smp = _batch(2, 150, 90)
+    tr1, tr2 = _fresh(True), _fresh(True)
+    torch.manual_seed(3)
+    _step(tr1, smp, (False, False))
+    torch.manual_seed(3)
+    sel = tr2._draw_selection(150, 90).cuda()
+    h = tr2._native_handle()
+    s = {k: v.contiguous() for k, v in smp.items()}
+    io = tr2._native_io(s, sel, False, False)
+    io.dp = 1
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for ph in (L.PC_STEP_FWD, L.PC_STEP_BWD, L.PC_STEP_UPD):
+        tr2._native_call(h, io, ph, stream)
+    torch.cuda.synchronize()
+    # (the popcount / stats reduction differs in launch structure only: same sums per sample)
+    assert torch.allclose(tr1.loss_out, tr2.loss_out, rtol=1e-6, atol=0)
+    assert torch.allclose(tr1.flat_g, tr2.flat_g, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(tr1.flat_p, tr2.flat_p, rtol=0, atol=1e-7)

@@ -184,10 +184,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     int rvalid = 0;                                       // how many of the segment's 4 pixels are inside the image (0 .. 4)
     auto issue = [&](int ch, int b, int y0, int x0) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
-        const bool ok = l_act && xg >= 0 && xg < p.W && (unsigned)y < (unsigned)p.H;
+        // DIRECT: a source placed at (0, 0) may be SMALLER than the conv domain -- the up-sampled half of an Up block's concatenated input
+        // when the skip map has an odd extent (zero F.pad on the bottom / right, networks.py:309-312): rows / columns beyond the extent of
+        // the chunk's own source are zeros.  (A chunk never straddles the two sources: the first one has 8 or 16 channels.)
+        const int sW = LD == LD_DIRECT ? (ch * CHUNK < CA ? q.a.W : q.b.W) : p.W;
+        const int sH = LD == LD_DIRECT ? (ch * CHUNK < CA ? q.a.H : q.b.H) : p.H;
+        const bool ok = l_act && xg >= 0 && xg < sW && (unsigned)y < (unsigned)sH;
         // a row whose width is not a multiple of 4 ends inside a segment: the tail of that segment is read (the row stride is a
         // multiple of 4, so the 16 bytes exist) and masked per pixel when it is written to LDS
-        rvalid = ok ? (p.W - xg < 4 ? p.W - xg : 4) : 0;
+        rvalid = ok ? (sW - xg < 4 ? sW - xg : 4) : 0;
         if (LD == LD_REFLECT) {
             // first layer: reflect padding + channel gather; handles its own bounds (segments may straddle x = 0 / W)
             rvalid = l_act ? 4 : 0;
@@ -1418,7 +1423,8 @@ int conv_src_mode(const pc_src& s, int H, int W) {
     // memory; the loader masks its tail per pixel.  POOL2 reads source columns 2 xg .. 2 xg + 7 of which only those below 2 W are
     // used: with 1 or 2 valid pixels in the last segment (W % 4 = 1, 2) the second 16-byte piece is not read at all, with 3
     // (W % 4 = 3) it ends at column 2 W + 1: the source row must then have at least 2 W + 2 floats.)
-    if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H == H && s.W == W) return 1;
+    // (a DIRECT source at the origin that ends before the conv domain does is zero beyond its extent: the loader masks per source)
+    if (s.mode == PC_SRC_DIRECT && s.oy == 0 && s.ox == 0 && s.H <= H && s.W <= W && s.H >= 1 && s.W >= 1) return 1;
     if (s.mode == PC_SRC_POOL2 && s.W == 2 * W && s.H >= 2 * H && ((W % 4) != 3 || s.rstride >= 2 * W + 2)) return 2;
     return 0;
 }

@@ -41,8 +41,12 @@ struct UbProb {
     const float* wd;          // [32 steps m = co * 4 + r][4 lk = c][16 li = ci]
     float* part;              // [nwg][PART]
 };
-struct UbArgs { UbProb pr[PC_MAX_GROUP]; int H, nblocks, blocks_per_img; };
+struct UbArgs { UbProb pr[PC_MAX_GROUP]; int H, W, ntx, nblocks, blocks_per_img; };
 
+// Round 5: the image is cut into column tiles of W (template) full-resolution columns (a.W = image width, a.ntx tiles per row block; the
+// last one may be ragged in multiples of 8 columns): the one-pixel column halo of an interior tile comes from the neighbouring columns
+// instead of the image border's zeros, so any width >= 16 that is a multiple of 8 is taken (census regions: run_train.py:186-202) -- at
+// W == a.W (the 64- and 128-wide levels of the 100 x 100 tiles) nothing changes, bit for bit.
 // Persistent workgroups: each walks blocks (tile, 4 low-res rows) with stride gridDim.x, keeps the weight-gradient accumulators and
 // the border sums in registers over all of them and writes ONE partial at the end; the G / z rows of block n + 1 are loaded into
 // registers while block n computes (the first version staged every block synchronously behind runtime integer divides and wrote a
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
     const UbProb& q = a.pr[blockIdx.y];
     constexpr int w = W / 2, W4 = W / 4, w4 = w / 4;
     const int H = a.H, h = H >> 1;
+    const int WI = a.W, wI = WI >> 1;                        // image width (full / low resolution)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     constexpr int GRS = W + 8;                               // G row: data at cols 4 .. W + 3, halo cols 3 and W + 4
@@ -85,15 +90,28 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
     (void)zsh;
 
     f32x4 RG[NG], RZ[NZ];
+    float RGh = 0.f, RZh = 0.f;                              // this thread's element of the column halos (interior tile edges)
+    // thread -> halo element: G: (co, row, side) for tid < 8 * UB_GROWS * 2 = 160; z: (ci, row, side) for tid < C * (UB_RB + 2) * 2
+    const int hg_side = tid & 1, hg_row = (tid >> 1) % UB_GROWS, hg_co = (tid >> 1) / UB_GROWS;
+    const int hz_side = tid & 1, hz_row = (tid >> 1) % (UB_RB + 2), hz_ci = (tid >> 1) / (UB_RB + 2);
+    auto decode = [&](int blk, int& b, int& i0, int& X0) {
+        b = blk / a.blocks_per_img;
+        const int r = blk - b * a.blocks_per_img, rb = r / a.ntx;
+        i0 = rb * UB_RB;
+        X0 = (r - rb * a.ntx) * W;
+    };
     auto fetch = [&](int blk) {
-        const int b = blk / a.blocks_per_img, i0 = (blk - b * a.blocks_per_img) * UB_RB;
+        int b, i0, X0;
+        decode(blk, b, i0, X0);
+        const int x0 = X0 >> 1;
         const float* gp = q.g + b * q.g_bs;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int e = tid + 256 * k, seg = e % W4, pr = e / W4, row = pr % UB_GROWS, co = pr / UB_GROWS;     // compile-time divisors
             const int Y = 2 * i0 - 1 + row;
             const int Yc = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
-            RG[k] = *reinterpret_cast<const f32x4*>(gp + co * q.g_cs + (int64_t)Yc * q.g_rs + 4 * seg);
+            const int X = X0 + 4 * seg;
+            RG[k] = *reinterpret_cast<const f32x4*>(gp + co * q.g_cs + (int64_t)Yc * q.g_rs + (X < WI ? X : 0));
         }
         const float* zp = q.z + b * q.z_bs;
 #pragma unroll
@@ -101,23 +119,48 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
             const int e = tid + 256 * k, seg = e % w4, pr = e / w4, row = pr % (UB_RB + 2), ci = pr / (UB_RB + 2);
             const int I = i0 - 1 + row;
             const int Ic = I < 0 ? 0 : (I >= h ? h - 1 : I);
-            RZ[k] = ci < C ? *reinterpret_cast<const f32x4*>(zp + ci * q.z_cs + (int64_t)Ic * q.z_rs + 4 * seg) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int x = x0 + 4 * seg;
+            RZ[k] = ci < C ? *reinterpret_cast<const f32x4*>(zp + ci * q.z_cs + (int64_t)Ic * q.z_rs + (x < wI ? x : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.ntx > 1) {
+            if (tid < 8 * UB_GROWS * 2) {
+                const int Y = 2 * i0 - 1 + hg_row, Yc = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
+                const int X = hg_side ? X0 + W : X0 - 1;
+                RGh = gp[hg_co * q.g_cs + (int64_t)Yc * q.g_rs + ((unsigned)X < (unsigned)WI ? X : 0)];
+            }
+            if (tid < C * (UB_RB + 2) * 2) {
+                const int I = i0 - 1 + hz_row, Ic = I < 0 ? 0 : (I >= h ? h - 1 : I);
+                const int x = hz_side ? x0 + w : x0 - 1;
+                RZh = zp[hz_ci * q.z_cs + (int64_t)Ic * q.z_rs + ((unsigned)x < (unsigned)wI ? x : 0)];
+            }
         }
     };
     auto commit = [&](int blk) {
-        const int b = blk / a.blocks_per_img, i0 = (blk - b * a.blocks_per_img) * UB_RB;
+        int b, i0, X0;
+        decode(blk, b, i0, X0);
+        const int x0 = X0 >> 1;
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int e = tid + 256 * k, seg = e % W4, pr = e / W4, row = pr % UB_GROWS, co = pr / UB_GROWS;
             const int Y = 2 * i0 - 1 + row;
-            *reinterpret_cast<f32x4*>(gimg + co * GCS + row * GRS + 4 + 4 * seg) = (unsigned)Y < (unsigned)H ? RG[k] : zero;
+            *reinterpret_cast<f32x4*>(gimg + co * GCS + row * GRS + 4 + 4 * seg) = ((unsigned)Y < (unsigned)H && X0 + 4 * seg < WI) ? RG[k] : zero;
         }
 #pragma unroll
         for (int k = 0; k < NZ; ++k) {
             const int e = tid + 256 * k, seg = e % w4, pr = e / w4, row = pr % (UB_RB + 2), ci = pr / (UB_RB + 2);
             const int I = i0 - 1 + row;
-            if (ci < C) *reinterpret_cast<f32x4*>(zimg + ci * ZCS + row * ZRS + 4 + 4 * seg) = (unsigned)I < (unsigned)h ? RZ[k] : zero;
+            if (ci < C) *reinterpret_cast<f32x4*>(zimg + ci * ZCS + row * ZRS + 4 + 4 * seg) = ((unsigned)I < (unsigned)h && x0 + 4 * seg < wI) ? RZ[k] : zero;
+        }
+        if (a.ntx > 1) {
+            if (tid < 8 * UB_GROWS * 2) {
+                const int Y = 2 * i0 - 1 + hg_row, X = hg_side ? X0 + W : X0 - 1;
+                gimg[hg_co * GCS + hg_row * GRS + (hg_side ? W + 4 : 3)] = ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)WI) ? RGh : 0.f;
+            }
+            if (tid < C * (UB_RB + 2) * 2) {
+                const int I = i0 - 1 + hz_row, x = hz_side ? x0 + w : x0 - 1;
+                zimg[hz_ci * ZCS + hz_row * ZRS + (hz_side ? w + 4 : 3)] = ((unsigned)I < (unsigned)h && (unsigned)x < (unsigned)wI) ? RZh : 0.f;
+            }
         }
     };
 
@@ -134,7 +177,9 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
     int blk = blockIdx.x;
     if (blk < a.nblocks) fetch(blk);
     for (; blk < a.nblocks; blk += gridDim.x) {
-        const int b = blk / a.blocks_per_img, i0 = (blk - b * a.blocks_per_img) * UB_RB;
+        int b, i0, X0;
+        decode(blk, b, i0, X0);
+        const int x0 = X0 >> 1;
         __syncthreads();                             // the previous block's MFMA reads of the images are done
         commit(blk);
         if (blk + (int)gridDim.x < a.nblocks) fetch(blk + gridDim.x);
@@ -155,12 +200,12 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
                 }
                 // D[j = 4 lk + e][ci = li]
                 const int i = i0 + il, j = 16 * jb + 4 * lk;
-                if (li < C && i < h) {
+                if (li < C && i < h && x0 + j < wI) {
                     const float* zr = zimg + li * ZCS + (il + 1) * ZRS + j + 4;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = zr[e] > 0.f ? acc[e] * zsc : 0.f;
-                    *reinterpret_cast<f32x4*>(q.gz + b * q.gz_bs + li * q.gz_cs + (int64_t)i * q.gz_rs + j) = v;
+                    *reinterpret_cast<f32x4*>(q.gz + b * q.gz_bs + li * q.gz_cs + (int64_t)i * q.gz_rs + x0 + j) = v;
                 }
             }
         }
@@ -206,7 +251,9 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
                     se += v[0] + v[2];
                     so += v[1] + v[3];
                 }
-                const float gf = qd == 0 ? gr[0] : 0.f, gl = qd == 3 ? gr[W4 - 1] : 0.f;
+                // first / last column of the IMAGE row (the tile that holds it, the quarter that holds it)
+                const int lc = WI - 1 - X0 - qd * W4;                 // image column WI - 1 relative to this quarter
+                const float gf = (qd == 0 && X0 == 0) ? gr[0] : 0.f, gl = (unsigned)lc < (unsigned)W4 ? gr[lc] : 0.f;
                 const int par = row & 1 ? 0 : 1;     // image row 1 = Y = 2 i0 (even)
                 sg[par][0] += se; sg[par][1] += so; sg[par][2] += gf; sg[par][3] += gl;
                 if (Y == 0) { sg[2][0] += se; sg[2][1] += so; sg[2][2] += gf; sg[2][3] += gl; }
@@ -435,7 +482,7 @@ extern "C" int64_t pc_conv3x3_up_bwd_ws_bytes(int B, int H, int C) {
 
 extern "C" int pc_conv3x3_up_bwd_ok(const pc_src* g, const pc_src* z, const pc_dst* gz, int H, int W, int Cs, int C) {
     if (g_pc_precision != PC_PREC_FP32 || !g || !z) return 0;
-    if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W != 64 && W != 128)) return 0;
+    if (!((Cs == 8 && C == 8) || (Cs == 16 && C == 16)) || (H & 3) || (W & 7) || W < 16) return 0;
     if (g->C != 8 || g->H != H || g->W != W || g->mode != PC_SRC_DIRECT || g->oy || g->ox || z->C != C || z->H * 2 != H || z->W * 2 != W ||
         z->mode != PC_SRC_DIRECT || z->oy || z->ox)
         return 0;
@@ -449,7 +496,9 @@ extern "C" int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc*
                                                int* part_out, void* stream) {
     if (n < 1 || n > PC_MAX_GROUP || !d || B < 1 || !nwg_out || !part_out) return PC_EINVAL;
     UbArgs a{};
-    a.H = H; a.blocks_per_img = ((H >> 1) + UB_RB - 1) / UB_RB;
+    const int TWc = W <= 64 ? 64 : 128;                    // column tile (template parameter of the kernel)
+    a.H = H; a.W = W; a.ntx = (W + TWc - 1) / TWc;
+    a.blocks_per_img = (((H >> 1) + UB_RB - 1) / UB_RB) * a.ntx;
     a.nblocks = B * a.blocks_per_img;
     const int nwg = a.nblocks < UB_MAX_WG ? a.nblocks : UB_MAX_WG;
     for (int i = 0; i < n; ++i) {
@@ -465,8 +514,8 @@ extern "C" int pc_conv3x3_up_bwd_partial_group(int n, const pc_conv_up_bwd_desc*
         p.part = (float*)s.ws;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int rc = C == 16 ? (W == 64 ? launch_up_bwd<16, 64>(a, n, nwg, st) : launch_up_bwd<16, 128>(a, n, nwg, st))
-                           : (W == 64 ? launch_up_bwd<8, 64>(a, n, nwg, st) : launch_up_bwd<8, 128>(a, n, nwg, st));
+    const int rc = C == 16 ? (TWc == 64 ? launch_up_bwd<16, 64>(a, n, nwg, st) : launch_up_bwd<16, 128>(a, n, nwg, st))
+                           : (TWc == 64 ? launch_up_bwd<8, 64>(a, n, nwg, st) : launch_up_bwd<8, 128>(a, n, nwg, st));
     *nwg_out = nwg;
     *part_out = C == 16 ? UbCfg<16>::PART : UbCfg<8>::PART;
     return rc;
@@ -517,7 +566,9 @@ extern "C" int pc_conv3x3_up_bwd_group(int n, const pc_conv_up_bwd_desc* d, int 
     UbArgs a{};
     UrArgs ur{};
     UcArgs uc{};
-    a.H = H; a.blocks_per_img = ((H >> 1) + UB_RB - 1) / UB_RB;
+    const int TWc = W <= 64 ? 64 : 128;
+    a.H = H; a.W = W; a.ntx = (W + TWc - 1) / TWc;
+    a.blocks_per_img = (((H >> 1) + UB_RB - 1) / UB_RB) * a.ntx;
     a.nblocks = B * a.blocks_per_img;
     const int nwg = a.nblocks < UB_MAX_WG ? a.nblocks : UB_MAX_WG;
     const int PART = C == 16 ? UbCfg<16>::PART : UbCfg<8>::PART;
@@ -540,8 +591,8 @@ extern "C" int pc_conv3x3_up_bwd_group(int n, const pc_conv_up_bwd_desc* d, int 
     ur.nwg = nwg; ur.PART = PART;
     uc.Cs = Cs; uc.C = C; uc.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
-    int rc = C == 16 ? (W == 64 ? launch_up_bwd<16, 64>(a, n, nwg, st) : launch_up_bwd<16, 128>(a, n, nwg, st))
-                     : (W == 64 ? launch_up_bwd<8, 64>(a, n, nwg, st) : launch_up_bwd<8, 128>(a, n, nwg, st));
+    int rc = C == 16 ? (TWc == 64 ? launch_up_bwd<16, 64>(a, n, nwg, st) : launch_up_bwd<16, 128>(a, n, nwg, st))
+                     : (TWc == 64 ? launch_up_bwd<8, 64>(a, n, nwg, st) : launch_up_bwd<8, 128>(a, n, nwg, st));
     if (rc) return rc;
     hipLaunchKernelGGL(up_reduce_kernel, dim3((PART + 15) / 16, n), dim3(256), 0, st, ur);
     PC_CHECK_LAUNCH();

@@ -475,6 +475,11 @@ class UNetEngine:
         finish()
 
 
+def up_bwd_w_ok(w):
+    """Widths the composed Up block's backward kernel takes (pc_conv3x3_up_bwd_ok: column tiles of 64 / 128, ragged in multiples of 8)."""
+    return w >= 16 and w % 8 == 0
+
+
 def stream_channel_order(streams):
     """Input channels (indices into the model input [R,G,B,NIR,VV,VH]) in the order the padded per-stream input holds them."""
     return [c for _, chmap, cin, _ in streams for c in chmap[:cin]]
@@ -625,9 +630,9 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
         if not (COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (h, w) == (2 * z[keys[0]].shape[2], 2 * z[keys[0]].shape[3])):
             return None
         outs = {k: E(c, h, w) for k in keys}
-        # (the composed BACKWARD kernels exist for 64- and 128-wide maps; a forward-only pass takes any geometry the kernel accepts,
-        # e.g. the 2048 / 1024-wide levels of an inference window)
-        if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or (any(saves) and w not in (64, 128)):
+        # (the composed BACKWARD kernel takes widths that are multiples of 8 (round 5: column tiles); a forward-only pass takes any
+        # geometry the forward kernel accepts, e.g. the 2076 / 1038-wide levels of an inference window)
+        if not all(ops.conv3x3_up_fwd_ok(skip[k], z[k], outs[k]) for k in keys) or (any(saves) and not up_bwd_w_ok(w)):
             return None
         ws = ops.conv3x3_up_fwd_group([{"skip": skip[k], "z": z[k], "w": ly(k, tag).w, "wt": ly(k, ttag).w, "bt": ly(k, ttag).b,
                                         "bn": ly(k, tag).bn, "out": outs[k], "ws": precomp.get((tag, k))} for k in keys])
@@ -636,9 +641,9 @@ def forward_multi(engines, X, pad_top, pad_left, Hp, Wp, saves, feats_list=None,
     # with the composed first conv nobody reads the up-sampled tensors u2 / u1 -- not even the backward pass (up_bwd.hip)
     fwd_only = not any(saves)          # (forward-only passes -- inference windows -- take any width the composed forward kernel accepts)
     compose2 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (H1, W1) == (2 * H2, 2 * W2) and H1 % 4 == 0 and \
-        (W1 in (64, 128) or fwd_only)
+        (up_bwd_w_ok(W1) or fwd_only)
     compose1 = COMPOSED_UP and FUSED_CONV_BWD and L.act_dtype() == torch.float32 and (Hp, Wp) == (2 * H1, 2 * W1) and Hp % 4 == 0 and \
-        (Wp in (64, 128) or fwd_only)
+        (up_bwd_w_ok(Wp) or fwd_only)
     precomp = {}
     if compose1 and compose2 and 2 * len(keys) <= 2 * L.PC_MAX_GROUP:
         # the composed operand images of both Up levels of all (network, stream) pairs: one launch (they only depend on the weights)

@@ -259,7 +259,9 @@ def test_conv3x3_up_fwd_group_vs_convt_then_conv(Cs, hw):
             assert (got[sl] - ref[sl]).abs().max().item() < 3e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("Cs,hw", [(8, (128, 128)), (16, (64, 64)), (8, (64, 64))])
+@pytest.mark.parametrize("Cs,hw", [(8, (128, 128)), (16, (64, 64)), (8, (64, 64)),
+                                   # round 5: column tiles (interior halos from the neighbouring tile, ragged last tile, narrow maps)
+                                   (8, (40, 256)), (8, (36, 416)), (16, (28, 208)), (16, (24, 136)), (8, (16, 24)), (16, (12, 16)), (8, (20, 96))])
 def test_conv3x3_up_bwd_group_vs_autograd(Cs, hw):
     """pc_conv3x3_up_bwd_group (backward of the up-sampled half of an Up block's first conv from the LOW-resolution map: data
     gradient through the composed 4 x 4 stride-2 window, weight gradient of the composed weights + parity / border sums, chain

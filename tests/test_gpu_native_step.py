@@ -178,5 +178,5 @@ def test_native_phases_split_like_a_data_parallel_step_equal_the_single_call():
     torch.cuda.synchronize()
     # (the popcount / stats reduction differs in launch structure only: same sums per sample)
     assert torch.allclose(tr1.loss_out, tr2.loss_out, rtol=1e-6, atol=0)
-    assert torch.allclose(tr1.flat_g, tr2.flat_g, rtol=1e-5, atol=1e-9)
+    assert (tr1.flat_g - tr2.flat_g).abs().max().item() <= 1e-5 * tr1.flat_g.abs().max().item()
     assert torch.allclose(tr1.flat_p, tr2.flat_p, rtol=0, atol=1e-7)

@@ -731,10 +731,11 @@ def _region_alg_flop(B, H, W, nsel, enc_ng, unet_ng):
     return 2.0 * mac
 
 
-def config3_regions_leg(torch, margs, dev, steps=3):
+def config3_regions_leg(torch, margs, dev, steps=10, blocks=5):
     """BASELINE config 3 as the reference RUNS it (run_train.py:186-202): weak_batch_size = 2 census regions of variable size, the
-    truncation regime of each batch decided by the real limit1 / limit2 / limit3 defaults, eager launches (no graph for varying
-    shapes).  A seeded list of batch geometries spanning 1e5 .. 9e6 px; Mpx/s over the whole list, algorithmic TFLOP/s."""
+    truncation regime of each batch decided by the real limit1 / limit2 / limit3 defaults, eager steps (no graph for varying shapes) through
+    the native executor (pc_train_step: one C-ABI call per step).  A seeded list of batch geometries spanning 1e5 .. 9e6 px; per shape
+    `blocks` timed blocks of `steps` steps each (3 warm-up steps), the MEDIAN block is reported; Mpx/s over the whole list, algorithmic TFLOP/s."""
     from popcorn_amd import ops
     from popcorn_amd.cli import limit_regime, train_parser
     from popcorn_amd.data import stats
@@ -756,29 +757,38 @@ def config3_regions_leg(torch, margs, dev, steps=3):
         x = ops.select_normalize(batch["raw"].to(dev), stats.BAND6, stats.MEAN6, stats.STD6)
         smp = {"input": x, "admin_mask": batch["admin_mask"].to(dev), "census_idx": batch["census_idx"].to(dev), "y": batch["y"].to(dev)}
         torch.manual_seed(3)
-        tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)          # warm-up (allocations, attribute queries)
+        for _ in range(3):
+            tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)      # warm-up (arena growth, attribute queries)
         torch.cuda.synchronize()
         nsel = int(tr.last["mask"].sum().item())
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        nb = blocks if B * H * W < 4e6 else 3
+        block_ms = []
+        for _ in range(nb):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = tr.step(dict(smp), encoder_no_grad=enc_ng, unet_no_grad=unet_ng)
+            torch.cuda.synchronize()
+            block_ms.append((time.perf_counter() - t0) / steps * 1e3)
+        dt = statistics.median(block_ms) * 1e-3
         lv = float(loss[0].item())
         if not (lv == lv) or abs(lv) == float("inf"):
             raise SystemExit(f"config3_regions: non-finite loss at {B}x{H}x{W}")
         fl = _region_alg_flop(B, H, W, nsel, enc_ng, unet_ng)
         rows.append({"batch": f"{B}x{H}x{W}", "Mpx": round(B * H * W / 1e6, 3), "regime": "head only" if unet_ng else ("decoder + head" if enc_ng else "all"),
                      "selected_px": nsel, "ms_per_step": round(dt * 1e3, 3), "Mpx_per_s": round(B * H * W / dt / 1e6, 1),
-                     "tflops": round(fl / dt / 1e12, 2)})
+                     "tflops": round(fl / dt / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / dt / FP32_MATRIX_PEAK, 4),
+                     "ms_per_step_blocks": [round(v, 3) for v in block_ms]})
         tot_px += B * H * W; tot_t += dt; tot_fl += fl
         del smp, x, batch
         torch.cuda.empty_cache()
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    native = tr.native_steps
     del tr, model
     torch.cuda.empty_cache()
     return {"workload": "run_train.py geometry: weak_batch_size=2 census regions, sizes 1e5..9e6 px, regime per batch from the default "
-                        "limit1/2/3 = 9e6/9e6/13e6, eager fused step (fp32), disc-shaped regions inside the crop",
+                        "limit1/2/3 = 9e6/9e6/13e6, eager fused step (fp32) through the native executor (one pc_train_step call per step), "
+                        "disc-shaped regions inside the crop; median of timed 10-step blocks per shape",
+            "native_executor_steps": native, "steps_per_block": steps,
             "Mpx_per_s": round(tot_px / tot_t / 1e6, 1), "step_tflops": round(tot_fl / tot_t / 1e12, 2),
             "frac_of_fp32_mfma_peak": round(tot_fl / tot_t / FP32_MATRIX_PEAK, 4), "peak_hbm_gib": round(peak, 2), "batches": rows}
 

@@ -550,6 +550,7 @@ typedef struct pc_step_plan {
 enum pc_step_data { PC_DATA_INPUT = 0,   /* data = normalised model input (B, 6, H, W) fp32 */
                     PC_DATA_RAW = 1,     /* data = raw tile (B, craw, H, W) fp32 (data/PopulationDataset.py:566-568 + utils/utils.py:105-127 fused) */
                     PC_DATA_SPLIT = 2 }; /* data = uint16 S2 digital numbers (B, 4, H, W), data2 = fp32 S1 (B, 2, H, W) */
+#define PC_STEP_SEL_MAX 16384
 #define PC_STEP_FWD 1      /* ingest .. head forward (+ popcount / stats unless the loss launch finishes them) */
 #define PC_STEP_BWD 2      /* loss, head backward, U-Net backward into flat_g */
 #define PC_STEP_UPD 4      /* clip + Adam */
@@ -557,8 +558,12 @@ typedef struct pc_step_io {
     int32_t B, H, W, data_kind;
     const void* data; const void* data2; int32_t craw, dp;          /* dp != 0: data parallel -- the caller all-reduces stats_dev between the
                                                                        FWD and BWD phases and flat_g between BWD and UPD */
-    const float* admin_mask; const int64_t* census_idx; const float* y; const uint8_t* sel;     /* sel: H row flags then W column flags */
+    const float* admin_mask; const int64_t* census_idx; const float* y;
+    const uint8_t* sel;          /* DEVICE: H row flags then W column flags (the two multinomial draws of get_sparsity_mask, popcorn.py:366-369) */
     int32_t encoder_no_grad, unet_no_grad; float inv_B; int32_t _pad;
+    const uint8_t* sel_host;     /* or HOST: the same H + W flags in host memory (sel is then ignored): they travel bit-packed in the kernel
+                                    arguments of a one-block launch -- no H2D copy command (and none of its dispatch latency) per step;
+                                    H + W <= PC_STEP_SEL_MAX */
     void* arena; int64_t arena_bytes;       /* device scratch, 256-byte aligned; contents are undefined between steps */
     /* results */
     int64_t arena_needed;                   /* bytes this geometry takes (always set; PC_ENOMEM when arena_bytes is smaller) */

@@ -114,6 +114,7 @@ class PcAdamGroups(C.Structure):
 PC_STEP_CONVS = 10
 PC_DATA_INPUT, PC_DATA_RAW, PC_DATA_SPLIT = 0, 1, 2
 PC_STEP_FWD, PC_STEP_BWD, PC_STEP_UPD = 1, 2, 4
+PC_STEP_SEL_MAX = 16384
 
 
 class PcStepStream(C.Structure):
@@ -141,7 +142,7 @@ class PcStepIo(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("data_kind", C.c_int32), ("data", C.c_void_p), ("data2", C.c_void_p),
                 ("craw", C.c_int32), ("dp", C.c_int32), ("admin_mask", C.c_void_p), ("census_idx", C.c_void_p), ("y", C.c_void_p),
                 ("sel", C.c_void_p), ("encoder_no_grad", C.c_int32), ("unet_no_grad", C.c_int32), ("inv_B", C.c_float), ("_pad", C.c_int32),
-                ("arena", C.c_void_p), ("arena_bytes", C.c_int64), ("arena_needed", C.c_int64), ("off_popcount", C.c_int64),
+                ("sel_host", C.c_void_p), ("arena", C.c_void_p), ("arena_bytes", C.c_int64), ("arena_needed", C.c_int64), ("off_popcount", C.c_int64),
                 ("off_popdense", C.c_int64), ("off_scale", C.c_int64), ("off_mask", C.c_int64), ("off_building", C.c_int64),
                 ("launches", C.c_int32), ("_pad2", C.c_int32)]
 

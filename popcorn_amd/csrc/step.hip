@@ -22,6 +22,7 @@ namespace {
 enum { L_INC1 = 0, L_INC2, L_D1A, L_D1B, L_D2A, L_D2B, L_UP2A, L_UP2B, L_UP1A, L_UP1B };
 enum { T_UP2 = 0, T_UP1 = 1 };
 constexpr int MAXK = PC_MAX_GROUP;        // (network, stream) pairs of one grouped launch
+constexpr long long PC_STEP_SIDE_PX_DEFAULT = 1ll << 40;      // pixels (B * Hp * Wp) up to which the extractor's chain runs on the side stream
 
 // ---- tensors ------------------------------------------------------------------------------------------------------------------------
 struct Ten {                               // planar fp32 view (B, C, H, W)
@@ -90,11 +91,20 @@ struct Step {
     pc_bn bn_nobias[2][PC_STEP_CONVS];          // trainable network: ReLU / BN factor of a layer's output (no conv bias)
     pc_bn bn_half[2][2];                        // d1b's factor for the two 8-channel halves of its output (pointers into the same BN tensors)
     float* ones2 = nullptr;                     // device {1, 1}: weights of the partial-logit sum
+    // small regions: the frozen extractor's forward chain runs on a side stream next to the trainable U-Net's (two chains of ~13 small,
+    // latency-bound launches each; at B = 64 tiles -- a full chip per launch -- every multi-stream attempt lost)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_dep[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ev_next = 0;
+    int64_t side_px = 0;                        // use the side stream when B * Hp * Wp <= side_px
+    int64_t side_bwd_px = 0;                    // backward: the weight-gradient-only launches on the side stream up to this many pixels
     // context of the step between its phases
     bool have_fwd = false;
     int B = 0, H = 0, W = 0, pt = 0, pl = 0, Hp = 0, Wp = 0;
     Ten feats, building, Xp_u;
     uint8_t* mask = nullptr;
+    const uint8_t* sel = nullptr;               // device selection flags of this step (io.sel, or unpacked from io.sel_host)
     int32_t* counts = nullptr;
     float* popcount = nullptr;
     float* popdense = nullptr;
@@ -121,6 +131,12 @@ inline void pad_geometry(int H, int W, int& pt, int& pb, int& pl, int& pr) {    
     pt = pb = pl = pr = 0;
     if (H % 32 != 0) { pt = (64 - H % 64) / 2; pb = (64 - H % 64) - pt; }
     if (W % 32 != 0) { pl = (64 - W % 64) / 2; pr = (64 - W % 64) - pl; }
+}
+
+// the per-step selection flags from HOST memory: bit-packed into the kernel arguments of a one-block launch that writes them as bytes
+struct SelBits { uint32_t w[PC_STEP_SEL_MAX / 32]; };
+__global__ __launch_bounds__(256) void sel_unpack_kernel(const SelBits b, uint8_t* out, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = (b.w[i >> 5] >> (i & 31)) & 1u;
 }
 
 struct Net {                   // one DualStreamUNet taking part in a forward pass
@@ -408,6 +424,19 @@ void forward(Step& X, pc_step_io& io) {
     X.building = A.act(B, 1, H, W, /*dense=*/true);
     io.off_building = reinterpret_cast<char*>(X.building.p) - A.base;
     X.counts = reinterpret_cast<int32_t*>(A.raw(16));
+    X.sel = io.sel;
+    uint8_t* sel_dev = io.sel_host ? reinterpret_cast<uint8_t*>(A.raw(H + W)) : nullptr;
+    auto unpack_sel = [&]() {          // (on the stream whose chain ends in the mask kernel)
+        if (!sel_dev) return;
+        X.sel = sel_dev;
+        if (!X.go()) return;
+        SelBits bits;
+        memset(&bits, 0, sizeof(bits));
+        for (int i = 0; i < H + W; ++i)
+            if (io.sel_host[i]) bits.w[i >> 5] |= 1u << (i & 31);
+        hipLaunchKernelGGL(sel_unpack_kernel, dim3(1), dim3(256), 0, X.st, bits, sel_dev, H + W);
+        X.rc((int)hipGetLastError());
+    };
     X.g_pc = reinterpret_cast<float*>(A.raw((int64_t)B * 4));
     X.head_ws = A.raw(pc_head_ws_bytes(B, H, W));
 
@@ -419,6 +448,7 @@ void forward(Step& X, pc_step_io& io) {
     pc_src fs{};
     const float* am = io.admin_mask;
     if (same_domain) {
+        unpack_sel();
         const Ten Xp = ingest(X, io, pt, pb, pl, pr);
         X.Xp_u = Xp;
         const Net nets[2] = {Net{&P.extractor, false, true}, Net{&P.unet, !X.unet_ng, false}};
@@ -429,22 +459,36 @@ void forward(Step& X, pc_step_io& io) {
         fs = S(feats[0]);
         const pc_dst db = D(X.building);
         if (X.go())
-            X.rc(pc_building_score_mask(&fs, X.ones2, P.extractor.fusion_b, &db, am, io.census_idx, io.sel, io.sel + H, P.occupancymodel, X.mask,
+            X.rc(pc_building_score_mask(&fs, X.ones2, P.extractor.fusion_b, &db, am, io.census_idx, X.sel, X.sel + H, P.occupancymodel, X.mask,
                                         X.counts, B, H, W, pt, pl, X.st));
     } else {
-        // the frozen extractor on its own 14-pixel reflect-padded domain (popcorn.py:279-322); its activations are released afterwards
+        // the frozen extractor on its own 14-pixel reflect-padded domain (popcorn.py:279-322)
+        const bool two = X.side != nullptr && (int64_t)B * Hp * Wp <= X.side_px;
+        hipStream_t main_st = X.st;
         const int64_t mark = A.off;
+        if (two && X.go()) {
+            // fork: the side chain starts behind everything already enqueued on the caller's stream (the batch's copies, the previous step)
+            X.rc((int)hipEventRecord(X.ev_fork, main_st));
+            X.rc((int)hipStreamWaitEvent(X.side, X.ev_fork, 0));
+        }
+        if (two) X.st = X.side;
         {
+            unpack_sel();
             const Ten Xb = ingest(X, io, p, p, p, p);
             const Net nb[1] = {Net{&P.extractor, false, true}};
             forward_nets(X, nb, 1, Xb, H + 2 * p, W + 2 * p, feats, nullptr);
             fs = S(feats[0]);
             const pc_dst db = D(X.building);
             if (X.go())
-                X.rc(pc_building_score_mask(&fs, X.ones2, P.extractor.fusion_b, &db, am, io.census_idx, io.sel, io.sel + H, P.occupancymodel,
+                X.rc(pc_building_score_mask(&fs, X.ones2, P.extractor.fusion_b, &db, am, io.census_idx, X.sel, X.sel + H, P.occupancymodel,
                                             X.mask, X.counts, B, H, W, p, p, X.st));
         }
-        A.off = mark;          // (stream order: everything that follows is enqueued behind the extractor's launches)
+        if (two) {
+            if (X.go()) X.rc((int)hipEventRecord(X.ev_join, X.side));
+            X.st = main_st;
+        } else {
+            A.off = mark;      // its activations are released (stream order: everything that follows is enqueued behind the extractor's launches)
+        }
         const Ten Xp = ingest(X, io, pt, pb, pl, pr);
         X.Xp_u = Xp;
         const Net nu[1] = {Net{&P.unet, !X.unet_ng, false}};
@@ -452,6 +496,7 @@ void forward(Step& X, pc_step_io& io) {
         forward_nets(X, nu, 1, Xp, Hp, Wp, feats, sv);
         X.feats = feats[0];
         X.sv[0] = svbuf[0][0]; X.sv[1] = svbuf[0][1];
+        if (two && X.go()) X.rc((int)hipStreamWaitEvent(main_st, X.ev_join, 0));      // join: the head needs the building score and the mask
     }
     (void)featsrc;
     // sparse head + occupancy product + census sums (popcorn.py:161-190,195-228)
@@ -563,8 +608,27 @@ void backward(Step& X, pc_step_io& io) {
         for (int i = 0; i < n; ++i)
             entry(ws[i], ST[blk[i].s].dw[blk[i].L], blk[i].with_db ? ST[blk[i].s].db[blk[i].L] : nullptr, nwg, 8, 8, 0, cin_total * 9, blk[i].c0_add * 9);
     };
+    // The weight-gradient-only launches (16-channel encoder layers, first layers) run on the side stream next to the data-gradient chain:
+    // they only feed the batched reduction at the end.  side_on(): everything enqueued on the caller's stream so far (the producers of the
+    // launch's operands) is ordered in front of the side stream's next launch.
+    hipStream_t main_st = X.st;
+    const bool two = X.side != nullptr && (int64_t)B * Hp * Wp <= X.side_bwd_px;
+    bool side_used = false;
+    auto side_on = [&]() {
+        if (!two) return;
+        if (X.go()) {
+            hipEvent_t ev = X.ev_dep[X.ev_next];
+            X.ev_next = (X.ev_next + 1) & 7;
+            X.rc((int)hipEventRecord(ev, main_st));
+            X.rc((int)hipStreamWaitEvent(X.side, ev, 0));
+        }
+        X.st = X.side;
+        side_used = true;
+    };
+    auto side_off = [&]() { X.st = main_st; };
     // grouped weight gradient of layer L over both streams: x = cat[a, b]
     auto wgrad = [&](int L, const Ten* a, int mode, const Ten* b, const Ten* g, int Cout, int h, int w, int cin_total) {
+        side_on();
         pc_src sa[2], sb[2], sg[2];
         pc_conv_wgrad_desc d[2];
         void* ws[2];
@@ -581,6 +645,7 @@ void backward(Step& X, pc_step_io& io) {
         int nwg = 0;
         if (X.go()) X.rc(pc_conv3x3_wgrad_partial_group(2, d, B, h, w, Cin, Cout, &nwg, X.st));
         for (int s = 0; s < 2; ++s) entry(ws[s], ST[s].dw[L], ST[s].db[L], nwg, Cin, Cout, 0, cin_total ? cin_total * 9 : 0, 0);
+        side_off();
     };
     struct Dg { const Ten* g; int s; int L; const Ten* act; const pc_bn* act_bn; Ten* out; int c0_add; };
     auto dgrad = [&](const Dg* q, int n, int Cin_total, int c0, int cn, int pool, int acc, int h, int w, int Cg) {
@@ -836,6 +901,7 @@ void backward(Step& X, pc_step_io& io) {
         }
         // first layers: one launch per stream (2 / 4 input channels) over the padded input
         int c0 = 0;
+        side_on();
         for (int s = 0; s < 2; ++s) {
             const Ten xin = chans(X.Xp_u, c0, ST[s].cin);
             const pc_src sa = S(xin), sg = S(G_a1[s]);
@@ -845,6 +911,11 @@ void backward(Step& X, pc_step_io& io) {
             entry(ws, ST[s].dw[L_INC1], ST[s].db[L_INC1], nwg, ST[s].cin, 8, 0);
             c0 += ST[s].cin;
         }
+        side_off();
+    }
+    if (side_used && X.go()) {         // join: the reduction reads the side stream's partials
+        X.rc((int)hipEventRecord(X.ev_join, X.side));
+        X.rc((int)hipStreamWaitEvent(main_st, X.ev_join, 0));
     }
     // ONE batched fixed-order reduction for all layers (+ the head), then the chain rule of the composed levels
     if (X.go()) X.rc(pc_wgrad_reduce_batch(R.n, R.e, X.st));
@@ -908,6 +979,21 @@ extern "C" void* pc_step_create(const pc_step_plan* plan) {
         delete X;
         return nullptr;
     }
+    {
+        const char* ev = getenv("POPCORN_STEP_SIDE_PX");          // A/B switch: 0 = never fork
+        X->side_px = ev ? atoll(ev) : PC_STEP_SIDE_PX_DEFAULT;
+        if (X->side_px > 0 && (hipStreamCreateWithFlags(&X->side, hipStreamNonBlocking) != hipSuccess ||
+                               hipEventCreateWithFlags(&X->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                               hipEventCreateWithFlags(&X->ev_join, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError();
+            X->side = nullptr;                                    // no side stream: the sequential form
+        }
+        for (int i = 0; i < 8 && X->side; ++i)
+            if (hipEventCreateWithFlags(&X->ev_dep[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); X->side = nullptr; }
+        // backward: measured on 2 x H x W regions (tools/ab_regions.sh): -2 % .. -1 % up to 4.3 Mpx, +1.5 % from 7 Mpx on
+        const char* eb = getenv("POPCORN_STEP_SIDE_BWD_PX");      // A/B switch: 0 = weight-gradient launches stay on the caller's stream
+        X->side_bwd_px = eb ? atoll(eb) : 5000000ll;
+    }
     return X;
 }
 
@@ -915,6 +1001,11 @@ extern "C" void pc_step_destroy(void* handle) {
     Step* X = reinterpret_cast<Step*>(handle);
     if (!X) return;
     if (X->ones2) (void)hipFree(X->ones2);
+    if (X->ev_fork) (void)hipEventDestroy(X->ev_fork);
+    if (X->ev_join) (void)hipEventDestroy(X->ev_join);
+    for (int i = 0; i < 8; ++i)
+        if (X->ev_dep[i]) (void)hipEventDestroy(X->ev_dep[i]);
+    if (X->side) (void)hipStreamDestroy(X->side);
     delete X;
 }
 
@@ -922,7 +1013,8 @@ extern "C" int pc_train_step(void* handle, pc_step_io* io, int phases, void* str
     Step* X = reinterpret_cast<Step*>(handle);
     if (!X || !io || io->B < 1 || io->H < 1 || io->W < 1 || !(phases & 7)) return PC_EINVAL;
     if (g_pc_precision != PC_PREC_FP32) return PC_ENOTSUP;
-    if ((phases & PC_STEP_FWD) && (!io->data || !io->admin_mask || !io->census_idx || !io->sel || (io->data_kind == PC_DATA_SPLIT && !io->data2)))
+    if ((phases & PC_STEP_FWD) && (!io->data || !io->admin_mask || !io->census_idx || (!io->sel && !io->sel_host) ||
+                                   (io->sel_host && io->H + io->W > PC_STEP_SEL_MAX) || (io->data_kind == PC_DATA_SPLIT && !io->data2)))
         return PC_EINVAL;
     if ((phases & PC_STEP_BWD) && !io->y) return PC_EINVAL;
     if (phases & PC_STEP_FWD) {

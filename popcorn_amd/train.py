@@ -395,7 +395,11 @@ class FusedTrainStep:
             if s["input"].shape[1] != 6 or s["input"].dtype != torch.float32:
                 raise ValueError("input must be a (B, 6, H, W) fp32 tensor")
             io.data_kind, io.data = L.PC_DATA_INPUT, s["input"].data_ptr()
-        io.admin_mask, io.census_idx, io.y, io.sel = s["admin_mask"].data_ptr(), s["census_idx"].data_ptr(), s["y"].data_ptr(), sel.data_ptr()
+        io.admin_mask, io.census_idx, io.y = s["admin_mask"].data_ptr(), s["census_idx"].data_ptr(), s["y"].data_ptr()
+        if sel.is_cuda:
+            io.sel = sel.data_ptr()
+        else:                       # host flags: they travel in the kernel arguments of the executor's first launch (no H2D copy command)
+            io.sel_host = sel.data_ptr()
         io.encoder_no_grad, io.unet_no_grad = int(bool(encoder_no_grad)), int(bool(unet_no_grad))
         io.inv_B = 1.0 / self.reducer.global_batch(B)
         io.dp = int(bool(self.reducer.active))
@@ -568,6 +572,18 @@ class FusedTrainStep:
         ev.record()
         return dst
 
+    def _throttle(self, depth=8):
+        """Bound how far the host runs ahead of the device (what the pinned selection ring did as a side effect): at most ``depth`` steps."""
+        ring = getattr(self, "_run_ahead", None)
+        if ring is None:
+            ring = self._run_ahead = [[torch.cuda.Event() for _ in range(depth)], 0]
+            for ev in ring[0]:
+                ev.record()
+        ev = ring[0][ring[1]]
+        ring[1] = (ring[1] + 1) % len(ring[0])
+        ev.synchronize()
+        ev.record()
+
     def step(self, sample, encoder_no_grad=False, unet_no_grad=False):
         """One optimisation step on ``sample`` = {input (B,6,H,W) normalised -- or raw (B,Craw,H,W), see ``raw_norm`` --,
         admin_mask, census_idx, y}.  Returns the device tensor loss_out[2] = {loss, regulariser} (no host sync)."""
@@ -577,11 +593,15 @@ class FusedTrainStep:
         if not self.use_graph:
             s = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in sample.items() if not k.startswith("_")}
             s["admin_mask"] = s["admin_mask"].float()
-            sel = self._sel_to_device(sel_host)
             with L.precision(self.model.precision), L.stream_scope():      # (one stream lookup for the step's ~40 launches)
                 if self._native_ok(s):
-                    self._native_step(s, sel, encoder_no_grad, unet_no_grad)
+                    if H + W <= L.PC_STEP_SEL_MAX:
+                        self._throttle()
+                        self._native_step(s, sel_host, encoder_no_grad, unet_no_grad)       # (consumed during the call: no ring slot)
+                    else:
+                        self._native_step(s, self._sel_to_device(sel_host), encoder_no_grad, unet_no_grad)
                     return self.loss_out
+                sel = self._sel_to_device(sel_host)
                 self._forward(s, sel, encoder_no_grad, unet_no_grad)
                 self.reducer.reduce_stats(self.stats)
                 self._backward(s, encoder_no_grad, unet_no_grad)

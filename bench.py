@@ -313,7 +313,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     achieved = flops / dur / 1e12
     pmc = _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    rp_us, rp_file = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else "head_bwd_pc_kernel", "bf16" if bf else "fp32")
+    rp_us, rp_file, rp_match = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else "head_bwd_pc_kernel<0>", "bf16" if bf else "fp32")
     kname = ("head_bwd_bf16_coop4_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, the 4 waves of a workgroup share the weight gradients through an LDS exchange + transposing reads, 2 workgroups per CU)" if bf else
              "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
     if bf:
@@ -323,7 +323,9 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
             "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "launch_us_eager_step": round(dur_eager * 1e6, 2),
-            "rocprof_us": rp_us, "rocprof_file": rp_file,
+            # STATIC fields: the tracked rocprofv3 average of this kernel, reported only when the tracked profile was collected from THIS
+            # tree's kernel sources (stamp); the live measurement of the run is `launch_us` / `frac`
+            "rocprof_us": rp_us, "rocprof_file": rp_file, "rocprof_stamp_matches_tree": rp_match,
             "rocprof_frac": (round(flops / (rp_us * 1e-6) / peak, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
             "timed": ("graph replay of the step split at the call (events around the middle graph)" if dur_graph else
                       "eager steps, events around the call behind a device-side spin"),
@@ -635,20 +637,35 @@ def cpu_baseline(torch, sd, seconds):
 
 
 def _rocprof_avg_us(kernel, precision):
-    """Average duration (us) of `kernel` in the NEWEST tracked rocprofv3 summary of this precision (profiles/r*_<prec>_graph_kernel_stats.csv:
-    `rocprofv3 --kernel-trace --stats` of this very bench command under graph replay), and the file it came from."""
+    """Average duration (us) of `kernel` (FULL name incl. template arguments, e.g. ``head_bwd_pc_kernel<0>``) in the NEWEST tracked
+    rocprofv3 summary of this precision (profiles/r*_<prec>_graph_kernel_stats.csv: `rocprofv3 --kernel-trace --stats` of this very bench
+    command under graph replay), and the file it came from -- but ONLY when that round's stamp (profiles/r*_stamp.json, sha256 of the
+    kernel sources the profile was collected from, tools/csrc_hash.py) equals the tree's: a static figure from another build would sit
+    on the live line as if it belonged to it.  Returns (us, file, stamp_matches)."""
     import csv
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{precision}_graph_kernel_stats.csv")),
-                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    rnd = lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1))  # noqa: E731
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{precision}_graph_kernel_stats.csv")), key=rnd)
     if not files:
-        return None, None
-    with open(files[-1]) as fh:
+        return None, None, False
+    f = files[-1]
+    match = False
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_hash import csrc_hash
+        stamp = json.load(open(os.path.join(ROOT, "profiles", f"r{rnd(f)}_stamp.json")))
+        match = stamp.get("csrc_sha256") == csrc_hash(ROOT)[0]
+    except Exception:
+        match = False
+    if not match:
+        return None, os.path.basename(f), False
+    strip = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()  # noqa: E731
+    with open(f) as fh:
         for row in csv.DictReader(fh):
-            if kernel in row["Name"]:
-                return round(float(row["AverageNs"]) / 1e3, 2), os.path.basename(files[-1])
-    return None, os.path.basename(files[-1])
+            if strip(row["Name"]) == kernel:
+                return round(float(row["AverageNs"]) / 1e3, 2), os.path.basename(f), True
+    return None, os.path.basename(f), True
 
 
 def fwd_parity(torch, margs, sd_cpu, batch, dev):

@@ -101,12 +101,20 @@ class Stitcher:
         y1 = (xy[:, 1] + ps - overlap).clamp(max=self.w)
         keep = (x1 > x0) & (y1 > y0)
         x0, x1, y0, y1 = x0[keep], x1[keep], y0[keep], y1[keep]
+        # ONE transient int32 plane, prefix sums in place, added to the counts band by band: 4 B/px of scratch (+ a band) instead of the
+        # 12 B/px of a fresh cumsum result per pass and an int16 copy -- at country scale (1e9 px) that was > 10 GB next to the 16 B/px
+        # of accumulators, in exactly the multi-GPU path meant for the largest rasters
         diff = torch.zeros(self.h + 1, self.w + 1, dtype=torch.int32, device=dev)
         m = torch.full((x0.numel(),), int(M), dtype=torch.int32, device=dev)
         for xs, ys, sgn in ((x0, y0, 1), (x0, y1, -1), (x1, y0, -1), (x1, y1, 1)):
             diff.index_put_((xs, ys), m * sgn, accumulate=True)
-        cnt = diff.cumsum(0, dtype=torch.int32).cumsum(1, dtype=torch.int32)[:self.h, :self.w]
-        self.count += cnt.to(self.count.dtype)
+        diff.cumsum_(0)
+        diff.cumsum_(1)
+        band = max(1, (1 << 26) // max(self.w, 1))               # rows per band: 64 M elements of int16 conversion scratch at most
+        for r0 in range(0, self.h, band):
+            r1 = min(self.h, r0 + band)
+            self.count[r0:r1] += diff[r0:r1, :self.w].to(self.count.dtype)
+        del diff
 
     def all_reduce(self, reducer: FlatReducer):
         """Multi-GPU, simple form: sum the full accumulators on every rank (interiors of regular windows are disjoint, the

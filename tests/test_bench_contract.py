@@ -102,3 +102,25 @@ def test_live_two_rank_bench_line_on_one_gpu_through_gloo():
     assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
     assert "bf16" not in d and "h2d" not in d and "soak" not in d          # N > 1: the extra legs are skipped (run stays short)
     assert d["cpu_baseline"] is None and "config3_regions" not in d
+
+
+@pytest.mark.gpu
+def test_live_eight_rank_bench_line_on_one_gpu_through_gloo():
+    """`bench.py --gpus 8` -- the command line of the driver's largest scaling run -- as a functional run on the ONE GPU of the test box
+    (POPCORN_DIST_BACKEND=gloo: eight ranks share the device): the launcher path, eight process groups members, the data-parallel step
+    structure and the contract of the line; must finish well inside two minutes of bench time."""
+    import time
+    env = dict(os.environ, POPCORN_DIST_BACKEND="gloo")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1", "--repeats", "2",
+                          "--prewarm-seconds", "0", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    dt = time.time() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert REQUIRED <= set(d)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["global_batch"] == 512 and c["parallelism"] == "dp8" and c["backend"] == "gloo" and c["ranks_seen"] == 8
+    assert c["collectives"] is True and c["collectives_per_step"] == 2 and c["dp_capture_failed"] is False and len(d["per_rank_ms_per_step"]) == 8
+    assert abs(d["value"] - 512 * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
+    print(f"\n[bench --gpus 8 on one GPU through gloo] {dt:.0f} s wall, {d['ms_per_step']:.2f} ms / step for 8 x 64 tiles")
+    assert dt < 240, dt

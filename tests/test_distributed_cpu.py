@@ -21,15 +21,19 @@ def _free_port():
     return p
 
 
-def _sample(B=4, H=48, W=40):
+def _sample(B=4, H=48, W=40, empty=()):
+    """empty: samples whose census id does not occur in their admin mask -- an EMPTY region (Nsel = 0, popcount = 0) on the rank that
+    gets them: its loss term and its gradient contribution must still enter the global sums correctly."""
     g = torch.Generator().manual_seed(77)
     x = torch.randn(B, 6, H, W, generator=g)
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     admin = torch.zeros(B, H, W)
     census = torch.arange(3, 3 + B, dtype=torch.int64)
     for b in range(B):
-        r = 10 + 3 * b                                   # unequal region sizes -> unequal Nsel per rank
+        r = 6 + (3 * b) % 14                             # unequal region sizes -> unequal Nsel per rank
         admin[b] = torch.where(((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < r * r, float(census[b]), 0.0)
+        if b in empty:
+            admin[b] = 0.0
     y = torch.rand(B, generator=g) * 300
     return {"input": x, "admin_mask": admin, "census_idx": census, "y": y}
 
@@ -49,16 +53,16 @@ def _local_grads(sd, s, inv_B, nsel_global, lam_weak=100.0, sreg=0.01):
     return names, [work[n].grad if work[n].grad is not None else torch.zeros_like(work[n]) for n in names]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B=4, empty=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from oracle import popcorn_oracle as O
     from popcorn_amd.distributed import FlatReducer, init_from_env, shard_indices
     r, lr, w = init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and dist.is_initialized()
     sd = O.load_golden_state(G)
-    full = _sample()
+    full = _sample(B=B, empty=empty)
     idx = shard_indices(full["input"].shape[0], rank, world)
     s = {k: v[idx] for k, v in full.items()}
     red = FlatReducer()
@@ -78,20 +82,40 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_allreduce_reproduces_single_process_gradient():
+def _get(q, procs, timeout=300):
+    """q.get that gives up as soon as a rank has died without reporting (instead of sitting out the whole timeout)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise RuntimeError("a rank died: " + str([p.exitcode for p in procs]))
+            if time.time() - t0 > timeout:
+                raise
+
+
+@pytest.mark.parametrize("world,B,empty", [(2, 4, ()), (4, 8, (5,)), (8, 16, (2, 13))])
+def test_n_rank_allreduce_reproduces_single_process_gradient(world, B, empty):
+    """2, 4 and 8 gloo ranks: unequal Nsel per rank; at world 4 / 8 ranks hold a sample with an EMPTY census
+    region next to a populated one (a forward call whose WHOLE batch selects nothing is not a case: the reference's sparse head raises
+    on it -- conv2d over a (C, 0, 1) image, popcorn.py:195-228 -- and so does the oracle) -- the SUM of the ranks' gradients under the
+    global normalisers {B_global, Nsel_global} equals the single-process gradient."""
     from oracle import popcorn_oracle as O
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, B, empty)) for r in range(world)]
     for p in procs:
         p.start()
-    stats, flat = q.get(timeout=300)
+    stats, flat = _get(q, procs)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=240)
         assert p.exitcode == 0
     sd = O.load_golden_state(G)
-    full = _sample()
+    full = _sample(B=B, empty=empty)
     torch.manual_seed(9)
     loss, out, grads, _ = O.train_step_grads(sd, dict(full))
     assert stats[0] == out["scale"].numel()

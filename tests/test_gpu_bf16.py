@@ -1015,3 +1015,28 @@ def test_bf16_transposed_conv_in_the_conv_epilogue_is_bit_identical(monkeypatch,
             assert torch.equal(outs[True][2][s][k], outs[False][2][s][k]), (s, k)
     exact2x = (Hp // 2) * 2 == Hp and (Wp // 2) * 2 == Wp
     assert n8[False] == 4 and n8[True] == (0 if exact2x else 4), (n8, exact2x)
+
+
+def test_bf16_training_step_with_and_without_the_fused_transposed_conv_epilogue_is_bit_identical(monkeypatch):
+    """``FUSED_UPT`` (up1's transposed conv in the epilogue of up2's second conv) in TRAINING: loss, every gradient and the parameters after
+    the step are bit-identical to the separate launch (the switch was only covered in forward passes)."""
+    from popcorn_amd import engine as E, ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=19, device="cuda", region="disc")
+    x = ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(E, "FUSED_UPT", flag)
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        m.set_precision("bf16")
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(4)
+        loss = tr.step({"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]})
+        torch.cuda.synchronize()
+        res[flag] = (loss.clone(), tr.flat_g.clone(), tr.flat_p.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

@@ -150,14 +150,14 @@ def _launch(world, band=True):
     return out
 
 
-@pytest.mark.parametrize("band", [True, False])
-def test_two_rank_evaluate_raster_equals_single_process(band):
+@pytest.mark.parametrize("band,world", [(True, 2), (False, 2), (True, 4)])
+def test_n_rank_evaluate_raster_equals_single_process(band, world):
     """Two processes (gloo group, both on the one GPU of the test box) shard the window list round-robin and accumulate into
     their own device stitchers.  band=True: the visit count comes from the window list (no count collective), the planes are
     reduced by row band, every rank finalises its band, the bands are gathered; band=False: the all-reduce form.  Either way the
     finalised maps equal the single-process run (300 rows over 2 ranks: bands of 150)."""
     one = _launch(1)
-    two = _launch(2, band)
+    two = _launch(world, band)           # (4 ranks: 30 windows -> shards of 8, 8, 7, 7; 300 rows -> bands of 75)
     for a, b, name in zip(one, two, ("mean", "std", "scale mean", "scale std")):
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)), name

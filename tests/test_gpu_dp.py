@@ -117,10 +117,12 @@ def _launch(world, use_graph):
     return out
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_rank_fused_step_equals_single_process(use_graph):
+@pytest.mark.parametrize("use_graph,world", [(False, 2), (True, 2), (False, 4)])
+def test_n_rank_fused_step_equals_single_process(use_graph, world):
+    """2 (and, eager = the native executor's FWD | BWD | UPD phase split around the two collectives, 4) gloo ranks sharing the one GPU of
+    the test box against the single-process step on the whole batch."""
     p1, l1 = _launch(1, use_graph)
-    p2, l2 = _launch(2, use_graph)
+    p2, l2 = _launch(world, use_graph)
     # rank 0 reports only its local part of the batch-mean loss; parameters are what must agree
     p1, p2 = torch.tensor(p1), torch.tensor(p2)
     scale = p1.abs().max().item()

@@ -416,3 +416,47 @@ def test_fused_step_without_occupancy_model_or_with_its_own_building_layer_vs_or
             assert e <= 2e-4 * max(g.abs().max().item(), 1e-3), (use_graph, nm, e)
         m.load_state_dict(sd)
         tr.sync_from_model()
+
+
+@pytest.mark.parametrize("with_buffer", [True, False])
+def test_captured_step_on_static_buffers_reads_the_given_building_layer(with_buffer):
+    """a sentinelbuildings = False model fed its own building layer THROUGH ``static_buffers()`` (the loader-facing static
+    set of a captured step).  The layer must be an input of the captured graph: the loss follows it when it changes, equals the eager
+    step's loss for the same layer, and differs from the frozen extractor's path."""
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    from popcorn_amd import ops
+    from popcorn_amd.data import stats
+    B, H, W = 2, 100, 100
+    b = make_raw_batch(B, H, W, seed=3, device="cuda", region="disc")
+    x = ops.select_normalize(b["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    layers = [torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(s)).cuda() for s in (4, 5)]
+
+    def fresh(use_graph):
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=False).cuda()
+        return FusedTrainStep(m, lr=0.0, weight_decay=0.0, gradient_clip=0.01, use_graph=use_graph)      # lr 0: the steps are comparable
+
+    eager = []
+    for lay in layers:
+        tr = fresh(False)
+        torch.manual_seed(5)
+        eager.append(tr.step({"input": x, "admin_mask": b["admin_mask"], "census_idx": b["census_idx"], "y": b["y"], "building_counts": lay})[0].item())
+    assert abs(eager[0] - eager[1]) > 1e-6 * abs(eager[0])
+    tr = fresh(True)
+    st = tr.static_buffers(B, H, W, building=with_buffer)
+    st["input"].copy_(x); st["admin_mask"].copy_(b["admin_mask"]); st["census_idx"].copy_(b["census_idx"]); st["y"].copy_(b["y"])
+    got = []
+    for lay in layers + layers[:1]:
+        if with_buffer:
+            st["building_counts"].copy_(lay)
+            smp = st
+        else:
+            smp = dict(st)
+            smp["building_counts"] = lay          # the static set plus the user's own tensor for the layer
+        torch.manual_seed(5)
+        got.append(tr.step(smp)[0].item())
+    torch.cuda.synchronize()
+    for g, e in zip(got, eager + eager[:1]):
+        assert abs(g - e) <= 1e-6 * abs(e), (got, eager)

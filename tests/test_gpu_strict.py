@@ -19,10 +19,14 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _switches(monkeypatch, **kw):
+    """A/B switches of the per-launch engine (engine.py) and of the step (train.py: DEFER_HEAD_REDUCE, NATIVE_STEP).  Any engine switch off
+    its default also routes eager steps away from the native executor (train.py: _native_ok), so the per-launch engine is what runs."""
     from popcorn_amd import engine as E
+    from popcorn_amd import train as T
     for k, v in kw.items():
-        assert hasattr(E, k)
-        monkeypatch.setattr(E, k, v)
+        mod = E if hasattr(E, k) else T
+        assert hasattr(mod, k)
+        monkeypatch.setattr(mod, k, v)
 
 
 def test_g5_reference_gradients_and_adam_on_the_layerwise_path_flat_bar(monkeypatch):
@@ -92,7 +96,10 @@ def test_config3_batch64_gradients_vs_oracle_on_the_layerwise_path_flat_bar(monk
 
 
 @pytest.mark.parametrize("switch", [dict(PADDED_INPUT=False), dict(COMPOSED_UP=False), dict(FUSED_LEVEL2=False), dict(FUSED_CONV_BWD=False),
-                                    dict(PADDED_INPUT=False, COMPOSED_UP=False, FUSED_LEVEL2=False, FUSED_CONV_BWD=False)])
+                                    dict(PADDED_INPUT=False, COMPOSED_UP=False, FUSED_LEVEL2=False, FUSED_CONV_BWD=False),
+                                    dict(DEFER_HEAD_REDUCE=False),        # the head backward reduces its own partials (one launch more)
+                                    dict(NATIVE_STEP=False),              # every engine switch at its default, per-launch engine
+                                    dict()])                              # ... and the native executor (pc_train_step)
 @pytest.mark.parametrize("shape", [(3, 100, 100), (2, 64, 48)])
 def test_training_step_under_every_engine_switch_vs_oracle(monkeypatch, switch, shape):
     """The A/B switches of engine.py in TRAINING (100 x 100: the geometry all fast paths apply to; 64 x 48: none of the 32 x 32-level

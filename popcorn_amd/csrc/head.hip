@@ -300,38 +300,57 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
 // popcount[b] = sum of the sample's partials (fixed order).  stats (optional, double[2]) = {Nsel, sum of scale over
 // the batch}: the two scalars the scale-regularisation term needs (utils/losses.py:74) -- and the only two numbers a
 // data-parallel run has to exchange before the backward pass.
-__global__ void head_popcount_reduce_kernel(const float* partial, float* popcount, int B, int nchunk, double* stats,
-                                            const int32_t* nsel_counts, double dense_count) {
-    __shared__ double ssum[64];
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// The per-sample sums of the head forward's chunk partials, by ONE block of 256 threads, in ONE fixed order shared by every kernel that
+// finishes them (the data-parallel reduce launch below and the single-process popcount + loss launch: a forced one-rank data-parallel
+// step must equal the plain step bit for bit, tests/test_gpu_dp.py).  tpb threads per sample (a power of two, 256 / B at most): each
+// sums every tpb-th partial, then a fixed tree inside the group.  (One thread per sample walked a census region's thousands of chunks
+// serially: 50 us at B = 2 x 0.45 Mpx for 20 KB of partials.)  Returns this thread's share of sum(scale) as a double (non-zero in the
+// threads that own a sample).
+__device__ __forceinline__ double pc_popcount_sums_block(const float* partial, int nchunk, int B, float* popcount, float* tsum, float* usum) {
     double sc = 0.0;
-    if (b < B) {
+    int tpb = 1;
+    while (2 * tpb * B <= 256) tpb *= 2;
+    for (int b0 = 0; b0 < B; b0 += 256 / tpb) {
+        const int b = b0 + (int)threadIdx.x / tpb, j = (int)threadIdx.x & (tpb - 1);
         float t = 0.f, u = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            t += partial[((int64_t)b * nchunk + c) * 2];
-            u += partial[((int64_t)b * nchunk + c) * 2 + 1];
-        }
-        popcount[b] = t;
-        sc = (double)u;
-    }
-    if (stats) {          // launched as ONE block when stats are requested
-        for (int bb = b + blockDim.x; bb < B; bb += blockDim.x) {
-            float t = 0.f, u = 0.f;
-            for (int c = 0; c < nchunk; ++c) {
-                t += partial[((int64_t)bb * nchunk + c) * 2];
-                u += partial[((int64_t)bb * nchunk + c) * 2 + 1];
+        if (b < B)
+            for (int c = j; c < nchunk; c += tpb) {
+                t += partial[((int64_t)b * nchunk + c) * 2];
+                u += partial[((int64_t)b * nchunk + c) * 2 + 1];
             }
-            popcount[bb] = t;
-            sc += (double)u;
-        }
-        ssum[threadIdx.x] = sc;
+        tsum[threadIdx.x] = t; usum[threadIdx.x] = u;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-            for (int i = 0; i < (int)blockDim.x; ++i) tot += ssum[i];
-            stats[0] = nsel_counts ? (double)nsel_counts[0] : dense_count;
-            stats[1] = tot;
+        for (int off = tpb >> 1; off > 0; off >>= 1) {
+            if (j < off) { tsum[threadIdx.x] += tsum[threadIdx.x + off]; usum[threadIdx.x] += usum[threadIdx.x + off]; }
+            __syncthreads();
         }
+        if (j == 0 && b < B) {
+            popcount[b] = tsum[threadIdx.x];
+            sc += (double)usum[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    return sc;
+}
+
+// popcount[b] = sum of the sample's partials (fixed order).  stats (optional, double[2]) = {Nsel, sum of scale over
+// the batch}: the two scalars the scale-regularisation term needs (utils/losses.py:74) -- and the only two numbers a
+// data-parallel run has to exchange before the backward pass.  ONE block of 256 threads.
+__global__ __launch_bounds__(256) void head_popcount_reduce_kernel(const float* partial, float* popcount, int B, int nchunk, double* stats,
+                                                                   const int32_t* nsel_counts, double dense_count) {
+    __shared__ double red[256];
+    __shared__ float tsum[256], usum[256];
+    const double sc = pc_popcount_sums_block(partial, nchunk, B, popcount, tsum, usum);
+    if (!stats) return;
+    red[threadIdx.x] = sc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = nsel_counts ? (double)nsel_counts[0] : dense_count;
+        stats[1] = red[0];
     }
 }
 
@@ -2536,7 +2555,7 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     if (flags & PC_HEAD_FWD_DEFER_REDUCE) return 0;               // pc_head_popcount_loss finishes popcount / stats (and the loss)
-    hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(stats ? 1 : (B + 63) / 64), dim3(64), 0, st, p.partial, popcount, B,
+    hipLaunchKernelGGL(head_popcount_reduce_kernel, dim3(1), dim3(256), 0, st, p.partial, popcount, B,
                        p.nchunk, stats, nsel_counts, (double)B * H * W);
     PC_CHECK_LAUNCH();
     return 0;
@@ -2550,33 +2569,8 @@ __global__ __launch_bounds__(256) void head_popcount_loss_kernel(const float* pa
     __shared__ double red[256];
     __shared__ double s_stats[2];
     __shared__ float tsum[256], usum[256];
-    double sc = 0.0;
-    // tpb threads per sample (a power of two, 256 / B at most): each sums every tpb-th chunk partial, then a fixed tree inside the group.
-    // (One thread per sample walked a census region's thousands of chunks serially: 50 us at B = 2 x 0.45 Mpx for 20 KB of partials.)
-    int tpb = 1;
-    while (2 * tpb * a.B <= 256) tpb *= 2;
-    for (int b0 = 0; b0 < a.B; b0 += 256 / tpb) {
-        const int b = b0 + (int)threadIdx.x / tpb, j = (int)threadIdx.x & (tpb - 1);
-        float t = 0.f, u = 0.f;
-        if (b < a.B)
-            for (int c = j; c < nchunk; c += tpb) {
-                t += partial[((int64_t)b * nchunk + c) * 2];
-                u += partial[((int64_t)b * nchunk + c) * 2 + 1];
-            }
-        tsum[threadIdx.x] = t; usum[threadIdx.x] = u;
-        __syncthreads();
-        for (int off = tpb >> 1; off > 0; off >>= 1) {
-            if (j < off) { tsum[threadIdx.x] += tsum[threadIdx.x + off]; usum[threadIdx.x] += usum[threadIdx.x + off]; }
-            __syncthreads();
-        }
-        if (j == 0 && b < a.B) {
-            popcount[b] = tsum[threadIdx.x];
-            sc += (double)usum[threadIdx.x];
-        }
-        __syncthreads();
-    }
-    // the same summation order as head_popcount_reduce_kernel's single 64-thread block would be a different one: this kernel's own
-    // fixed order (thread-strided partial sums, then a tree) -- deterministic, and the value only enters the regulariser
+    const double sc = pc_popcount_sums_block(partial, nchunk, a.B, popcount, tsum, usum);
+    // (the same orders as head_popcount_reduce_kernel: per-sample sums by the shared routine, sum(scale) by the same 256-leaf tree)
     red[threadIdx.x] = sc;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {

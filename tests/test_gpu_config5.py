@@ -158,10 +158,18 @@ def test_n_rank_evaluate_raster_equals_single_process(band, world):
     finalised maps equal the single-process run (300 rows over 2 ranks: bands of 150)."""
     one = _launch(1)
     two = _launch(world, band)           # (4 ranks: 30 windows -> shards of 8, 8, 7, 7; 300 rows -> bands of 75)
-    for a, b, name in zip(one, two, ("mean", "std", "scale mean", "scale std")):
+    for a, b, name, mean in zip(one, two, ("mean", "std", "scale mean", "scale std"), (None, one[0], None, one[2])):
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)), name
-        np.testing.assert_allclose(b[fin], a[fin], rtol=2e-5, atol=2e-6, err_msg=name)
+        if mean is None:
+            np.testing.assert_allclose(b[fin], a[fin], rtol=2e-5, atol=2e-6, err_msg=name)
+            continue
+        # std = sqrt(sum x^2 / n - mean^2) (run_eval.py:140-154): what a different summation order across ranks moves is the
+        # VARIANCE, by a few ulp of mean^2 -- a near-zero std then moves by sqrt of that (4e-6 absolute / 3.5e-4 relative at
+        # std 1e-2, world 4).  The bound is therefore on the variance: 8 ulp of (mean^2 + var), fp32.
+        va, vb, m2 = a[fin].astype(np.float64) ** 2, b[fin].astype(np.float64) ** 2, mean[fin].astype(np.float64) ** 2
+        bound = 8 * 2.0 ** -23 * (m2 + va) + 1e-12
+        assert np.all(np.abs(vb - va) <= bound), (name, float(np.max(np.abs(vb - va) / bound)))
 
 
 def _band_census_rank(rank, world, port, q):

@@ -287,6 +287,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     ops.head_bwd = timed
     trainer.use_graph = False
     trainer.reducer = _LocalReducer()
+    trainer._native_ok = lambda s: False      # the per-launch engine (same kernels): the native executor never passes through ops.head_bwd
     try:
         for r in range(reps + 2):
             torch.manual_seed(1)
@@ -294,6 +295,7 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
         torch.cuda.synchronize()
     finally:
         ops.head_bwd = orig
+        del trainer._native_ok
         trainer.use_graph, trainer.reducer = saved_graph, saved_reducer
         trainer.flat_p.copy_(snap[0]); trainer.m.copy_(snap[1]); trainer.v.copy_(snap[2]); trainer.step_count.copy_(snap[3])
     dur_eager = statistics.median([t0.elapsed_time(t1) for t0, t1 in rec[2:]]) * 1e-3
@@ -528,6 +530,7 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
 
     saved_graph = trainer.use_graph
     trainer.use_graph = False
+    trainer._native_ok = lambda s: False      # the per-launch engine (same kernels): the wrapped ops functions are its launches
     patches = [wrap(ops, "conv3x3_fwd_group", "conv_fwd", c_fwd), wrap(ops, "conv3x3_dgrad_group", "conv_dgrad", c_dgrad),
                wrap(ops, "level2_fwd_group", "level2_fused", c_level2),
                wrap(ops.WgradBatch, "level2_bwd_group", "level2_fused", c_level2_bwd),
@@ -553,6 +556,7 @@ def conv_class_sweep(torch, trainer, sample, reps=3):
     finally:
         for obj, attr, orig in patches:
             setattr(obj, attr, orig)
+        del trainer._native_ok
         trainer.use_graph = saved_graph
         trainer.flat_p.copy_(snap[0]); trainer.m.copy_(snap[1]); trainer.v.copy_(snap[2]); trainer.step_count.copy_(snap[3])
     mpeak = BF16_MATRIX_PEAK if trainer.model.precision == "bf16" else FP32_MATRIX_PEAK

@@ -691,14 +691,16 @@ __global__ __launch_bounds__(256, 1) void head_bwd_kernel(const HeadBwdArgs a) {
 
 // Phase profile of the producer waves (debug builds only: make CXXFLAGS+=-DPOPCORN_HEAD_PROF; tools/ablate_head.py prints it)
 #ifdef POPCORN_HEAD_PROF
-__device__ long long g_head_prof[256 * 16];
+__device__ long long g_head_prof[2048 * 16];
 #define HP_DECL long long hp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long hp_t = 0, hp_a = 0; int hp_last = -1
 #define HP_ACQ0 hp_a = (long long)__builtin_readcyclecounter()
 #define HP_ACQ1 hp_acc[9] += (long long)__builtin_readcyclecounter() - hp_a
 #define HP_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)__builtin_readcyclecounter(); \
                         if (hp_last >= 0) hp_acc[hp_last] += t_ - hp_t; hp_t = t_; hp_last = (k); } while (0)
 #define HP_DUMP do { HP_MARK(8); if (wave == 0 && lane == 0) for (int k_ = 0; k_ < 10; ++k_) g_head_prof[blockIdx.x * 16 + k_] = hp_acc[k_]; } while (0)
+#define HP_DUMP_WAVE do { HP_MARK(8); if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) g_head_prof[(blockIdx.x * 4 + wave) * 16 + k_] = hp_acc[k_]; } while (0)
 #else
+#define HP_DUMP_WAVE
 #define HP_DECL
 #define HP_ACQ0
 #define HP_ACQ1
@@ -1553,9 +1555,11 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     const int niter = (a.total_groups + gstep - 1) / gstep;
     int gg = blockIdx.x * H4_WAVES + wave;
     if (gg < a.total_groups) fetch(gg);
+    HP_DECL;
     for (int it = 0; it < niter; ++it, gg += gstep) {
         const bool live = gg < a.total_groups;
         bool wrote = false;
+        HP_MARK(0);                                   // phase 0: loop top (consume the prefetch, issue the next one)
         if (live) {
             const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
             const int q = g * 16 + li;
@@ -1584,6 +1588,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
             hu32x4 m1[2], m2[2];                          // 0xffff per bf16 half of hb1 / hb2 that is non-zero (= passed its ReLU)
             f32x4 h3[4];
             float gout = 0.f;
+            HP_MARK(1);                               // phase 1: forward chain
             if (active) {
                 // ---- forward chain (lane = pixel, registers = hidden 16*mb + 4*lk + r)
                 const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
@@ -1618,6 +1623,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 gout = (sel && outv > 0.f) ? gup : 0.f;
                 active = __any(gout != 0.f);
             }
+            HP_MARK(2);                               // phase 2: backward chain + the gradient store
             if (active) {
                 if (lk == 0) db6 += gout;
                 // ---- backward chain: G3 = relu'(h3) . w6 . gout;  G2 = relu'(h2) . (W4^T G3);  G1 = relu'(h1) . (W2^T G2);  g_x = W0^T G1
@@ -1671,6 +1677,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                     }
                     pc_st4(gxp, o4);
                 }
+                HP_MARK(3);                           // phase 3: exchange writes
                 // ---- operands of the weight gradients into this wave's slot: rows = pixels, 8-byte pieces of 4 channels
                 // (pack t holds hidden 16*(2t) + 4*lk .. +3 and 16*(2t+1) + 4*lk .. +3)
                 // piece p = lk + 4 * k of row li goes to physical piece p ^ li: low bits lk ^ (li & 3), block k ^ (li >> 2)
@@ -1701,7 +1708,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(d + 32 * k) = z2;
             }
         }
+        HP_MARK(4);                                   // phase 4: first barrier (exchange complete)
         __syncthreads();
+        HP_MARK(5);                                   // phase 5: weight gradients (transposing reads + MFMAs)
         // ---- weight gradients over the 4 groups: 2 K-steps of 32 pixels (slots 2*ks, 2*ks + 1)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1729,8 +1738,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(xb + t_offx), hc_tr(xb + t_offx2)), dW0, 0, 0, 0);
             }
         }
+        HP_MARK(6);                                   // phase 6: second barrier (slots free again)
         __syncthreads();
     }
+    HP_DUMP_WAVE;
 
     // ---- workgroup partial (layout of head_bwd_pc_kernel): every 16x16 block has ONE owner; dw6 / db6 are summed over the waves
     // D layout of a block: lane = (m >> 2) * 16 + n, register = m & 3  (m = row = gradient's hidden unit, n = column)
@@ -2796,6 +2807,20 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
             once4.mark();
         }
         hipLaunchKernelGGL(head_bwd_bf16_coop4_kernel, dim3(nwg), dim3(256), H4_END, st, a);
+#ifdef POPCORN_HEAD_PROF
+        if (getenv("POPCORN_HEAD_PROF")) {
+            static long long hp[2048 * 16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_head_prof), sizeof(hp));
+            double tot[10] = {0};
+            const int nw = nwg * 4;
+            for (int w = 0; w < nw && w < 2048; ++w) for (int k = 0; k < 10; ++k) tot[k] += (double)hp[w * 16 + k];
+            const double nit = (double)((a.total_groups + nw - 1) / nw);
+            fprintf(stderr, "head_bwd_bf16_coop4 phases, cycles per iteration and wave (loop top, forward chain, backward chain + store, exchange writes, barrier 1, weight gradients, barrier 2, after the loop; %d workgroups, %.0f iterations):", nwg, nit);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %.0f", tot[k] / nw / nit);
+            fprintf(stderr, " %.0f\n", tot[8] / nw);
+        }
+#endif
     }
     else if (use_pc) {
         if (a.dbg == 1) hipLaunchKernelGGL(head_bwd_pc_kernel<1>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);

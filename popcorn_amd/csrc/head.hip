@@ -698,9 +698,18 @@ __device__ long long g_head_prof[2048 * 16];
 #define HP_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)__builtin_readcyclecounter(); \
                         if (hp_last >= 0) hp_acc[hp_last] += t_ - hp_t; hp_t = t_; hp_last = (k); } while (0)
 #define HP_DUMP do { HP_MARK(8); if (wave == 0 && lane == 0) for (int k_ = 0; k_ < 10; ++k_) g_head_prof[blockIdx.x * 16 + k_] = hp_acc[k_]; } while (0)
-#define HP_DUMP_WAVE do { HP_MARK(8); if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) g_head_prof[(blockIdx.x * 4 + wave) * 16 + k_] = hp_acc[k_]; } while (0)
+// the bf16 kernel's stamps: seven scalar accumulators with compile-time bucket indices (hp_acc[hp_last] above is a dynamically indexed array =
+// scratch memory, and every scratch access waits for vmcnt(0): the stamps then absorb the latency of the prefetch loads in flight)
+#define HQ_DECL long long hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0, hq4 = 0, hq5 = 0, hq6 = 0, hq_t = 0, hq_n = 0
+#define HQ_NOW(v) do { __builtin_amdgcn_sched_barrier(0); v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HQ_CLOSE(acc) do { HQ_NOW(hq_n); acc += hq_n - hq_t; hq_t = hq_n; } while (0)
+#define HQ_DUMP do { if (lane == 0) { long long* d_ = &g_head_prof[(blockIdx.x * 4 + wave) * 16]; d_[0] = hq0; d_[1] = hq1; d_[2] = hq2; d_[3] = hq3; \
+                                      d_[4] = hq4; d_[5] = hq5; d_[6] = hq6; } } while (0)
 #else
-#define HP_DUMP_WAVE
+#define HQ_DECL
+#define HQ_NOW(v)
+#define HQ_CLOSE(acc)
+#define HQ_DUMP
 #define HP_DECL
 #define HP_ACQ0
 #define HP_ACQ1
@@ -1555,11 +1564,11 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     const int niter = (a.total_groups + gstep - 1) / gstep;
     int gg = blockIdx.x * H4_WAVES + wave;
     if (gg < a.total_groups) fetch(gg);
-    HP_DECL;
+    HQ_DECL;
+    HQ_NOW(hq_t);
     for (int it = 0; it < niter; ++it, gg += gstep) {
         const bool live = gg < a.total_groups;
         bool wrote = false;
-        HP_MARK(0);                                   // phase 0: loop top (consume the prefetch, issue the next one)
         if (live) {
             const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
             const int q = g * 16 + li;
@@ -1588,7 +1597,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
             hu32x4 m1[2], m2[2];                          // 0xffff per bf16 half of hb1 / hb2 that is non-zero (= passed its ReLU)
             f32x4 h3[4];
             float gout = 0.f;
-            HP_MARK(1);                               // phase 1: forward chain
+            HQ_CLOSE(hq0);                            // phase 0: loop top (consume the prefetch, issue the next one)
             if (active) {
                 // ---- forward chain (lane = pixel, registers = hidden 16*mb + 4*lk + r)
                 const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
@@ -1623,7 +1632,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 gout = (sel && outv > 0.f) ? gup : 0.f;
                 active = __any(gout != 0.f);
             }
-            HP_MARK(2);                               // phase 2: backward chain + the gradient store
+            HQ_CLOSE(hq1);                            // phase 1: forward chain
             if (active) {
                 if (lk == 0) db6 += gout;
                 // ---- backward chain: G3 = relu'(h3) . w6 . gout;  G2 = relu'(h2) . (W4^T G3);  G1 = relu'(h1) . (W2^T G2);  g_x = W0^T G1
@@ -1677,7 +1686,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                     }
                     pc_st4(gxp, o4);
                 }
-                HP_MARK(3);                           // phase 3: exchange writes
+                HQ_CLOSE(hq2);                        // phase 2: backward chain + the gradient store
                 // ---- operands of the weight gradients into this wave's slot: rows = pixels, 8-byte pieces of 4 channels
                 // (pack t holds hidden 16*(2t) + 4*lk .. +3 and 16*(2t+1) + 4*lk .. +3)
                 // piece p = lk + 4 * k of row li goes to physical piece p ^ li: low bits lk ^ (li & 3), block k ^ (li >> 2)
@@ -1708,9 +1717,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(d + 32 * k) = z2;
             }
         }
-        HP_MARK(4);                                   // phase 4: first barrier (exchange complete)
+        HQ_CLOSE(hq3);                                // phase 3: exchange writes (inactive groups: their zero rows)
         __syncthreads();
-        HP_MARK(5);                                   // phase 5: weight gradients (transposing reads + MFMAs)
+        HQ_CLOSE(hq4);                                // phase 4: first barrier (exchange complete)
         // ---- weight gradients over the 4 groups: 2 K-steps of 32 pixels (slots 2*ks, 2*ks + 1)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1738,10 +1747,11 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
                 dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hc_pair(hc_tr(xb + t_offx), hc_tr(xb + t_offx2)), dW0, 0, 0, 0);
             }
         }
-        HP_MARK(6);                                   // phase 6: second barrier (slots free again)
+        HQ_CLOSE(hq5);                                // phase 5: weight gradients (transposing reads + MFMAs)
         __syncthreads();
+        HQ_CLOSE(hq6);                                // phase 6: second barrier (slots free again)
     }
-    HP_DUMP_WAVE;
+    HQ_DUMP;
 
     // ---- workgroup partial (layout of head_bwd_pc_kernel): every 16x16 block has ONE owner; dw6 / db6 are summed over the waves
     // D layout of a block: lane = (m >> 2) * 16 + n, register = m & 3  (m = row = gradient's hidden unit, n = column)
@@ -2816,9 +2826,9 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
             const int nw = nwg * 4;
             for (int w = 0; w < nw && w < 2048; ++w) for (int k = 0; k < 10; ++k) tot[k] += (double)hp[w * 16 + k];
             const double nit = (double)((a.total_groups + nw - 1) / nw);
-            fprintf(stderr, "head_bwd_bf16_coop4 phases, cycles per iteration and wave (loop top, forward chain, backward chain + store, exchange writes, barrier 1, weight gradients, barrier 2, after the loop; %d workgroups, %.0f iterations):", nwg, nit);
+            fprintf(stderr, "head_bwd_bf16_coop4 phases, cycles per iteration and wave (loop top, forward chain, backward chain + store, exchange writes, barrier 1, weight gradients, barrier 2; %d workgroups, %.0f iterations):", nwg, nit);
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %.0f", tot[k] / nw / nit);
-            fprintf(stderr, " %.0f\n", tot[8] / nw);
+            fprintf(stderr, "\n");
         }
 #endif
     }

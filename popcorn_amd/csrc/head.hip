@@ -216,25 +216,29 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     // gather is unconditional (clamped pixel) so that it does not sit behind the selection branch.
     // (the epilogue's building score and admin id come with the same prefetch: read where they are used they are one more exposed
     // round trip at the tail of every group)
+    // NOTHING in the prefetch may use a loaded value (round 5: `sel = valid && mask[..] != 0` inside it made every group wait for its
+    // mask byte -- s_waitcnt vmcnt(0), the preceding stores included -- before the remaining loads were even issued; the raw byte and
+    // the raw feature values travel to the next iteration instead), and the optional inputs are read unconditionally (from the
+    // building map when absent, value ignored) so that the number of loads in flight does not depend on a branch
     float bld_n = 0.f, adm_n = 0.f;
-    auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
+    unsigned msk_n = 1;
+    const uint8_t* const mask_or_dummy = p.mask ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
+    const float* const admin_or_dummy = p.admin ? p.admin : p.building;
+    auto fetch = [&](int g, bool& valid, float (&xv)[4]) {
         const int q = g * 16 + li;
-        const bool valid = q < HW && g < g_end;
+        valid = q < HW && g < g_end;
         const int qc = valid ? q : 0;
-        sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        msk_n = mask_or_dummy[(int64_t)b * HW + qc];
         bld_n = p.building[(int64_t)b * HW + qc];
-        if (p.admin) adm_n = p.admin[(int64_t)b * HW + qc];
+        adm_n = admin_or_dummy[(int64_t)b * HW + qc];
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
         const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = fp[(4 * j + lk) * p.feat.cstride];
-            xv[j] = valid ? v : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) xv[j] = fp[(4 * j + lk) * p.feat.cstride];
     };
-    bool sel_n = false;
+    bool valid_n = false;
     float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g_begin < g_end) fetch(g_begin, sel_n, xv_n);
+    if (g_begin < g_end) fetch(g_begin, valid_n, xv_n);
     f32x4 w6f[4];                  // the last layer's row and bias stay in registers (as in the backward's producer waves)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lds[L_W6 + 16 * mb + 4 * lk]);
@@ -243,12 +247,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
         const int q = g * 16 + li;
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
-        const bool sel = sel_n;
+        const bool sel = valid_n && (p.mask ? msk_n != 0 : true);
         const float bld = bld_n, adm = adm_n;
         float xv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = xv_n[j];
-        fetch(g + 1, sel_n, xv_n);
+        for (int j = 0; j < 4; ++j) xv[j] = valid_n ? xv_n[j] : 0.f;
+        fetch(g + 1, valid_n, xv_n);
         float outv = 0.f;
         if (__any(sel)) {
             // software-pipelined chain (the helpers of the backward's producer waves): every contraction's first weight fragments are
@@ -1214,13 +1218,15 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
 // K-slot conventions (identical for both operands, so the hardware's internal K order is irrelevant):
 //   64-wide contraction, instruction t of 2:  slot (lk, j) -> hidden unit 16*(2t + (j >> 2)) + 4*lk + (j & 3)
 //       (= D-layout registers h[2t][0..3], h[2t+1][0..3] of the lane, packed in order)
-//   16-wide feature contraction (layer 1):    slot (lk, j) -> feature channel 4*j + lk       (the gather order of `fetch`)
+//   16-wide feature contraction (layer 1):    slot (lk, j) -> feature channel 4*lk + j       (one 8-byte load per lane: the four
+//       channels arrive packed, as the operand -- round 5; rounds 2-4 gathered channel 4*j + lk with four 2-byte loads and converted them
+//       to fp32 inside the prefetch, which made every prefetch wait for its own loads: profiles/r5_head_bwd_bf16_phases.json)
 //   32-pixel contraction (weight gradients):  slot (lk, j) -> pixel 8*lk + j of a pair of 16-pixel groups
 typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
 typedef short hs16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
 // LDS image (bytes): ready-made fragments, lane-linear
-constexpr int HB_A1 = 0;                          // [4 mb][64 lanes][4 bf16]   W0[16mb+i][4j+lk]
+constexpr int HB_A1 = 0;                          // [4 mb][64 lanes][4 bf16]   W0[16mb+i][4lk+j]
 constexpr int HB_A2 = HB_A1 + 4 * 64 * 8;         // [4 mb2][2 t][64][8 bf16]   W2[16mb2+i][unit(t,lk,j)]
 constexpr int HB_A3 = HB_A2 + 8 * 64 * 16;        // same for W4
 constexpr int HB_T3 = HB_A3 + 8 * 64 * 16;        // [4 mi][2 t][64][8]         W4[unit(t,lk,j)][16mi+i]
@@ -1236,7 +1242,7 @@ __device__ __forceinline__ void head_stage_weights_bf16(unsigned char* lds, cons
     auto bits = [](float x) { return (unsigned short)(__float_as_uint(pc_bf16r(x)) >> 16); };
     for (int e = tid; e < 4 * 64 * 4; e += nt) {
         const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
-        h[HB_A1 / 2 + e] = bits(p.w0[(16 * mb + (lane & 15)) * 16 + 4 * j + (lane >> 4)]);
+        h[HB_A1 / 2 + e] = bits(p.w0[(16 * mb + (lane & 15)) * 16 + 4 * (lane >> 4) + j]);
     }
     for (int e = tid; e < 8 * 64 * 8; e += nt) {
         const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, t = f & 1, mb2 = f >> 1;
@@ -1351,34 +1357,38 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     // (the epilogue's building score and admin id come with the same prefetch: read where they are used they are one more exposed
     // round trip at the tail of every group)
     float bld_n = 0.f, adm_n = 0.f;
-    auto fetch = [&](int g, bool& sel, float (&xv)[4]) {
+    // (nothing in the prefetch may USE a loaded value -- a conversion, a select on it: the compiler then waits for the load right where
+    // it was issued and the prefetch hides nothing; the raw bits travel to the next iteration)
+    // the optional inputs are read unconditionally (from the building map when absent, value ignored): with a load count that depends
+    // on a branch the compiler's s_waitcnt for the PREVIOUS group's values must assume the fewest new loads in flight and ends up
+    // waiting for the first of the new ones
+    unsigned msk_n = 1;
+    const uint8_t* const mask_or_dummy = p.mask ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
+    const float* const admin_or_dummy = p.admin ? p.admin : p.building;
+    auto fetch = [&](int g, bool& valid, uint2& xq) {
         const int q = g * 16 + li;
-        const bool valid = q < HW && g < g_end;
+        valid = q < HW && g < g_end;
         const int qc = valid ? q : 0;
-        sel = valid && (p.mask ? p.mask[(int64_t)b * HW + qc] != 0 : true);
+        msk_n = mask_or_dummy[(int64_t)b * HW + qc];
         bld_n = p.building[(int64_t)b * HW + qc];
-        if (p.admin) adm_n = p.admin[(int64_t)b * HW + qc];
+        adm_n = admin_or_dummy[(int64_t)b * HW + qc];
         const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
-        // channels-last feature map: the 16 channels of the pixel are contiguous
+        // channels-last feature map: the 16 channels of the pixel are contiguous; this lane's K-slots are channels 4*lk .. +3
         const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride +
                               (int64_t)(p.px + x) * p.feat.xstride;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = pc_ld1(fp + 4 * j + lk);
-            xv[j] = valid ? v : 0.f;
-        }
+        xq = *reinterpret_cast<const uint2*>(fp + 4 * lk);
     };
-    bool sel_n = false;
-    float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g_begin < g_end) fetch(g_begin, sel_n, xv_n);
+    bool valid_n = false;
+    uint2 xq_n = make_uint2(0u, 0u);
+    if (g_begin < g_end) fetch(g_begin, valid_n, xq_n);
     for (int g = g_begin; g < g_end; ++g) {
         const int q = g * 16 + li;
         const bool valid = q < HW;
         const int64_t pix = (int64_t)b * HW + q;
-        const bool sel = sel_n;
+        const bool sel = valid_n && (p.mask ? msk_n != 0 : true);
         const float bld = bld_n, adm = adm_n;
-        const hs16x4 xb = hb_pack4(xv_n[0], xv_n[1], xv_n[2], xv_n[3]);
-        fetch(g + 1, sel_n, xv_n);
+        const hs16x4 xb = __builtin_bit_cast(hs16x4, valid_n ? xq_n : make_uint2(0u, 0u));
+        fetch(g + 1, valid_n, xq_n);
         float outv = 0.f;
         if (__any(sel)) {
             int lane_o = lane;
@@ -1537,7 +1547,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     const int t_offx2 = (lk >> 1) * H4_SLOT + H4_X + (t_r0 + 4) * H4_XROW + 8 * ((li & 3) ^ (((t_r0 + 4) ^ ((t_r0 + 4) >> 2)) & 3));
 
     // per-group inputs, fetched one group ahead
-    float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
+    float n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
     long long n_cen = 0;          // the two per-sample scalars ride with the prefetch (raw; converted where used): read at their point of
                                   // use they are two dependent, fully exposed memory round trips per group (see head_bwd_pc_kernel)
     uint2 n_f4 = make_uint2(0u, 0u);
@@ -1550,9 +1560,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
         const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
         const pc_bf16_t* fp = reinterpret_cast<const pc_bf16_t*>(p.feat.ptr) + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride +
                               (int64_t)(p.px + x) * p.feat.xstride;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) n_xv[j] = pc_ld1(fp + 4 * j + lk);
-        n_f4 = *reinterpret_cast<const uint2*>(fp + 4 * lk);          // channels 4*lk .. +3: mask of the fused ReLU backward AND the dW0 operand
+        n_f4 = *reinterpret_cast<const uint2*>(fp + 4 * lk);          // channels 4*lk .. +3: the layer-1 operand (K-slots of this lane), the
+                                                                      // mask of the fused ReLU backward AND the dW0 operand -- raw bits:
+                                                                      // nothing here may use a loaded value (see head_fwd_bf16_kernel)
         n_msk = p.mask ? p.mask[pix] : 1;
         n_bld = p.building[pix];
         if (p.admin) { n_adm = p.admin[pix]; n_cen = p.census[b]; }
@@ -1575,9 +1585,6 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
             const bool valid = q < HW;
             const int y = valid ? (int)pc_div((uint32_t)q, p.div_w) : 0, x = valid ? q - y * p.W : 0;
             const bool sel = valid && n_msk != 0;
-            float xv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = valid ? n_xv[j] : 0.f;
             const uint2 f4 = valid ? n_f4 : make_uint2(0u, 0u);
             float gup = 0.f;
             if (sel) {
@@ -1600,7 +1607,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
             HQ_CLOSE(hq0);                            // phase 0: loop top (consume the prefetch, issue the next one)
             if (active) {
                 // ---- forward chain (lane = pixel, registers = hidden 16*mb + 4*lk + r)
-                const hs16x4 xb = hb_pack4(xv[0], xv[1], xv[2], xv[3]);
+                const hs16x4 xb = __builtin_bit_cast(hs16x4, f4);
                 {
                     f32x4 h1[4];
 #pragma unroll

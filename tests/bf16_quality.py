@@ -2,7 +2,7 @@
 stands behind BASELINE config 4).  A teacher (the same architecture with another head initialisation) labels synthetic
 census regions, so that there is something to learn; two students start from identical parameters and see identical batches
 and selection grids, one in fp32 and one in PC_PREC_BF16.  Shared by tests/test_gpu_bf16.py (assertion) and
-tools/bf16_training_quality.py (the table in DESIGN.md section 7)."""
+tools/bf16_training_quality.py (the table in DESIGN_HISTORY.md section 7)."""
 import torch
 
 

@@ -696,7 +696,7 @@ def test_bf16_training_tracks_fp32_training_over_200_steps():
     alike, at different places), so the comparison is on MEDIANS over the last 10 epochs and inside that scatter: loss within 35 %
     (recorded: fp32 0.0200, bf16 0.0242; the fp32 run with another summation order lands 0.0196 - 0.0237, and 0.0261 with round 5's
     parallel popcount sums -- a quarter of the first epoch's 0.1025 is 0.0256, inside that scatter, hence a third), R^2 within 0.03
-    (0.963 vs 0.960; table in DESIGN.md section 7).  What it rules out is a bf16 run that stalls, diverges or converges elsewhere."""
+    (0.963 vs 0.960; table in DESIGN_HISTORY.md section 7).  What it rules out is a bf16 run that stalls, diverges or converges elsewhere."""
     from tests.bf16_quality import run
     r = run(steps=200)
     l32, l16 = r["loss_median_last_10_epochs"]["fp32"], r["loss_median_last_10_epochs"]["bf16"]

@@ -1,6 +1,6 @@
 """Seeded random geometries (beyond the hand-picked shapes of test_gpu_sizes.py) through the drop-in forward and the fused
 train step vs the CPU oracle.  Gradients are judged like tools/fuzz_train.py: <= 2e-4 relative against the fp32 oracle, or
--- when a max-pool arg-max / ReLU tie flipped in one of the two fp32 evaluations ("Gradient parity and ties")
+-- when a max-pool arg-max / ReLU tie flipped in one of the two fp32 evaluations (DESIGN.md section 0 "Ties"; DESIGN_HISTORY.md "Gradient parity and ties")
 -- the mismatch must be of that kind: identical loss, and an fp64 oracle that is no further from the HIP result than ~1e-3."""
 import random
 

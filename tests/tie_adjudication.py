@@ -1,4 +1,4 @@
-"""Adjudication of a gradient mismatch between the HIP path and an fp32 reference ("Gradient parity and ties").
+"""Adjudication of a gradient mismatch between the HIP path and an fp32 reference (DESIGN.md section 0 "Ties"; DESIGN_HISTORY.md "Gradient parity and ties").
 
 The backward pass contains discrete decisions -- the ReLU mask of every layer and the arg-max of every 2 x 2 pooling window -- and an
 activation within fp32 rounding of a tie flips one of them in one of two fp32 evaluations; the affected gradients then move by

@@ -1436,6 +1436,215 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
     }
 }
 
+
+// ---- fp32 results on the bf16 matrix pipe: 3-way operand splits (round 5) -----------------------------------------------------------
+// An fp32 number is EXACTLY the sum of three bf16 numbers (a1 = rn(a), a2 = rn(a - a1), a3 = rn(a - a1 - a2): 8 + 8 + 8 mantissa bits,
+// same exponent range; each difference is exact in fp32).  A product a * b is then the sum of nine bf16 x bf16 products, each exact in
+// the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the three smallest (a2 b3, a3 b2, a3 b3: <= 2^-23 of the product together) are
+// dropped, the other six are accumulated smallest first.  Per product the error is of the size of ONE fp32 rounding -- the class of
+// error the fp32 MFMA's own fma chain makes at every step -- and the contraction runs at 6 x 16 cycles per 32 K-slots instead of
+// 8 x 32 on v_mfma_f32_16x16x4_f32: 2.67x the matrix rate for the price of 11 VALU instructions per pair of activations (weights are
+// split once per step, by the pack launch).  The head is the one kernel class of the fp32 step that is bound by the matrix pipe
+// (forward 0.72 of the fp32 MFMA peak in issued work), which is where this pays; the conv class is half memory-bound and gained 10 %
+// in round 2's prototype.  POPCORN_HEAD_SPLIT=0 selects the fp32-MFMA kernel (A/B and tests).
+//   LDS image: three planes (split index) of the bf16 forward fragments A1 | A2 | A3 (offsets HB_A1 / HB_A2 / HB_A3 inside a plane),
+//   then fp32 b0[64] b2[64] b4[64] w6[64] b6.
+constexpr int HS_PLANE = HB_T3;
+constexpr int HS_F32 = 3 * HS_PLANE;
+constexpr int HS_END = HS_F32 + (4 * 64 + 4) * 4;
+
+__device__ __forceinline__ void hs_split3(float x, unsigned short (&o)[3]) {
+    const float a1 = pc_bf16r(x), r1 = x - a1, a2 = pc_bf16r(r1), r2 = r1 - a2, a3 = pc_bf16r(r2);
+    o[0] = (unsigned short)(__float_as_uint(a1) >> 16);
+    o[1] = (unsigned short)(__float_as_uint(a2) >> 16);
+    o[2] = (unsigned short)(__float_as_uint(a3) >> 16);
+}
+
+__device__ __forceinline__ void head_stage_weights_split(unsigned char* img, const HeadArgs& p, int tid, int nt) {
+    unsigned short* h = reinterpret_cast<unsigned short*>(img);
+    unsigned short o[3];
+    for (int e = tid; e < 4 * 64 * 4; e += nt) {
+        const int j = e & 3, lane = (e >> 2) & 63, mb = e >> 8;
+        hs_split3(p.w0[(16 * mb + (lane & 15)) * 16 + 4 * (lane >> 4) + j], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) h[(pl * HS_PLANE + HB_A1) / 2 + e] = o[pl];
+    }
+    for (int e = tid; e < 8 * 64 * 8; e += nt) {
+        const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, t = f & 1, mb2 = f >> 1;
+        const int u = hb_unit(t, lane >> 4, j), i = lane & 15;
+        hs_split3(p.w2[(16 * mb2 + i) * HID + u], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) h[(pl * HS_PLANE + HB_A2) / 2 + e] = o[pl];
+        hs_split3(p.w4[(16 * mb2 + i) * HID + u], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) h[(pl * HS_PLANE + HB_A3) / 2 + e] = o[pl];
+    }
+    float* f = reinterpret_cast<float*>(img + HS_F32);
+    for (int e = tid; e < 64; e += nt) {
+        f[e] = p.b0[e];
+        f[64 + e] = p.b2[e];
+        f[128 + e] = p.b4[e];
+        f[192 + e] = p.w6[e];
+    }
+    if (tid == 0) f[256] = p.b6[0];
+}
+
+// one pair of fp32 values -> the three packed bf16 pairs of its split
+__device__ __forceinline__ void hs_split_pair(float x0, float x1, unsigned& q1, unsigned& q2, unsigned& q3) {
+    q1 = pc_pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(q1 << 16), r1 = x1 - __uint_as_float(q1 & 0xffff0000u);
+    q2 = pc_pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(q2 << 16), s1 = r1 - __uint_as_float(q2 & 0xffff0000u);
+    q3 = pc_pack_bf16(s0, s1);
+}
+// the 16 values of a lane (D layout: h[mb][r] = hidden 16*mb + 4*lk + r) -> packed operands o[split][t] of the next 64-wide contraction
+__device__ __forceinline__ void hs_split_pack(const f32x4 (&h)[4], hbf16x8 (&o)[3][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        hu32x4 q[3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const f32x4& v = h[2 * t + (d >> 1)];
+            unsigned q1, q2, q3;
+            hs_split_pair(v[2 * (d & 1)], v[2 * (d & 1) + 1], q1, q2, q3);
+            q[0][d] = q1; q[1][d] = q2; q[2][d] = q3;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) o[pl][t] = __builtin_bit_cast(hbf16x8, q[pl]);
+    }
+}
+// 64 -> 64 layer on split operands: o1[mb2] = bias + W . h, six partial products per K-step, smallest first; the four accumulators
+// of the layer take turns (independent MFMA chains)
+__device__ __forceinline__ void hs_layer64(const unsigned char* lds, int a_off, const float* bias, int lane, int lk,
+                                           const hbf16x8 (&hb)[3][2], f32x4 (&o1)[4]) {
+#pragma unroll
+    for (int mb2 = 0; mb2 < 4; ++mb2) o1[mb2] = *reinterpret_cast<const f32x4*>(&bias[16 * mb2 + 4 * lk]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl) {                 // weight split index; activation split indices 0 .. 2 - pl
+            hbf16x8 fr[4];
+#pragma unroll
+            for (int mb2 = 0; mb2 < 4; ++mb2) fr[mb2] = hb_frag8(lds, pl * HS_PLANE + a_off, mb2, t, lane);
+#pragma unroll
+            for (int q = 2 - pl; q >= 0; --q)
+#pragma unroll
+                for (int mb2 = 0; mb2 < 4; ++mb2)
+                    o1[mb2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[mb2], hb[q][t], o1[mb2], 0, 0, 0);
+        }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void head_fwd_split_kernel(const HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    head_copy_image(ldsb, p.wimage, HS_END);
+    __syncthreads();
+    const float* lf = reinterpret_cast<const float*>(ldsb + HS_F32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4 w6f[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
+    const float b6v = lf[256];
+    const int b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const float cid = p.census ? (float)p.census[b] : 0.f;
+    float pc_sum = 0.f, sc_sum = 0.f;
+    const int g_begin = (blockIdx.x * NW + wave) * p.groups_per_wave;
+    int g_end = g_begin + p.groups_per_wave;
+    if (g_end > p.groups) g_end = p.groups;
+    // prefetch of the next group's inputs: raw values only, unconditional loads (see head_fwd_kernel)
+    float bld_n = 0.f, adm_n = 0.f;
+    unsigned msk_n = 1;
+    const uint8_t* const mask_or_dummy = p.mask ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
+    const float* const admin_or_dummy = p.admin ? p.admin : p.building;
+    auto fetch = [&](int g, bool& valid, float (&xv)[4]) {
+        const int q = g * 16 + li;
+        valid = q < HW && g < g_end;
+        const int qc = valid ? q : 0;
+        msk_n = mask_or_dummy[(int64_t)b * HW + qc];
+        bld_n = p.building[(int64_t)b * HW + qc];
+        adm_n = admin_or_dummy[(int64_t)b * HW + qc];
+        const int y = (int)pc_div((uint32_t)qc, p.div_w), x = qc - y * p.W;
+        const float* fp = p.feat.ptr + b * p.feat.bstride + (int64_t)(p.py + y) * p.feat.rstride + p.px + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = fp[(4 * lk + j) * p.feat.cstride];          // K-slots of this lane: channels 4*lk .. +3
+    };
+    bool valid_n = false;
+    float xv_n[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g_begin < g_end) fetch(g_begin, valid_n, xv_n);
+    for (int g = g_begin; g < g_end; ++g) {
+        const int q = g * 16 + li;
+        const bool valid = q < HW;
+        const int64_t pix = (int64_t)b * HW + q;
+        const bool sel = valid_n && (p.mask ? msk_n != 0 : true);
+        const float bld = bld_n, adm = adm_n;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = valid_n ? xv_n[j] : 0.f;
+        fetch(g + 1, valid_n, xv_n);
+        float outv = 0.f;
+        if (__any(sel)) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));          // opaque: keeps the fragment reads in the loop
+            f32x4 h[4], acc[4];
+            {
+                unsigned x1[2], x2[2], x3[2];
+                hs_split_pair(xv[0], xv[1], x1[0], x2[0], x3[0]);
+                hs_split_pair(xv[2], xv[3], x1[1], x2[1], x3[1]);
+                const hs16x4 xb[3] = {__builtin_bit_cast(hs16x4, make_uint2(x1[0], x1[1])), __builtin_bit_cast(hs16x4, make_uint2(x2[0], x2[1])),
+                                      __builtin_bit_cast(hs16x4, make_uint2(x3[0], x3[1]))};
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) {
+                    hs16x4 fr[4];
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) fr[mb] = hb_frag4(ldsb, pl * HS_PLANE + HB_A1, mb, lane_o);
+#pragma unroll
+                    for (int qq = 2 - pl; qq >= 0; --qq)
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) h[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fr[mb], xb[qq], h[mb], 0, 0, 0);
+                }
+            }
+            hb_relu4(h);
+            hbf16x8 hb[3][2];
+            hs_split_pack(h, hb);
+            hs_layer64(ldsb, HB_A2, lf + 64, lane_o, lk, hb, acc);
+            hb_relu4(acc);
+            hs_split_pack(acc, hb);
+            hs_layer64(ldsb, HB_A3, lf + 128, lane_o, lk, hb, h);
+            hb_relu4(h);
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h[mb][r], s);
+            s = pc_xor16_sum(s);
+            s = pc_xor32_sum(s);
+            outv = sel ? s + b6v : 0.f;
+        }
+        if (valid && lk == 0) {
+            const float scale = outv > 0.f ? outv : (outv != outv ? outv : 0.f);        // NaN-propagating ReLU (see head_fwd_kernel)
+            const float pd = scale * bld;
+            if (p.scale_map) p.scale_map[pix] = scale;
+            p.popdense[pix] = pd;
+            const bool region = p.admin ? (adm == cid) : true;
+            pc_sum += region ? pd : 0.f;
+            sc_sum += scale;
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (lk == 0) { red[wave * 16 + li] = pc_sum; red[16 * NW + wave * 16 + li] = sc_sum; }
+    __syncthreads();
+    if (tid < 2) {
+        float t = 0.f;
+        for (int i = 0; i < 16 * NW; ++i) t += red[tid * 16 * NW + i];
+        p.partial[((int64_t)b * p.nchunk + blockIdx.x) * 2 + tid] = t;
+    }
+}
+
 // ---- bf16 backward, cooperative form -------------------------------------------------------------------------------------
 // The first bf16 kernel kept all 160 weight-gradient accumulator registers in every wave and computed every chain twice (a
 // second, transposed orientation: mfma with swapped operands) to get their operands: one wave per SIMD, 116 MFMAs and two sets
@@ -1801,16 +2010,18 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
 // backward, 2: bf16 forward, 3: bf16 backward)
 // blocks 0..7 assemble image `kind` into img; blocks 8..15 (PC_HEAD_FWD_PACK_BOTH: a 16-block launch) the backward's image of the same
 // mode (kind + 1) into img2
+// (kind 4: the fp32 forward on 3-way split bf16 operands, head_fwd_split_kernel; its backward partner is kind 1)
 __global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* img, int kind, void* img2) {
     const int second = blockIdx.x >= 8 ? 1 : 0;
     const int tid = (blockIdx.x - 8 * second) * blockDim.x + threadIdx.x, nt = 8 * blockDim.x;
-    if (second) { img = img2; kind += 1; }
+    if (second) { img = img2; kind = kind == 4 ? 1 : kind + 1; }
     if (kind == 0) head_stage_weights(reinterpret_cast<float*>(img), p, tid, nt);
     else if (kind == 1) head_stage_weights_bwd(reinterpret_cast<float*>(img), p, tid, nt);
+    else if (kind == 4) head_stage_weights_split(reinterpret_cast<unsigned char*>(img), p, tid, nt);
     else head_stage_weights_bf16(reinterpret_cast<unsigned char*>(img), p, kind == 3, tid, nt);
 }
 constexpr int HEAD_IMG_BYTES = 96 * 1024;      // room for the largest image (fp32 backward: LB_SCR floats = 72 KB)
-static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES, "weight image slot");
+static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES && HS_END <= HEAD_IMG_BYTES, "weight image slot");
 // the images live in the unused tail of the backward partial area of the workspace (pc_head_ws_bytes reserves 512 x 12288
 // floats, the backward uses at most 512 x PE_TOTAL = 395 x 12288): slot 0 forward, slot 1 backward
 __host__ inline void* head_image_slot(void* ws, int B, int H, int W, int slot) {
@@ -2529,25 +2740,39 @@ extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
 // One round of workgroups: every workgroup stages the 36 KB of weights, so the launch holds exactly the workgroups that are resident at
 // once (B images x chunks-per-image <= resident) and each wave walks enough 16-pixel groups to cover its image chunk -- with a fixed 8
 // groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on 1024 slots, i.e. a second, quarter-full round.
-static int head_fwd_chunks(int B, int H, int W, int* groups_per_wave, int* nchunk) {
-    static int resident = 0;
+constexpr int HS_NW = 8;              // waves per workgroup of head_fwd_split_kernel (two workgroups per CU: four waves per SIMD)
+static int head_split_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* ev = getenv("POPCORN_HEAD_SPLIT");
+        on = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    return on;
+}
+static int head_fwd_chunks(int B, int H, int W, bool split, int* groups_per_wave, int* nchunk) {
+    static int resident[2] = {0, 0};
     static pc_once_per_device once;
     if (once.need()) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_kernel));
         if (e != hipSuccess) return (int)e;
-        resident = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
+        resident[0] = pc_resident_workgroups(fa.numRegs, L_END * sizeof(float));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&head_fwd_split_kernel<HS_NW>));
+        if (e != hipSuccess) return (int)e;
+        // pc_resident_workgroups counts 256-thread workgroups: an HS_NW-wave workgroup takes HS_NW / 4 of those register slots
+        resident[1] = pc_resident_workgroups(fa.numRegs * (HS_NW / 4), HS_END);
         once.mark();
     }
+    const int nw = split ? HS_NW : 4;
     const int groups = (H * W + 15) / 16;
-    int chunks = resident / (B > 0 ? B : 1);                      // chunks per image that fit in one round
-    const int max_chunks = (groups + 31) / 32;                    // never fewer than 8 groups per wave (workspace bound)
+    int chunks = resident[split ? 1 : 0] / (B > 0 ? B : 1);       // chunks per image that fit in one round
+    const int max_chunks = (groups + 8 * nw - 1) / (8 * nw);      // never fewer than 8 groups per wave (workspace bound)
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
-    int gpw = (groups + 4 * chunks - 1) / (4 * chunks);
+    int gpw = (groups + nw * chunks - 1) / (nw * chunks);
     if (gpw < 8) gpw = 8;
     *groups_per_wave = gpw;
-    *nchunk = (groups + 4 * gpw - 1) / (4 * gpw);
+    *nchunk = (groups + nw * gpw - 1) / (nw * gpw);
     return 0;
 }
 
@@ -2567,8 +2792,9 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     p.groups = (H * W + 15) / 16;
     p.div_w = pc_make_fastdiv(W);
     p.div_groups = pc_make_fastdiv(p.groups);
+    const bool split = !p.bf && head_split_on();
     {
-        const int rc = head_fwd_chunks(B, H, W, &p.groups_per_wave, &p.nchunk);
+        const int rc = head_fwd_chunks(B, H, W, split, &p.groups_per_wave, &p.nchunk);
         if (rc) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -2577,9 +2803,10 @@ extern "C" int pc_head_fwd(const pc_src* feat, int py, int px, const float* cons
     void* img = head_image_slot(ws, B, H, W, 0);
     p.wimage = img;
     const bool both = (flags & PC_HEAD_FWD_PACK_BOTH) != 0;
-    hipLaunchKernelGGL(head_pack_kernel, dim3(both ? 16 : 8), dim3(256), 0, st, p, img, p.bf ? 2 : 0, head_image_slot(ws, B, H, W, 1));
+    hipLaunchKernelGGL(head_pack_kernel, dim3(both ? 16 : 8), dim3(256), 0, st, p, img, p.bf ? 2 : (split ? 4 : 0), head_image_slot(ws, B, H, W, 1));
     PC_CHECK_LAUNCH();
     if (p.bf) hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(p.nchunk, B), dim3(256), HB_END, st, p);
+    else if (split) hipLaunchKernelGGL(head_fwd_split_kernel<HS_NW>, dim3(p.nchunk, B), dim3(64 * HS_NW), HS_END, st, p);
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(p.nchunk, B), dim3(256), L_END * sizeof(float), st, p);
     PC_CHECK_LAUNCH();
     if (flags & PC_HEAD_FWD_DEFER_REDUCE) return 0;               // pc_head_popcount_loss finishes popcount / stats (and the loss)
@@ -2619,7 +2846,7 @@ extern "C" int pc_head_popcount_loss(void* ws, int B, int H, int W, const int32_
                                      float* loss_out, float* g_popcount, float* g_scale_const, void* stream) {
     if (!ws || !y || !lam4 || !popcount || !loss_out || !g_popcount || !g_scale_const || B < 1) return PC_EINVAL;
     int gpw = 0, nchunk = 0;
-    const int rc = head_fwd_chunks(B, H, W, &gpw, &nchunk);
+    const int rc = head_fwd_chunks(B, H, W, g_pc_precision != PC_PREC_BF16 && head_split_on(), &gpw, &nchunk);      // (as pc_head_fwd chose)
     if (rc) return rc;
     pc_loss_args a{};
     a.y = y;

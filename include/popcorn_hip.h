@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 7
+#define PC_ABI_VERSION 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -111,6 +111,18 @@ int pc_sizeof(int which);
 enum pc_precision { PC_PREC_FP32 = 0, PC_PREC_BF16 = 1 };
 int pc_set_precision(int mode);
 int pc_get_precision(void);
+
+/* fp32 mode only: how the sparse head (popcorn.py:80-85,161-190; pc_head_fwd / pc_head_bwd) multiplies.
+ *   1 (default; POPCORN_HEAD_SPLIT=0 in the environment starts with 0): every fp32 operand is split EXACTLY into three bf16 numbers
+ *     (8 + 8 + 8 mantissa bits) and a product is the fp32-accumulated sum of six bf16 x bf16 partial products on
+ *     v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 -- the three dropped ones are below 2^-23 of the product, i.e. the per-product error is
+ *     of the size of one fp32 rounding; results pass every fp32 parity test of the repository unchanged;
+ *   0: v_mfma_f32_16x16x4_f32 (one fma chain per accumulator: the summation structure closest to the reference's fp32 GEMMs; the
+ *     strict flat-bar parity tests and A/B runs use it).
+ * Process-global, read when a call is enqueued (a forward call packs the weight images of BOTH head kernels: switch between steps, not
+ * between a forward and its backward).  Returns the previous / the current setting. */
+int pc_set_head_split(int on);
+int pc_get_head_split(void);
 
 /* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
  * Input channels = a.C + b.C (torch.cat([skip, up]) fused, networks.py:318); conv domain H x W, batch B.

@@ -709,7 +709,13 @@ __device__ long long g_head_prof[2048 * 16];
 #define HQ_CLOSE(acc) do { HQ_NOW(hq_n); acc += hq_n - hq_t; hq_t = hq_n; } while (0)
 #define HQ_DUMP do { if (lane == 0) { long long* d_ = &g_head_prof[(blockIdx.x * 4 + wave) * 16]; d_[0] = hq0; d_[1] = hq1; d_[2] = hq2; d_[3] = hq3; \
                                       d_[4] = hq4; d_[5] = hq5; d_[6] = hq6; } } while (0)
+#define HR_DECL long long hr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, hr_t = 0, hr_n = 0
+#define HR_CLOSE(k) do { HQ_NOW(hr_n); hr[k] += hr_n - hr_t; hr_t = hr_n; } while (0)
+#define HR_DUMP do { if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) g_head_prof[(blockIdx.x * 4 + wave) * 16 + k_] = hr[k_]; } while (0)
 #else
+#define HR_DECL
+#define HR_CLOSE(k)
+#define HR_DUMP
 #define HQ_DECL
 #define HQ_NOW(v)
 #define HQ_CLOSE(acc)
@@ -720,495 +726,6 @@ __device__ long long g_head_prof[2048 * 16];
 #define HP_MARK(k)
 #define HP_DUMP
 #endif
-
-// ---- head backward, producer / consumer form ----------------------------------------------------------------------
-// The single-role kernel above needs 209 accumulator registers per wave for the three weight-gradient GEMMs, which
-// pins it at ONE wave per SIMD: every global-load, LDS round trip and VALU stretch of that wave idles the matrix pipe
-// (measured 0.50 of the fp32 MFMA peak).  Here a 512-thread workgroup runs two roles with <= 256 registers each, i.e.
-// two waves per SIMD:
-//   producers (waves 0-3): per 16-pixel group, forward recompute + the data-gradient chain (288 MFMAs, ~130 registers);
-//       after each layer they hand the (G = pre-activation gradient, H = layer input) pair to their consumer through
-//       a 2-slot LDS ring as (hidden x pixel) matrices;
-//   consumers (waves 4-7): the weight-gradient GEMMs dW += G . H^T (144 MFMAs per group) and the bias gradients (row
-//       sums of G), accumulated in registers for the whole kernel.
-// Hand-off: per pair two LDS counters (produced / consumed) + a done flag, polled with s_sleep; LDS operations of a wave
-// are performed in order, so "data writes, then counter write" needs no fence beyond a compiler barrier.  Slots carry
-// no tag: every processed group emits exactly three slots (layer 3, 2, 1), so slot k is of kind k % 3.
-constexpr int PC_LKS = 80;                                // floats per (block, lk) row of a slot matrix: 16 lanes x 4 + 16 (the 4 lk rows
-                                                          // of a block start 16 banks apart: conflict-free transposing reads)
-constexpr int PC_MBS = 4 * PC_LKS;                        // per 16-row block
-constexpr int PC_MAT = 4 * PC_MBS;                        // one 64 x 16 matrix (1280 floats)
-constexpr int PC_SLOT = 2 * PC_MAT;                       // G + H
-constexpr int PC_NSLOT = 2;
-constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is shared with the single-role kernel
-constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
-constexpr int LP_END = LP_FLAGS + 16;
-
-template <int DBG>        // ablation builds (tools/ablate_head.py): 1 consumer idle, 2 no hand-off; 0 = the product kernel (as run-time flags the
-                          // two switches put a branch around every ring write of the producer: 14 extra basic blocks in its group loop)
-__global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const HeadArgs& p = a.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int pair = wave & 3;
-    const bool producer = wave < 4;
-    head_copy_image(lds, p.wimage, LB_SCR * (int)sizeof(float));     // forward + transposed fragments, biases (head_stage_weights_bwd)
-    int* flags = reinterpret_cast<int*>(lds + LP_FLAGS);
-    if (tid < 16) flags[tid] = 0;
-    __syncthreads();
-
-    float* ring = lds + LP_RING + pair * PC_NSLOT * PC_SLOT;
-    // LDS-address-space pointers: through a generic `volatile int*` the polls and counter updates become FLAT instructions, whose
-    // completion is waited for with vmcnt(0) -- i.e. behind every global load and store the wave has in flight
-    typedef __attribute__((address_space(3))) volatile int lds_flag;
-    lds_flag* prod_p = (lds_flag*)(flags + pair * 4 + 0);
-    lds_flag* cons_p = (lds_flag*)(flags + pair * 4 + 1);
-    lds_flag* done_p = (lds_flag*)(flags + pair * 4 + 2);
-    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
-
-    // Role-private accumulators: declared here (they feed the common reduction below) but initialised ONLY inside the
-    // role that owns them, so that their live ranges do not extend through the other role's code (a shared
-    // zero-initialisation made the allocator keep all 160 accumulator registers live in the producer: 157 spills).
-    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4];
-    float dbs[3][4];          // consumer: bias-gradient partial sums (row 16q + li, pixels = lk mod 4)
-    float db6;
-
-    if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(2);   // producers are the critical path: they win the
-                                                                                    // MFMA arbitration, the consumer fills their bubbles
-    if (producer) {
-        db6 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int HW = p.H * p.W;
-        const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
-        float fscale[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            fscale[r] = 1.f;
-            if (a.fuse_feat_bn) {
-                const int c = 4 * lk + r;
-                float sh;
-                pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
-            }
-        }
-        int nprod = 0;
-        HP_DECL;
-        // c_early: the consumer's counter as read one phase earlier (it only grows: a stale value is merely conservative) -- the
-        // LDS round trip of the poll is then hidden behind that phase instead of sitting in front of every slot
-        auto acquire = [&](int c_early) -> float* {
-            HP_ACQ0;
-            if (nprod - __builtin_amdgcn_readfirstlane(c_early) >= PC_NSLOT) {
-                while (true) {
-                    const int c = __builtin_amdgcn_readfirstlane(*cons_p);
-                    if (nprod - c < PC_NSLOT) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            asm volatile("" ::: "memory");
-            HP_ACQ1;
-            return ring + (nprod % PC_NSLOT) * PC_SLOT;
-        };
-        auto release = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ++nprod;
-            if (lane == 0) *prod_p = nprod;
-        };
-        // Per-group inputs are fetched one group ahead (raw loads only).  The group index is wave-uniform, so the sample index and
-        // everything per sample live in scalar registers; optional inputs get a valid dummy address (the building map) and a
-        // select instead of a branch around their load, and the last iteration prefetches a clamped (valid) group: the loop top is
-        // straight-line code -- written with a branch per optional load and the (b, y, x) arithmetic done twice it cost ~2,300
-        // cycles of a ~15,000-cycle group with the matrix pipe idle.
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        int vzero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-        const bool has_msk = p.mask != nullptr, has_adm = p.admin != nullptr, has_gpc = a.g_popcount != nullptr;
-        const bool has_gpd = a.g_popdense != nullptr, has_gsm = a.g_scale_map != nullptr, has_fbn = a.fuse_feat_bn != 0;
-        const uint8_t* msk_p = has_msk ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
-        const float* adm_p = has_adm ? p.admin : p.building;
-        const float* gpd_p = has_gpd ? a.g_popdense : p.building;
-        const float* gsm_p = has_gsm ? a.g_scale_map : p.building;
-        const unsigned fcs = (unsigned)p.feat.cstride, gcs = (unsigned)a.g_feat.cstride;
-        float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
-        long long n_cen = 0;          // raw: the int64 -> float conversion at the point of USE (inside fetch it is a wait for the loads just issued)
-        unsigned n_msk = 1, n_go = 0;
-        bool n_valid = false;
-        int n_b = 0;
-        // The prefetch in five stages: inside the group loop they run one per K-step in the shadow of the second layer's MFMAs
-        // (head_mm64_pf's hook); stage 4 also sends the PREVIOUS group's gradient out -- behind the loads: stored at the end of its
-        // own iteration it sat in front of the next iteration's wait for the prefetched inputs (vmcnt counts loads and stores in one
-        // queue).
-        float pend_o[4] = {0.f, 0.f, 0.f, 0.f};
-        float* pend_p = nullptr;
-        const float* f_fb = nullptr;
-        unsigned f_fo = 0, f_qq = 0;
-        int64_t f_pb = 0;
-        int f_b = 0;
-        auto fetch_stage = [&](int st, int gg) {
-            if (st == 0) {
-                const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
-                const int q = g * 16 + li;
-                n_valid = q < HW;
-                n_b = f_b = b;
-                f_qq = n_valid ? (unsigned)q : 0u;
-                const unsigned y = pc_div(f_qq, p.div_w), x = f_qq - y * (unsigned)p.W;
-                f_fb = p.feat.ptr + b * p.feat.bstride;
-                f_fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
-                n_go = (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
-                f_pb = (int64_t)b * HW;
-            } else if (st == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) n_xv[j] = f_fb[f_fo + (unsigned)(4 * j + lk) * fcs];
-            } else if (st == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) n_fv[j] = f_fb[f_fo + (unsigned)(4 * lk + j) * fcs];   // (only used with fuse_feat_bn; n_xv's cache lines)
-            } else if (st == 3) {
-                n_msk = msk_p[f_pb + f_qq];
-                n_bld = p.building[f_pb + f_qq];
-                n_adm = adm_p[f_pb + f_qq];
-                n_gpd = gpd_p[f_pb + f_qq];
-                n_gsm = gsm_p[f_pb + f_qq];
-            } else if (st == 4) {
-                // the two per-sample scalars as well: read at their point of use they were two DEPENDENT, fully exposed memory
-                // round trips at the top of every group
-                // (indexed with an opaque per-lane zero: a provably uniform load result is moved to scalar registers by the compiler
-                // with v_readfirstlane RIGHT HERE, behind a vmcnt(0) wait for everything the prefetch has just issued)
-                if (has_adm) n_cen = p.census[f_b + vzero];
-                if (has_gpc) n_gpc = a.g_popcount[f_b + vzero];
-                if (pend_p) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
-                    pend_p = nullptr;
-                }
-            }
-        };
-        auto fetch = [&](int gg) {
-#pragma unroll
-            for (int st = 0; st < 5; ++st) fetch_stage(st, gg);
-        };
-        const int gstep = gridDim.x * 4;
-        constexpr bool handoff = !(DBG & 2);
-        // Slot matrices are stored as the producer HOLDS them (D layout: lane (pixel li, lk), register block mb = rows 16 mb + 4 lk
-        // + r): one 16-byte write per block, [mb][lk][PC_LKS] floats with the lane's 4 values at li * 4 -- the consumer does the
-        // transposing reads.  (The first form scattered every element into a [row][pixel] matrix: 32 ds_write_b32 per slot on the
-        // producer, the critical path, where every LDS instruction costs the wave ~30-40 cycles of MFMA issue --
-        // profiles/r3_mfma_peak.json, lds variants at 1 wave per SIMD.)
-        const int sbase = lk * PC_LKS + li * 4;
-        auto put = [&](float* sl, int mb, const f32x4 (&G)[4], const f32x4 (&Hm)[4]) {
-            *reinterpret_cast<f32x4*>(&sl[mb * PC_MBS + sbase]) = G[mb];
-            *reinterpret_cast<f32x4*>(&sl[PC_MAT + mb * PC_MBS + sbase]) = Hm[mb];
-        };
-        // the last layer's row (this lane's 16 hidden units) and bias stay in registers: read at their point of use they are 9 LDS round
-        // trips per group in a stretch with no matrix instruction to hide them
-        f32x4 w6f[4], a1f[4], b0f[4];         // (and the first layer's fragments + bias: the group loop started with their round trip)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            w6f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_W6 + 16 * mb + 4 * lk]);
-            a1f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_A1 + (mb * 64 + lane) * 4]);
-            b0f[mb] = *reinterpret_cast<const f32x4*>(&lds[LB_B0 + 16 * mb + 4 * lk]);
-        }
-        const float b6v = lds[LB_W6 + 64];
-        int gg = blockIdx.x * 4 + wv;
-        if (gg < a.total_groups) fetch(gg);
-        for (; gg < a.total_groups; gg += gstep) {
-            const bool valid = n_valid;
-            const bool sel = valid && (!has_msk || n_msk != 0);
-            float* const gp = a.g_feat.ptr + n_b * a.g_feat.bstride + n_go;       // this lane's pixel of the gradient map, channel 0
-            float xv[4], fvv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = (valid && has_fbn) ? n_fv[j] : 1.f; }
-            float gup = 0.f;
-            {
-                const bool region = !has_adm || n_adm == (float)n_cen;
-                float u = gsc;
-                u += (has_gpc && region) ? n_gpc * n_bld : 0.f;
-                u += has_gpd ? n_gpd * n_bld : 0.f;
-                u += has_gsm ? n_gsm : 0.f;
-                gup = sel ? u : 0.f;
-            }
-            const int gnx = gg + gstep < a.total_groups ? gg + gstep : a.total_groups - 1;   // (clamped: the last prefetch is a dummy)
-            // g_feat is written exactly once per element by this kernel (no zero-fill pass in front of it): crop pixels
-            // by the producer that owns their group -- zeros when the group is skipped --, the border by the consumers
-            auto store_zero = [&]() {
-                if (a.zero_in_kernel && valid) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gp[(unsigned)(4 * lk + r) * gcs] = 0.f;
-                }
-            };
-            if (!__any(sel)) { fetch(gnx); store_zero(); continue; }
-            HP_MARK(0);
-            // Every contraction gets its first fragments from the phase before it (fa / fb, alternating), and the ReLU / ReLU' of its
-            // input blocks 1-3 happens in the shadow of its own first K-steps (block mb + 1 in step 4 mb): a layer boundary costs the
-            // ReLU of ONE block, not an LDS round trip + 16-32 VALU instructions with the matrix pipe idle.
-            f32x4 h1[4], h2[4], h3[4], fa[4], fb[4];
-            head_frag0(lds, LB_A2, 4, lane, fa);
-            head_bias4(lds, LB_B2, lk, h2);          // (in flight during the first layer: the scheduling barriers below keep it up here)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) h1[mb] = b0f[mb];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) h1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[mb][j], xv[j], h1[mb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            relu_block(h1[0]);
-            head_mm64_pf(lds, LB_A2, lane, h1, h2, fa, LB_A3, 4, fb, [&](int st) {
-                if (!(st & 3) && st < 12) relu_block(h1[(st >> 2) + 1]);
-                if ((st & 1) && st < 10) fetch_stage(st >> 1, gnx);
-                if (st == 12) head_bias4(lds, LB_B4, lk, h3);
-            });
-            relu_block(h2[0]);
-            head_mm64_pf(lds, LB_A3, lane, h2, h3, fb, LB_T3, 4, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(h2[(st >> 2) + 1]); });
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) relu_block(h3[mb]);
-            HP_MARK(1);
-            const int c_early0 = *cons_p;
-            float s = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
-            s = pc_xor16_sum(s);
-            s = pc_xor32_sum(s);
-            const float outv = s + b6v;
-            const float gout = (sel && outv > 0.f) ? gup : 0.f;
-            if (!__any(gout != 0.f)) { store_zero(); continue; }
-
-            f32x4 g3[4], g2[4], g1[4];
-            if (lk == 0) db6 += gout;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                    g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
-                }
-            HP_MARK(2);
-            // The three hand-offs (slot kind 0: (G3, H2) -> dW4, db4; 1: (G2, H1) -> dW2, db2; 2: (G1, X) -> dW0, db0) are written
-            // one element pair per K-step in the shadow of the NEXT contraction's MFMAs -- as a block in front of it, the 32 scattered
-            // LDS writes + their wait were ~600-1,000 cycles per slot with the matrix pipe idle.
-            float* sl = handoff ? acquire(c_early0) : nullptr;
-            HP_MARK(3);
-            const int c_early1 = *cons_p;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            head_mm64_pf(lds, LB_T3, lane, g3, g2, fa, LB_T2, 4, fb, [&](int st) { if (handoff && (st & 3) == 1) put(sl, st >> 2, g3, h2); });
-            if (handoff) release();
-            mask_block(g2[0], h2[0]);
-            HP_MARK(4);
-            sl = handoff ? acquire(c_early1) : nullptr;
-            HP_MARK(5);
-            const int c_early2 = *cons_p;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            head_mm64_pf(lds, LB_T2, lane, g2, g1, fb, LB_T1, 1, fa, [&](int st) {
-                if (handoff && (st & 3) == 1) put(sl, st >> 2, g2, h1);           // (block mb was masked in step 4 (mb - 1))
-                if (!(st & 3) && st < 12) mask_block(g2[(st >> 2) + 1], h2[(st >> 2) + 1]);
-            });
-            if (handoff) release();
-            mask_block(g1[0], h1[0]);
-            mask_block(g1[1], h1[1]);
-            HP_MARK(6);
-            sl = handoff ? acquire(c_early2) : nullptr;
-            HP_MARK(7);
-            f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA dependent latency
-#pragma unroll                                                                       // (40 cyc) exceeds the issue interval (32)
-            for (int mb = 0; mb < 4; mb += 2) {
-                const f32x4 t4 = fa[mb], u4 = fa[mb + 1];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
-                    gx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[r], g1[mb + 1][r], gx2, 0, 0, 0);
-                    if (mb == 0 && r < 2) mask_block(g1[2 + r], h1[2 + r]);
-                    if (handoff) {            // G1 block r in step (0, r) -- blocks 2, 3 are masked in steps (0, 0), (0, 1) --, X in (2, 0)
-                        if (mb == 0) *reinterpret_cast<f32x4*>(&sl[r * PC_MBS + sbase]) = g1[r];
-                        else if (r == 0) *reinterpret_cast<f32x4*>(&sl[PC_MAT + sbase]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (handoff) release();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
-            if (valid) {
-                pend_p = gp;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float o = gx[r];
-                    if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
-                    pend_o[r] = o;
-                }
-            }
-        }
-        if (pend_p) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
-        }
-        HP_DUMP;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) *done_p = 1;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dW0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (a.zero_in_kernel) {
-            // The consumers have nothing to do until the first slot arrives: they write the zero border of g_feat (the
-            // padding frame around the H x W crop: 39 % of a 128 x 128 map for 100 x 100 tiles) -- the only part of the
-            // gradient map the producers never touch.  One (b, c, row) job per half-wave: rows above / below the crop in
-            // full (16-byte stores when the row allows), crop rows only left and right of it.
-            const int Hp = a.Hp, Wp = a.Wp;
-            const int l32 = tid & 31;
-            const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + ((tid - 256) >> 5);
-            const int njobs = p.B * 16 * Hp;
-            const bool v4 = (Wp & 3) == 0;
-            const int right0 = p.px + p.W;
-            for (int j = hw; j < njobs; j += nhw) {
-                const int row = j % Hp;
-                float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
-                if (row < p.py || row >= p.py + p.H) {
-                    if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
-                    else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
-                } else if (p.px <= 16 && Wp - right0 <= 16) {
-                    // both side strips in one store: lanes 0-15 the left one, lanes 16-31 the right one
-                    const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
-                    if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0.f;
-                } else {
-                    for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
-                    for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
-                }
-            }
-        }
-        int ncons = 0;
-        // wait until slot `ncons` has been produced; returns false when the producer has finished without producing it
-        auto wait_slot = [&]() -> bool {
-            while (true) {
-                if (__builtin_amdgcn_readfirstlane(*prod_p) > ncons) return true;
-                if (__builtin_amdgcn_readfirstlane(*done_p)) return __builtin_amdgcn_readfirstlane(*prod_p) > ncons;
-                __builtin_amdgcn_s_sleep(2);
-            }
-        };
-        // fetch the (G, H) fragments of the current slot and hand the slot back
-        auto take = [&](f32x4 (&af)[4], f32x4 (&bf)[4], bool x_only) {
-            asm volatile("" ::: "memory");
-            // transposing reads: fragment (q, ks) = element (row 16 q + li, pixel 4 ks + lk) = register li & 3 of the producer lane
-            // (pixel, lk' = li >> 2), block q; for X (16 channels x 16 pixels, channel 4 j + lk' in register j) the two are swapped.
-            // Lanes hit 16 (li >> 2) + 4 lk + (li & 3) (mod 32) = every bank twice: conflict-free 4-byte reads, paired by the compiler
-            // into ds_read2_b32 (ks, ks + 1 are 16 floats apart).
-            const float* gm = ring + (ncons % PC_NSLOT) * PC_SLOT;
-            const float* hm = gm + PC_MAT;
-            const int cb = (li >> 2) * PC_LKS + lk * 4 + (li & 3), xb = (li & 3) * PC_LKS + lk * 4 + (li >> 2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    af[q][ks] = gm[q * PC_MBS + cb + 16 * ks];
-                    bf[q][ks] = x_only ? hm[xb + 16 * ks] : hm[q * PC_MBS + cb + 16 * ks];
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ++ncons;
-            if (lane == 0) *cons_p = ncons;          // slot is free again: everything needed is in registers
-        };
-        // every processed group emits exactly three slots, in this order: no tags, no dynamic dispatch
-        while (wait_slot()) {
-            f32x4 af[4], bf[4];
-            take(af, bf, false);                                             // (G3, H2) -> dW4, db4
-            if (DBG & 1) { wait_slot(); take(af, bf, false); wait_slot(); take(af, bf, true); continue; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dbs[2][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        dW4[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW4[mb][nb], 0, 0, 0);
-            wait_slot();
-            take(af, bf, false);                                             // (G2, H1) -> dW2, db2
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dbs[1][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        dW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW2[mb][nb], 0, 0, 0);
-            wait_slot();
-            take(af, bf, true);                                              // (G1, X) -> dW0, db0
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dbs[0][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[0][ks], dW0[mb], 0, 0, 0);
-        }
-    }
-
-    // ---- reductions: producers own dw6 / db6, consumers own dW4, dW2, dW0 and the bias sums
-    if (producer) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
-        db6 = lane_sum16(db6);
-    } else {
-#pragma unroll
-        for (int l3 = 0; l3 < 3; ++l3)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = dbs[l3][q];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                dbs[l3][q] = v;
-            }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int stage = 0; stage < 2; ++stage) {
-        if (!producer) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    *reinterpret_cast<f32x4*>(&lds[pair * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
-        }
-        __syncthreads();
-        for (int e = tid; e < 4096; e += 512)
-            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
-        __syncthreads();
-    }
-    {
-        float* w = lds + pair * 1344;       // [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1]
-        if (!producer) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
-            if (lk == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w[1088 + 16 * q + li] = dbs[0][q];
-                    w[1152 + 16 * q + li] = dbs[1][q];
-                    w[1216 + 16 * q + li] = dbs[2][q];
-                }
-            }
-        } else if (li == 0) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[1024 + 16 * mb + 4 * lk + r] = dw6[mb][r];
-            if (lk == 0) w[1280] = db6;
-        }
-        __syncthreads();
-        for (int e = tid; e < 1281; e += 512) {
-            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
-            part[PE_W0 + e] = t;
-        }
-    }
-}
 
 // ---- bf16 mode (PC_PREC_BF16): the head on v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 ---------------------------------------
 // The 64-wide contractions take 2 instructions of K = 32 instead of 16 fp32 ones, so the matrix pipe stops being the limit.
@@ -1437,6 +954,14 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const HeadArgs p) {
 }
 
 
+// transposing LDS read ([4 rows][16 columns] of bf16 -> lane c receives column c) and the pairing of two of them into one operand
+__device__ __forceinline__ hs16x4 hc_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(p));
+}
+__device__ __forceinline__ hbf16x8 hc_pair(hs16x4 a, hs16x4 b) {
+    return __builtin_bit_cast(hbf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // ---- fp32 results on the bf16 matrix pipe: 3-way operand splits (round 5) -----------------------------------------------------------
 // An fp32 number is EXACTLY the sum of three bf16 numbers (a1 = rn(a), a2 = rn(a - a1), a3 = rn(a - a1 - a2): 8 + 8 + 8 mantissa bits,
 // same exponent range; each difference is exact in fp32).  A product a * b is then the sum of nine bf16 x bf16 products, each exact in
@@ -1645,6 +1170,837 @@ __global__ __launch_bounds__(64 * NW) void head_fwd_split_kernel(const HeadArgs 
     }
 }
 
+// ---- head backward, producer / consumer form ----------------------------------------------------------------------
+// The single-role kernel above needs 209 accumulator registers per wave for the three weight-gradient GEMMs, which
+// pins it at ONE wave per SIMD: every global-load, LDS round trip and VALU stretch of that wave idles the matrix pipe
+// (measured 0.50 of the fp32 MFMA peak).  Here a 512-thread workgroup runs two roles with <= 256 registers each, i.e.
+// two waves per SIMD:
+//   producers (waves 0-3): per 16-pixel group, forward recompute + the data-gradient chain (288 MFMAs, ~130 registers);
+//       after each layer they hand the (G = pre-activation gradient, H = layer input) pair to their consumer through
+//       a 2-slot LDS ring as (hidden x pixel) matrices;
+//   consumers (waves 4-7): the weight-gradient GEMMs dW += G . H^T (144 MFMAs per group) and the bias gradients (row
+//       sums of G), accumulated in registers for the whole kernel.
+// Hand-off: per pair two LDS counters (produced / consumed) + a done flag, polled with s_sleep; LDS operations of a wave
+// are performed in order, so "data writes, then counter write" needs no fence beyond a compiler barrier.  Slots carry
+// no tag: every processed group emits exactly three slots (layer 3, 2, 1), so slot k is of kind k % 3.
+constexpr int PC_LKS = 80;                                // floats per (block, lk) row of a slot matrix: 16 lanes x 4 + 16 (the 4 lk rows
+                                                          // of a block start 16 banks apart: conflict-free transposing reads)
+constexpr int PC_MBS = 4 * PC_LKS;                        // per 16-row block
+constexpr int PC_MAT = 4 * PC_MBS;                        // one 64 x 16 matrix (1280 floats)
+constexpr int PC_SLOT = 2 * PC_MAT;                       // G + H
+constexpr int PC_NSLOT = 2;
+constexpr int LP_RING = LB_W6 + 64 + 4;                  // weights image is shared with the single-role kernel
+constexpr int LP_FLAGS = LP_RING + 4 * PC_NSLOT * PC_SLOT;
+constexpr int LP_END = LP_FLAGS + 16;
+
+// ---- split-operand producer of head_bwd_pc_kernel<DBG, true> (round 5) ---------------------------------------------------------------
+// The producer's chain (forward recompute + data gradients: 288 of the kernel's 432 fp32 MFMAs per 16 pixels) on the bf16 matrix pipe
+// with 3-way split operands, six partial products per K-step (see head_fwd_split_kernel): 228 instructions of 16 cycles instead of 288
+// of 32.  Its results have the D layout of the fp32 instruction (both are 16 x 16 tiles in 4 registers), so the ring slots, the consumer
+// waves and the reductions are untouched.  Weight image: three split planes of the ROW-MAJOR matrices W2 | W4 | W0 -- one image serves
+// the forward fragments (A = W: ds_read_b128 of the lane's 8 K-slots) AND the data-gradient fragments (A = W^T: two
+// ds_read_b64_tr_b16 per fragment), which is what lets three planes fit next to the ring (55 KB instead of 3 x 37).  Columns of a
+// 64-wide row are stored in K-slot order (position 32 t + 8 lk + j <-> unit 16 (2t + (j >> 2)) + 4 lk + (j & 3)) and the 16-byte pieces of
+// a row are XOR-swizzled with (row >> 1) & 7: the forward reads of a 16-lane service group (8 rows of one lk + the other 8 rows of its
+// neighbour) then hit all 64 banks once; the transposing reads take a 2-way conflict (4 LDS cycles instead of 2: the LDS array is not
+// what this kernel waits for).
+constexpr int LS_W2 = 0, LS_W4 = 8192, LS_W0 = 16384, LS_PLANE = 18432;     // bytes inside a plane
+constexpr int LS_F32 = 3 * LS_PLANE;                                        // floats: b0[64] b2[64] b4[64] w6[64] b6
+constexpr int LS_WEND = LS_F32 + (4 * 64 + 4) * 4;                          // 56,336 bytes
+constexpr int LPS_RING = LS_WEND / 4;                                       // (floats) ring and flags as in the fp32 form
+constexpr int LPS_FLAGS = LPS_RING + 4 * PC_NSLOT * PC_SLOT;
+constexpr int LPS_END = LPS_FLAGS + 16;
+static_assert(LS_WEND % 16 == 0 && LPS_END * 4 <= 160 * 1024 && 4 * 4096 <= LPS_FLAGS, "split-producer LDS map");
+
+__device__ __forceinline__ void head_stage_weights_bsplit(unsigned char* img, const HeadArgs& p, int tid, int nt) {
+    unsigned short o[3];
+    for (int e = tid; e < 64 * 64; e += nt) {
+        const int row = e >> 6, c = e & 63;
+        const int pos = (c >> 5) * 32 + ((c >> 2) & 3) * 8 + ((c >> 4) & 1) * 4 + (c & 3);
+        const int byte = row * 128 + (((pos >> 3) ^ ((row >> 1) & 7)) * 16) + (pos & 7) * 2;
+        hs_split3(p.w2[e], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(img + pl * LS_PLANE + LS_W2 + byte) = o[pl];
+        hs_split3(p.w4[e], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(img + pl * LS_PLANE + LS_W4 + byte) = o[pl];
+    }
+    for (int e = tid; e < 64 * 16; e += nt) {
+        hs_split3(p.w0[e], o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(img + pl * LS_PLANE + LS_W0 + e * 2) = o[pl];
+    }
+    float* f = reinterpret_cast<float*>(img + LS_F32);
+    for (int e = tid; e < 64; e += nt) {
+        f[e] = p.b0[e];
+        f[64 + e] = p.b2[e];
+        f[128 + e] = p.b4[e];
+        f[192 + e] = p.w6[e];
+    }
+    if (tid == 0) f[256] = p.b6[0];
+}
+
+// per-lane byte offsets of the fragment reads (computed once per wave)
+struct LsLane {
+    int a[2];        // forward fragment (t): row i of a 16-row block, the lane's 16-byte K-slot piece
+    int t[2];        // data-gradient fragment, input-unit block pair mi >> 1 = 0 / 1: row 4 lk + (li >> 2) of a 16-row block, quad li & 3
+    int a0, t0;      // W0: forward fragment (8 bytes: channels 4 lk .. + 3 of row i) / transposed (row 4 lk + (li >> 2), quad li & 3)
+};
+__device__ __forceinline__ LsLane ls_lane(int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    LsLane L;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) L.a[t] = li * 128 + (((t * 4 + lk) ^ ((li >> 1) & 7)) * 16);
+    const int sw = (2 * lk + (li >> 3)) & 7;
+    L.t[0] = (4 * lk + (li >> 2)) * 128 + (((li & 3) ^ sw) * 16);
+    L.t[1] = L.t[0] ^ 64;
+    L.a0 = li * 32 + lk * 8;
+    L.t0 = (4 * lk + (li >> 2)) * 32 + (li & 3) * 8;
+    return L;
+}
+__device__ __forceinline__ hbf16x8 ls_frag_a(const unsigned char* w, const LsLane& L, int mb2, int t) {
+    return __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(w + mb2 * 2048 + L.a[t]));
+}
+__device__ __forceinline__ hbf16x8 ls_frag_t(const unsigned char* w, const LsLane& L, int mi, int t) {
+    const unsigned char* q = w + L.t[mi >> 1] + (mi & 1) * 8;
+    return hc_pair(hc_tr(q + (2 * t) * 2048), hc_tr(q + (2 * t + 1) * 2048));
+}
+// o1[mb2] += W . h  (SPLIT forward fragments) or W^T . g (transposed fragments), six partial products per K-step, smallest first
+template <bool TR>
+__device__ __forceinline__ void ls_layer64(const unsigned char* planes, int w_off, const LsLane& L, const hbf16x8 (&hb)[3][2], f32x4 (&o1)[4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl) {
+            hbf16x8 fr[4];
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+                fr[mo] = TR ? ls_frag_t(planes + pl * LS_PLANE + w_off, L, mo, t) : ls_frag_a(planes + pl * LS_PLANE + w_off, L, mo, t);
+#pragma unroll
+            for (int q = 2 - pl; q >= 0; --q)
+#pragma unroll
+                for (int mo = 0; mo < 4; ++mo) o1[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[mo], hb[q][t], o1[mo], 0, 0, 0);
+        }
+}
+
+// The same contraction with its fragment reads one step ahead of the instructions that use them (the producer is ONE wave of its role
+// per SIMD: an LDS round trip in front of every 4 - 12 instructions was half of its forward phase, profiles/r5_head_bwd_split_phases.json).
+// Six steps (K-step t, weight plane pl) of 4 / 8 / 12 instructions; fr: the fragments of step 0, loaded by the caller one phase earlier;
+// nxt(fr): issues the reads of the first fragments of whatever contraction FOLLOWS, in the shadow of this one's last step.
+template <bool TR>
+__device__ __forceinline__ void ls_load4(const unsigned char* planes, int w_off, const LsLane& L, int t, int pl, hbf16x8 (&fr)[4]) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) fr[mo] = TR ? ls_frag_t(planes + pl * LS_PLANE + w_off, L, mo, t) : ls_frag_a(planes + pl * LS_PLANE + w_off, L, mo, t);
+}
+template <bool TR, class Next>
+__device__ __forceinline__ void ls_layer64_pf(const unsigned char* planes, int w_off, const LsLane& L, const hbf16x8 (&hb)[3][2], f32x4 (&o1)[4],
+                                              hbf16x8 (&fr)[4], Next&& nxt) {
+    hbf16x8 fb[4];
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int t = st / 3, pl = 2 - st % 3;
+        hbf16x8 (&cur)[4] = (st & 1) ? fb : fr;
+        hbf16x8 (&oth)[4] = (st & 1) ? fr : fb;
+        if (st < 5) ls_load4<TR>(planes, w_off, L, (st + 1) / 3, 2 - (st + 1) % 3, oth);
+        else nxt(oth);                                   // (step 5 is odd: `oth` is fr)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 2 - pl; q >= 0; --q)
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) o1[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[mo], hb[q][t], o1[mo], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// two blocks (one K-step's worth of the next contraction's operand) -> their three split planes
+template <int T>
+__device__ __forceinline__ void hs_split_t(const f32x4& a, const f32x4& b, hbf16x8 (&o)[3][2]) {
+    hu32x4 q[3];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x4& v = d < 2 ? a : b;
+        unsigned q1, q2, q3;
+        hs_split_pair(v[2 * (d & 1)], v[2 * (d & 1) + 1], q1, q2, q3);
+        q[0][d] = q1; q[1][d] = q2; q[2][d] = q3;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) o[pl][T] = __builtin_bit_cast(hbf16x8, q[pl]);
+}
+__device__ __forceinline__ void relu_block2(f32x4& a, f32x4& b) { relu_block(a); relu_block(b); }
+// four fp32 values (the four K-slots of a lane in v_mfma_f32_16x16x16_bf16) -> their three split planes
+__device__ __forceinline__ void hs_split4(const f32x4& v, hs16x4 (&o)[3]) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    hs_split_pair(v[0], v[1], a1, a2, a3);
+    hs_split_pair(v[2], v[3], b1, b2, b3);
+    o[0] = __builtin_bit_cast(hs16x4, make_uint2(a1, b1));
+    o[1] = __builtin_bit_cast(hs16x4, make_uint2(a2, b2));
+    o[2] = __builtin_bit_cast(hs16x4, make_uint2(a3, b3));
+}
+// consumer side of the split form: dW[mb][nb] += G block mb . (H block nb)^T over the slot's 16 pixels, six partial products
+template <int NB>
+__device__ __forceinline__ void hs_wgrad16(const f32x4 (&af)[4], const f32x4 (&bf)[4], f32x4 (&dW)[4][4]) {
+    hs16x4 as[4][3];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) hs_split4(af[mb], as[mb]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        hs16x4 bs[3];
+        hs_split4(bf[nb], bs);
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+            for (int qq = 2 - pl; qq >= 0; --qq)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    dW[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as[mb][pl], bs[qq], dW[mb][nb], 0, 0, 0);
+    }
+}
+
+template <int DBG, bool SPL>   // SPL: the producer's chain on split bf16 operands (above).  DBG: ablation builds (tools/ablate_head.py): 1 consumer idle, 2 no hand-off; 0 = the product kernel (as run-time flags the
+                          // two switches put a branch around every ring write of the producer: 14 extra basic blocks in its group loop)
+__global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const HeadArgs& p = a.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int pair = wave & 3;
+    const bool producer = wave < 4;
+    // fp32 form: forward + transposed fragments, biases (head_stage_weights_bwd); SPL: the three split planes (head_stage_weights_bsplit)
+    head_copy_image(lds, p.wimage, SPL ? LS_WEND : LB_SCR * (int)sizeof(float));
+    int* flags = reinterpret_cast<int*>(lds + (SPL ? LPS_FLAGS : LP_FLAGS));
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();
+
+    float* ring = lds + (SPL ? LPS_RING : LP_RING) + pair * PC_NSLOT * PC_SLOT;
+    // LDS-address-space pointers: through a generic `volatile int*` the polls and counter updates become FLAT instructions, whose
+    // completion is waited for with vmcnt(0) -- i.e. behind every global load and store the wave has in flight
+    typedef __attribute__((address_space(3))) volatile int lds_flag;
+    lds_flag* prod_p = (lds_flag*)(flags + pair * 4 + 0);
+    lds_flag* cons_p = (lds_flag*)(flags + pair * 4 + 1);
+    lds_flag* done_p = (lds_flag*)(flags + pair * 4 + 2);
+    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
+
+    // Role-private accumulators: declared here (they feed the common reduction below) but initialised ONLY inside the
+    // role that owns them, so that their live ranges do not extend through the other role's code (a shared
+    // zero-initialisation made the allocator keep all 160 accumulator registers live in the producer: 157 spills).
+    f32x4 dW4[4][4], dW2[4][4], dW0[4], dw6[4];
+    float dbs[3][4];          // consumer: bias-gradient partial sums (row 16q + li, pixels = lk mod 4)
+    float db6;
+
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(2);   // producers are the critical path: they win the
+                                                                                    // MFMA arbitration, the consumer fills their bubbles
+    if (producer) {
+        db6 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int HW = p.H * p.W;
+        const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
+        float fscale[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fscale[r] = 1.f;
+            if (a.fuse_feat_bn) {
+                const int c = 4 * lk + r;
+                float sh;
+                pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
+            }
+        }
+        int nprod = 0;
+        HP_DECL;
+        HR_DECL;
+        HQ_NOW(hr_t);
+        // c_early: the consumer's counter as read one phase earlier (it only grows: a stale value is merely conservative) -- the
+        // LDS round trip of the poll is then hidden behind that phase instead of sitting in front of every slot
+        auto acquire = [&](int c_early) -> float* {
+            HP_ACQ0;
+            if (nprod - __builtin_amdgcn_readfirstlane(c_early) >= PC_NSLOT) {
+                while (true) {
+                    const int c = __builtin_amdgcn_readfirstlane(*cons_p);
+                    if (nprod - c < PC_NSLOT) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            asm volatile("" ::: "memory");
+            HP_ACQ1;
+            return ring + (nprod % PC_NSLOT) * PC_SLOT;
+        };
+        auto release = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++nprod;
+            if (lane == 0) *prod_p = nprod;
+        };
+        // Per-group inputs are fetched one group ahead (raw loads only).  The group index is wave-uniform, so the sample index and
+        // everything per sample live in scalar registers; optional inputs get a valid dummy address (the building map) and a
+        // select instead of a branch around their load, and the last iteration prefetches a clamped (valid) group: the loop top is
+        // straight-line code -- written with a branch per optional load and the (b, y, x) arithmetic done twice it cost ~2,300
+        // cycles of a ~15,000-cycle group with the matrix pipe idle.
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        int vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+        const bool has_msk = p.mask != nullptr, has_adm = p.admin != nullptr, has_gpc = a.g_popcount != nullptr;
+        const bool has_gpd = a.g_popdense != nullptr, has_gsm = a.g_scale_map != nullptr, has_fbn = a.fuse_feat_bn != 0;
+        const uint8_t* msk_p = has_msk ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
+        const float* adm_p = has_adm ? p.admin : p.building;
+        const float* gpd_p = has_gpd ? a.g_popdense : p.building;
+        const float* gsm_p = has_gsm ? a.g_scale_map : p.building;
+        const unsigned fcs = (unsigned)p.feat.cstride, gcs = (unsigned)a.g_feat.cstride;
+        float n_xv[4], n_fv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
+        long long n_cen = 0;          // raw: the int64 -> float conversion at the point of USE (inside fetch it is a wait for the loads just issued)
+        unsigned n_msk = 1, n_go = 0;
+        bool n_valid = false;
+        int n_b = 0;
+        // The prefetch in five stages: inside the group loop they run one per K-step in the shadow of the second layer's MFMAs
+        // (head_mm64_pf's hook); stage 4 also sends the PREVIOUS group's gradient out -- behind the loads: stored at the end of its
+        // own iteration it sat in front of the next iteration's wait for the prefetched inputs (vmcnt counts loads and stores in one
+        // queue).
+        float pend_o[4] = {0.f, 0.f, 0.f, 0.f};
+        float* pend_p = nullptr;
+        const float* f_fb = nullptr;
+        unsigned f_fo = 0, f_qq = 0;
+        int64_t f_pb = 0;
+        int f_b = 0;
+        auto fetch_stage = [&](int st, int gg) {
+            if (st == 0) {
+                const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
+                const int q = g * 16 + li;
+                n_valid = q < HW;
+                n_b = f_b = b;
+                f_qq = n_valid ? (unsigned)q : 0u;
+                const unsigned y = pc_div(f_qq, p.div_w), x = f_qq - y * (unsigned)p.W;
+                f_fb = p.feat.ptr + b * p.feat.bstride;
+                f_fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
+                n_go = (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
+                f_pb = (int64_t)b * HW;
+            } else if (st == 1) {
+                // SPL: K-slot (lk, j) of the first layer = channel 4 lk + j (as in the split forward kernel): the operand IS the lane's
+                // own four channels, which the fused ReLU backward of the feature layers reads as well (no second set of loads)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n_xv[j] = f_fb[f_fo + (unsigned)(SPL ? 4 * lk + j : 4 * j + lk) * fcs];
+            } else if (st == 2) {
+                if constexpr (!SPL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) n_fv[j] = f_fb[f_fo + (unsigned)(4 * lk + j) * fcs];   // (only used with fuse_feat_bn; n_xv's cache lines)
+                }
+            } else if (st == 3) {
+                n_msk = msk_p[f_pb + f_qq];
+                n_bld = p.building[f_pb + f_qq];
+                n_adm = adm_p[f_pb + f_qq];
+                n_gpd = gpd_p[f_pb + f_qq];
+                n_gsm = gsm_p[f_pb + f_qq];
+            } else if (st == 4) {
+                // the two per-sample scalars as well: read at their point of use they were two DEPENDENT, fully exposed memory
+                // round trips at the top of every group
+                // (indexed with an opaque per-lane zero: a provably uniform load result is moved to scalar registers by the compiler
+                // with v_readfirstlane RIGHT HERE, behind a vmcnt(0) wait for everything the prefetch has just issued)
+                if (has_adm) n_cen = p.census[f_b + vzero];
+                if (has_gpc) n_gpc = a.g_popcount[f_b + vzero];
+                if (pend_p) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
+                    pend_p = nullptr;
+                }
+            }
+        };
+        auto fetch = [&](int gg) {
+#pragma unroll
+            for (int st = 0; st < 5; ++st) fetch_stage(st, gg);
+        };
+        const int gstep = gridDim.x * 4;
+        constexpr bool handoff = !(DBG & 2);
+        // Slot matrices are stored as the producer HOLDS them (D layout: lane (pixel li, lk), register block mb = rows 16 mb + 4 lk
+        // + r): one 16-byte write per block, [mb][lk][PC_LKS] floats with the lane's 4 values at li * 4 -- the consumer does the
+        // transposing reads.  (The first form scattered every element into a [row][pixel] matrix: 32 ds_write_b32 per slot on the
+        // producer, the critical path, where every LDS instruction costs the wave ~30-40 cycles of MFMA issue --
+        // profiles/r3_mfma_peak.json, lds variants at 1 wave per SIMD.)
+        const int sbase = lk * PC_LKS + li * 4;
+        auto put = [&](float* sl, int mb, const f32x4 (&G)[4], const f32x4 (&Hm)[4]) {
+            *reinterpret_cast<f32x4*>(&sl[mb * PC_MBS + sbase]) = G[mb];
+            *reinterpret_cast<f32x4*>(&sl[PC_MAT + mb * PC_MBS + sbase]) = Hm[mb];
+        };
+        // the last layer's row (this lane's 16 hidden units) and bias stay in registers: read at their point of use they are 9 LDS round
+        // trips per group in a stretch with no matrix instruction to hide them
+        f32x4 w6f[4], a1f[4], b0f[4];         // (and the first layer's fragments + bias: the group loop started with their round trip)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            w6f[mb] = *reinterpret_cast<const f32x4*>(&lds[(SPL ? LS_F32 / 4 + 192 : LB_W6) + 16 * mb + 4 * lk]);
+            a1f[mb] = SPL ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(&lds[LB_A1 + (mb * 64 + lane) * 4]);
+            b0f[mb] = *reinterpret_cast<const f32x4*>(&lds[(SPL ? LS_F32 / 4 : LB_B0) + 16 * mb + 4 * lk]);
+        }
+        const float b6v = lds[SPL ? LS_F32 / 4 + 256 : LB_W6 + 64];
+        const LsLane LL = ls_lane(lane);
+        int gg = blockIdx.x * 4 + wv;
+        if (gg < a.total_groups) fetch(gg);
+        for (; gg < a.total_groups; gg += gstep) {
+            const bool valid = n_valid;
+            const bool sel = valid && (!has_msk || n_msk != 0);
+            float* const gp = a.g_feat.ptr + n_b * a.g_feat.bstride + n_go;       // this lane's pixel of the gradient map, channel 0
+            float xv[4], fvv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[j] = valid ? n_xv[j] : 0.f; fvv[j] = (valid && has_fbn) ? (SPL ? n_xv[j] : n_fv[j]) : 1.f; }
+            float gup = 0.f;
+            {
+                const bool region = !has_adm || n_adm == (float)n_cen;
+                float u = gsc;
+                u += (has_gpc && region) ? n_gpc * n_bld : 0.f;
+                u += has_gpd ? n_gpd * n_bld : 0.f;
+                u += has_gsm ? n_gsm : 0.f;
+                gup = sel ? u : 0.f;
+            }
+            const int gnx = gg + gstep < a.total_groups ? gg + gstep : a.total_groups - 1;   // (clamped: the last prefetch is a dummy)
+            // g_feat is written exactly once per element by this kernel (no zero-fill pass in front of it): crop pixels
+            // by the producer that owns their group -- zeros when the group is skipped --, the border by the consumers
+            auto store_zero = [&]() {
+                if (a.zero_in_kernel && valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gp[(unsigned)(4 * lk + r) * gcs] = 0.f;
+                }
+            };
+            if (!__any(sel)) { fetch(gnx); store_zero(); continue; }
+            if constexpr (SPL) {
+                // ---- the chain on split bf16 operands (straight-line: with 16-cycle instructions the layer boundaries are VALU work --
+                // the splits -- that the consumer wave's fp32 MFMAs fill)
+                fetch(gnx);
+                HR_CLOSE(0);                              // loop top (consume the prefetch, issue the next one)
+                const unsigned char* const wpl = reinterpret_cast<const unsigned char*>(lds);
+                const float* const lf = reinterpret_cast<const float*>(wpl + LS_F32);
+                f32x4 h1[4], h2[4], h3[4];
+                hbf16x8 ob[3][2];
+                hbf16x8 fr[4];
+                {
+                    unsigned x1[2], x2[2], x3[2];
+                    hs_split_pair(xv[0], xv[1], x1[0], x2[0], x3[0]);
+                    hs_split_pair(xv[2], xv[3], x1[1], x2[1], x3[1]);
+                    const hs16x4 xb[3] = {__builtin_bit_cast(hs16x4, make_uint2(x1[0], x1[1])), __builtin_bit_cast(hs16x4, make_uint2(x2[0], x2[1])),
+                                          __builtin_bit_cast(hs16x4, make_uint2(x3[0], x3[1]))};
+                    hs16x4 f1[3][4];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb)
+                            f1[pl][mb] = __builtin_bit_cast(hs16x4, *reinterpret_cast<const uint2*>(wpl + pl * LS_PLANE + LS_W0 + mb * 512 + LL.a0));
+                    ls_load4<false>(wpl, LS_W2, LL, 0, 2, fr);                 // the second layer's first fragments
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) h2[mb] = *reinterpret_cast<const f32x4*>(&lf[64 + 16 * mb + 4 * lk]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int qq = 2 - pl; qq >= 0; --qq)
+#pragma unroll
+                            for (int mb = 0; mb < 4; ++mb) h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1[pl][mb], xb[qq], h1[mb], 0, 0, 0);
+                }
+                hb_relu4(h1);
+                hs_split_pack(h1, ob);
+                ls_layer64_pf<false>(wpl, LS_W2, LL, ob, h2, fr, [&](hbf16x8 (&f)[4]) {
+                    ls_load4<false>(wpl, LS_W4, LL, 0, 2, f);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) h3[mb] = *reinterpret_cast<const f32x4*>(&lf[128 + 16 * mb + 4 * lk]);
+                });
+                hb_relu4(h2);
+                hs_split_pack(h2, ob);
+                ls_layer64_pf<false>(wpl, LS_W4, LL, ob, h3, fr, [&](hbf16x8 (&f)[4]) { ls_load4<true>(wpl, LS_W4, LL, 0, 2, f); });
+                hb_relu4(h3);
+                HR_CLOSE(1);                              // forward chain
+                const int c_early0 = *cons_p;
+                float s = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
+                s = pc_xor16_sum(s);
+                s = pc_xor32_sum(s);
+                const float outv = s + b6v;
+                const float gout = (sel && outv > 0.f) ? gup : 0.f;
+                if (!__any(gout != 0.f)) { store_zero(); continue; }
+                f32x4 g3[4], g2[4], g1[4];
+                if (lk == 0) db6 += gout;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                        g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
+                    }
+                HR_CLOSE(2);                              // output layer + G3
+                float* sl = handoff ? acquire(c_early0) : nullptr;
+                HR_CLOSE(3);                              // wait for slot 0
+                const int c_early1 = *cons_p;
+                if (handoff) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) put(sl, mb, g3, h2);
+                    release();
+                }
+                HR_CLOSE(4);                              // slot 0 writes
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                hs_split_pack(g3, ob);
+                ls_layer64_pf<true>(wpl, LS_W4, LL, ob, g2, fr, [&](hbf16x8 (&f)[4]) { ls_load4<true>(wpl, LS_W2, LL, 0, 2, f); });
+                mask_block(g2[0], h2[0]);
+                mask_block(g2[1], h2[1]);
+                mask_block(g2[2], h2[2]);
+                mask_block(g2[3], h2[3]);
+                HR_CLOSE(5);                              // data gradient of layer 3
+                sl = handoff ? acquire(c_early1) : nullptr;
+                HR_CLOSE(6);
+                const int c_early2 = *cons_p;
+                if (handoff) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) put(sl, mb, g2, h1);
+                    release();
+                }
+                HR_CLOSE(7);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                hs_split_pack(g2, ob);
+                // (what follows is the 16-channel data gradient: its fragments of planes 2 and 1 -- [plane][K-step] -- come with the last step)
+                ls_layer64_pf<true>(wpl, LS_W2, LL, ob, g1, fr, [&](hbf16x8 (&f)[4]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned char* q0 = wpl + (2 - (k >> 1)) * LS_PLANE + LS_W0 + LL.t0 + (k & 1) * 32 * 32;
+                        f[k] = hc_pair(hc_tr(q0), hc_tr(q0 + 16 * 32));
+                    }
+                });
+                mask_block(g1[0], h1[0]);
+                mask_block(g1[1], h1[1]);
+                mask_block(g1[2], h1[2]);
+                mask_block(g1[3], h1[3]);
+                HR_CLOSE(8);                              // data gradient of layer 2
+                sl = handoff ? acquire(c_early2) : nullptr;
+                HR_CLOSE(9);
+                if (handoff) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&sl[mb * PC_MBS + sbase]) = g1[mb];
+                    *reinterpret_cast<f32x4*>(&sl[PC_MAT + sbase]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+                    release();
+                }
+                HR_CLOSE(10);
+                hbf16x8 fz[2];                            // plane 0 of the 16-channel data gradient's fragments
+                {
+                    const unsigned char* q0 = wpl + LS_W0 + LL.t0;
+                    fz[0] = hc_pair(hc_tr(q0), hc_tr(q0 + 16 * 32));
+                    fz[1] = hc_pair(hc_tr(q0 + 32 * 32), hc_tr(q0 + 48 * 32));
+                }
+                hs_split_pack(g1, ob);
+                f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) {
+                    const hbf16x8 f0 = pl == 0 ? fz[0] : fr[2 * (2 - pl)], f1 = pl == 0 ? fz[1] : fr[2 * (2 - pl) + 1];
+#pragma unroll
+                    for (int qq = 2 - pl; qq >= 0; --qq) {
+                        gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, ob[qq][0], gx, 0, 0, 0);
+                        gx2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, ob[qq][1], gx2, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
+                if (valid) {
+                    pend_p = gp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float o = gx[r];
+                        if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
+                        pend_o[r] = o;
+                    }
+                }
+                HR_CLOSE(11);                             // data gradient of layer 1 (features)
+            } else {
+            HP_MARK(0);
+            // Every contraction gets its first fragments from the phase before it (fa / fb, alternating), and the ReLU / ReLU' of its
+            // input blocks 1-3 happens in the shadow of its own first K-steps (block mb + 1 in step 4 mb): a layer boundary costs the
+            // ReLU of ONE block, not an LDS round trip + 16-32 VALU instructions with the matrix pipe idle.
+            f32x4 h1[4], h2[4], h3[4], fa[4], fb[4];
+            head_frag0(lds, LB_A2, 4, lane, fa);
+            head_bias4(lds, LB_B2, lk, h2);          // (in flight during the first layer: the scheduling barriers below keep it up here)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) h1[mb] = b0f[mb];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) h1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[mb][j], xv[j], h1[mb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            relu_block(h1[0]);
+            head_mm64_pf(lds, LB_A2, lane, h1, h2, fa, LB_A3, 4, fb, [&](int st) {
+                if (!(st & 3) && st < 12) relu_block(h1[(st >> 2) + 1]);
+                if ((st & 1) && st < 10) fetch_stage(st >> 1, gnx);
+                if (st == 12) head_bias4(lds, LB_B4, lk, h3);
+            });
+            relu_block(h2[0]);
+            head_mm64_pf(lds, LB_A3, lane, h2, h3, fb, LB_T3, 4, fa, [&](int st) { if (!(st & 3) && st < 12) relu_block(h2[(st >> 2) + 1]); });
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) relu_block(h3[mb]);
+            HP_MARK(1);
+            const int c_early0 = *cons_p;
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
+            s = pc_xor16_sum(s);
+            s = pc_xor32_sum(s);
+            const float outv = s + b6v;
+            const float gout = (sel && outv > 0.f) ? gup : 0.f;
+            if (!__any(gout != 0.f)) { store_zero(); continue; }
+
+            f32x4 g3[4], g2[4], g1[4];
+            if (lk == 0) db6 += gout;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
+                    g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
+                }
+            HP_MARK(2);
+            // The three hand-offs (slot kind 0: (G3, H2) -> dW4, db4; 1: (G2, H1) -> dW2, db2; 2: (G1, X) -> dW0, db0) are written
+            // one element pair per K-step in the shadow of the NEXT contraction's MFMAs -- as a block in front of it, the 32 scattered
+            // LDS writes + their wait were ~600-1,000 cycles per slot with the matrix pipe idle.
+            float* sl = handoff ? acquire(c_early0) : nullptr;
+            HP_MARK(3);
+            const int c_early1 = *cons_p;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            head_mm64_pf(lds, LB_T3, lane, g3, g2, fa, LB_T2, 4, fb, [&](int st) { if (handoff && (st & 3) == 1) put(sl, st >> 2, g3, h2); });
+            if (handoff) release();
+            mask_block(g2[0], h2[0]);
+            HP_MARK(4);
+            sl = handoff ? acquire(c_early1) : nullptr;
+            HP_MARK(5);
+            const int c_early2 = *cons_p;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            head_mm64_pf(lds, LB_T2, lane, g2, g1, fb, LB_T1, 1, fa, [&](int st) {
+                if (handoff && (st & 3) == 1) put(sl, st >> 2, g2, h1);           // (block mb was masked in step 4 (mb - 1))
+                if (!(st & 3) && st < 12) mask_block(g2[(st >> 2) + 1], h2[(st >> 2) + 1]);
+            });
+            if (handoff) release();
+            mask_block(g1[0], h1[0]);
+            mask_block(g1[1], h1[1]);
+            HP_MARK(6);
+            sl = handoff ? acquire(c_early2) : nullptr;
+            HP_MARK(7);
+            f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA dependent latency
+#pragma unroll                                                                       // (40 cyc) exceeds the issue interval (32)
+            for (int mb = 0; mb < 4; mb += 2) {
+                const f32x4 t4 = fa[mb], u4 = fa[mb + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx = __builtin_amdgcn_mfma_f32_16x16x4f32(t4[r], g1[mb][r], gx, 0, 0, 0);
+                    gx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[r], g1[mb + 1][r], gx2, 0, 0, 0);
+                    if (mb == 0 && r < 2) mask_block(g1[2 + r], h1[2 + r]);
+                    if (handoff) {            // G1 block r in step (0, r) -- blocks 2, 3 are masked in steps (0, 0), (0, 1) --, X in (2, 0)
+                        if (mb == 0) *reinterpret_cast<f32x4*>(&sl[r * PC_MBS + sbase]) = g1[r];
+                        else if (r == 0) *reinterpret_cast<f32x4*>(&sl[PC_MAT + sbase]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (handoff) release();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gx[r] += gx2[r];
+            if (valid) {
+                pend_p = gp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float o = gx[r];
+                    if (a.fuse_feat_bn) o = fvv[r] > 0.f ? o * fscale[r] : 0.f;
+                    pend_o[r] = o;
+                }
+            }
+            }      // (!SPL)
+        }
+        if (pend_p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend_p[(unsigned)(4 * lk + r) * gcs] = pend_o[r];
+        }
+        if constexpr (SPL) { HR_DUMP; } else { HP_DUMP; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *done_p = 1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dW0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dbs[0][i] = dbs[1][i] = dbs[2][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dW4[i][j] = dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.zero_in_kernel) {
+            // The consumers have nothing to do until the first slot arrives: they write the zero border of g_feat (the
+            // padding frame around the H x W crop: 39 % of a 128 x 128 map for 100 x 100 tiles) -- the only part of the
+            // gradient map the producers never touch.  One (b, c, row) job per half-wave: rows above / below the crop in
+            // full (16-byte stores when the row allows), crop rows only left and right of it.
+            const int Hp = a.Hp, Wp = a.Wp;
+            const int l32 = tid & 31;
+            const int nhw = gridDim.x * 8, hw = blockIdx.x * 8 + ((tid - 256) >> 5);
+            const int njobs = p.B * 16 * Hp;
+            const bool v4 = (Wp & 3) == 0;
+            const int right0 = p.px + p.W;
+            for (int j = hw; j < njobs; j += nhw) {
+                const int row = j % Hp;
+                float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
+                if (row < p.py || row >= p.py + p.H) {
+                    if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                } else if (p.px <= 16 && Wp - right0 <= 16) {
+                    // both side strips in one store: lanes 0-15 the left one, lanes 16-31 the right one
+                    const int xs = l32 < 16 ? l32 : right0 + (l32 - 16);
+                    if (l32 < 16 ? l32 < p.px : xs < Wp) rp[xs] = 0.f;
+                } else {
+                    for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
+                    for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
+                }
+            }
+        }
+        int ncons = 0;
+        // wait until slot `ncons` has been produced; returns false when the producer has finished without producing it
+        auto wait_slot = [&]() -> bool {
+            while (true) {
+                if (__builtin_amdgcn_readfirstlane(*prod_p) > ncons) return true;
+                if (__builtin_amdgcn_readfirstlane(*done_p)) return __builtin_amdgcn_readfirstlane(*prod_p) > ncons;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        // fetch the (G, H) fragments of the current slot and hand the slot back
+        auto take = [&](f32x4 (&af)[4], f32x4 (&bf)[4], bool x_only) {
+            asm volatile("" ::: "memory");
+            // transposing reads: fragment (q, ks) = element (row 16 q + li, pixel 4 ks + lk) = register li & 3 of the producer lane
+            // (pixel, lk' = li >> 2), block q; for X (16 channels x 16 pixels, channel 4 j + lk' in register j) the two are swapped.
+            // Lanes hit 16 (li >> 2) + 4 lk + (li & 3) (mod 32) = every bank twice: conflict-free 4-byte reads, paired by the compiler
+            // into ds_read2_b32 (ks, ks + 1 are 16 floats apart).
+            const float* gm = ring + (ncons % PC_NSLOT) * PC_SLOT;
+            const float* hm = gm + PC_MAT;
+            const int cb = (li >> 2) * PC_LKS + lk * 4 + (li & 3), xb = (li & 3) * PC_LKS + lk * 4 + (li >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    af[q][ks] = gm[q * PC_MBS + cb + 16 * ks];
+                    bf[q][ks] = x_only ? hm[(SPL ? cb : xb) + 16 * ks] : hm[q * PC_MBS + cb + 16 * ks];     // (SPL: X holds channel 4 lk' + j in register j)
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++ncons;
+            if (lane == 0) *cons_p = ncons;          // slot is free again: everything needed is in registers
+        };
+        // every processed group emits exactly three slots, in this order: no tags, no dynamic dispatch
+        while (wait_slot()) {
+            f32x4 af[4], bf[4];
+            take(af, bf, false);                                             // (G3, H2) -> dW4, db4
+            if (DBG & 1) { wait_slot(); take(af, bf, false); wait_slot(); take(af, bf, true); continue; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[2][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+            if constexpr (SPL) hs_wgrad16<4>(af, bf, dW4);
+            else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        dW4[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW4[mb][nb], 0, 0, 0);
+            }
+            wait_slot();
+            take(af, bf, false);                                             // (G2, H1) -> dW2, db2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[1][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+            if constexpr (SPL) hs_wgrad16<4>(af, bf, dW2);
+            else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        dW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[nb][ks], dW2[mb][nb], 0, 0, 0);
+            }
+            wait_slot();
+            take(af, bf, true);                                              // (G1, X) -> dW0, db0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dbs[0][q] += (af[q][0] + af[q][1]) + (af[q][2] + af[q][3]);
+            if constexpr (SPL) {
+                hs16x4 xs[3];
+                hs_split4(bf[0], xs);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    hs16x4 as[3];
+                    hs_split4(af[mb], as);
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int qq = 2 - pl; qq >= 0; --qq)
+                            dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as[pl], xs[qq], dW0[mb], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    dW0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][ks], bf[0][ks], dW0[mb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- reductions: producers own dw6 / db6, consumers own dW4, dW2, dW0 and the bias sums
+    if (producer) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
+        db6 = lane_sum16(db6);
+    } else {
+#pragma unroll
+        for (int l3 = 0; l3 < 3; ++l3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = dbs[l3][q];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                dbs[l3][q] = v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int stage = 0; stage < 2; ++stage) {
+        if (!producer) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    *reinterpret_cast<f32x4*>(&lds[pair * 4096 + ((mb * 4 + nb) * 64 + lane) * 4]) = stage == 0 ? dW4[mb][nb] : dW2[mb][nb];
+        }
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 512)
+            part[(stage == 0 ? PE_W4 : PE_W2) + e] = ((lds[e] + lds[4096 + e]) + lds[8192 + e]) + lds[12288 + e];
+        __syncthreads();
+    }
+    {
+        float* w = lds + pair * 1344;       // [dW0 1024][dw6 64][db0 64][db2 64][db4 64][db6 1]
+        if (!producer) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4*>(&w[(mb * 64 + lane) * 4]) = dW0[mb];
+            if (lk == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w[1088 + 16 * q + li] = dbs[0][q];
+                    w[1152 + 16 * q + li] = dbs[1][q];
+                    w[1216 + 16 * q + li] = dbs[2][q];
+                }
+            }
+        } else if (li == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[1024 + 16 * mb + 4 * lk + r] = dw6[mb][r];
+            if (lk == 0) w[1280] = db6;
+        }
+        __syncthreads();
+        for (int e = tid; e < 1281; e += 512) {
+            const float t = ((lds[e] + lds[1344 + e]) + lds[2688 + e]) + lds[4032 + e];
+            part[PE_W0 + e] = t;
+        }
+    }
+}
+
 // ---- bf16 backward, cooperative form -------------------------------------------------------------------------------------
 // The first bf16 kernel kept all 160 weight-gradient accumulator registers in every wave and computed every chain twice (a
 // second, transposed orientation: mfma with swapped operands) to get their operands: one wave per SIMD, 116 MFMAs and two sets
@@ -1663,12 +2019,6 @@ __global__ __launch_bounds__(64 * NW) void head_fwd_split_kernel(const HeadArgs 
 // dW0: 38 chain + 15 weight-gradient MFMAs per wave and group, 48 accumulator registers.
 constexpr int HC_EX = (HB_END + 15) & ~15;        // exchange area behind the weight images
 
-__device__ __forceinline__ hs16x4 hc_tr(const unsigned char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(p));
-}
-__device__ __forceinline__ hbf16x8 hc_pair(hs16x4 a, hs16x4 b) {
-    return __builtin_bit_cast(hbf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
 
 constexpr int H4_ROW = 128, H4_T = 16 * H4_ROW;
 constexpr int H4_H1 = 0, H4_H2 = H4_T, H4_G3 = 2 * H4_T, H4_G2 = 3 * H4_T, H4_G1 = 4 * H4_T, H4_X = 5 * H4_T;
@@ -2010,18 +2360,21 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
 // backward, 2: bf16 forward, 3: bf16 backward)
 // blocks 0..7 assemble image `kind` into img; blocks 8..15 (PC_HEAD_FWD_PACK_BOTH: a 16-block launch) the backward's image of the same
 // mode (kind + 1) into img2
-// (kind 4: the fp32 forward on 3-way split bf16 operands, head_fwd_split_kernel; its backward partner is kind 1)
+// (kind 4: the fp32 forward on 3-way split bf16 operands, head_fwd_split_kernel; kind 5: its backward partner, the split planes of the
+// producer waves of head_bwd_pc_kernel<., true>)
 __global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs p, void* img, int kind, void* img2) {
     const int second = blockIdx.x >= 8 ? 1 : 0;
     const int tid = (blockIdx.x - 8 * second) * blockDim.x + threadIdx.x, nt = 8 * blockDim.x;
-    if (second) { img = img2; kind = kind == 4 ? 1 : kind + 1; }
+    if (second) { img = img2; kind = kind == 4 ? 5 : kind + 1; }
     if (kind == 0) head_stage_weights(reinterpret_cast<float*>(img), p, tid, nt);
     else if (kind == 1) head_stage_weights_bwd(reinterpret_cast<float*>(img), p, tid, nt);
     else if (kind == 4) head_stage_weights_split(reinterpret_cast<unsigned char*>(img), p, tid, nt);
+    else if (kind == 5) head_stage_weights_bsplit(reinterpret_cast<unsigned char*>(img), p, tid, nt);
     else head_stage_weights_bf16(reinterpret_cast<unsigned char*>(img), p, kind == 3, tid, nt);
 }
 constexpr int HEAD_IMG_BYTES = 96 * 1024;      // room for the largest image (fp32 backward: LB_SCR floats = 72 KB)
-static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES && HS_END <= HEAD_IMG_BYTES, "weight image slot");
+static_assert(LB_SCR * 4 <= HEAD_IMG_BYTES && HB_END <= HEAD_IMG_BYTES && L_END * 4 <= HEAD_IMG_BYTES && HS_END <= HEAD_IMG_BYTES && LS_WEND <= HEAD_IMG_BYTES,
+              "weight image slot");
 // the images live in the unused tail of the backward partial area of the workspace (pc_head_ws_bytes reserves 512 x 12288
 // floats, the backward uses at most 512 x PE_TOTAL = 395 x 12288): slot 0 forward, slot 1 backward
 __host__ inline void* head_image_slot(void* ws, int B, int H, int W, int slot) {
@@ -2741,13 +3094,20 @@ extern "C" int64_t pc_head_ws_bytes(int B, int H, int W) {
 // once (B images x chunks-per-image <= resident) and each wave walks enough 16-pixel groups to cover its image chunk -- with a fixed 8
 // groups per wave a B = 64 batch of 100 x 100 tiles was 1280 workgroups on 1024 slots, i.e. a second, quarter-full round.
 constexpr int HS_NW = 8;              // waves per workgroup of head_fwd_split_kernel (two workgroups per CU: four waves per SIMD)
+static int g_head_split = -1;
 static int head_split_on() {
-    static int on = -1;
-    if (on < 0) {
+    if (g_head_split < 0) {
         const char* ev = getenv("POPCORN_HEAD_SPLIT");
-        on = (ev && ev[0] == '0') ? 0 : 1;
+        const char* sr = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");          // (the ablation's single-role backward is an fp32-MFMA kernel:
+        g_head_split = ((ev && ev[0] == '0') || (sr && sr[0] == '1')) ? 0 : 1;      // both head kernels then keep the fp32 images)
     }
-    return on;
+    return g_head_split;
+}
+extern "C" int pc_get_head_split(void) { return head_split_on(); }
+extern "C" int pc_set_head_split(int on) {
+    const int prev = head_split_on();
+    g_head_split = on ? 1 : 0;
+    return prev;
 }
 static int head_fwd_chunks(int B, int H, int W, bool split, int* groups_per_wave, int* nchunk) {
     static int resident[2] = {0, 0};
@@ -2974,6 +3334,12 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     if (!feat || !hw || !building || !dhw || !g_feat || !ws) return PC_EINVAL;
     if (admin_mask && !census_idx) return PC_EINVAL;
     const bool bfmode = g_pc_precision == PC_PREC_BF16;          // bf16 mode: feat and g_feat are channels-last bf16 tensors
+    static int use_pc = -1;
+    if (use_pc < 0) {
+        const char* ev = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");
+        use_pc = (ev && ev[0] == '1') ? 0 : 1;
+    }
+    const bool split = !bfmode && use_pc && head_split_on();     // fp32 mode: the producer waves' chain on split bf16 operands
     if (bfmode) {
         if (!pc_cl_ok(*feat) || feat->xstride < 16 || !pc_cl_ok(*g_feat) || g_feat->xstride != 16 || g_feat->rstride != 16 * Wp ||
             g_feat->bstride != (int64_t)16 * Hp * Wp)
@@ -2984,11 +3350,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     }
     hipStream_t st = (hipStream_t)stream;
     if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
-    static int use_pc = -1;
-    if (use_pc < 0) {
-        const char* ev = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");
-        use_pc = (ev && ev[0] == '1') ? 0 : 1;
-    }
     const char* zv = getenv("POPCORN_HEAD_ZERO_FILL");            // A/B switch: 1 = the round-1 separate zero-fill launch
     const bool zero_launch = !bfmode && (!use_pc || (zv && zv[0] == '1'));
     if (zero_launch) {
@@ -3022,9 +3383,14 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LB_END * sizeof(float)));
         if (e2 != hipSuccess) return (int)e2;
-        for (const void* f : {reinterpret_cast<const void*>(&head_bwd_pc_kernel<0>), reinterpret_cast<const void*>(&head_bwd_pc_kernel<1>),
-                              reinterpret_cast<const void*>(&head_bwd_pc_kernel<2>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(&head_bwd_pc_kernel<0, false>), reinterpret_cast<const void*>(&head_bwd_pc_kernel<1, false>),
+                              reinterpret_cast<const void*>(&head_bwd_pc_kernel<2, false>)}) {
             e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_END * sizeof(float)));
+            if (e2 != hipSuccess) return (int)e2;
+        }
+        for (const void* f : {reinterpret_cast<const void*>(&head_bwd_pc_kernel<0, true>), reinterpret_cast<const void*>(&head_bwd_pc_kernel<1, true>),
+                              reinterpret_cast<const void*>(&head_bwd_pc_kernel<2, true>)}) {
+            e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LPS_END * sizeof(float)));
             if (e2 != hipSuccess) return (int)e2;
         }
         once.mark();
@@ -3033,7 +3399,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         void* img = head_image_slot(ws, B, H, W, 1);
         p.wimage = img;
         if (!(flags & PC_HEAD_BWD_PACKED)) {
-            hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 3 : 1, (void*)nullptr);
+            hipLaunchKernelGGL(head_pack_kernel, dim3(8), dim3(256), 0, st, p, img, p.bf ? 3 : (split ? 5 : 1), (void*)nullptr);
             PC_CHECK_LAUNCH();
         }
     }
@@ -3066,10 +3432,29 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
         }
 #endif
     }
+    else if (use_pc && split) {
+        if (a.dbg == 1) hipLaunchKernelGGL((head_bwd_pc_kernel<1, true>), dim3(nwg), dim3(512), LPS_END * sizeof(float), st, a);
+        else if (a.dbg == 2) hipLaunchKernelGGL((head_bwd_pc_kernel<2, true>), dim3(nwg), dim3(512), LPS_END * sizeof(float), st, a);
+        else hipLaunchKernelGGL((head_bwd_pc_kernel<0, true>), dim3(nwg), dim3(512), LPS_END * sizeof(float), st, a);
+#ifdef POPCORN_HEAD_PROF
+        if (getenv("POPCORN_HEAD_PROF")) {
+            static long long hp[2048 * 16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_head_prof), sizeof(hp));
+            double tot[12] = {0};
+            const int nw = nwg * 4;
+            for (int w = 0; w < nw && w < 2048; ++w) for (int k = 0; k < 12; ++k) tot[k] += (double)hp[w * 16 + k];
+            const double ngr = (double)a.total_groups / nw;
+            fprintf(stderr, "head_bwd_pc split producer phases, cycles per group (loop top, forward, out+g3, wait0, put0, dgrad3, wait1, put1, dgrad2, wait2, put2, gx+store):");
+            for (int k = 0; k < 12; ++k) fprintf(stderr, " %.0f", tot[k] / nw / ngr);
+            fprintf(stderr, "\n");
+        }
+#endif
+    }
     else if (use_pc) {
-        if (a.dbg == 1) hipLaunchKernelGGL(head_bwd_pc_kernel<1>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
-        else if (a.dbg == 2) hipLaunchKernelGGL(head_bwd_pc_kernel<2>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
-        else hipLaunchKernelGGL(head_bwd_pc_kernel<0>, dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+        if (a.dbg == 1) hipLaunchKernelGGL((head_bwd_pc_kernel<1, false>), dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+        else if (a.dbg == 2) hipLaunchKernelGGL((head_bwd_pc_kernel<2, false>), dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
+        else hipLaunchKernelGGL((head_bwd_pc_kernel<0, false>), dim3(nwg), dim3(512), LP_END * sizeof(float), st, a);
 #ifdef POPCORN_HEAD_PROF
         if (getenv("POPCORN_HEAD_PROF")) {
             static long long hp[256 * 16];

@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                 while (true) {
                     const int c = __builtin_amdgcn_readfirstlane(*cons_p);
                     if (nprod - c < PC_NSLOT) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    if (!SPL) __builtin_amdgcn_s_sleep(2);        // (SPL: the phases between two hand-offs are a third as long: poll back to back)
                 }
             }
             asm volatile("" ::: "memory");
@@ -1558,8 +1558,8 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
             if constexpr (SPL) {
                 // ---- the chain on split bf16 operands (straight-line: with 16-cycle instructions the layer boundaries are VALU work --
                 // the splits -- that the consumer wave's fp32 MFMAs fill)
-                fetch(gnx);
-                HR_CLOSE(0);                              // loop top (consume the prefetch, issue the next one)
+                fetch_stage(0, gnx);                      // (index arithmetic; the loads go out in the shadow of the layers' last steps)
+                HR_CLOSE(0);                              // loop top (consume the prefetch)
                 const unsigned char* const wpl = reinterpret_cast<const unsigned char*>(lds);
                 const float* const lf = reinterpret_cast<const float*>(wpl + LS_F32);
                 f32x4 h1[4], h2[4], h3[4];
@@ -1596,10 +1596,16 @@ __global__ __launch_bounds__(512, 2) void head_bwd_pc_kernel(const HeadBwdArgs a
                     ls_load4<false>(wpl, LS_W4, LL, 0, 2, f);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) h3[mb] = *reinterpret_cast<const f32x4*>(&lf[128 + 16 * mb + 4 * lk]);
+                    fetch_stage(1, gnx);
+                    fetch_stage(2, gnx);
                 });
                 hb_relu4(h2);
                 hs_split_pack(h2, ob);
-                ls_layer64_pf<false>(wpl, LS_W4, LL, ob, h3, fr, [&](hbf16x8 (&f)[4]) { ls_load4<true>(wpl, LS_W4, LL, 0, 2, f); });
+                ls_layer64_pf<false>(wpl, LS_W4, LL, ob, h3, fr, [&](hbf16x8 (&f)[4]) {
+                    ls_load4<true>(wpl, LS_W4, LL, 0, 2, f);
+                    fetch_stage(3, gnx);
+                    fetch_stage(4, gnx);
+                });
                 hb_relu4(h3);
                 HR_CLOSE(1);                              // forward chain
                 const int c_early0 = *cons_p;

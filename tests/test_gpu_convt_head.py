@@ -138,9 +138,20 @@ def test_compact_masked_order():
         assert torch.equal(out[:k].cpu(), src[mask])
 
 
+@pytest.fixture
+def head_form(request):
+    """The head kernels' multiplication form (popcorn_hip.h: pc_set_head_split): 1 = exact 3-way bf16 operand splits on the bf16 matrix
+    pipe (default), 0 = fp32 MFMA."""
+    from popcorn_amd import _lib as L
+    prev = L.lib().pc_set_head_split(int(request.param))
+    yield int(request.param)
+    L.lib().pc_set_head_split(prev)
+
+
+@pytest.mark.parametrize("head_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("shape", [(2, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
-def test_head_fwd_vs_oracle(sparse, shape):
+def test_head_fwd_vs_oracle(sparse, shape, head_form):
     from oracle import popcorn_oracle as O
     from popcorn_amd import ops
     B, H, W, Hp, Wp, py, px = shape
@@ -174,9 +185,56 @@ def test_head_fwd_vs_oracle(sparse, shape):
     torch.testing.assert_close(pc2.cpu(), ref2, rtol=2e-5, atol=1e-4)
 
 
+def test_head_split_products_have_the_error_of_fp32_arithmetic():
+    """The split form (six bf16 x bf16 partial products of exact 3-way operand splits, fp32 accumulation) against the head evaluated in
+    FLOAT64, next to the fp32-MFMA form on the same inputs: forward outputs, the feature gradient and the weight gradients of both forms
+    sit at the distance of fp32 rounding from the exact values -- the split form is not a reduced-precision mode."""
+    from oracle import popcorn_oracle as O
+    from popcorn_amd import ops, _lib as L
+    B, H, W, Hp, Wp, py, px = 3, 100, 100, 128, 128, 14, 14
+    sd = O.load_golden_state(G)
+    names = [f"head.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+    work = {n: sd[n].double().clone().requires_grad_(True) for n in names}
+    feat = _mk(B, 16, Hp, Wp, seed=31)
+    fd = feat.double().requires_grad_(True)
+    gen = torch.Generator().manual_seed(32)
+    building = torch.rand(B, 1, H, W, generator=gen)
+    g_pc = torch.randn(B, generator=gen)
+    x = fd[:, :, py:py + H, px:px + W]
+    h = x
+    for i in (0, 2, 4, 6):
+        h = F.conv2d(h, work[f"head.{i}.weight"], work[f"head.{i}.bias"])
+        if i != 6:
+            h = F.relu(h)
+    scale = F.relu(h[:, 0])
+    pc = (scale * building[:, 0].double()).sum((1, 2))
+    (pc * g_pc.double()).sum().backward()
+    ht = [sd[n].cuda() for n in names]
+    rel = lambda a, r: ((a.double() - r).abs().max() / r.abs().max()).item()  # noqa: E731
+    err = {}
+    for form in (1, 0):
+        prev = L.lib().pc_set_head_split(form)
+        try:
+            s_map, _, pc_gpu = ops.head_fwd(feat.cuda(), py, px, H, W, ht, building.cuda())
+            grads, g_feat = ops.head_bwd(feat.cuda(), py, px, H, W, ht, building.cuda(), g_popcount=g_pc.cuda())
+        finally:
+            L.lib().pc_set_head_split(prev)
+        err[form] = {"scale": rel(s_map.cpu(), scale.detach()), "popcount": rel(pc_gpu.cpu(), pc.detach()),
+                     "g_feat": rel(g_feat.cpu(), fd.grad), "dW": max(rel(g.cpu()[:1] if n.startswith("head.6") else g.cpu(),
+                                                                       work[n].grad[:1] if n.startswith("head.6") else work[n].grad)
+                                                                   for n, g in zip(names, grads))}
+    print(f"\n[head forms vs float64] split: {err[1]}   fp32 MFMA: {err[0]}")
+    for form in (1, 0):
+        assert err[form]["scale"] < 3e-6 and err[form]["popcount"] < 3e-6, err          # (fp32 epsilon = 6e-8; four layers of 16 / 64-term sums)
+        assert err[form]["g_feat"] < 1e-5 and err[form]["dW"] < 1e-5, err              # (sums over 30,000 pixels)
+    for k in err[1]:
+        assert err[1][k] < 4 * err[0][k] + 1e-7, (k, err)                                # the same class, not merely inside the bar
+
+
+@pytest.mark.parametrize("head_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("shape", [(3, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
-def test_head_bwd_vs_oracle_autograd(sparse, shape):
+def test_head_bwd_vs_oracle_autograd(sparse, shape, head_form):
     """All four upstream-gradient routes at once; reference = torch autograd through the oracle head."""
     from oracle import popcorn_oracle as O
     from popcorn_amd import ops

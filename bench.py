@@ -313,13 +313,19 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
     flops = float(FLOP_HEAD_BWD_PX) * nsel
     issued = float(FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX) * nsel
     achieved = flops / dur / 1e12
-    pmc = _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
+    pmc = _pmc("r5_pmc_head_bwd.json") or _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    rp_us, rp_file, rp_match = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else "head_bwd_pc_kernel<0>", "bf16" if bf else "fp32")
+    split = (not bf) and bool(L.lib().pc_get_head_split())
+    rp_us, rp_file, rp_match = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else ("head_bwd_pc_kernel<0, true>" if split else "head_bwd_pc_kernel<0, false>"),
+                                               "bf16" if bf else "fp32")
     kname = ("head_bwd_bf16_coop4_kernel (sparse head backward, bf16 MFMA 16x16x32 / 16x16x16, the 4 waves of a workgroup share the weight gradients through an LDS exchange + transposing reads, 2 workgroups per CU)" if bf else
-             "head_bwd_pc_kernel (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)")
+             ("head_bwd_pc_kernel<0, true> (sparse head backward, producer/consumer waves; fp32 results through exact 3-way bf16 operand "
+              "splits: six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, fp32 accumulation -- measured "
+              "against float64 at the accuracy of the fp32-MFMA form, tests/test_gpu_convt_head.py)" if split else
+              "head_bwd_pc_kernel<0, false> (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)"))
     if bf:
-        pmc = _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or _pmc("r2_pmc_head_bwd_bf16.json")
+        pmc = (_pmc("r5_pmc_head_bwd_bf16.json") or _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or
+               _pmc("r2_pmc_head_bwd_bf16.json"))
         traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     return {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call",
             "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -333,10 +339,16 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
                       "eager steps, events around the call behind a device-side spin"),
             "alg_flop_per_launch": flops, "units_per_launch": nsel,
             "unit_def": f"selected pixel, {FLOP_HEAD_BWD_PX} flop (SURVEY.md 8d head backward)",
-            "executed_mfma_view": {"flop_per_unit": FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX,
-                                   "achieved_tflops": round(issued / dur / 1e12, 3),
-                                   "frac": round(issued / dur / peak, 4),
-                                   "note": "includes the forward chain recomputed in registers (not algorithmic work)"},
+            "executed_mfma_view": ({"flop_per_unit": 6 * (FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX),
+                                    "achieved_tflops": round(6 * issued / dur / 1e12, 3), "peak": BF16_MATRIX_PEAK / 1e12,
+                                    "frac": round(6 * issued / dur / BF16_MATRIX_PEAK, 4),
+                                    "note": "what the bf16 matrix pipe executes: six bf16 partial products per fp32 product, the forward chain "
+                                            "recomputed in registers included -- against the bf16 peak; `frac` above is the ALGORITHMIC fp32 work "
+                                            "against the fp32 matrix peak (the arithmetic type of the results)"} if split else
+                                   {"flop_per_unit": FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX,
+                                    "achieved_tflops": round(issued / dur / 1e12, 3),
+                                    "frac": round(issued / dur / peak, 4),
+                                    "note": "includes the forward chain recomputed in registers (not algorithmic work)"}),
             "alg_bytes_per_launch": nsel * (16 * esz + 4 + 4 + 1) + B * 16 * (H + 28) * (W + 28) * esz}
 
 
@@ -379,7 +391,8 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
     nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
-    pmc = (_pmc("r4_pmc_conv_8to8_bf16.json" if esz == 2 else "r4_pmc_conv_8to8.json") or
+    pmc = (_pmc("r5_pmc_conv_8to8_bf16.json" if esz == 2 else "r5_pmc_conv_8to8.json") or
+           _pmc("r4_pmc_conv_8to8_bf16.json" if esz == 2 else "r4_pmc_conv_8to8.json") or
            _pmc("r3_pmc_conv_8to8_bf16.json" if esz == 2 else "r3_pmc_conv_8to8.json"))
     return {"bound": "hbm", "kernel": f"{'conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)' if esz == 2 else 'conv3x3_mfma_kernel<8,8,fwd> (fp32)'} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
@@ -1114,6 +1127,11 @@ def main():
                                    "clip 0.01, Adam, rwa flags), every pixel of every tile selected",
                        "global_batch": B * world, "tile": "15x100x100 -> 6x100x100 (128x128 internal)",
                        "parallelism": f"dp{world}", "graph": not args.no_graph,
+                       # fp32 mode: the sparse head's products are exact 3-way bf16 operand splits on the bf16 matrix pipe, accumulated in
+                       # fp32 (popcorn_hip.h: pc_set_head_split; fp32 accuracy measured against float64 in tests/test_gpu_convt_head.py);
+                       # every other kernel of the fp32 step is v_mfma_f32_16x16x4_f32
+                       "head_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_head_split() else "fp32_mfma") if args.precision == "fp32"
+                                         else "bf16"),
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "collectives": bool(trainer.reducer.active),
                        "collectives_per_step": 2 if trainer.reducer.active else 0,

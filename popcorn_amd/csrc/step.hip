@@ -94,6 +94,8 @@ struct Step {
     // small regions: the frozen extractor's forward chain runs on a side stream next to the trainable U-Net's (two chains of ~13 small,
     // latency-bound launches each; at B = 64 tiles -- a full chip per launch -- every multi-stream attempt lost)
     hipStream_t side = nullptr;
+    hipStream_t side_for = nullptr;             // the caller's stream the side stream was measured against (pick_side_stream)
+    bool side_picked = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_dep[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int ev_next = 0;
@@ -957,6 +959,70 @@ int run(Step& X, pc_step_io& io, int phases, bool dry) {
 
 }  // namespace
 
+namespace {
+// ---- the side stream must not share a hardware queue with the caller's stream -----------------------------------------------------
+// HIP multiplexes its streams onto a handful of hardware queues (4 by default) in creation order: a side stream that lands on the
+// caller's queue runs its kernels IN ORDER with the caller's, and the fork buys nothing (the same effect serialised the copy stream of
+// bench.py's host-feed legs in round 4: popcorn_amd/data/feed.py).  Which stream aliases depends on what the process created before, so
+// the choice is MEASURED at the first step on a caller's stream, with the launch pattern of a small-region step: a fork, twelve 10 us
+// spin kernels on either stream with a cross-stream dependency every fourth one (the backward's side_on), a join.  (Two long kernels
+// alone overlap even on a shared queue; what serialises a shared queue are the barrier packets of the event waits: 1.47 instead of
+// 0.57 ms per 2 x 230 x 220 step, tools/step_side_alias_probe.py.)  About 130 us when the two chains run side by side, 250+ when they
+// do not; up to six fresh streams are tried, the first that overlaps is kept.
+__global__ void step_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+void pick_side_stream(Step& X, hipStream_t main_st) {
+    X.side_picked = true;
+    X.side_for = main_st;
+    if (!X.side) return;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t0) (void)hipEventDestroy(t0);
+        return;
+    }
+    const long long ticks = 10 * 100;                       // 10 us of the 100 MHz wall clock
+    hipStream_t best = X.side;
+    float best_ms = 1e9f;
+    hipStream_t cand = X.side;
+    hipStream_t tried[6];
+    int ntried = 0;
+    for (int k = 0; k < 6 && cand; ++k) {
+        tried[ntried++] = cand;
+        float ms = 1e9f;
+        for (int rep = 0; rep < 2; ++rep) {                 // (the first round also absorbs the kernel's first-launch cost)
+            bool ok = hipEventRecord(t0, main_st) == hipSuccess && hipEventRecord(X.ev_fork, main_st) == hipSuccess &&
+                      hipStreamWaitEvent(cand, X.ev_fork, 0) == hipSuccess;
+            for (int i = 0; i < 12; ++i) {
+                hipLaunchKernelGGL(step_spin_kernel, dim3(1), dim3(64), 0, main_st, ticks);
+                hipLaunchKernelGGL(step_spin_kernel, dim3(1), dim3(64), 0, cand, ticks);
+                if ((i & 3) == 3 && i < 11)
+                    ok = ok && hipEventRecord(X.ev_dep[i >> 2], main_st) == hipSuccess && hipStreamWaitEvent(cand, X.ev_dep[i >> 2], 0) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(X.ev_join, cand) == hipSuccess && hipStreamWaitEvent(main_st, X.ev_join, 0) == hipSuccess &&
+                 hipEventRecord(t1, main_st) == hipSuccess && hipEventSynchronize(t1) == hipSuccess;
+            float e = 1e9f;
+            if (!ok || hipEventElapsedTime(&e, t0, t1) != hipSuccess) { (void)hipGetLastError(); e = 1e9f; }
+            if (rep == 1) ms = e;
+        }
+        if (ms < best_ms) { best_ms = ms; best = cand; }
+        if (ms < 0.19f) break;                              // side by side
+        cand = nullptr;
+        if (k + 1 < 6 && hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); cand = nullptr; }
+    }
+    for (int i = 0; i < ntried; ++i)
+        if (tried[i] != best) (void)hipStreamDestroy(tried[i]);
+    X.side = best;
+    if (getenv("POPCORN_CONV_DBG")) fprintf(stderr, "pc_train_step: side stream %p, probe pattern took %.3f ms (%d tried)\n", (void*)best, best_ms, ntried);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+}
+
+}  // namespace
+
 extern "C" void* pc_step_create(const pc_step_plan* plan) {
     if (!plan) return nullptr;
     Step* X = new (std::nothrow) Step();
@@ -1025,6 +1091,7 @@ extern "C" int pc_train_step(void* handle, pc_step_io* io, int phases, void* str
         if (pt >= io->H || pb >= io->H || pl >= io->W || pr >= io->W || p >= io->H || p >= io->W) return PC_EINVAL;
     }
     X->st = reinterpret_cast<hipStream_t>(stream);
+    if (X->side && (!X->side_picked || X->side_for != X->st)) pick_side_stream(*X, X->st);
     // dry pass: the same code path with launches off -- sizes the arena (bump allocation is deterministic)
     // (a FWD-only call of a data-parallel step is sized for its BWD / UPD calls too: they continue in the same arena)
     Step probe = *X;

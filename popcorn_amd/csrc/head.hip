@@ -2362,510 +2362,6 @@ __global__ __launch_bounds__(256, 2) void head_bwd_bf16_coop4_kernel(const HeadB
     }
 }
 
-// ---- fp32 head backward, cooperative split form (round 5) ---------------------------------------------------------------------------
-// The structure of head_bwd_bf16_coop4_kernel with the arithmetic of the split producer above: EVERY wave runs the forward + backward chain
-// of its own 16-pixel group on split bf16 operands (lane = pixel, everything in registers), and the waves of a workgroup share the weight
-// gradients through an LDS exchange -- rows [pixel][unit] of bf16, one set per SPLIT PLANE, written from the operand planes the chain has
-// computed anyway and read back through ds_read_b64_tr_b16 with K = 32 PIXELS per v_mfma_f32_16x16x32_bf16, six partial products per
-// K-step.  No roles, no ring, no polling, no splitting on the consuming side (the producer / consumer form splits every hand-off again in
-// the consumer and pairs one producer with one consumer per SIMD: two latency chains of equal length).  Three planes of five 64-wide
-// tensors do not fit next to the weights, so the exchange runs in THREE PHASES through one buffer of (G, H) planes per wave --
-// (G3, H2) -> dW4, (G2, H1) -> dW2, (G1, X) -> dW0 -- with the next data-gradient contraction of the chain between a phase's writes and
-// its barrier.  8 waves per workgroup = two independent 4-wave domains, one workgroup per CU; wave w of a domain accumulates row block w of
-// dW4 / dW2 (four column blocks) and of dW0 over the domain's 64 pixels (2 K-steps); bias gradients = one more instruction per plane against an
-// all-ones operand.  LDS: 55 KB of weight planes (the producer form's image, shared by both domains) + 8 x 12 KB of exchange = 151 KB.
-constexpr int HX_ROW = 128, HX_PLANE = 16 * HX_ROW, HX_TENS = 3 * HX_PLANE, HX_SLOT = 2 * HX_TENS;
-constexpr int HX_XROW = 32, HX_XPLANE = 16 * HX_XROW;
-constexpr int HX_NW = 8;
-constexpr int HX_EX = LS_WEND;
-constexpr int HX_END = HX_EX + HX_NW * HX_SLOT;
-static_assert(HX_EX % 16 == 0 && HX_END <= 160 * 1024 && (HX_NW * 65 + 8) * 4 <= HX_EX, "cooperative split form: LDS map");
-
-__global__ __launch_bounds__(512, 2) void head_bwd_coops_kernel(const HeadBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    const HeadArgs& p = a.f;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: block ownership and slot addresses in scalar registers
-    const int li = lane & 15, lk = lane >> 4;
-    head_copy_image(ldsb, p.wimage, LS_WEND);
-    // the exchange area starts as zeros: a slot that was never written must not feed NaN bit patterns into 0 * x
-    for (int e = tid; e < HX_NW * HX_SLOT / 16; e += 512) reinterpret_cast<uint4*>(ldsb + HX_EX)[e] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    if (tid < 2) *reinterpret_cast<int*>(ldsb + LS_WEND - 12 + 4 * tid) = 0;       // the two domains' barrier counters (padding words of the image)
-    __syncthreads();
-    const unsigned char* const wpl = ldsb;
-    const float* const lf = reinterpret_cast<const float*>(ldsb + LS_F32);
-    float* part = a.partial + (int64_t)blockIdx.x * PE_TOTAL;
-    const float b6v = lf[256];
-    const LsLane LL = ls_lane(lane);
-    const int HW = p.H * p.W;
-
-    if (a.zero_in_kernel) {
-        // padding frame of the planar gradient map (the crop is written below, zeros included): one (b, c, row) job per half-wave
-        const int Hp = a.Hp, Wp = a.Wp;
-        const int l32 = tid & 31;
-        const int nhw = gridDim.x * 16, hw = blockIdx.x * 16 + (tid >> 5);
-        const int njobs = p.B * 16 * Hp;
-        const bool v4 = (Wp & 3) == 0;
-        const int right0 = p.px + p.W;
-        for (int j = hw; j < njobs; j += nhw) {
-            const int row = j % Hp;
-            float* rp = a.g_feat.ptr + (int64_t)(j / Hp) * a.g_feat.cstride + (int64_t)row * a.g_feat.rstride;
-            if (row < p.py || row >= p.py + p.H) {
-                if (v4) for (int x4 = 4 * l32; x4 < Wp; x4 += 128) *reinterpret_cast<f32x4*>(rp + x4) = f32x4{0.f, 0.f, 0.f, 0.f};
-                else for (int x1 = l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
-            } else {
-                for (int x1 = l32; x1 < p.px; x1 += 32) rp[x1] = 0.f;
-                for (int x1 = right0 + l32; x1 < Wp; x1 += 32) rp[x1] = 0.f;
-            }
-        }
-    }
-
-    // ---- this wave's weight-gradient blocks
-    // TWO independent 4-wave domains per workgroup (waves 0-3 / 4-7: one wave of each per SIMD): each exchanges and synchronises on its
-    // own (an LDS counter per domain, not s_barrier), so that one domain's chain phases run under the other's weight-gradient phases --
-    // in lock-step over all 8 waves the two waves of a SIMD were always in the same kind of phase (332 us against 293 for the
-    // producer / consumer form).  Wave w of a domain owns row block w of dW4 / dW2 (all four column blocks) and of dW0.
-    const int dom = wave >> 2, my_mb = wave & 3;
-    f32x4 dW4[4], dW2[4], dW0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 dB4 = f32x4{0.f, 0.f, 0.f, 0.f}, dB2 = dB4, dB0 = dB4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dW4[i] = dW2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    typedef __attribute__((address_space(3))) volatile int lds_ctr;
-    lds_ctr* const bar_p = (lds_ctr*)(ldsb + LS_WEND - 12 + 4 * dom);      // (padding words behind b6 in the image's float block)
-    int bar_n = 0;
-    auto dbar = [&]() {
-        bar_n += 4;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)bar_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__builtin_amdgcn_readfirstlane(*bar_p) < bar_n) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
-    const hbf16x8 ones8 = __builtin_bit_cast(hbf16x8, hu32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-    f32x4 dw6[4];
-    float db6 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dw6[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float gsc = a.g_scale_const ? *a.g_scale_const : 0.f;
-    float fscale[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        fscale[r] = 1.f;
-        if (a.fuse_feat_bn) {
-            const int c = 4 * lk + r;
-            float sh;
-            pc_bn_fold(a.fbn[c >> 3], c & 7, fscale[r], sh);
-        }
-    }
-    unsigned char* const ex = ldsb + HX_EX + dom * 4 * HX_SLOT;          // this domain's four slots
-    unsigned char* const my = ex + my_mb * HX_SLOT;
-    // transposing reads (head_bwd_bf16_coop4_kernel's): lane supplies pixel row r0 = 8 * (lk & 1) + (li >> 2) (second read: r0 + 4) and
-    // column quad li & 3 of a [4 pixels][16 units] block; k-group lk = pixels 8 * lk .. + 7 of a 32-pixel pair of slots
-    const int t_r0 = 8 * (lk & 1) + (li >> 2);
-    const int t_off = (lk >> 1) * HX_SLOT + t_r0 * HX_ROW + 8 * ((li & 3) ^ (t_r0 & 3));
-    const int t_sel = 32 * (t_r0 >> 2);
-    const int t_offx = (lk >> 1) * HX_SLOT + HX_TENS + t_r0 * HX_XROW + 8 * ((li & 3) ^ ((t_r0 ^ (t_r0 >> 2)) & 3));
-    const int t_offx2 = (lk >> 1) * HX_SLOT + HX_TENS + (t_r0 + 4) * HX_XROW + 8 * ((li & 3) ^ (((t_r0 + 4) ^ ((t_r0 + 4) >> 2)) & 3));
-    // exchange writes: the packed planes of a 64-wide tensor (pack t holds units 16 (2t) + 4 lk .. + 3 and 16 (2t + 1) + 4 lk .. + 3 of pixel li)
-    // (li / lk pass through an empty asm in every helper: their swizzled addresses are loop-invariant, and the compiler otherwise keeps
-    // all ~40 of them in registers for the whole kernel -- 95 spilled registers; recomputed per call they cost a few VALU instructions)
-    auto put = [&](int tensor, const hbf16x8 (&v)[3][2]) {
-        int oli = li, olk = lk;
-        asm volatile("" : "+v"(oli), "+v"(olk));
-        unsigned char* d = my + tensor + oli * HX_ROW + 8 * (olk ^ (oli & 3));
-        const int bs = 32 * (oli >> 2);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const hu32x4 q4 = __builtin_bit_cast(hu32x4, v[pl][t]);
-                *reinterpret_cast<uint2*>(d + pl * HX_PLANE + ((32 * (2 * t)) ^ bs)) = make_uint2(q4[0], q4[1]);
-                *reinterpret_cast<uint2*>(d + pl * HX_PLANE + ((32 * (2 * t + 1)) ^ bs)) = make_uint2(q4[2], q4[3]);
-            }
-    };
-    // ReLU' of this lane's 16 units from plane 0 of the H rows it has just written (rn(h) is non-zero exactly when h > 0, down to the
-    // subnormals): the fp32 activations need not stay in registers for the masks of the data gradients
-    auto my_h_mask = [&](hu32x4 (&m)[2]) {
-        int oli = li, olk = lk;
-        asm volatile("" : "+v"(oli), "+v"(olk));
-        const unsigned char* d = my + HX_TENS + oli * HX_ROW + 8 * (olk ^ (oli & 3));
-        const int bs = 32 * (oli >> 2);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint2 lo = *reinterpret_cast<const uint2*>(d + ((32 * (2 * t)) ^ bs)), hi = *reinterpret_cast<const uint2*>(d + ((32 * (2 * t + 1)) ^ bs));
-            m[t] = hb_nzmask(__builtin_bit_cast(hbf16x8, hu32x4{lo.x, lo.y, hi.x, hi.y}));
-        }
-    };
-    auto zero_g = [&]() {               // nothing to contribute in this phase: zero gradient rows (the H rows of an earlier group stay: finite x 0)
-        const uint2 z2 = make_uint2(0u, 0u);
-        int oli = li, olk = lk;
-        asm volatile("" : "+v"(oli), "+v"(olk));
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            unsigned char* d = my + pl * HX_PLANE + oli * HX_ROW + 8 * olk;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(d + 32 * k) = z2;
-        }
-    };
-    // operand block `blk` (16 units) of plane `pl` of tensor `tensor` for K-step ks: two transposed reads
-    auto frag = [&](int to, int ts, int ks, int tensor, int pl, int blk) {
-        const unsigned char* base = ex + 2 * ks * HX_SLOT + to + tensor + pl * HX_PLANE;
-        const int o = (32 * blk) ^ ts;
-        return hc_pair(hc_tr(base + o), hc_tr(base + 4 * HX_ROW + (o ^ 32)));
-    };
-    // one phase's weight gradients: dW[i] += G block my_mb . (H block nb0 + i)^T over the workgroup's 128 pixels, bias = row sums of G
-    auto wgrad64 = [&](f32x4 (&dW)[4], f32x4& dB) {
-        int to = t_off, ts = t_sel;
-        asm volatile("" : "+v"(to), "+v"(ts));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            hbf16x8 av[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) av[pl] = frag(to, ts, ks, 0, pl, my_mb);
-#pragma unroll
-            for (int pl = 2; pl >= 0; --pl) dB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pl], ones8, dB, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hbf16x8 bv[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bv[pl] = frag(to, ts, ks, HX_TENS, pl, i);
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)
-#pragma unroll
-                    for (int q = 2 - pl; q >= 0; --q) dW[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pl], bv[q], dW[i], 0, 0, 0);
-            }
-        }
-    };
-
-    // ---- per-group inputs, fetched one group ahead: raw values only, a fixed number of loads (optional inputs read from the building map)
-    const bool has_msk = p.mask != nullptr, has_adm = p.admin != nullptr, has_gpc = a.g_popcount != nullptr;
-    const bool has_gpd = a.g_popdense != nullptr, has_gsm = a.g_scale_map != nullptr;
-    const uint8_t* msk_p = has_msk ? p.mask : reinterpret_cast<const uint8_t*>(p.building);
-    const float* adm_p = has_adm ? p.admin : p.building;
-    const float* gpd_p = has_gpd ? a.g_popdense : p.building;
-    const float* gsm_p = has_gsm ? a.g_scale_map : p.building;
-    const float* gpc_p = has_gpc ? a.g_popcount : p.building;
-    const int64_t* cen_p = has_adm ? p.census : reinterpret_cast<const int64_t*>(p.building);
-    const unsigned fcs = (unsigned)p.feat.cstride, gcs = (unsigned)a.g_feat.cstride;
-    float n_xv[4], n_bld = 0.f, n_adm = 0.f, n_gpd = 0.f, n_gsm = 0.f, n_gpc = 0.f;
-    long long n_cen = 0;
-    unsigned n_msk = 1;
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    auto fetch = [&](int gq) {
-        const int b = (int)pc_div((uint32_t)gq, p.div_groups), g = gq - b * p.groups;
-        const int q = g * 16 + li;
-        const unsigned qq = q < HW ? (unsigned)q : 0u;
-        const unsigned y = pc_div(qq, p.div_w), x = qq - y * (unsigned)p.W;
-        const float* fb = p.feat.ptr + b * p.feat.bstride;
-        const unsigned fo = (unsigned)(p.py + (int)y) * (unsigned)p.feat.rstride + (unsigned)p.px + x;
-        const int64_t pb = (int64_t)b * HW + qq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) n_xv[j] = fb[fo + (unsigned)(4 * lk + j) * fcs];
-        n_msk = msk_p[pb];
-        n_bld = p.building[pb];
-        n_adm = adm_p[pb];
-        n_gpd = gpd_p[pb];
-        n_gsm = gsm_p[pb];
-        n_cen = cen_p[(has_adm ? b : 0) + vzero];
-        n_gpc = gpc_p[(has_gpc ? b : 0) + vzero];
-    };
-    const int gstep = gridDim.x * HX_NW;
-    const int niter = (a.total_groups + gstep - 1) / gstep;
-    int gg = blockIdx.x * HX_NW + wave;
-    if (gg < a.total_groups) fetch(gg);
-    for (int it = 0; it < niter; ++it, gg += gstep) {
-        const bool live = gg < a.total_groups;
-        bool active = false;
-        f32x4 h1[4], h2[4], g3[4], g2[4], g1[4];
-        hu32x4 g2m[2] = {hu32x4{0u, 0u, 0u, 0u}, hu32x4{0u, 0u, 0u, 0u}};
-        hbf16x8 ob[3][2], fr[4];
-        float xv[4];
-        float* gp = nullptr;
-        bool valid = false;
-        if (live) {
-            const int b = (int)pc_div((uint32_t)gg, p.div_groups), g = gg - b * p.groups;
-            const int q = g * 16 + li;
-            valid = q < HW;
-            const unsigned qq = valid ? (unsigned)q : 0u;
-            const unsigned y = pc_div(qq, p.div_w), x = qq - y * (unsigned)p.W;
-            gp = a.g_feat.ptr + b * a.g_feat.bstride + (unsigned)(p.py + (int)y) * (unsigned)a.g_feat.rstride + (unsigned)p.px + x;
-            const bool sel = valid && (!has_msk || n_msk != 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = valid ? n_xv[j] : 0.f;
-            float gup = 0.f;
-            {
-                const bool region = !has_adm || n_adm == (float)n_cen;
-                float u = gsc;
-                u += (has_gpc && region) ? n_gpc * n_bld : 0.f;
-                u += has_gpd ? n_gpd * n_bld : 0.f;
-                u += has_gsm ? n_gsm : 0.f;
-                gup = sel ? u : 0.f;
-            }
-            active = __any(sel);
-            if (active) {
-                // ---- forward chain on split operands (the split producer's)
-                f32x4 h3[4];
-                {
-                    unsigned x1[2], x2[2], x3[2];
-                    hs_split_pair(xv[0], xv[1], x1[0], x2[0], x3[0]);
-                    hs_split_pair(xv[2], xv[3], x1[1], x2[1], x3[1]);
-                    const hs16x4 xb[3] = {__builtin_bit_cast(hs16x4, make_uint2(x1[0], x1[1])), __builtin_bit_cast(hs16x4, make_uint2(x2[0], x2[1])),
-                                          __builtin_bit_cast(hs16x4, make_uint2(x3[0], x3[1]))};
-                    hs16x4 f1[3][4];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                        for (int mb = 0; mb < 4; ++mb)
-                            f1[pl][mb] = __builtin_bit_cast(hs16x4, *reinterpret_cast<const uint2*>(wpl + pl * LS_PLANE + LS_W0 + mb * 512 + LL.a0));
-                    ls_load4<false>(wpl, LS_W2, LL, 0, 2, fr);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) h1[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) h2[mb] = *reinterpret_cast<const f32x4*>(&lf[64 + 16 * mb + 4 * lk]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int pl = 2; pl >= 0; --pl)
-#pragma unroll
-                        for (int qq2 = 2 - pl; qq2 >= 0; --qq2)
-#pragma unroll
-                            for (int mb = 0; mb < 4; ++mb) h1[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1[pl][mb], xb[qq2], h1[mb], 0, 0, 0);
-                }
-                hb_relu4(h1);
-                hs_split_pack(h1, ob);
-                ls_layer64_pf<false>(wpl, LS_W2, LL, ob, h2, fr, [&](hbf16x8 (&f)[4]) {
-                    ls_load4<false>(wpl, LS_W4, LL, 0, 2, f);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) h3[mb] = *reinterpret_cast<const f32x4*>(&lf[128 + 16 * mb + 4 * lk]);
-                });
-                hb_relu4(h2);
-                hs_split_pack(h2, ob);
-                f32x4 w6f[4];                     // (the last layer's row: read per group, 16 registers less across the rest of the iteration)
-                ls_layer64_pf<false>(wpl, LS_W4, LL, ob, h3, fr, [&](hbf16x8 (&f)[4]) {
-                    ls_load4<true>(wpl, LS_W4, LL, 0, 2, f);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) w6f[mb] = *reinterpret_cast<const f32x4*>(&lf[192 + 16 * mb + 4 * lk]);
-                });
-                hb_relu4(h3);
-                float s = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(w6f[mb][r], h3[mb][r], s);
-                s = pc_xor16_sum(s);
-                s = pc_xor32_sum(s);
-                const float outv = s + b6v;
-                const float gout = (sel && outv > 0.f) ? gup : 0.f;
-                active = __any(gout != 0.f);
-                if (active) {
-                    if (lk == 0) db6 += gout;
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dw6[mb][r] = fmaf(gout, h3[mb][r], dw6[mb][r]);
-                            g3[mb][r] = h3[mb][r] > 0.f ? w6f[mb][r] * gout : 0.f;
-                        }
-                }
-            }
-            if (!active && a.zero_in_kernel && valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(unsigned)(4 * lk + r) * gcs] = 0.f;
-            }
-        }
-        // ---- phase A: (G3, H2) -> dW4, dB4; the layer-3 data gradient between the writes and the barrier
-        if (active) {
-            put(HX_TENS, ob);                         // H2 planes: still in ob (the third layer's operand)
-            hs_split_pack(g3, ob);
-            put(0, ob);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) g2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ls_layer64_pf<true>(wpl, LS_W4, LL, ob, g2, fr, [&](hbf16x8 (&f)[4]) {});
-            // (the ReLU mask is applied to the packed planes of G2 in phase B, from plane 0 of the H2 rows still in this wave's slot)
-        } else {
-            zero_g();
-        }
-        dbar();
-        wgrad64(dW4, dB4);
-        dbar();
-        // ---- phase B: (G2, H1) -> dW2, dB2; the layer-2 data gradient in between
-        if (active) {
-            my_h_mask(g2m);                       // ReLU' of H2 (read before the H1 planes replace them)
-            {
-                // H1 again from the four feature values (24 instructions of K = 16): 16 registers less across the first phase
-                unsigned x1[2], x2[2], x3[2];
-                hs_split_pair(xv[0], xv[1], x1[0], x2[0], x3[0]);
-                hs_split_pair(xv[2], xv[3], x1[1], x2[1], x3[1]);
-                const hs16x4 xb[3] = {__builtin_bit_cast(hs16x4, make_uint2(x1[0], x1[1])), __builtin_bit_cast(hs16x4, make_uint2(x2[0], x2[1])),
-                                      __builtin_bit_cast(hs16x4, make_uint2(x3[0], x3[1]))};
-                f32x4 hh[4];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) hh[mb] = *reinterpret_cast<const f32x4*>(&lf[16 * mb + 4 * lk]);
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl) {
-                    hs16x4 f1[4];
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-                        f1[mb] = __builtin_bit_cast(hs16x4, *reinterpret_cast<const uint2*>(wpl + pl * LS_PLANE + LS_W0 + mb * 512 + LL.a0));
-#pragma unroll
-                    for (int qq2 = 2 - pl; qq2 >= 0; --qq2)
-#pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) hh[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1[mb], xb[qq2], hh[mb], 0, 0, 0);
-                }
-                hb_relu4(hh);
-                hs_split_pack(hh, ob);
-            }
-            put(HX_TENS, ob);
-            ls_load4<true>(wpl, LS_W2, LL, 0, 2, fr);
-            hs_split_pack(g2, ob);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) { ob[pl][0] = hb_and(ob[pl][0], g2m[0]); ob[pl][1] = hb_and(ob[pl][1], g2m[1]); }
-            put(0, ob);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) g1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ls_layer64_pf<true>(wpl, LS_W2, LL, ob, g1, fr, [&](hbf16x8 (&f)[4]) {});
-        } else {
-            zero_g();
-        }
-        dbar();
-        wgrad64(dW2, dB2);
-        dbar();
-        // ---- phase C: (G1, X) -> dW0, dB0; the feature gradient in between.  The X planes (16 units: 32-byte rows) occupy the head of the
-        // H region.  The NEXT group's inputs are fetched here (raw loads; a phase, two barriers and the loop top ahead of their use): at
-        // the top of the iteration they would occupy 12 registers through all of it.
-        if (gg + gstep < a.total_groups) fetch(gg + gstep);
-        if (active) {
-            my_h_mask(g2m);                       // ReLU' of H1, from its plane 0 (read BEFORE the X planes replace the head of the H region)
-            {
-                unsigned x1[2], x2[2], x3[2];
-                hs_split_pair(xv[0], xv[1], x1[0], x2[0], x3[0]);
-                hs_split_pair(xv[2], xv[3], x1[1], x2[1], x3[1]);
-                const uint2 xq[3] = {make_uint2(x1[0], x1[1]), make_uint2(x2[0], x2[1]), make_uint2(x3[0], x3[1])};
-                int oli = li, olk = lk;
-                asm volatile("" : "+v"(oli), "+v"(olk));
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    *reinterpret_cast<uint2*>(my + HX_TENS + pl * HX_XPLANE + oli * HX_XROW + 8 * (olk ^ ((oli ^ (oli >> 2)) & 3))) = xq[pl];
-            }
-            hbf16x8 fz[3][2];                         // the 16-channel data gradient's fragments [plane][K-step]
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const unsigned char* q0 = wpl + pl * LS_PLANE + LS_W0 + LL.t0;
-                fz[pl][0] = hc_pair(hc_tr(q0), hc_tr(q0 + 16 * 32));
-                fz[pl][1] = hc_pair(hc_tr(q0 + 32 * 32), hc_tr(q0 + 48 * 32));
-            }
-            hs_split_pack(g1, ob);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) { ob[pl][0] = hb_and(ob[pl][0], g2m[0]); ob[pl][1] = hb_and(ob[pl][1], g2m[1]); }
-            put(0, ob);
-            f32x4 gx = f32x4{0.f, 0.f, 0.f, 0.f}, gx2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int pl = 2; pl >= 0; --pl) {
-                const hbf16x8 f0 = fz[pl][0], f1 = fz[pl][1];
-#pragma unroll
-                for (int qq2 = 2 - pl; qq2 >= 0; --qq2) {
-                    gx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, ob[qq2][0], gx, 0, 0, 0);
-                    gx2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, ob[qq2][1], gx2, 0, 0, 0);
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float o = gx[r] + gx2[r];
-                    if (a.fuse_feat_bn) o = xv[r] > 0.f ? o * fscale[r] : 0.f;
-                    gp[(unsigned)(4 * lk + r) * gcs] = o;
-                }
-            }
-        } else {
-            zero_g();
-        }
-        dbar();
-        {
-            int to = t_off, ts = t_sel, tx = t_offx, tx2 = t_offx2;
-            asm volatile("" : "+v"(to), "+v"(ts), "+v"(tx), "+v"(tx2));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const unsigned char* xb = ex + 2 * ks * HX_SLOT;
-                hbf16x8 av[3], bv[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    av[pl] = frag(to, ts, ks, 0, pl, my_mb);
-                    bv[pl] = hc_pair(hc_tr(xb + pl * HX_XPLANE + tx), hc_tr(xb + pl * HX_XPLANE + tx2));
-                }
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl) {
-                    dB0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pl], ones8, dB0, 0, 0, 0);
-#pragma unroll
-                    for (int q = 2 - pl; q >= 0; --q) dW0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pl], bv[q], dW0, 0, 0, 0);
-                }
-            }
-        }
-        dbar();
-    }
-    __syncthreads();
-
-    // ---- workgroup partial (layout of head_bwd_pc_kernel): every 16 x 16 block has ONE owner; dw6 / db6 are summed over the waves
-    // the two domains hold a full set of blocks each: domain 1 parks its accumulators in the (now idle) exchange area, domain 0 adds and writes
-    {
-        f32x4* const park = reinterpret_cast<f32x4*>(ldsb + HX_EX) + (my_mb * 12) * 64 + lane;      // [wave of the domain][12 blocks][64 lanes]
-        if (dom == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { park[i * 64] = dW4[i]; park[(4 + i) * 64] = dW2[i]; }
-            park[8 * 64] = dW0; park[9 * 64] = dB4; park[10 * 64] = dB2; park[11 * 64] = dB0;
-        }
-        __syncthreads();
-        if (dom == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 o4 = park[i * 64], o2 = park[(4 + i) * 64];
-                f32x4 s4 = dW4[i], s2 = dW2[i];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s4[r] += o4[r]; s2[r] += o2[r]; }
-                *reinterpret_cast<f32x4*>(&part[PE_W4 + ((my_mb * 4 + i) * 64 + lane) * 4]) = s4;
-                *reinterpret_cast<f32x4*>(&part[PE_W2 + ((my_mb * 4 + i) * 64 + lane) * 4]) = s2;
-            }
-            {
-                const f32x4 o0 = park[8 * 64];
-                f32x4 s0 = dW0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s0[r] += o0[r];
-                *reinterpret_cast<f32x4*>(&part[PE_W0 + (my_mb * 64 + lane) * 4]) = s0;
-            }
-            // bias gradients: every column of the ones-block holds the row sums; column 0 = lanes li == 0, row m = 4 * lk + register
-            if (li == 0) {
-                const f32x4 b4 = park[9 * 64], b2 = park[10 * 64], b0 = park[11 * 64];
-                f32x4 t4 = dB4, t2 = dB2, t0 = dB0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { t4[r] += b4[r]; t2[r] += b2[r]; t0[r] += b0[r]; }
-                *reinterpret_cast<f32x4*>(&part[PE_B4 + 16 * my_mb + 4 * lk]) = t4;
-                *reinterpret_cast<f32x4*>(&part[PE_B2 + 16 * my_mb + 4 * lk]) = t2;
-                *reinterpret_cast<f32x4*>(&part[PE_B0 + 16 * my_mb + 4 * lk]) = t0;
-            }
-        }
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dw6[mb][r] = lane_sum16(dw6[mb][r]);
-    db6 = lane_sum16(db6);
-    float* red = reinterpret_cast<float*>(ldsb);
-    __syncthreads();
-    if (li == 0) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 65 + 16 * mb + 4 * lk + r] = dw6[mb][r];
-        if (lk == 0) red[wave * 65 + 64] = db6;
-    }
-    __syncthreads();
-    if (tid < 65) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < HX_NW; ++w) t += red[w * 65 + tid];
-        part[(tid < 64 ? PE_W6 + tid : PE_B6)] = t;
-    }
-}
-
 // assembles the LDS weight image of the head kernel that follows, once, in global memory (kind 0: fp32 forward, 1: fp32
 // backward, 2: bf16 forward, 3: bf16 backward)
 // blocks 0..7 assemble image `kind` into img; blocks 8..15 (PC_HEAD_FWD_PACK_BOTH: a 16-block launch) the backward's image of the same
@@ -3609,14 +3105,14 @@ static int head_split_on() {
     if (g_head_split < 0) {
         const char* ev = getenv("POPCORN_HEAD_SPLIT");
         const char* sr = getenv("POPCORN_HEAD_BWD_SINGLE_ROLE");          // (the ablation's single-role backward is an fp32-MFMA kernel:
-        g_head_split = ((ev && ev[0] == '0') || (sr && sr[0] == '1')) ? 0 : ((ev && ev[0] == '2') ? 2 : 1);      // both head kernels then keep the fp32 images)
+        g_head_split = ((ev && ev[0] == '0') || (sr && sr[0] == '1')) ? 0 : 1;      // both head kernels then keep the fp32 images)
     }
     return g_head_split;
 }
 extern "C" int pc_get_head_split(void) { return head_split_on(); }
 extern "C" int pc_set_head_split(int on) {
     const int prev = head_split_on();
-    g_head_split = on < 0 ? 0 : (on > 2 ? 2 : on);
+    g_head_split = on ? 1 : 0;
     return prev;
 }
 static int head_fwd_chunks(int B, int H, int W, bool split, int* groups_per_wave, int* nchunk) {
@@ -3817,13 +3313,11 @@ extern "C" int pc_compact_masked(const float* src, const uint8_t* mask, float* o
 
 // workgroup partials of the backward call: behind the forward's partials in ws; one per workgroup of the kernel the mode launches
 // (fp32: one 8-wave workgroup per CU, 4 groups in flight each; bf16: two 4-wave workgroups per CU, 2 x 79 KB of LDS)
-static int head_split_on();
 static void head_bwd_partial_geometry(void* ws, int B, int H, int W, bool bf, float** partial, int* nwg) {
     const int groups = (H * W + 15) / 16, total_groups = B * groups;
     const int64_t nchunk = (groups + 31) / 32 + 1;
     *partial = reinterpret_cast<float*>(ws) + B * nchunk * 2;
-    const bool coop = !bf && head_split_on() == 2;               // the cooperative split form: 8 groups per workgroup and iteration
-    const int per = bf ? H4_WAVES : (coop ? HX_NW : 4), cap = bf ? 512 : 256;
+    const int per = bf ? H4_WAVES : 4, cap = bf ? 512 : 256;
     int n = (total_groups + per - 1) / per;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -3943,15 +3437,6 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
             fprintf(stderr, "\n");
         }
 #endif
-    }
-    else if (use_pc && split && head_split_on() == 2) {
-        static pc_once_per_device once5;
-        if (once5.need()) {
-            hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_coops_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HX_END);
-            if (e5 != hipSuccess) return (int)e5;
-            once5.mark();
-        }
-        hipLaunchKernelGGL(head_bwd_coops_kernel, dim3(nwg), dim3(512), HX_END, st, a);
     }
     else if (use_pc && split) {
         if (a.dbg == 1) hipLaunchKernelGGL((head_bwd_pc_kernel<1, true>), dim3(nwg), dim3(512), LPS_END * sizeof(float), st, a);

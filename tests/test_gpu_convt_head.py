@@ -148,7 +148,7 @@ def head_form(request):
     L.lib().pc_set_head_split(prev)
 
 
-@pytest.mark.parametrize("head_form", [1, 0, 2], indirect=True)
+@pytest.mark.parametrize("head_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("shape", [(2, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
 def test_head_fwd_vs_oracle(sparse, shape, head_form):
@@ -231,7 +231,7 @@ def test_head_split_products_have_the_error_of_fp32_arithmetic():
         assert err[1][k] < 4 * err[0][k] + 1e-7, (k, err)                                # the same class, not merely inside the bar
 
 
-@pytest.mark.parametrize("head_form", [1, 0, 2], indirect=True)
+@pytest.mark.parametrize("head_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("shape", [(3, 100, 100, 128, 128, 14, 14), (1, 37, 29, 64, 64, 13, 17)])
 def test_head_bwd_vs_oracle_autograd(sparse, shape, head_form):

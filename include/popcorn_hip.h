@@ -535,6 +535,10 @@ int pc_select_normalize(const float* raw, int Craw, const int* band6, const floa
  * The plan (parameter pointers, BN descriptors, optimiser constants) is built once per trainer (pc_step_create); a step passes only
  * its batch.  PC_PREC_FP32, dual-stream (S1 + S2) models whose building score comes from the frozen extractor; anything else
  * returns PC_ENOTSUP and the caller keeps the per-launch path (same kernels, launched through the entry points above).
+ * Small regions fork the frozen extractor's chain and the weight-gradient launches onto an internal side stream; WHICH stream is
+ * measured at the first call on a caller's stream (HIP multiplexes streams onto a few hardware queues, and a side stream on the
+ * caller's queue serialises with it): that first call launches a few microsecond-long probe kernels and synchronises once, so
+ * pc_train_step is an EAGER entry point -- not to be called on a stream that is being captured into a graph.
  * Conv layer order of the arrays below: inc.conv.0, inc.conv.3, down1.conv.0, down1.conv.3, down2.conv.0, down2.conv.3,
  * up2.conv.0, up2.conv.3, up1.conv.0, up1.conv.3 (networks.py:121-151,253-320); transposed convs: up2.up, up1.up. */
 #define PC_STEP_CONVS 10

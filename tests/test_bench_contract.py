@@ -32,21 +32,32 @@ def _check_line(d, extras):
 
 
 def test_committed_final_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_final.json")))
     _check_line(d, extras=True)
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32"
-    assert d["value"] >= 36300.0                          # >= 36.3 k patches/s (step <= 1.76 ms)
-    # round 4: the metric's second half and the other configurations ride on the same line
+    assert d["value"] >= 40000.0 and d["ms_per_step"] <= 1.60          # step <= 1.60 ms (>= 40 k patches/s)
+    assert d["config"]["head_products"] == "split3_bf16_fp32acc"          # how the fp32 head multiplies is named on the line
+    # the metric's second half and the other configurations ride on the same line
     fp = d["fwd_parity"]
     assert fp["ok"] is True and fp["max_rel"] <= 1e-4 and {"popdensemap", "popcount", "scale"} <= set(fp)
     assert d["config5"]["windows_per_s"] > 0 and d["config5"]["finite"] is True
     c3 = d["config3_regions"]
     assert len(c3["batches"]) >= 6 and max(b["Mpx"] for b in c3["batches"]) > 9.0 and {"all", "head only"} <= {b["regime"] for b in c3["batches"]}
+    # aggregate >= 0.38 of the fp32 matrix peak, smallest region step <= 0.6 ms, medians of 10-step blocks
+    assert c3["frac_of_fp32_mfma_peak"] >= 0.38 and min(b["ms_per_step"] for b in c3["batches"]) <= 0.6 and c3["steps_per_block"] >= 10
     r = d["roofline"]
-    assert r["rocprof_us"] and r["rocprof_file"].startswith("r") and abs(r["rocprof_frac"] - r["alg_flop_per_launch"] / (r["rocprof_us"] * 1e-6) / 157.3e12) < 2e-3
-    assert d["h2d"]["h2d_gbps_needed_8_ranks"] > 0 and d["h2d"]["host_pinned_gbps_measured"] > 0 and len(d["h2d"]["legs"]) == 3
-    b = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_final_bf16.json")))
-    assert b["dtype"].startswith("bf16") and b["value"] > 1.9 * d["value"]
+    assert r["rocprof_us"] and r["rocprof_file"].startswith("r5") and r["rocprof_stamp_matches_tree"] is True
+    assert abs(r["rocprof_frac"] - r["alg_flop_per_launch"] / (r["rocprof_us"] * 1e-6) / 157.3e12) < 2e-3
+    assert r["rocprof_us"] <= 290.0                                       # head backward <= 290 us under rocprofv3
+    assert r["frac"] <= 1.0 and r["executed_mfma_view"]["frac"] <= 1.0
+    # the host-feed legs in byte order (narrower feed = not slower), each within 7 % of the resident step
+    legs = d["h2d"]["legs"]
+    res = d["h2d"]["resident_same_block"]["ms_per_step"]
+    assert len(legs) == 3 and all(l["ms_per_step"] <= 1.07 * res for l in legs)
+    assert legs[1]["ms_per_step"] <= legs[0]["ms_per_step"] * 1.01 <= legs[2]["ms_per_step"] * 1.02
+    assert d["h2d"]["h2d_gbps_needed_8_ranks"] > 0 and d["h2d"]["host_pinned_gbps_measured"] > 0
+    b = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_final_bf16.json")))
+    assert b["dtype"].startswith("bf16") and b["value"] > 1.8 * d["value"]
 
 
 @pytest.mark.gpu

@@ -298,10 +298,11 @@ typedef struct pc_level2_fwd_desc {
 } pc_level2_fwd_desc;
 int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2);
 int pc_level2_fwd_group(int n, const pc_level2_fwd_desc* d, int B, void* stream);
-/* Backward of the two convolutions of that level in ONE launch (PC_PREC_FP32), given g2 = dL/d(conv2 output) (already times
+/* Backward of the two convolutions of that level in ONE launch (both arithmetic modes: level2.hip; channels-last bf16 tensors
+ * in PC_PREC_BF16: level2_cl.hip, one partial per tile, *nwg_out = B, replacing two pc_conv3x3_bwd_group launches), given g2 = dL/d(conv2 output) (already times
  * relu'(c2) * bn2 scale: pc_convt2x2_bwd_group writes it): weight / bias gradient partials of both layers (ws2: dW2, db2 from
- * g2 x c1; ws1: dW1, db1 from g1 x x; 8 partials per tile in the layout pc_wgrad_reduce_batch finishes as kind 0, Cin = Cout = 16:
- * *nwg_out = 8 B, each ws pc_level2_bwd_ws_bytes(B) bytes), the data gradient g1 = relu'(c1) * bn1 scale * conv^T(g2, w2) kept in
+ * g2 x c1; ws1: dW1, db1 from g1 x x; fp32: 2 partials per tile in the layout pc_wgrad_reduce_batch finishes as kind 0, Cin = Cout = 16:
+ * *nwg_out = 2 B, each ws pc_level2_bwd_ws_bytes(B) bytes), the data gradient g1 = relu'(c1) * bn1 scale * conv^T(g2, w2) kept in
  * LDS, and the MaxPool2d(2) backward of conv^T(g1, w1) accumulated into `out` (B x 16 x 64 x 64: the first arg-max of every 2 x 2
  * window of `act`, times relu'(act) * act_bn scale).  Replaces two pc_conv3x3_wgrad_partial_group and two
  * pc_conv3x3_dgrad_group launches; same geometry rule as the forward (pc_level2_bwd_ok). */

@@ -508,6 +508,8 @@ bool plane_ok(const void* p, int64_t bs, int64_t cs, int rs, int xs, int dtype) 
 // level2_cl.hip: the channels-last bf16 form of the forward kernel (PC_PREC_BF16)
 bool pc_level2_fwd_cl_ok(const pc_src* x, const pc_dst* u2);
 int pc_level2_fwd_cl_launch(int n, const pc_level2_fwd_desc* d, int B, hipStream_t stream);
+bool pc_level2_bwd_cl_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const pc_src* act, const pc_dst* out);
+int pc_level2_bwd_cl_launch(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, long long* ts, hipStream_t stream);
 
 extern "C" int pc_level2_fwd_ok(const pc_src* x, const pc_dst* u2) {
     if (g_pc_precision == PC_PREC_BF16) return pc_level2_fwd_cl_ok(x, u2) ? 1 : 0;
@@ -558,6 +560,7 @@ static bool src_ok(const pc_src* s, int Cc, int Hh, int Ww) {
 }
 
 extern "C" int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src* x, const pc_src* act, const pc_dst* out) {
+    if (g_pc_precision == PC_PREC_BF16) return pc_level2_bwd_cl_ok(g2, c1, x, act, out) ? 1 : 0;
     if (g_pc_precision != PC_PREC_FP32 || !out) return 0;
     return src_ok(g2, 16, 32, 32) && src_ok(c1, 16, 32, 32) && src_ok(x, 16, 32, 32) && src_ok(act, 16, 64, 64) &&
            plane_ok(out->ptr, out->bstride, out->cstride, out->rstride, out->xstride, out->dtype);
@@ -565,6 +568,7 @@ extern "C" int pc_level2_bwd_ok(const pc_src* g2, const pc_src* c1, const pc_src
 
 extern "C" int pc_level2_bwd_group(int n, const pc_level2_bwd_desc* d, int B, int* nwg_out, void* stream) {
     if (n < 1 || n > PC_MAX_GROUP || B < 1 || !d || !nwg_out) return PC_EINVAL;
+    if (g_pc_precision == PC_PREC_BF16) return pc_level2_bwd_cl_launch(n, d, B, nwg_out, g_l2_ts, (hipStream_t)stream);
     B2Args a;
     a.ts = g_l2_ts;
     for (int i = 0; i < n; ++i) {

@@ -13,6 +13,7 @@
 //     transposed conv fills the top-left 2h x 2w of it): the two-source conv then sees two sources of identical layout;
 //   * a pooled source is handed over cropped to even extents (MaxPool2d(2) floors).
 #include "common.h"
+#include <chrono>
 
 #include <string.h>
 #include <new>
@@ -1023,6 +1024,10 @@ void pick_side_stream(Step& X, hipStream_t main_st) {
 
 }  // namespace
 
+// debug (tools/host_time_eager.py): host nanoseconds of the last call's sizing pass and of its launching pass
+static double g_step_host_ns[2] = {0, 0};
+extern "C" void pc_debug_step_host_ns(double* out) { out[0] = g_step_host_ns[0]; out[1] = g_step_host_ns[1]; }
+
 extern "C" void* pc_step_create(const pc_step_plan* plan) {
     if (!plan) return nullptr;
     Step* X = new (std::nothrow) Step();
@@ -1094,12 +1099,16 @@ extern "C" int pc_train_step(void* handle, pc_step_io* io, int phases, void* str
     if (X->side && (!X->side_picked || X->side_for != X->st)) pick_side_stream(*X, X->st);
     // dry pass: the same code path with launches off -- sizes the arena (bump allocation is deterministic)
     // (a FWD-only call of a data-parallel step is sized for its BWD / UPD calls too: they continue in the same arena)
+    const auto t_a = std::chrono::steady_clock::now();
     Step probe = *X;
     int rc = run(probe, *io, (phases & PC_STEP_FWD) ? (PC_STEP_FWD | PC_STEP_BWD | PC_STEP_UPD) : phases, true);
     if (rc) return rc;
     io->arena_needed = probe.ar.peak + 256;
     if (!io->arena || io->arena_bytes < io->arena_needed || (reinterpret_cast<uintptr_t>(io->arena) & 255)) return PC_ENOMEM;
+    const auto t_b = std::chrono::steady_clock::now();
     rc = run(*X, *io, phases, false);
     io->launches = X->launches;
+    g_step_host_ns[0] = std::chrono::duration<double, std::nano>(t_b - t_a).count();
+    g_step_host_ns[1] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_b).count();
     return rc;
 }

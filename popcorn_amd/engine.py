@@ -68,6 +68,7 @@ def trainable_names(prefix="unetmodel.", streams=("sar_stream", "optical_stream"
 FUSED_CONV_BWD = os.environ.get("POPCORN_FUSED_CONV_BWD", "1") != "0"
 # fp32: the whole 32 x 32 level (down2's DoubleConv + up2's transposed conv) in one launch (POPCORN_FUSED_LEVEL2=0: three launches)
 FUSED_LEVEL2 = os.environ.get("POPCORN_FUSED_LEVEL2", "1") != "0"
+FUSED_LEVEL2_BWD = os.environ.get("POPCORN_FUSED_LEVEL2_BWD", "1") != "0"      # (A/B of the backward launch alone)
 # fp32: the first conv of an Up block reads the LOW-resolution map through composed (transposed conv o conv) weights instead of an
 # up-sampled tensor (POPCORN_COMPOSED_UP=0: transposed-conv launch + two-source conv)
 COMPOSED_UP = os.environ.get("POPCORN_COMPOSED_UP", "1") != "0"
@@ -422,9 +423,10 @@ class UNetEngine:
             finish()
             return
         # encoder
-        if FUSED_LEVEL2 and not bf and all(A[s].get("pb2") is not None and
+        if FUSED_LEVEL2 and FUSED_LEVEL2_BWD and all(A[s].get("pb2") is not None and
                                             ops.level2_bwd_ok(G_c2[s], A[s]["c1"], A[s]["pb2"], A[s]["b2"], G_b2[s]) for s in S):
             # the 32 x 32 level: both weight gradients, the data gradient chain d2b -> d2a and the pooling scatter in one launch
+            # (both arithmetic modes: level2.hip / level2_cl.hip)
             wb.level2_bwd_group([{"g2": G_c2[s], "c1": A[s]["c1"], "x": A[s]["pb2"], "w1": ly(s, "d2a").w, "w2": ly(s, "d2b").w,
                                   "bn1": ly(s, "d2a").bn_nobias, "act": A[s]["b2"], "act_bn": ly(s, "d1b").bn_nobias, "out": G_b2[s],
                                   "dw1": grads[prefix + ly(s, "d2a").wname], "db1": grads[prefix + ly(s, "d2a").bname],

@@ -331,8 +331,10 @@ def conv3x3_up_bwd_group(problems, accumulate=False):
 
 def level2_bwd_ok(g2, c1, x, act, out):
     """Does the one-launch backward of the 32 x 32 level (pc_level2_bwd_group) take these tensors?"""
+    adt = L.act_dtype()                    # fp32 mode: planar fp32 (level2.hip); bf16 mode: channels-last bf16 (level2_cl.hip)
+    unit = 3 if adt == torch.float32 else 1
     for t, shp in ((g2, (16, 32, 32)), (c1, (16, 32, 32)), (x, (16, 32, 32)), (act, (16, 64, 64)), (out, (16, 64, 64))):
-        if t is None or t.dim() != 4 or tuple(t.shape[1:]) != shp or t.dtype != torch.float32 or t.stride(3) != 1:
+        if t is None or t.dim() != 4 or tuple(t.shape[1:]) != shp or t.dtype != adt or t.stride(unit) != 1:
             return False
     sg, sc, sx, sa, do = L.src(g2), L.src(c1), L.src(x), L.src(act), L.dst(out)
     return bool(L.lib().pc_level2_bwd_ok(C.byref(sg), C.byref(sc), C.byref(sx), C.byref(sa), C.byref(do)))

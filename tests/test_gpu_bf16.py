@@ -923,6 +923,53 @@ def test_bf16_whole_level_forward_kernel_is_bit_identical_to_the_three_launches(
         assert ops.level2_fwd_ok(L.empty_act(2, 16, 32, 32, "cuda"), L.empty_act(2, 16, 64, 64, "cuda"))
 
 
+@pytest.mark.parametrize("B,nprob", [(3, 2), (1, 1), (5, 4)])
+def test_bf16_whole_level_backward_kernel_against_the_two_launches(B, nprob):
+    """level2_bwd_cl_kernel (both conv layers of the 32 x 32 level: data-gradient chain, pooling scatter, both weight / bias gradients
+    in one launch, the intermediate gradient never leaves LDS) against conv3x3_bwd_cl_kernel<16, 16> + <16, 16, pool> on the same
+    operands: the accumulated full-resolution gradient is BIT-identical (same MFMA order per accumulator, same rounding point of the
+    intermediate); the weight gradients are sums over other pixel groups and agree to fp32 summation noise."""
+    from popcorn_amd import ops, _lib as L
+    import torch.nn.functional as F
+    probs_f, probs_l, keep = [], [], []
+    with L.precision("bf16"):
+        for i in range(nprob):
+            act = _bf(F.relu(_mk(B, 16, 64, 64, seed=300 + 10 * i)))
+            x = F.max_pool2d(act, 2)
+            c1 = _bf(F.relu(_mk(B, 16, 32, 32, seed=301 + 10 * i)))
+            g2 = _bf(_mk(B, 16, 32, 32, seed=302 + 10 * i))
+            w1 = _mk(16, 16, 3, 3, seed=303 + 10 * i, scale=0.2).cuda()
+            w2 = _mk(16, 16, 3, 3, seed=304 + 10 * i, scale=0.2).cuda()
+            bn1 = [t.cuda() for t in _bn(16, 305 + 10 * i)]
+            bna = [t.cuda() for t in _bn(16, 306 + 10 * i)]
+            prev = _bf(_mk(B, 16, 64, 64, seed=307 + 10 * i))
+            keep.append((bn1, bna))
+            d = {"g2": _dev(g2), "c1": _dev(c1), "x": _dev(x), "act": _dev(act), "w1": w1, "w2": w2,
+                 "bn1": L.bn(None, *bn1), "act_bn": L.bn(None, *bna)}
+            mk = lambda: {k: torch.full(sh, float("nan"), device="cuda") for k, sh in
+                          (("dw1", (16, 16, 3, 3)), ("db1", (16,)), ("dw2", (16, 16, 3, 3)), ("db2", (16,)))}
+            probs_f.append(dict(d, out=_dev(prev), **mk()))
+            probs_l.append(dict(d, out=_dev(prev), g1=L.empty_act(B, 16, 32, 32, "cuda"), **mk()))
+            assert ops.level2_bwd_ok(d["g2"], d["c1"], d["x"], d["act"], probs_f[-1]["out"])
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.level2_bwd_group(probs_f)
+        wb.finish()
+        wb = ops.WgradBatch(torch.device("cuda"))
+        wb.conv3x3_bwd_group([{"g": p["g2"], "x": p["c1"], "w": p["w2"], "out": p["g1"], "dw": p["dw2"], "db": p["db2"], "x_bn": p["bn1"]}
+                              for p in probs_l], 16, 0)
+        wb.conv3x3_bwd_group([{"g": p["g1"], "x": p["x"], "w": p["w1"], "out": p["out"], "dw": p["dw1"], "db": p["db1"],
+                               "pool_act": p["act"], "x_bn": p["act_bn"]} for p in probs_l], 16, 0)
+        wb.finish()
+        torch.cuda.synchronize()
+        assert not ops.level2_bwd_ok(torch.zeros(2, 16, 32, 32, device="cuda"), probs_f[0]["c1"], probs_f[0]["x"], probs_f[0]["act"],
+                                     probs_f[0]["out"])                                                          # fp32 container
+    for pf, pl in zip(probs_f, probs_l):
+        assert torch.equal(pf["out"], pl["out"])
+        for k in ("dw1", "db1", "dw2", "db2"):
+            a, b = pf[k].double(), pl[k].double()
+            assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_bf16_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_graph):
     """bf16 mode: the step fed the RAW 15-band tile (first launch = pc_ingest_cl8: select + normalise + pad + round into the shared

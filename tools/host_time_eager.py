@@ -55,3 +55,52 @@ for _ in range(n):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+# ---- where the host's time goes: the pieces of one native step, each alone (7 calls into an idle queue, best of 5)
+import ctypes as C                                                   # noqa: E402
+from popcorn_amd import _lib as L                                    # noqa: E402
+
+
+def best_of(fn, reps=5, n=7):
+    b_ = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        d = (time.perf_counter() - t0) / n
+        b_ = d if b_ is None or d < b_ else b_
+    torch.cuda.synchronize()
+    return b_ * 1e3
+
+
+if tr.native_steps:
+    s = {k: v.contiguous() for k, v in smp.items()}
+    s["admin_mask"] = s["admin_mask"].float()
+    sel = tr._draw_selection(H, W)
+    with L.precision(m.precision), L.stream_scope():
+        h = tr._native_handle()
+        io = tr._native_io(s, sel, False, False)
+        stream = L.stream_ptr()
+        io.arena, io.arena_bytes = tr._arena.data_ptr(), tr._arena.numel()
+        lib = L.lib()
+        full = L.PC_STEP_FWD | L.PC_STEP_BWD | L.PC_STEP_UPD
+        print("pieces (ms/step): draw_selection %.3f  sample dict %.3f  _native_io %.3f  pc_train_step %.3f (fwd %.3f, bwd %.3f, upd %.3f)  phases=0 %.3f" % (
+            best_of(lambda: tr._draw_selection(H, W)),
+            best_of(lambda: {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in smp.items()}["admin_mask"].float()),
+            best_of(lambda: tr._native_io(s, sel, False, False)),
+            best_of(lambda: lib.pc_train_step(h, C.byref(io), full, stream)),
+            best_of(lambda: lib.pc_train_step(h, C.byref(io), L.PC_STEP_FWD, stream)),
+            best_of(lambda: lib.pc_train_step(h, C.byref(io), L.PC_STEP_BWD, stream)),
+            best_of(lambda: lib.pc_train_step(h, C.byref(io), L.PC_STEP_UPD, stream)),
+            best_of(lambda: lib.pc_train_step(h, C.byref(io), 0, stream))))
+        ns = (C.c_double * 2)()
+        lib.pc_debug_step_host_ns.argtypes = [C.POINTER(C.c_double)]
+        acc = [0.0, 0.0]
+        torch.cuda.synchronize()
+        for _ in range(7):
+            lib.pc_train_step(h, C.byref(io), full, stream)
+            lib.pc_debug_step_host_ns(ns)
+            acc[0] += ns[0]
+            acc[1] += ns[1]
+        torch.cuda.synchronize()
+        print("inside pc_train_step: sizing pass %.1f us, launching pass %.1f us, %d launches + event calls" % (acc[0] / 7e3, acc[1] / 7e3, io.launches))

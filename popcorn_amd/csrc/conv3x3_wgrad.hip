@@ -898,42 +898,60 @@ struct RbEntry {
     int dw_co_stride;                         // conv3x3: elements between output channels of dw (0 = Cin * 9)
     int src_cin, src_ci0;                     // conv3x3: channel window of the partials (pc_wgrad_reduce_desc), src_cin = Cin: all
 };
-// blk0: first workgroup of every entry (prefix sums of ceil(outputs / 16)): a flat grid -- as (max outputs / 16) x entries, two
+// blk0: first workgroup of every entry (prefix sums of ceil(outputs / RB_OUT)): a flat grid -- as (max outputs / 16) x entries, two
 // thirds of the workgroups of a step's list had nothing to do.  head: the 8 gradient tensors of the sparse head (kind 3, at most one
 // such entry per launch)
 struct RbArgs { RbEntry e[RB_MAX]; int blk0[RB_MAX + 1]; int n; float* head[8]; };
 
+// sum of at(w) over this thread's slice of the partial list (w = slice, slice + RB_SL, ...): sixteen independent chains, so that a thread
+// has sixteen loads in flight per round (the kernel's time is rounds x loaded memory latency: 512 partials = 2 rounds; 8 with four chains)
+constexpr int RB_OUT = 32, RB_SL = 256 / RB_OUT;      // outputs per workgroup (one 128-byte line of every partial) x slices of the list
+template <class F>
+__device__ __forceinline__ float rb_sum(int slice, int nwg, F at) {
+    float s[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = 0.f;
+    int w = slice;
+    for (; w + 15 * RB_SL < nwg; w += 16 * RB_SL) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += at(w + RB_SL * k);
+    }
+    for (; w + 3 * RB_SL < nwg; w += 4 * RB_SL) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += at(w + RB_SL * k);
+    }
+    for (; w < nwg; w += RB_SL) s[0] += at(w);
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+        for (int k = 0; k < h; ++k) s[k] += s[k + h];
+    return s[0];
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a) {
+    // workgroups bx, bx + 1 read the two 64-byte halves of the same 128-byte lines of every partial: consecutive ones on the same XCD
+    // (its L2 then fetches a line once; spread round-robin over the eight XCDs every line came out of HBM twice)
+    const int gb = pc_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int ei = 0;
-    while (ei + 1 < a.n && (int)blockIdx.x >= a.blk0[ei + 1]) ++ei;
+    while (ei + 1 < a.n && gb >= a.blk0[ei + 1]) ++ei;
     const RbEntry& q = a.e[ei];
-    const int bx = (int)blockIdx.x - a.blk0[ei];
+    const int bx = gb - a.blk0[ei];
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const int slice = tid >> 4, o = bx * 16 + (tid & 15);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int slice = tid / RB_OUT, o = bx * RB_OUT + (tid % RB_OUT);
+    float s0 = 0.f;
     int n_w, n_out;
     if (q.kind == 3) {
         // the head backward's workgroup partials (head.hip, common.h: pc_head_partial_target): 16 consecutive elements x 16 slices of
         // the partial list; the output index is the inverse of the MFMA fragment layout
         n_w = n_out = PC_PE_TOTAL;
-        if (o < n_out) {
-            int w = slice;
-            for (; w + 48 < q.nwg; w += 64) {
-                const float* q0 = q.partial + (int64_t)w * PC_PE_TOTAL + o;
-                s0 += q0[0];
-                s1 += q0[(int64_t)16 * PC_PE_TOTAL];
-                s2 += q0[(int64_t)32 * PC_PE_TOTAL];
-                s3 += q0[(int64_t)48 * PC_PE_TOTAL];
-            }
-            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * PC_PE_TOTAL + o];
-        }
-        red[tid] = (s0 + s1) + (s2 + s3);
+        if (o < n_out) s0 = rb_sum(slice, q.nwg, [&](int w) { return q.partial[(int64_t)w * PC_PE_TOTAL + o]; });
+        red[tid] = s0;
         __syncthreads();
-        if (tid < 16 && o < n_out) {
+        if (tid < RB_OUT && o < n_out) {
             float tot = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
+            for (int k = 0; k < RB_SL; ++k) tot += red[k * RB_OUT + tid];
             int t, idx;
             pc_head_partial_target(o, t, idx);
             if (t >= 0 && a.head[t]) {
@@ -957,32 +975,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
             const int tap = o % 9, ci = (o / 9) % q.Cin + q.src_ci0, co = o / (9 * q.Cin);
             const int chunk = ci / CINC, cil = ci % CINC;
             const int oc = co * (CINC * 9) + cil * 9 + tap;
-            const float* base = q.partial + (int64_t)chunk * q.nwg * EC;
-            int w = slice;
-            for (; w + 48 < q.nwg; w += 64) {
-                const float* q0 = base + (int64_t)w * EC;
-                s0 += q0[oc];
-                s1 += q0[(int64_t)16 * EC + oc];
-                s2 += q0[(int64_t)32 * EC + oc];
-                s3 += q0[(int64_t)48 * EC + oc];
-            }
-            for (; w < q.nwg; w += 16) s0 += base[(int64_t)w * EC + oc];
+            const float* base = q.partial + (int64_t)chunk * q.nwg * EC + oc;
+            s0 = rb_sum(slice, q.nwg, [&](int w) { return base[(int64_t)w * EC]; });
         } else if (o < n_out) {
-            const int co = o - n_w;
-            for (int w = slice; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * EC + q.Cout * CINC * 9 + co];
+            const float* base = q.partial + q.Cout * CINC * 9 + (o - n_w);
+            s0 = rb_sum(slice, q.nwg, [&](int w) { return base[(int64_t)w * EC]; });
         }
     } else if (q.kind == 2) {
         // raw sum of Cin floats per partial (up_bwd.hip: composed-weight gradient accumulators + border sums; the chain-rule
         // launch that follows turns the total into parameter gradients)
         n_w = n_out = q.Cin;
-        if (o < n_w) {
-            int w = slice;
-            for (; w + 16 < q.nwg; w += 32) {
-                s0 += q.partial[(int64_t)w * q.Cin + o];
-                s1 += q.partial[(int64_t)(w + 16) * q.Cin + o];
-            }
-            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * q.Cin + o];
-        }
+        if (o < n_w) s0 = rb_sum(slice, q.nwg, [&](int w) { return q.partial[(int64_t)w * q.Cin + o]; });
     } else {
         const int C = q.Cin, NBK = C / 4, E = NBK * 256 + NBK * 64;
         n_w = C * C * 4;
@@ -990,15 +993,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
         if (o < n_w) {
             const int ci = o / (4 * C), ng = o % (4 * C);
             const int e = (((ng >> 4) * 64) + (ci >> 2) * 16 + (ng & 15)) * 4 + (ci & 3);
-            int w = slice;
-            for (; w + 16 < q.nwg; w += 32) {
-                s0 += q.partial[(int64_t)w * E + e];
-                s1 += q.partial[(int64_t)(w + 16) * E + e];
-            }
-            for (; w < q.nwg; w += 16) s0 += q.partial[(int64_t)w * E + e];
+            s0 = rb_sum(slice, q.nwg, [&](int w) { return q.partial[(int64_t)w * E + e]; });
         } else if (o < n_out) {
             const int co = o - n_w;
-            for (int w = slice; w < q.nwg; w += 16) {
+            for (int w = slice; w < q.nwg; w += RB_SL) {
                 const float* pq = q.partial + (int64_t)w * E + NBK * 256;
                 float t = 0.f;
 #pragma unroll
@@ -1011,12 +1009,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
             }
         }
     }
-    red[tid] = (s0 + s1) + (s2 + s3);
+    red[tid] = s0;
     __syncthreads();
-    if (tid < 16 && o < n_out) {
+    if (tid < RB_OUT && o < n_out) {
         float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += red[k * 16 + tid];
+        for (int k = 0; k < RB_SL; ++k) tot += red[k * RB_OUT + tid];
         int64_t od = o;
         if (q.kind == 0 && q.dw_co_stride > 0 && o < n_w) od = (int64_t)(o / (q.Cin * 9)) * q.dw_co_stride + o % (q.Cin * 9);
         float* dstp = o < n_w ? q.dw + od : q.db + (o - n_w);
@@ -1060,7 +1058,7 @@ extern "C" int pc_wgrad_reduce_batch(int n, const pc_wgrad_reduce_desc* d, void*
                 a.e[i] = RbEntry{s.partial, s.dw, s.db, s.nwg, s.Cin, s.Cout, s.kind, s.accumulate, s.dw_co_stride, src_cin, s.kind == 0 ? s.src_ci0 : 0};
                 n_out = s.kind == 0 ? s.Cout * s.Cin * 9 + s.Cout : (s.kind == 2 ? s.Cin : s.Cin * s.Cin * 4 + s.Cin);
             }
-            a.blk0[i + 1] = a.blk0[i] + (n_out + 15) / 16;
+            a.blk0[i + 1] = a.blk0[i] + (n_out + RB_OUT - 1) / RB_OUT;
         }
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(a.blk0[m]), dim3(256), 0, st, a);
         PC_CHECK_LAUNCH();

@@ -2518,12 +2518,13 @@ __global__ void zero_words_kernel(uint32_t* p, int n) {
 struct ScoreMaskArgs {
     pc_src feat; const float* w; const float* bias; pc_dst out;      // 1x1 conv + sigmoid + crop (as outconv_sigmoid_crop)
     const float* admin; const int64_t* census; const uint8_t* rowsel; const uint8_t* colsel;
-    int occ; uint8_t* mask; int32_t* counts; unsigned* scratch;      // scratch: {acc nsel, acc nregion, ticket, -}, zeroed before the launch
+    int occ; uint8_t* mask; int32_t* counts; unsigned* scratch;      // scratch: one packed 64-bit accumulator {nsel, nregion, ticket} (see the kernel), zero between launches
     int B, H, W, py, px;
     int bf;
 };
 
-__global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) {
+constexpr int SM_THREADS = 1024;       // 16 waves per block, at most one block per CU: B = 64 tiles (160 k four-pixel items) in ONE round of loads
+__global__ __launch_bounds__(SM_THREADS) void score_mask_kernel(const ScoreMaskArgs a) {
     const int64_t n = (int64_t)a.B * a.H * a.W;
     float wv[16];
 #pragma unroll
@@ -2589,25 +2590,30 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
         nsel += m;
         nreg += region;
     }
-    __shared__ int red[2][4];
+    __shared__ int red[2][SM_THREADS / 64];
     __shared__ unsigned last;
     for (int off = 32; off > 0; off >>= 1) { nsel += __shfl_down(nsel, off); nreg += __shfl_down(nreg, off); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nsel; red[1][threadIdx.x >> 6] = nreg; }
     __syncthreads();
+    __shared__ unsigned long long tot_sh;
     if (threadIdx.x == 0) {
-        const int s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        // integer counts: order-independent, exact.  ONE 64-bit atomic per block {nsel | nregion << 32}: device-scope
-        // atomics on one address retire at ~13 ns each (2048 blocks x 3 atomics took 80 us)
-        if (s0 | s1) atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), (unsigned long long)(unsigned)s0 | ((unsigned long long)(unsigned)s1 << 32));
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int w = 0; w < SM_THREADS / 64; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
+        // integer counts: order-independent, exact.  ONE 64-bit atomic per block carries {nsel : 27 | nregion : 27 | ticket : 10}
+        // (device-scope atomics on one address retire at ~13 ns each, and every dependent one is a round trip to the memory side:
+        // counts, ticket and the last block's read of the totals were three of them); the block that draws the last ticket has the
+        // totals in the returned value
         __threadfence();
-        last = atomicAdd(&a.scratch[2], 1u) == gridDim.x - 1 ? 1u : 0u;
+        const unsigned long long add = (unsigned long long)(unsigned)s0 | ((unsigned long long)(unsigned)s1 << 27) | (1ull << 54);
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), add);
+        last = (unsigned)(old >> 54) == gridDim.x - 1 ? 1u : 0u;
+        tot_sh = old + add;
     }
     __syncthreads();
     if (!last) return;
     __threadfence();
-    const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(a.scratch), 0ull);
-    const unsigned tot_sel = (unsigned)tot, tot_reg = (unsigned)(tot >> 32);
-    __syncthreads();                       // every thread of this block has read the totals before counts[0] is fixed up
+    const unsigned tot_sel = (unsigned)(tot_sh & ((1ull << 27) - 1)), tot_reg = (unsigned)((tot_sh >> 27) & ((1ull << 27) - 1));
     if (tot_sel == 0) {
         // an empty selection falls back to the region mask (popcorn.py:374-375)
         for (unsigned i = threadIdx.x; i < (unsigned)n; i += blockDim.x) {
@@ -2620,7 +2626,7 @@ __global__ __launch_bounds__(256) void score_mask_kernel(const ScoreMaskArgs a) 
         a.counts[1] = (int32_t)tot_reg;
         // this block is the last one alive: leave the accumulator and the ticket at zero for the next call (which is ordered
         // behind this kernel on the stream), instead of a zeroing launch in front of every call
-        a.scratch[0] = 0u; a.scratch[1] = 0u; a.scratch[2] = 0u;
+        a.scratch[0] = 0u; a.scratch[1] = 0u;
         __threadfence();
     }
 }
@@ -3245,8 +3251,9 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     if (!feat || !w || !bias || !building_out || !admin_mask || !census_idx || !rowsel || !colsel || !mask || !counts ||
         feat->C < 1 || feat->C > 16)
         return PC_EINVAL;
-    static unsigned* scratch = nullptr;     // {acc nsel, acc nregion, ticket, -}: device-scope atomics only; zero between calls (the
-                                            // kernel's last block resets it), zeroed once here
+    if ((int64_t)B * H * W >= ((int64_t)1 << 27)) return PC_EINVAL;      // the packed 64-bit accumulator holds two 27-bit counts
+    static unsigned* scratch = nullptr;     // one 64-bit word {nsel : 27 | nregion : 27 | ticket : 10}: device-scope atomics only; zero
+                                            // between calls (the kernel's last block resets it), zeroed once here
     if (!scratch) {
         hipError_t e = hipMalloc(&scratch, 4 * sizeof(unsigned));
         if (e != hipSuccess) return (int)e;
@@ -3260,10 +3267,10 @@ extern "C" int pc_building_score_mask(const pc_src* feat, const float* w, const 
     a.rowsel = rowsel; a.colsel = colsel; a.occ = occupancymodel; a.mask = mask; a.counts = counts; a.scratch = scratch;
     a.B = B; a.H = H; a.W = W; a.py = py; a.px = px; a.bf = g_pc_precision == PC_PREC_BF16;
     const int64_t n = (int64_t)B * H * W;
-    int grid = (int)((n + 255) / 256);
+    int grid = (int)((n + SM_THREADS - 1) / SM_THREADS);
     if (grid > 256) grid = 256;            // one block per CU: the per-block atomics are the serial part
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(score_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(score_mask_kernel, dim3(grid), dim3(SM_THREADS), 0, (hipStream_t)stream, a);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -970,6 +970,47 @@ def test_bf16_whole_level_backward_kernel_against_the_two_launches(B, nprob):
             assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), k
 
 
+def test_bf16_train_step_with_the_whole_level_backward_kernel_equals_the_layerwise_step(monkeypatch):
+    """A bf16 train step with level2_bwd_cl_kernel in it against the same step with the two layer launches (POPCORN_FUSED_LEVEL2_BWD):
+    the data gradients are bit-identical, so every gradient outside the level's two conv layers is too; the level's own four weight /
+    bias gradients are sums over other pixel groups (fp32 summation noise) -- and the kernel really ran."""
+    from popcorn_amd import engine as E, ops
+    from popcorn_amd.data import stats
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import POPCORN
+    from popcorn_amd.train import FusedTrainStep
+    batch = make_raw_batch(3, 100, 100, seed=19, device="cuda", region="disc")
+    x = ops.select_normalize(batch["raw"], stats.BAND6, stats.MEAN6, stats.STD6)
+    grads, calls = {}, {}
+    orig = ops.WgradBatch.level2_bwd_group
+    for flag in (True, False):
+        monkeypatch.setattr(E, "FUSED_LEVEL2_BWD", flag)
+        n = [0]
+
+        def counted(self, problems, _n=n):
+            _n[0] += 1
+            return orig(self, problems)
+        monkeypatch.setattr(ops.WgradBatch, "level2_bwd_group", counted)
+        torch.manual_seed(1600)
+        m = POPCORN(input_channels=6, occupancymodel=True, pretrained=True, biasinit=0.9407, sentinelbuildings=True).cuda()
+        m.set_precision("bf16")
+        tr = FusedTrainStep(m, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(4)
+        tr.step({"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]})
+        torch.cuda.synchronize()
+        grads[flag] = {k: v.clone() for k, v in tr.grads.items()}
+        calls[flag] = n[0]
+    assert calls == {True: 1, False: 0}
+    level = [k for k in grads[True] if ".down2." in k and ".conv." in k]
+    assert len(level) >= 8                                           # two streams x two layers x (weight, bias)
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        if k in level and (k.endswith("conv.0.weight") or k.endswith("conv.0.bias") or k.endswith("conv.3.weight") or k.endswith("conv.3.bias")):
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-12), k
+        else:
+            assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_bf16_fused_step_from_raw_tiles_equals_step_from_normalised_input(use_graph):
     """bf16 mode: the step fed the RAW 15-band tile (first launch = pc_ingest_cl8: select + normalise + pad + round into the shared

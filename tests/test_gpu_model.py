@@ -131,6 +131,13 @@ def test_train_step_vs_reference_golden(model):
                 cpu_s = {k: torch.from_numpy(g[k]) for k in ("input", "admin_mask", "census_idx", "y")}
                 assert worst < 5e-3, worst
                 assert_tie_flip(sd_before, cpu_s, sample0["input"], hip_g, ref_g, 1700, worst)
+            # and without any adjudication: the fp64 oracle made to take the HIP forward's side at every ReLU mask / pooling arg-max
+            # (O.ForceDecisions) is the HIP gradients' neighbour -- what separates them from the fixture is those decisions alone
+            from tests.tie_adjudication import forced_decision_distance
+            cpu_s = {k: torch.from_numpy(g[k]) for k in ("input", "admin_mask", "census_idx", "y")}
+            wf, wname, flips, _ = forced_decision_distance(sd_before, cpu_s, sample0["input"], hip_g, 1700)
+            print(f"\n[shared decisions] golden train step: HIP vs fp64 oracle under the HIP forward's decisions {wf:.2e} ({wname}); flips {flips}")
+            assert wf < 1e-4, (wf, wname, flips)
             for k in [k for k in g.files if k.startswith("step0/lossdict/")]:
                 kk = k[len("step0/lossdict/"):].replace("|", "/")
                 assert abs(ld[kk] - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), kk

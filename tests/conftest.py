@@ -30,3 +30,12 @@ def pytest_terminal_summary(terminalreporter):
     tr.write_sep("-", f"tie adjudications: {len(ADJUDICATED)} comparison(s) passed through a proven decision flip")
     for r in ADJUDICATED:
         tr.write_line(f"  {r['test']}: worst {r['worst']:.2e}, flips {r['flips']}, w_hip {r['w_hip']:.2e}, w_ref {r['w_ref']:.2e}")
+    try:
+        from tests.tie_adjudication import SHARED
+    except Exception:
+        return
+    if SHARED:
+        tr.write_sep("-", f"shared decisions: {len(SHARED)} gradient comparison(s) against the fp64 oracle on the HIP side of every ReLU / arg-max decision, "
+                          f"worst residual {max(r['residual'] for r in SHARED):.2e} (bar 1e-4)")
+        for r in SHARED:
+            tr.write_line(f"  {r['test']}: {r['residual']:.2e} ({r['tensor']}), differing sites {r['flips']}")

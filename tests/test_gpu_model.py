@@ -183,6 +183,11 @@ def test_grad_truncation_modes_vs_oracle(model, flags):
         from tests.tie_adjudication import assert_tie_flip        # above the bar only through a proven ReLU / arg-max tie flip
         assert worst < 5e-3, worst
         assert_tie_flip(sd, dict(sample), s["input"], {n: got[n].cpu() for n in ref_grads}, ref_grads, 5, worst, **flags)
+    # under shared decisions (the fp64 oracle on the HIP side of every ReLU mask / arg-max, tests/tie_adjudication.py) nothing is left
+    from tests.tie_adjudication import forced_decision_distance
+    wf, wname, flips, _ = forced_decision_distance(sd, dict(sample), s["input"], {n: got[n].cpu() for n in ref_grads}, 5, **flags)
+    print(f"\n[shared decisions] truncation regime {flags}: HIP vs fp64 oracle under the HIP forward's decisions {wf:.2e} ({wname}); flips {flips}")
+    assert wf < 1e-4, (wf, wname, flips)
     model.zero_grad()
 
 

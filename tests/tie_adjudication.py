@@ -21,6 +21,7 @@ import torch
 from oracle import popcorn_oracle as O
 
 ADJUDICATED = []       # one record per mismatch that passed through assert_tie_flip (printed in the session summary, conftest.py)
+SHARED = []            # one record per forced_decision_distance comparison (residual under shared decisions, sites that differed)
 
 
 def rel(a, r):
@@ -124,6 +125,8 @@ def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, 
     decision set).  Returns (worst, name of the worst tensor, {"relu", "pool": sites where the oracle alone decides differently,
     "head": inverted head units}, loss)."""
     acts, pools, hip_feats = hip_decision_sites(sd, x_dev, bool(flags.get("encoder_no_grad")))
+    if flags.get("unet_no_grad"):
+        acts, pools = [], []                      # nothing in the U-Net carries gradient: only the head has decisions
     sd32 = sd
     if fp64:
         sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -158,4 +161,6 @@ def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, 
                 break
     flips = dict(best[2])
     flips["head"] = hf
+    import os
+    SHARED.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "residual": best[0], "tensor": best[1], "flips": flips})
     return best[0], best[1], flips, best[3]

@@ -67,7 +67,7 @@ def parse():
                          "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
     ap.add_argument("--extras-multi", action="store_true",
                     help="N > 1: also run the `bf16` and `h2d` legs (default: skipped, the multi-GPU run stays under two minutes)")
-    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `config3_regions`, `config5`")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `grad_parity`, `config3_regions`, `config5`")
     ap.add_argument("--soak-steps", type=int, default=1500)
     ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed steps in front of the W warm-up steps until this much wall time has passed: the part's clocks settle "
@@ -716,6 +716,42 @@ def fwd_parity(torch, margs, sd_cpu, batch, dev):
     return res
 
 
+def grad_parity(torch, margs, sd_cpu, batch, dev, ntiles=8):
+    """The training half of the parity statement on the bench line: ONE fused train step (eager, fp32) on the first `ntiles` tiles of the
+    synthetic batch, its 56 gradients against the CPU oracle -- fp32 as it is, and fp64 under SHARED decisions (the oracle takes the HIP
+    forward's side at every ReLU mask / pooling arg-max, tests/tie_adjudication.py: no tie is left to flip, the residual is rounding)."""
+    try:
+        from oracle import popcorn_oracle as O
+        from popcorn_amd import ops
+        from popcorn_amd.data import stats
+        from popcorn_amd.model import get_model_kwargs, model_dict
+        from popcorn_amd.train import FusedTrainStep
+        from tests.tie_adjudication import forced_decision_distance, rel
+        torch.manual_seed(1600)
+        model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
+        model.load_state_dict(sd_cpu)
+        raw = batch["raw"][:ntiles]
+        x = ops.select_normalize(raw.to(dev), stats.BAND6, stats.MEAN6, stats.STD6)
+        cpu = {"input": O.select_normalize(raw.cpu()), "admin_mask": batch["admin_mask"][:ntiles].cpu(),
+               "census_idx": batch["census_idx"][:ntiles].cpu(), "y": batch["y"][:ntiles].cpu()}
+        tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01)
+        torch.manual_seed(13)
+        loss = tr.step({"input": x, "admin_mask": cpu["admin_mask"].to(dev), "census_idx": cpu["census_idx"].to(dev), "y": cpu["y"].to(dev)})
+        torch.cuda.synchronize()
+        hip = {n: g.cpu() for n, g in tr.grads.items()}
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+        torch.manual_seed(13)
+        l32, _, g32, _ = O.train_step_grads(sd_cpu, dict(cpu))
+        wf, name, flips, l64 = forced_decision_distance(sd_cpu, cpu, x, hip, 13)
+        return {"config": f"B={ntiles} 100x100, one fused train step vs the CPU oracle, 56 gradients, max over tensors of max-abs-err / max(|ref|, 1e-3)",
+                "vs_fp32_oracle": max(rel(hip[n], g32[n]) for n in g32), "loss_rel_err": abs(loss[0].item() - l64.item()) / max(1.0, abs(l64.item())),
+                "vs_fp64_oracle_under_shared_decisions": wf, "worst_tensor": name,
+                "decisions_the_fp64_oracle_alone_takes_differently": {k: (len(v) if isinstance(v, list) else v) for k, v in flips.items()},
+                "tolerance": 1e-4, "ok": bool(wf <= 1e-4)}
+    except Exception as e:            # a checker's failure must not take the measured line with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 FLOP_FWD_PX = 2 * (9040 + 9072 + 9344)        # SURVEY.md 8d per pixel: trainable U-Net + building extractor + head = 54,912 flop
 
 
@@ -1178,6 +1214,7 @@ def main():
             # BASELINE's other configurations on the same line: forward parity of config[1] against the CPU oracle (the metric's
             # second half), config[2] at the reference's real region geometry, config[4]'s sliding windows
             res["fwd_parity"] = fwd_parity(torch, margs, sd_cpu, batch, dev)
+            res["grad_parity"] = grad_parity(torch, margs, sd_cpu, batch, dev)
             del trainer, model
             torch.cuda.empty_cache()
             res["config3_regions"] = config3_regions_leg(torch, margs, dev)

@@ -249,6 +249,8 @@ int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0
                          int* nwg_out, void* stream);
 /* ablation switches for tools/ablate_conv.py (0,0 = normal operation) */
 void pc_debug_conv(int dbg, int max_grid);
+/* debug: buffer of 8 x int64 per workgroup receiving wall-clock stamps of the conv kernels' phases (NULL = off; tools/conv_timeline.py) */
+void pc_debug_conv_ts(void* buf);
 
 /* ---- conv3x3 weight/bias gradient.  x = forward input (a,b sources as in fwd), g as in dgrad.
  * dw: [Cout][Cin][3][3], db: [Cout]; (=|+=).  ws: workspace of pc_conv3x3_wgrad_ws_bytes(). */
@@ -592,6 +594,9 @@ typedef struct pc_step_io {
 void* pc_step_create(const pc_step_plan* plan);
 void pc_step_destroy(void* handle);
 int pc_train_step(void* handle, pc_step_io* io, int phases, void* stream);
+/* debug: host nanoseconds the LAST pc_train_step call spent in its sizing pass (out[0]) and in its launching pass (out[1])
+ * (tools/host_time_eager.py) */
+void pc_debug_step_host_ns(double* out);
 
 /* pc_reflect_pad_select / pc_select_normalize_pad / pc_ingest_split (planar form) for rows of any width and an output whose rows are
  * out_rstride >= Wp floats apart (planes of Hp * out_rstride): kind as enum pc_step_data; mean == NULL: no normalisation. */

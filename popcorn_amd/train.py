@@ -17,6 +17,7 @@ import ctypes as C
 import gc
 import os
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -35,6 +36,19 @@ DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
 NATIVE_STEP = os.environ.get("POPCORN_NATIVE_STEP", "1") != "0"
 _LAYER_TAGS = ("inc1", "inc2", "d1a", "d1b", "d2a", "d2b", "up2a", "up2b", "up1a", "up1b")      # pc_step_stream's layer order
 _CONVT_TAGS = ("up2t", "up1t")
+
+
+_ONES = {}
+
+
+def _ones(n):
+    """torch.ones(n) of the two multinomial draws per step, kept per size (the draw reads it only)."""
+    t = _ONES.get(n)
+    if t is None:
+        if len(_ONES) > 4096:
+            _ONES.clear()
+        t = _ONES[n] = torch.ones(n)
+    return t
 
 
 class _ArenaOutputs:
@@ -549,12 +563,12 @@ class FusedTrainStep:
     def _draw_selection(H, W):
         """The two CPU-generator multinomial draws of get_sparsity_mask (popcorn.py:366-369)."""
         sub = 60
-        xi = torch.ones(H).multinomial(num_samples=min(sub, H), replacement=False)
-        yi = torch.ones(W).multinomial(num_samples=min(sub, W), replacement=False)
-        sel = torch.zeros(H + W, dtype=torch.uint8)
-        sel[xi] = 1
-        sel[H + yi] = 1
-        return sel
+        xi = _ones(H).multinomial(num_samples=min(sub, H), replacement=False)
+        yi = _ones(W).multinomial(num_samples=min(sub, W), replacement=False)
+        sel = np.zeros(H + W, dtype=np.uint8)          # (numpy: two index_put calls cost more than the draws' own bookkeeping)
+        sel[xi.numpy()] = 1
+        sel[H + yi.numpy()] = 1
+        return torch.from_numpy(sel)
 
     def _sel_to_device(self, sel_host, dst=None):
         """The per-step row / column selection (H + W bytes drawn on the CPU generator, like the reference) goes to the device

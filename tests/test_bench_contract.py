@@ -40,6 +40,8 @@ def test_committed_final_bench_line_keeps_the_contract():
     # the metric's second half and the other configurations ride on the same line
     fp = d["fwd_parity"]
     assert fp["ok"] is True and fp["max_rel"] <= 1e-4 and {"popdensemap", "popcount", "scale"} <= set(fp)
+    gp = d["grad_parity"]          # the training half: 56 gradients of one step against the fp64 oracle under shared ReLU / arg-max decisions
+    assert gp["ok"] is True and gp["vs_fp64_oracle_under_shared_decisions"] <= 1e-4 and gp["vs_fp32_oracle"] < 5e-3
     assert d["config5"]["windows_per_s"] > 0 and d["config5"]["finite"] is True
     c3 = d["config3_regions"]
     assert len(c3["batches"]) >= 6 and max(b["Mpx"] for b in c3["batches"]) > 9.0 and {"all", "head only"} <= {b["regime"] for b in c3["batches"]}

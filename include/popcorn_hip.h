@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 8
+#define PC_ABI_VERSION 9
 
 /* error codes (negative; positive values are hipError_t) */
 #define PC_EINVAL (-1)     /* bad argument / unsupported channel combination */
@@ -123,6 +123,18 @@ int pc_get_precision(void);
  * between a forward and its backward).  Returns the previous / the current setting. */
 int pc_set_head_split(int on);
 int pc_get_head_split(void);
+
+/* fp32 mode only (round 6, ABI 9): how the 3x3 convolution kernels that have a split-operand form multiply (today: the fused
+ * data + weight gradient pc_conv3x3_bwd_group; networks.py:259-266 backward).  Same arithmetic as pc_set_head_split:
+ *   1 (default; POPCORN_CONV_SPLIT=0 in the environment starts with 0): operands are split exactly into three bf16 numbers when a strip is
+ *     staged into LDS (once per strip, not per use), products are six bf16 x bf16 partial products accumulated in fp32 on
+ *     v_mfma_f32_16x16x32_bf16; also opens the forms that exist only this way (16 gradient channels, the Down blocks' pool_act);
+ *   0: v_mfma_f32_16x16x4_f32 kernels only (8 -> 8 channels; the strict flat-bar tests and A/B runs).
+ * Process-global, read when a call is enqueued.  Returns the previous / the current setting. */
+int pc_set_conv_split(int on);
+int pc_get_conv_split(void);
+/* does pc_conv3x3_bwd_group take these fp32 tensors (planar, aligned; Cg = 8 or 16 gradient channels, 8 x channels)?  1 / 0 */
+int pc_conv3x3_bwd_ok(const pc_src* g, const pc_src* x, const pc_dst* out, const pc_src* pool_act, int B, int H, int W);
 
 /* ---- conv3x3 (+BN +ReLU) forward: nn.Conv2d(3,pad 1) -> BatchNorm2d(eval) -> ReLU, networks.py:259-266.
  * Input channels = a.C + b.C (torch.cat([skip, up]) fused, networks.py:318); conv domain H x W, batch B.
@@ -247,6 +259,9 @@ typedef struct pc_conv_bwd_desc {
 } pc_conv_bwd_desc;
 int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                          int* nwg_out, void* stream);
+/* ablation switches of the split-operand fused backward kernel (tools/time_conv_bwd.py --ablate; 0 = normal operation): 1 no split / LDS
+ * writes, 2 no data-gradient matrix phase, 4 no weight-gradient matrix phase, 8 no prefetch loads, 16 no epilogue */
+void pc_debug_conv_bwd(int dbg);
 /* ablation switches for tools/ablate_conv.py (0,0 = normal operation) */
 void pc_debug_conv(int dbg, int max_grid);
 /* debug: buffer of 8 x int64 per workgroup receiving wall-clock stamps of the conv kernels' phases (NULL = off; tools/conv_timeline.py) */

@@ -99,7 +99,7 @@ class PcLevel2BwdDesc(C.Structure):
                 ("ws1", C.c_void_p), ("ws2", C.c_void_p)]
 
 
-PC_ABI_VERSION = 8
+PC_ABI_VERSION = 9
 PC_MAX_GROUP = 4
 PC_ADAM_MAX_SEG, PC_ADAM_GROUPS = 8, 4
 PC_EINVAL, PC_ENOGPU, PC_ENOMEM, PC_ENOTSUP = -1, -2, -3, -4

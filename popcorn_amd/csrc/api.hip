@@ -14,6 +14,22 @@ extern "C" int pc_set_precision(int mode) {
 
 extern "C" int pc_get_precision(void) { return g_pc_precision; }
 
+// ---- multiplication form of the fp32 conv kernels (popcorn_hip.h: pc_set_conv_split) --------------------------------------------------
+static int g_conv_split = -1;
+int pc_conv_split_on() {
+    if (g_conv_split < 0) {
+        const char* ev = getenv("POPCORN_CONV_SPLIT");
+        g_conv_split = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    return g_conv_split;
+}
+extern "C" int pc_get_conv_split(void) { return pc_conv_split_on(); }
+extern "C" int pc_set_conv_split(int on) {
+    const int prev = pc_conv_split_on();
+    g_conv_split = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int pc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

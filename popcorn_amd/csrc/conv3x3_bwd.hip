@@ -37,6 +37,8 @@ struct BwdProb {
 struct BwdArgs {
     BwdProb pr[MAXG];
     int accumulate;         // gx += instead of =
+    int dbg;                // ablation switches of conv3x3_bwd_s3_kernel (pc_debug_conv_bwd): 1 no split / LDS writes, 2 no data-gradient matrix
+                            // phase, 4 no weight-gradient matrix phase, 8 no prefetch loads, 16 no epilogue
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
     pc_fastdiv div_tx, div_tpi;
@@ -599,7 +601,525 @@ int launch_bwd_f32(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
     *nwg_out = nwg;
     return 0;
 }
+
+// ---- fp32 (planar tensors) on the bf16 matrix pipe (round 6): conv3x3_bwd_s3_kernel<GC, POOL> ----------------------------------------
+// The channels-last kernel above with fp32 tensors at both ends.  The planar fp32 strips of g (GC = 8 or 16 channels) and x (8 channels)
+// are loaded exactly as conv3x3_bwd_f32_kernel loads them (one aligned 16-byte piece per lane and channel, prefetched one strip ahead)
+// and SPLIT ONCE, while they are written to LDS: every fp32 value is exactly the sum of three bf16 numbers (common.h: pc_split_pair), so
+// a lane turns its 4 pixels x 8 channels into 3 planes x 4 channels-last 16-byte slots.  From there on the operands are
+// conv3x3_bwd_cl_kernel's: one ds_read_b128 is the K = 32 = (4 rows x 8 channels) pixel operand of the data gradient, two
+// ds_read_b64_tr_b16 the K = 32 pixels operand of the weight gradient; every product is six bf16 x bf16 partial products (the three
+// smallest of the nine, together below 2^-23 of the product, are dropped), accumulated in fp32 smallest first -- 6 x 16 matrix cycles per
+// 32 K-slots against 8 x 32 on v_mfma_f32_16x16x4_f32, and ONE LDS read per 24 (data gradient) / 6-12 (weight gradient) instructions
+// against one per instruction.  Data-gradient operands are swapped against the channels-last kernel (A = pixels, B = weights) so that a
+// lane holds FOUR CONSECUTIVE PIXELS of one channel: the planar fp32 epilogue of conv3x3_bwd_f32_kernel (ReLU mask from the x image,
+// BN scale, +=, 16-byte stores), or the MaxPool2d(2) backward scatter of conv3x3_mfma_kernel's vector epilogue (POOL: x is the saved
+// pooled copy of pool_act).  Three planes of (GC / 8 + 1) strip images per wave = 27 / 34.6 KB: one workgroup per CU, one wave per SIMD,
+// up to 512 registers -- the weights' B fragments (all three planes) stay in registers.  GC = 16 with a 16-channel x runs as two
+// problems (column blocks of x) over the same g.
+// Phase profile of conv3x3_bwd_s3_kernel (debug builds only: tools/build_variant.sh prof -DPOPCORN_BWD_PROF; POPCORN_BWD_PROF=1 prints
+// cycles per strip and wave: waiting for the prefetched loads, split + LDS writes, issue of the next prefetch, data-gradient matrix
+// phase, epilogue, weight-gradient matrix phase)
+#ifdef POPCORN_BWD_PROF
+__device__ long long g_bwd_prof[4096 * 8];
+#define BQ_DECL long long bq0 = 0, bq1 = 0, bq2 = 0, bq3 = 0, bq4 = 0, bq5 = 0, bq_t = 0, bq_n = 0
+#define BQ_NOW(v) do { __builtin_amdgcn_sched_barrier(0); v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BQ_START BQ_NOW(bq_t)
+#define BQ_CLOSE(acc) do { BQ_NOW(bq_n); acc += bq_n - bq_t; bq_t = bq_n; } while (0)
+#define BQ_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define BQ_WAITLGKM asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define BQ_DUMP do { if (lane == 0) { long long* o_ = g_bwd_prof + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8; \
+                     o_[0] = bq0; o_[1] = bq1; o_[2] = bq2; o_[3] = bq3; o_[4] = bq4; o_[5] = bq5; o_[6] = my_tiles; } } while (0)
+#else
+#define BQ_DECL
+#define BQ_START
+#define BQ_CLOSE(acc)
+#define BQ_WAITVM
+#define BQ_WAITLGKM
+#define BQ_DUMP
+#endif
+
+// wave priority of the matrix phases (build-time experiment: -DPOPCORN_BWD_PRIO=n)
+#ifndef POPCORN_BWD_PRIO
+#define POPCORN_BWD_PRIO 0
+#endif
+#if POPCORN_BWD_PRIO
+#define S3_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define S3_PRIO(n)
+#endif
+
+template <int GC>
+struct S3Cfg {
+    static constexpr int NG = GC / 8;
+    static constexpr int BSL = 35;                             // slots per strip row: slot s = pixel x0 - 1 + s (34 used)
+    static constexpr int IMG = SROWS * BSL * 16;               // bytes of one 8-channel plane image
+    static constexpr int PLANE = (NG + 1) * IMG;               // one split plane of a wave: NG images of g, one of x
+    static constexpr int WAVE_B = 3 * PLANE;
+    static constexpr int BW_CO = NG * 24, BW_DYS = 8 * BW_CO;  // weight image of one plane: [dy plane 0..3][x channel][g chunk][dx][8 g ch] bf16
+    static constexpr int WPL = 4 * BW_DYS * 2;                 // ... in bytes (prologue only: it overlays the strip images)
+    static constexpr int NBLK = 6;                             // weight-gradient accumulator blocks per 8 g channels: [dx][2 halves of x's channels]
+    static constexpr int EC = GC * 72 + GC;
+    static constexpr size_t RED_B = (size_t)4 * NBLK * 256 * sizeof(float);
+    static constexpr size_t LDS_B = (size_t)4 * WAVE_B > RED_B ? (size_t)4 * WAVE_B : RED_B;
+    static_assert(3 * WPL <= 4 * WAVE_B, "the prologue's weight image overlays the strip images");
+    static constexpr int WAVES_PER_SIMD = (size_t)2 * LDS_B <= 160 * 1024 ? 2 : 1;
+};
+
+// a wave-uniform value the compiler must keep in a scalar register: without this hipcc re-loads kernel-argument fields (descriptor
+// pointers, strides, flags) with s_load + s_waitcnt at every use inside the strip loop -- four dependent scalar-memory round trips per
+// epilogue, 1,800 cycles per strip in the first version of this kernel (profiles/r6_conv_bwd_s3_phases.json)
+template <typename T>
+__device__ __forceinline__ T s3_pin(T v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// ... and a pinned base pointer that keeps the GLOBAL address space (a pointer that went through the asm as a generic one comes back as
+// flat_load / flat_store, which count on vmcnt AND lgkmcnt: every LDS wait then drains the prefetch)
+typedef __attribute__((address_space(1))) char* s3_gptr;
+typedef __attribute__((address_space(1))) const f32x4* s3_gld4;
+typedef __attribute__((address_space(1))) f32x4* s3_gst4;
+__device__ __forceinline__ s3_gptr s3_pin_global(const void* ptr) {
+    uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    asm volatile("" : "+s"(v));
+    return (s3_gptr)v;
+}
+
+template <int GC, bool POOL>
+__global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3_kernel(const BwdArgs p) {
+    using Cfg = S3Cfg<GC>;
+    constexpr int NG = Cfg::NG, BSL = Cfg::BSL, IMG = Cfg::IMG, PLANE = Cfg::PLANE, NBLK = Cfg::NBLK, EC = Cfg::EC;
+    constexpr int BW_CO = Cfg::BW_CO, BW_DYS = Cfg::BW_DYS;
+    constexpr int SL0 = 1;                                                   // slot of pixel x0
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const BwdProb& q = p.pr[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int s_row = li >> 3, col = li & 7;
+    unsigned char* const wimg = ldsb + wave * Cfg::WAVE_B;                   // plane pl at wimg + pl * PLANE: g images, then the x image
+
+    // ---- wave-uniform descriptor fields, pinned in scalar registers for the whole kernel
+    const s3_gptr g_base = s3_pin_global(q.g.ptr), x_base = s3_pin_global(q.x.ptr), o_base = s3_pin_global(q.out.ptr);
+    const unsigned g_bs = s3_pin((unsigned)q.g.bstride), g_cs = s3_pin((unsigned)q.g.cstride * 4u), g_rs = s3_pin((unsigned)q.g.rstride);
+    const unsigned x_bs = s3_pin((unsigned)q.x.bstride), x_cs = s3_pin((unsigned)q.x.cstride * 4u), x_rs = s3_pin((unsigned)q.x.rstride);
+    const unsigned o_bs = s3_pin((unsigned)q.out.bstride), o_cs = s3_pin((unsigned)q.out.cstride), o_rs = s3_pin((unsigned)q.out.rstride);
+    const int H = s3_pin(p.H), W = s3_pin(p.W);
+    const int maskf = s3_pin(q.mask), accf = s3_pin(p.accumulate), dbg = s3_pin(p.dbg);
+    const s3_gptr a_base = s3_pin_global(POOL ? q.pool_act.ptr : q.x.ptr);
+    const unsigned a_bs = s3_pin((unsigned)(POOL ? q.pool_act.bstride : 0)), a_cs = s3_pin((unsigned)(POOL ? q.pool_act.cstride : 0)),
+                   a_rs = s3_pin((unsigned)(POOL ? q.pool_act.rstride : 0));
+
+    // ---- loader: lane = (row of the 6-row strip, 16-byte segment of the 40-float row x0 - 4 ..), both tensors.  Byte offsets inside a
+    //      tensor are 32-bit (the launcher checks the extents): one scalar base per channel + one vector offset per lane
+    const int l_r = lane / 10, l_seg = lane - l_r * 10;
+    const bool l_act = lane < 60;
+    f32x4 RG[GC], RX[8];
+    bool rvalid = false;
+    auto issue = [&](int b, int y0, int x0) {
+        const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
+        const bool ok = l_act && xg >= 0 && xg < W && (unsigned)y < (unsigned)H;
+        rvalid = ok;
+        const unsigned go = ok ? ((unsigned)b * g_bs + (unsigned)y * g_rs + (unsigned)xg) * 4u : 0u;
+        const unsigned xo = ok ? ((unsigned)b * x_bs + (unsigned)y * x_rs + (unsigned)xg) * 4u : 0u;
+#pragma unroll
+        for (int it = 0; it < GC; ++it) RG[it] = *(s3_gld4)(g_base + (size_t)(it * g_cs) + go);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) RX[it] = *(s3_gld4)(x_base + (size_t)(it * x_cs) + xo);
+    };
+    // split + transpose while staging: pixel e of the lane's four = slot 4 * l_seg + e - 3 of row l_r (the outer three pixels of the first and
+    // of the last segment are not part of the strip), its 8 channels = one 16-byte slot per plane
+    auto commit = [&]() {
+        // strips that touch the image border: zero what lies outside (wave-uniform test; interior strips skip the selects)
+        if (__builtin_amdgcn_ballot_w64(l_act && !rvalid) != 0) {
+#pragma unroll
+            for (int it = 0; it < GC; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) RG[it][e] = rvalid ? RG[it][e] : 0.f;
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) RX[it][e] = rvalid ? RX[it][e] : 0.f;
+        }
+        u32x4* const d0 = reinterpret_cast<u32x4*>(wimg) + l_r * BSL + 4 * l_seg - 3;
+#pragma unroll
+        for (int c = 0; c < NG + 1; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x4 q1, q2, q3;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float v0 = c < NG ? RG[(c < NG ? c : 0) * 8 + 2 * d][e] : RX[2 * d][e];
+                    const float v1 = c < NG ? RG[(c < NG ? c : 0) * 8 + 2 * d + 1][e] : RX[2 * d + 1][e];
+                    unsigned a1, a2, a3;
+                    pc_split_pair(v0, v1, a1, a2, a3);
+                    q1[d] = a1; q2[d] = a2; q3[d] = a3;
+                }
+                // e = 3 exists in every segment but the last, e = 0 in every segment but the first, e = 1, 2 in the inner ones
+                const bool w_ok = l_act && (e == 3 ? l_seg < 9 : (e == 0 ? l_seg > 0 : (l_seg > 0 && l_seg < 9)));
+                if (w_ok) {
+                    u32x4* d = d0 + c * (IMG / 16) + e;
+                    d[0] = q1;
+                    d[PLANE / 16] = q2;
+                    d[2 * (PLANE / 16)] = q3;
+                }
+            }
+    };
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        b = (int)pc_div((uint32_t)tile, p.div_tpi);
+        const int rem = tile - b * p.tiles_x * p.tiles_y;
+        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
+        x0 = (rem - ty * p.tiles_x) * TW;
+        y0 = ty * TH + 4 * wave;
+    };
+    int b = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) {
+        strip_coords(0, b, y0, x0);
+        issue(b, y0, x0);
+    }
+
+    // ---- data-gradient weights, split: "output" channel = x channel, K channel = g channel, taps flipped; three planes of
+    //      [dy plane 0..3][x ch][g chunk][dx][8 g ch] bf16, plane dy = 3 all zero (the (row, output row) pairs that are not a tap).  The image
+    //      lives where the strip images will (the first strip is still in registers) and only until the B fragments are read from it.
+    unsigned short* const w2h = reinterpret_cast<unsigned short*>(ldsb);
+    constexpr int NWR = (GC * 8 * 9 + 255) / 256;
+    float wreg[NWR];
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+        const int e = tid + k * 256;
+        const int ec = e < GC * 72 ? e : 0;
+        const int tap = ec % 9, gch = (ec / 9) % GC, xch = ec / (9 * GC);
+        wreg[k] = q.w[xch * 9 + gch * q.w_ci_stride + (8 - tap)];
+    }
+    float bn_g = 1.f, bn_v = 1.f;
+    if (maskf && q.bn.gamma) { bn_g = q.bn.gamma[col]; bn_v = q.bn.var[col]; }
+    for (int e = tid; e < 3 * 4 * BW_DYS / 2; e += 256) reinterpret_cast<unsigned*>(w2h)[e] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+        const int e = tid + k * 256;
+        if (e < GC * 72) {
+            const int tap = e % 9, gch = (e / 9) % GC, xch = e / (9 * GC);
+            const float a1 = pc_bf16r(wreg[k]), r1 = wreg[k] - a1, a2 = pc_bf16r(r1), a3 = r1 - a2;
+            const int o = (tap / 3) * BW_DYS + xch * BW_CO + (gch / 8) * 24 + (tap % 3) * 8 + (gch % 8);
+            w2h[o] = (unsigned short)(__float_as_uint(a1) >> 16);
+            w2h[4 * BW_DYS + o] = (unsigned short)(__float_as_uint(a2) >> 16);
+            w2h[8 * BW_DYS + o] = pc_f2bf(a3);
+        }
+    }
+    __syncthreads();
+    const float e_scale = (maskf && q.bn.gamma) ? bn_g * (1.0f / sqrtf(bn_v + q.bn.eps)) : 1.f;
+    asm volatile("" : : "v"(e_scale));
+    // B fragments of the data gradient, all planes, for the whole kernel: lane (n = (s_row, x channel col), K group lk = strip row)
+    bf16x8 wq[3][NG][3];
+    {
+        const unsigned short* const wlane = w2h + (((unsigned)(lk - s_row) <= 2u) ? lk - s_row : 3) * BW_DYS + col * BW_CO;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    wq[pl][gc][dx] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wlane + pl * 4 * BW_DYS + gc * 24 + dx * 8));
+    }
+    __syncthreads();                 // the weight image is dead from here on: the strip images take its place
+
+    // ---- weight-gradient reads (conv3x3_bwd_cl_kernel's): lane supplies pixel row j = li >> 2 and column quad tq = li & 3
+    const int t_j = li >> 2, t_q = li & 3;
+    const int a_off = ((1 + (t_q >> 1)) * BSL + SL0 + 8 * lk + t_j) * 16 + 8 * (t_q & 1);
+    const int b_off = (t_q * BSL + (SL0 - 1) + 8 * lk + t_j) * 16;
+    f32x4 wacc[NG][NBLK], bacc[NG];
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+#pragma unroll
+    for (int mb = 0; mb < NG; ++mb) {
+        bacc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) wacc[mb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* const ixb = wimg + NG * IMG;                       // plane 0 of the x image
+    // sign of the layer's input at the lane's output pixels: first split plane of the x image (rn_bf16 keeps sign and zero)
+    const unsigned short* const xs0 = reinterpret_cast<const unsigned short*>(ixb + ((1 + s_row) * BSL + SL0 + 4 * lk) * 16) + col;
+
+    BQ_DECL;
+    BQ_START;
+    for (int k = 0; k < my_tiles; ++k) {
+        BQ_WAITVM;
+        BQ_CLOSE(bq0);
+        if (!(dbg & 1)) commit();
+        BQ_WAITLGKM;
+        BQ_CLOSE(bq1);
+        int nb_ = b, ny0 = y0, nx0 = x0;
+        if (k + 1 < my_tiles) {
+            strip_coords(k + 1, nb_, ny0, nx0);
+            if (!(dbg & 8)) issue(nb_, ny0, nx0);
+        }
+        BQ_CLOSE(bq2);
+        // the mask operands of the epilogue, read ahead of the matrix phase
+        unsigned short xm[POOL ? 1 : 16];
+        if constexpr (!POOL) {
+            if (maskf) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xm[4 * u + r] = xs0[((u >> 1) * 2 * BSL + (u & 1) * 16 + r) * 8];
+            }
+        }
+        // ---- data gradient: a 3x3 conv over g, K = 4 rows x 8 channels per instruction, six partial products per K-step
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        S3_PRIO(POPCORN_BWD_PRIO);
+        if (!(dbg & 2))
+#pragma unroll
+        for (int gc = 0; gc < NG; ++gc)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 av[3][4];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const u32x4* lrow = reinterpret_cast<const u32x4*>(wimg + pl * PLANE + gc * IMG) + lk * BSL + (SL0 - 1) + li + dx;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[pl][u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSL + (u & 1) * 16]);
+                }
+#pragma unroll
+                for (int pw = 2; pw >= 0; --pw)               // weight split index; pixel split indices 2 - pw .. 0: smallest products first
+#pragma unroll
+                    for (int pa = 2 - pw; pa >= 0; --pa)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pa][u], wq[pw][gc][dx], acc[u], 0, 0, 0);
+            }
+        S3_PRIO(0);
+#ifdef POPCORN_BWD_PROF
+        asm volatile("" : : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+#endif
+        BQ_CLOSE(bq3);
+        // lane holds (x channel col, y = y0 + 2*(u>>1) + s_row, x = x0 + (u&1)*16 + 4*lk + r)
+        if (dbg & 16) {
+        } else if constexpr (POOL) {
+            // MaxPool2d(2) backward: the lane's four pooled pixels cover 8 x 2 full-resolution pixels = two 16-byte pieces per row of
+            // pool_act and of the accumulated output; the gradient goes to the first arg-max of every window
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int y = y0 + 2 * (u >> 1) + s_row, x = x0 + (u & 1) * 16 + 4 * lk;
+                if (y < H && x < W) {
+                    const f32x4 v = acc[u];
+                    const s3_gptr a0 = a_base + (size_t)(((unsigned)b * a_bs + (unsigned)col * a_cs + (unsigned)(2 * y) * a_rs + (unsigned)(2 * x)) * 4u);
+                    const s3_gptr o0 = o_base + (size_t)(((unsigned)b * o_bs + (unsigned)col * o_cs + (unsigned)(2 * y) * o_rs + (unsigned)(2 * x)) * 4u);
+                    f32x4 A[2][2], O[2][2];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            A[rr][h] = *(s3_gld4)(a0 + (size_t)((rr * a_rs + 4 * h) * 4u));
+                            O[rr][h] = *(s3_gld4)(o0 + (size_t)((rr * o_rs + 4 * h) * 4u));
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int h = r >> 1, e = (r & 1) * 2;
+                        const float w00 = A[0][h][e], w01 = A[0][h][e + 1], w10 = A[1][h][e], w11 = A[1][h][e + 1];
+                        int am = 0;
+                        float m = w00;
+                        if (w01 > m) { m = w01; am = 1; }
+                        if (w10 > m) { m = w10; am = 2; }
+                        if (w11 > m) { m = w11; am = 3; }
+                        const float gv = m > 0.f ? v[r] * e_scale : 0.f;
+                        O[0][h][e] += am == 0 ? gv : 0.f;
+                        O[0][h][e + 1] += am == 1 ? gv : 0.f;
+                        O[1][h][e] += am == 2 ? gv : 0.f;
+                        O[1][h][e + 1] += am == 3 ? gv : 0.f;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) *(s3_gst4)(o0 + (size_t)((rr * o_rs + 4 * h) * 4u)) = O[rr][h];
+                }
+            }
+        } else {
+            if (maskf) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned short h = xm[4 * u + r];
+                        acc[u][r] = (h != 0 && !(h & 0x8000u)) ? acc[u][r] * e_scale : 0.f;
+                    }
+            }
+            const unsigned ob = ((unsigned)b * o_bs + (unsigned)col * o_cs + (unsigned)(y0 + s_row) * o_rs + (unsigned)(x0 + 4 * lk)) * 4u;
+            const bool full = __builtin_amdgcn_readfirstlane((y0 + 4 <= H) && (x0 + TW <= W));
+            if (full) {
+                // interior strip: no bounds checks, four 16-byte stores from one base address
+                s3_gptr op[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) op[u] = o_base + (size_t)(ob + ((u >> 1) * 2 * o_rs + (u & 1) * 16) * 4u);
+                if (accf) {
+                    f32x4 o4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o4[u] = *(s3_gld4)op[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[u][r] += o4[u][r];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *(s3_gst4)op[u] = acc[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int y = y0 + 2 * (u >> 1) + s_row, x = x0 + (u & 1) * 16 + 4 * lk;
+                    if (y < H && x < W) {
+                        const s3_gptr op = o_base + (size_t)(ob + ((u >> 1) * 2 * o_rs + (u & 1) * 16) * 4u);
+                        f32x4 v = acc[u];
+                        if (accf) {
+                            const f32x4 o4 = *(s3_gld4)op;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                        }
+                        *(s3_gst4)op = v;
+                    }
+                }
+            }
+        }
+        BQ_CLOSE(bq4);
+        // ---- weight gradient of the strip: D_dx[(s,co)][(v,ci)] += sum_x g[co][y0+2rpi+s][x] * x[ci][y0+2rpi+v-1][x+dx-1]
+        //      three accumulator blocks (the dx of one half of x's channels) take turns: no instruction waits for its predecessor
+        S3_PRIO(POPCORN_BWD_PRIO);
+        if (!(dbg & 4))
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            bf16x8 av[NG][3];
+#pragma unroll
+            for (int mb = 0; mb < NG; ++mb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned char* ga = wimg + pl * PLANE + mb * IMG + 2 * rpi * BSL * 16 + a_off;
+                    av[mb][pl] = bw_pair(bw_tr(ga), bw_tr(ga + 4 * 16));
+                }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                bf16x8 bv[3][3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned char* xb = ixb + pl * PLANE + 2 * rpi * BSL * 16 + b_off + dx * 16 + 8 * nb;
+                        bv[dx][pl] = bw_pair(bw_tr(xb), bw_tr(xb + 4 * 16));
+                    }
+                if (nb == 0) {
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int mb = 0; mb < NG; ++mb) bacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][pl], ones8, bacc[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int pg = 2; pg >= 0; --pg)
+#pragma unroll
+                    for (int px = 2 - pg; px >= 0; --px)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int mb = 0; mb < NG; ++mb)
+                                wacc[mb][dx * 2 + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][pg], bv[dx][px], wacc[mb][dx * 2 + nb], 0, 0, 0);
+            }
+        }
+        S3_PRIO(0);
+#ifdef POPCORN_BWD_PROF
+#pragma unroll
+        for (int mb = 0; mb < NG; ++mb)
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) asm volatile("" : : "v"(wacc[mb][i]));
+#endif
+        BQ_CLOSE(bq5);
+        b = nb_; y0 = ny0; x0 = nx0;
+    }
+    BQ_DUMP;
+
+    // ---- cross-wave reduction through LDS (fixed order), one compacted partial per workgroup (conv3x3_bwd_cl_kernel's, XC = 8)
+    float* lds = reinterpret_cast<float*>(ldsb);
+    float* part = q.partial + (int64_t)blockIdx.x * EC;
+    auto wsum = [&](int e) { return ((lds[e] + lds[NBLK * 256 + e]) + lds[2 * NBLK * 256 + e]) + lds[3 * NBLK * 256 + e]; };
+#pragma unroll
+    for (int mb = 0; mb < NG; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) *reinterpret_cast<f32x4*>(&lds[((wave * NBLK + nb) * 64 + lane) * 4]) = wacc[mb][nb];
+        __syncthreads();
+        for (int idx = tid; idx < 8 * 72; idx += 256) {
+            const int c8 = idx / 72, rem = idx - c8 * 72;
+            const int cil = rem / 9, tap = rem - cil * 9, dy = tap / 3, dx = tap - dy * 3;
+            const int blk = dx * 2 + (cil >> 2);
+            const int n0 = 4 * dy + (cil & 3), n1 = n0 + 4;
+            const int m0 = c8, m1 = 8 + c8;
+            const int e0 = (blk * 64 + (m0 >> 2) * 16 + n0) * 4 + (m0 & 3);
+            const int e1 = (blk * 64 + (m1 >> 2) * 16 + n1) * 4 + (m1 & 3);
+            part[(mb * 8 + c8) * 72 + rem] = wsum(e0) + wsum(e1);
+        }
+    }
+    __syncthreads();
+    if (li == 0) {
+#pragma unroll
+        for (int mb = 0; mb < NG; ++mb) *reinterpret_cast<f32x4*>(&lds[(wave * NG + mb) * 16 + 4 * lk]) = bacc[mb];
+    }
+    __syncthreads();
+    if (tid < GC) {
+        const int mb = tid >> 3, c8 = tid & 7;
+        const int ea = mb * 16 + c8, eb = ea + 8;
+        const float sa = ((lds[ea] + lds[NG * 16 + ea]) + lds[2 * NG * 16 + ea]) + lds[3 * NG * 16 + ea];
+        const float sb = ((lds[eb] + lds[NG * 16 + eb]) + lds[2 * NG * 16 + eb]) + lds[3 * NG * 16 + eb];
+        part[GC * 72 + tid] = sa + sb;
+    }
+}
+
+template <int GC, bool POOL>
+int launch_bwd_s3(BwdArgs& p, int n, int* nwg_out, hipStream_t stream) {
+    using Cfg = S3Cfg<GC>;
+    static int resident = 0;
+    static pc_once_per_device once;
+    if (once.need()) {
+        const void* fn = reinterpret_cast<const void*>(&conv3x3_bwd_s3_kernel<GC, POOL>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_B);
+        if (e != hipSuccess) return (int)e;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        resident = pc_resident_workgroups(fa.numRegs, Cfg::LDS_B);
+        once.mark();
+        if (getenv("POPCORN_CONV_DBG"))
+            fprintf(stderr, "conv3x3_bwd_s3<%d,%d>: %d regs, %zu B LDS -> %d resident workgroups\n", GC, (int)POOL, fa.numRegs, (size_t)Cfg::LDS_B, resident);
+    }
+    int nwg = resident / n;
+    if (nwg > 512) nwg = 512;
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    if (nwg < 1) nwg = 1;
+    const int rounds = (p.ntiles + nwg - 1) / nwg;
+    nwg = (p.ntiles + rounds - 1) / rounds;
+    hipLaunchKernelGGL((conv3x3_bwd_s3_kernel<GC, POOL>), dim3(nwg, n), dim3(256), Cfg::LDS_B, stream, p);
+    PC_CHECK_LAUNCH();
+    *nwg_out = nwg;
+#ifdef POPCORN_BWD_PROF
+    if (getenv("POPCORN_BWD_PROF")) {
+        static long long hp[4096 * 8];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_bwd_prof), sizeof(hp));
+        double tot[6] = {0}, strips = 0;
+        const int nw = nwg * n * 4 < 4096 ? nwg * n * 4 : 4096;
+        for (int w = 0; w < nw; ++w) {
+            for (int k = 0; k < 6; ++k) tot[k] += (double)hp[w * 8 + k];
+            strips += (double)hp[w * 8 + 6];
+        }
+        fprintf(stderr, "conv3x3_bwd_s3<%d,%d> phases, cycles per strip and wave (load wait, split + LDS writes, prefetch issue, dgrad, epilogue, wgrad; %d waves, %.1f strips each):",
+                GC, (int)POOL, nw, strips / nw);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", tot[k] / strips);
+        fprintf(stderr, "\n");
+    }
+#endif
+    return 0;
+}
 }  // namespace
+
+static int g_bwd_dbg = 0;
+extern "C" void pc_debug_conv_bwd(int dbg) { g_bwd_dbg = dbg; }
 
 extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                                     int* nwg_out, void* stream) {
@@ -607,6 +1127,7 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     const bool f32 = g_pc_precision != PC_PREC_BF16;
     BwdArgs p{};
     int GC = 0, XC = 0;
+    bool use_s3 = true;
     for (int i = 0; i < n; ++i) {
         if (!d[i].g || !d[i].x || !d[i].w || !d[i].out || !d[i].ws) return PC_EINVAL;
         BwdProb& q = p.pr[i];
@@ -616,16 +1137,29 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         if (q.g.C != GC || q.x.C != XC || q.x.mode != PC_SRC_DIRECT || q.g.mode != PC_SRC_DIRECT || c0i < 0 || c0i + XC > Cin_total)
             return PC_EINVAL;
         if (f32) {
-            // planar fp32, 8 -> 8 channels, 16-byte aligned rows, x placed at (0, 0) with the extent of g
+            // planar fp32, 16-byte aligned rows, x (8 channels) placed at (0, 0) with the extent of g; 8 gradient channels, or -- split-operand
+            // form only -- 16, or the Down blocks' pool_act scatter
             auto al = [](const void* ptr, int64_t bs, int64_t cs, int rs) {
                 return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
             };
             const pc_dst& o = *d[i].out;
-            if (GC != 8 || XC != 8 || d[i].pool_act || W % 4 != 0 || q.g.dtype != PC_F32 || q.x.dtype != PC_F32 || o.dtype != PC_F32 ||
+            // (the split-operand kernel addresses with 32-bit byte offsets inside a tensor: extents beyond 4 GB keep the fp32-MFMA kernel)
+            auto fits32 = [&](int64_t bs) { return bs > 0 && (int64_t)B * bs < ((int64_t)1 << 30); };
+            bool s3 = pc_conv_split_on() != 0 && fits32(q.g.bstride) && fits32(q.x.bstride) && fits32(o.bstride) &&
+                      (!d[i].pool_act || fits32(d[i].pool_act->bstride));
+            use_s3 = use_s3 && s3;
+            if (!((GC == 8 && !d[i].pool_act) || (s3 && (GC == 8 || GC == 16))) || XC != 8 || W % 4 != 0 || q.g.dtype != PC_F32 ||
+                q.x.dtype != PC_F32 || o.dtype != PC_F32 ||
                 !pc_planar(q.g) || !pc_planar(q.x) || !pc_planar(o) || q.x.oy != 0 || q.x.ox != 0 || q.x.H != H || q.x.W != W ||
                 !al(q.g.ptr, q.g.bstride, q.g.cstride, q.g.rstride) || !al(q.x.ptr, q.x.bstride, q.x.cstride, q.x.rstride) ||
                 !al(o.ptr, o.bstride, o.cstride, o.rstride))
                 return PC_EINVAL;
+            if (d[i].pool_act) {
+                const pc_src& a = *d[i].pool_act;
+                // (the scatter always accumulates, as in bf16 mode)
+                if (a.dtype != PC_F32 || !pc_planar(a) || a.mode != PC_SRC_DIRECT || a.oy || a.ox || !al(a.ptr, a.bstride, a.cstride, a.rstride))
+                    return PC_EINVAL;
+            }
         } else if (!pc_cl_ok(q.g) || !pc_cl_ok(q.x) || !pc_cl_ok(*d[i].out)) {
             return PC_EINVAL;
         }
@@ -638,11 +1172,12 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
         if (d[i].pool_act) {
             // the scatter always accumulates and always applies the producer's ReLU / BN factor
             q.pool_act = *d[i].pool_act;
-            if (!pc_cl_ok(q.pool_act) || !d[i].x_bn || q.pool_act.C != XC || q.pool_act.H < 2 * H || q.pool_act.W < 2 * W) return PC_EINVAL;
+            if ((!f32 && !pc_cl_ok(q.pool_act)) || !d[i].x_bn || q.pool_act.C != XC || q.pool_act.H < 2 * H || q.pool_act.W < 2 * W) return PC_EINVAL;
         }
         q.partial = reinterpret_cast<float*>(d[i].ws);
     }
     p.accumulate = accumulate;
+    p.dbg = g_bwd_dbg;
     p.B = B; p.H = H; p.W = W;
     p.tiles_x = (W + TW - 1) / TW;
     p.tiles_y = (H + TH - 1) / TH;
@@ -651,7 +1186,11 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     p.div_tx = pc_make_fastdiv(p.tiles_x);
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     hipStream_t st = (hipStream_t)stream;
-    if (f32) return launch_bwd_f32(p, n, nwg_out, st);
+    if (f32) {
+        if (!use_s3) return launch_bwd_f32(p, n, nwg_out, st);
+        if (d[0].pool_act) return GC == 8 ? launch_bwd_s3<8, true>(p, n, nwg_out, st) : launch_bwd_s3<16, true>(p, n, nwg_out, st);
+        return GC == 8 ? launch_bwd_s3<8, false>(p, n, nwg_out, st) : launch_bwd_s3<16, false>(p, n, nwg_out, st);
+    }
     if (d[0].pool_act) {
         if (GC == 16 && XC == 8) return launch_bwd<16, 8, true>(p, n, nwg_out, st);
         if (GC == 16 && XC == 16) return launch_bwd<16, 16, true>(p, n, nwg_out, st);
@@ -661,4 +1200,29 @@ extern "C" int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_to
     if (GC == 8 && XC == 16) return launch_bwd<8, 16, false>(p, n, nwg_out, st);
     if (GC == 16 && XC == 16) return launch_bwd<16, 16, false>(p, n, nwg_out, st);
     return PC_EINVAL;
+}
+
+// fp32 mode: would pc_conv3x3_bwd_group take this problem?  (the executors ask before they choose between the fused launch and the
+// data-gradient + weight-gradient pair)
+extern "C" int pc_conv3x3_bwd_ok(const pc_src* g, const pc_src* x, const pc_dst* out, const pc_src* pool_act, int B, int H, int W) {
+    if (!g || !x || !out || g_pc_precision == PC_PREC_BF16) return 0;
+    auto al = [](const void* ptr, int64_t bs, int64_t cs, int rs) {
+        return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && bs % 4 == 0 && cs % 4 == 0 && rs % 4 == 0;
+    };
+    auto fits32 = [](int64_t bs, int B) { return bs > 0 && (int64_t)B * bs < ((int64_t)1 << 30); };
+    const bool s3 = pc_conv_split_on() != 0 && fits32(g->bstride, B) && fits32(x->bstride, B) && fits32(out->bstride, B) &&
+                    (!pool_act || fits32(pool_act->bstride, B));
+    if (!((g->C == 8 && !pool_act) || (s3 && (g->C == 8 || g->C == 16))) || x->C != 8 || W % 4 != 0) return 0;
+    if (g->dtype != PC_F32 || x->dtype != PC_F32 || out->dtype != PC_F32 || !pc_planar(*g) || !pc_planar(*x) || !pc_planar(*out)) return 0;
+    if (g->mode != PC_SRC_DIRECT || x->mode != PC_SRC_DIRECT || x->oy || x->ox || x->H != H || x->W != W) return 0;
+    if (!al(g->ptr, g->bstride, g->cstride, g->rstride) || !al(x->ptr, x->bstride, x->cstride, x->rstride) ||
+        !al(out->ptr, out->bstride, out->cstride, out->rstride))
+        return 0;
+    if (pool_act) {
+        const pc_src& a = *pool_act;
+        if (a.dtype != PC_F32 || !pc_planar(a) || a.mode != PC_SRC_DIRECT || a.oy || a.ox || a.C != 8 || a.H < 2 * H || a.W < 2 * W ||
+            !al(a.ptr, a.bstride, a.cstride, a.rstride))
+            return 0;
+    }
+    return 1;
 }

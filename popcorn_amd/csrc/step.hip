@@ -91,6 +91,7 @@ struct Step {
     pc_step_plan plan;
     pc_bn bn_nobias[2][PC_STEP_CONVS];          // trainable network: ReLU / BN factor of a layer's output (no conv bias)
     pc_bn bn_half[2][2];                        // d1b's factor for the two 8-channel halves of its output (pointers into the same BN tensors)
+    pc_bn bn_half_d1a[2][2];                    // ... and d1a's (the fused backward of d1b runs per 8-channel half of its input)
     float* ones2 = nullptr;                     // device {1, 1}: weights of the partial-logit sum
     // small regions: the frozen extractor's forward chain runs on a side stream next to the trainable U-Net's (two chains of ~13 small,
     // latency-bound launches each; at B = 64 tiles -- a full chip per launch -- every multi-stream attempt lost)
@@ -593,9 +594,9 @@ void backward(Step& X, pc_step_io& io) {
     const bool enc_ng = X.enc_ng;
 
     // data + weight gradient of an 8 -> 8 layer (or of an 8-channel column block of a wider one) in ONE launch, both streams
-    struct Blk { const Ten* g; const Ten* x; const pc_bn* x_bn; Ten* out; int L; int s; int c0_add; bool with_db; };
+    struct Blk { const Ten* g; const Ten* x; const pc_bn* x_bn; Ten* out; int L; int s; int c0_add; bool with_db; const Ten* pool_act = nullptr; };
     auto bwd8 = [&](const Blk* blk, int n, int cin_total, int h, int w) {
-        pc_src sg[MAXK], sx[MAXK];
+        pc_src sg[MAXK], sx[MAXK], spa[MAXK];
         pc_dst dout[MAXK];
         pc_conv_bwd_desc d[MAXK];
         void* ws[MAXK];
@@ -605,11 +606,21 @@ void backward(Step& X, pc_step_io& io) {
             memset(&d[i], 0, sizeof(d[i]));
             d[i].g = &sg[i]; d[i].x = &sx[i]; d[i].w = ST[blk[i].s].w[blk[i].L]; d[i].x_bn = blk[i].x_bn; d[i].out = &dout[i]; d[i].ws = ws[i];
             d[i].c0_add = blk[i].c0_add;
+            if (blk[i].pool_act) { spa[i] = S(*blk[i].pool_act); d[i].pool_act = &spa[i]; }     // Down block: scatter (+=) into the full-resolution gradient
         }
         int nwg = 0;
-        if (X.go()) X.rc(pc_conv3x3_bwd_group(n, d, cin_total, 0, 0, B, h, w, &nwg, X.st));
+        if (X.go()) X.rc(pc_conv3x3_bwd_group(n, d, cin_total, 0, blk[0].pool_act ? 1 : 0, B, h, w, &nwg, X.st));
         for (int i = 0; i < n; ++i)
-            entry(ws[i], ST[blk[i].s].dw[blk[i].L], blk[i].with_db ? ST[blk[i].s].db[blk[i].L] : nullptr, nwg, 8, 8, 0, cin_total * 9, blk[i].c0_add * 9);
+            entry(ws[i], ST[blk[i].s].dw[blk[i].L], blk[i].with_db ? ST[blk[i].s].db[blk[i].L] : nullptr, nwg, 8, blk[i].g->C, 0, cin_total * 9,
+                  blk[i].c0_add * 9);
+    };
+    // does the fused launch take this (gradient, input block, output, pooled-from) combination?  (split-operand form, aligned fp32 tensors)
+    auto bwd_ok = [&](const Ten& g, const Ten& x, const Ten& out, const Ten* pool_act, int h, int w) {
+        const pc_src sg = S(g), sx = S(x);
+        const pc_dst dout = D(out);
+        pc_src spa;
+        if (pool_act) spa = S(*pool_act);
+        return pc_conv3x3_bwd_ok(&sg, &sx, &dout, pool_act ? &spa : nullptr, B, h, w) != 0;
     };
     // The weight-gradient-only launches (16-channel encoder layers, first layers) run on the side stream next to the data-gradient chain:
     // they only feed the batched reduction at the end.  side_on(): everything enqueued on the caller's stream so far (the producers of the
@@ -875,14 +886,34 @@ void backward(Step& X, pc_step_io& io) {
             for (int s = 0; s < 2; ++s) q[s] = Dg{&G_c1[s], s, L_D2A, &sv[s].b2, &X.bn_nobias[s][L_D1B], &G_b2[s], 0};
             dgrad(q, 2, 16, 0, 16, 1, 1, H2, W2, 16);
         }
-        {
+        for (int s = 0; s < 2; ++s) G_b1[s] = A.act(B, 16, H1, W1);
+        // down1 (16 channels @ H1 x W1), round 6: data + weight gradient of each layer in ONE launch of the split-operand kernel -- d1b as the two
+        // 8-channel halves of its input over the same 16-channel gradient (two problems per stream), d1a with the max-pool scatter into
+        // inc2's gradient -- instead of four launches (weight gradient 16 -> 16, data gradient 16 -> 16, weight gradient 8 -> 16, pooled
+        // data gradient 16 -> 8)
+        bool fused_d1 = sv[0].pa2.ok() && 4 <= MAXK;
+        for (int s = 0; s < 2 && fused_d1; ++s) {
+            const Ten xh = chans(sv[s].b1, 8, 8), oh = chans(G_b1[s], 8, 8);
+            fused_d1 = bwd_ok(G_b2[s], xh, oh, nullptr, H1, W1) && bwd_ok(G_b1[s], sv[s].pa2, G_a2[s], &sv[s].a2, H1, W1);
+        }
+        if (fused_d1) {
+            Blk b[4];
+            Ten xh[2][2], oh[2][2];
+            for (int s = 0; s < 2; ++s)
+                for (int i = 0; i < 2; ++i) {
+                    xh[s][i] = chans(sv[s].b1, 8 * i, 8);
+                    oh[s][i] = chans(G_b1[s], 8 * i, 8);
+                    b[2 * s + i] = Blk{&G_b2[s], &xh[s][i], &X.bn_half_d1a[s][i], &oh[s][i], L_D1B, s, 8 * i, i == 0};
+                }
+            bwd8(b, 4, 16, H1, W1);
+            Blk a[2];
+            for (int s = 0; s < 2; ++s) a[s] = Blk{&G_b1[s], &sv[s].pa2, &X.bn_nobias[s][L_INC2], &G_a2[s], L_D1A, s, 0, true, &sv[s].a2};
+            bwd8(a, 2, 8, H1, W1);
+        } else {
             Ten x[2] = {sv[0].b1, sv[1].b1};
             wgrad(L_D1B, x, PC_SRC_DIRECT, nullptr, G_b2, 16, H1, W1, 0);
             Dg q[2];
-            for (int s = 0; s < 2; ++s) {
-                G_b1[s] = A.act(B, 16, H1, W1);
-                q[s] = Dg{&G_b2[s], s, L_D1B, &sv[s].b1, &X.bn_nobias[s][L_D1A], &G_b1[s], 0};
-            }
+            for (int s = 0; s < 2; ++s) q[s] = Dg{&G_b2[s], s, L_D1B, &sv[s].b1, &X.bn_nobias[s][L_D1A], &G_b1[s], 0};
             dgrad(q, 2, 16, 0, 16, 0, 0, H1, W1, 16);
             if (sv[0].pa2.ok()) {
                 Ten xa[2] = {sv[0].pa2, sv[1].pa2};
@@ -1042,6 +1073,9 @@ extern "C" void* pc_step_create(const pc_step_plan* plan) {
             pc_bn b = X->bn_nobias[s][L_D1B];
             if (b.gamma) { b.gamma += 8 * i; b.beta += 8 * i; b.mean += 8 * i; b.var += 8 * i; }
             X->bn_half[s][i] = b;
+            pc_bn a = X->bn_nobias[s][L_D1A];
+            if (a.gamma) { a.gamma += 8 * i; a.beta += 8 * i; a.mean += 8 * i; a.var += 8 * i; }
+            X->bn_half_d1a[s][i] = a;
         }
     }
     float one[2] = {1.f, 1.f};

@@ -445,12 +445,35 @@ class UNetEngine:
                 else:
                     wgs("d2a", "b2", G_c1, a_mode=L.PC_SRC_POOL2)
                 dg("d2a", G_c1, G_b2, 0, 16, {s: A[s]["b2"] for s in S}, "d1b", pool=True, acc=True)
+        G_b1 = {s: E(16, H1, W1) for s in S}
+        # fp32, round 6: down1's two layers through the split-operand fused backward (pc_conv3x3_bwd_group with 16 gradient channels: d1b as the
+        # two 8-channel halves of its input over the same gradient, d1a with the max-pool scatter) instead of four launches; same calls
+        # in the same order as the native executor (csrc/step.hip)
+        fused_d1 = FUSED_CONV_BWD and not bf and 2 * len(S) <= L.PC_MAX_GROUP and all(
+            A[s].get("pa2") is not None and ops.conv3x3_bwd_ok(G_b2[s], A[s]["b1"][:, 8:16], G_b1[s][:, 8:16]) and
+            ops.conv3x3_bwd_ok(G_b1[s], A[s]["pa2"], G_a2[s], pool_act=A[s]["a2"]) for s in S)
         if fuse:
-            G_b1 = bwd8("d1b", G_b2, "b1", "d1a", {s: E(16, H1, W1) for s in S}, cin_total=16)
+            bwd8("d1b", G_b2, "b1", "d1a", G_b1, cin_total=16)
+        elif fused_d1:
+            probs = []
+            for s in S:
+                lay = ly(s, "d1b")
+                for i in (0, 1):
+                    probs.append({"g": G_b2[s], "x": A[s]["b1"][:, 8 * i:8 * i + 8], "w": lay.w, "out": G_b1[s][:, 8 * i:8 * i + 8],
+                                  "dw": grads[prefix + lay.wname], "db": grads[prefix + lay.bname] if i == 0 else None,
+                                  "x_bn": ly(s, "d1a").bn_slice(8 * i, 8), "c0_add": 8 * i})
+            wb.conv3x3_bwd_group(probs, 16, 0)
         else:
             wgs("d1b", "b1", G_b2)
-            G_b1 = dg("d1b", G_b2, {s: E(16, H1, W1) for s in S}, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
-        if fuse and all(A[s].get("pa2") is not None for s in S):
+            dg("d1b", G_b2, G_b1, 0, 16, {s: A[s]["b1"] for s in S}, "d1a")
+        if fused_d1:
+            probs = []
+            for s in S:
+                lay = ly(s, "d1a")
+                probs.append({"g": G_b1[s], "x": A[s]["pa2"], "w": lay.w, "out": G_a2[s], "dw": grads[prefix + lay.wname],
+                              "db": grads[prefix + lay.bname], "x_bn": ly(s, "inc2").bn_nobias, "pool_act": A[s]["a2"]})
+            wb.conv3x3_bwd_group(probs, 8, 0, accumulate=True)
+        elif fuse and all(A[s].get("pa2") is not None for s in S):
             bwd8("d1a", G_b1, "pa2", "inc2", G_a2, cin_total=8, pool_key="a2")
         else:
             if all(A[s].get("pa2") is not None for s in S):

@@ -128,6 +128,17 @@ def conv3x3_dgrad_group(problems, c0, cn, pool=False, accumulate=False):
                                            L.stream_ptr()), "pc_conv3x3_dgrad_group")
 
 
+def conv3x3_bwd_ok(g, x, out, pool_act=None):
+    """fp32 mode: does the one-launch backward of a conv layer (WgradBatch.conv3x3_bwd_group) take this gradient / 8-channel input
+    block / output (and, for a Down block's first layer, the full-resolution activation the input was pooled from)?"""
+    if g.dtype != torch.float32:
+        return False
+    B, _, H, W = g.shape
+    sg, sx, d = L.src(g), L.src(x), L.dst(out)
+    spa = L.src(pool_act) if pool_act is not None else None
+    return bool(L.lib().pc_conv3x3_bwd_ok(C.byref(sg), C.byref(sx), C.byref(d), C.byref(spa) if spa is not None else None, B, H, W))
+
+
 def conv3x3_bn_relu(a, w, bias, gamma=None, beta=None, mean=None, var=None, eps=1e-5, relu=True, **kw):
     return conv3x3_raw(a, w, L.bn(bias, gamma, beta, mean, var, eps), relu=relu, **kw)
 

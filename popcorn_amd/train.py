@@ -339,7 +339,13 @@ class FusedTrainStep:
     def _native_handle(self):
         m = self.model
         engs = m.engines()
-        if self._native is not None and self._native[2] is engs:
+        # everything the C plan bakes in besides pointers: a trainer whose public attributes are reassigned after construction
+        # (raw_norm by bench.py / tools / tests, the loss weights by a schedule) must not keep stepping with the stale copy
+        band, mean, std = self.raw_norm
+        baked = (tuple(int(b) for b in band[:6]), tuple(float(v) for v in mean[:6]), tuple(float(v) for v in std[:6]),
+                 tuple(float(v) for v in self.lam4), float(self.lam_weak), float(self.sreg), float(self.clip or 0.0), float(self.wd),
+                 tuple(float(b) for b in self.betas), float(self.eps), int(m.p), int(bool(m.occupancymodel)))
+        if self._native is not None and self._native[2] is engs and self._native[6] == baked:
             return self._native[0]
         if self._native is not None:
             L.lib().pc_step_destroy(self._native[0])
@@ -395,7 +401,7 @@ class FusedTrainStep:
         h = L.lib().pc_step_create(C.byref(plan))
         if not h:
             raise L.PopcornHipError("pc_step_create failed")
-        self._native = (h, plan, engs, keep, ht, hg)
+        self._native = (h, plan, engs, keep, ht, hg, baked)
         return h
 
     def _native_io(self, s, sel, encoder_no_grad, unet_no_grad):
@@ -403,16 +409,32 @@ class FusedTrainStep:
         B, _, H, W = s[dk[0]].shape
         io = L.PcStepIo()
         io.B, io.H, io.W = B, H, W
+        # the executor takes raw device pointers: everything the per-launch engine checks tensor by tensor (device, dtype, layout) is
+        # checked here, so that a CPU tensor or a wrong dtype raises instead of faulting on the GPU / training on reinterpreted bytes
+        L.require_device(*(s[k] for k in dk), s["admin_mask"], s["census_idx"], s["y"])
+
+        def want(key, dtype, shape=None):
+            t = s[key]
+            if t.dtype != dtype or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
+                raise ValueError(f"{key}: expected a contiguous {dtype} tensor" + (f" of shape {shape}" if shape else "") +
+                                 f", got {t.dtype} {tuple(t.shape)}" + ("" if t.is_contiguous() else " (non-contiguous)"))
         if dk == ("raw_s2", "raw_s1"):
             if s["raw_s2"].shape[1] != 4 or s["raw_s1"].shape[1] != 2 or s["raw_s2"].dtype != torch.uint16:
                 raise ValueError("raw_s2 / raw_s1: the 4 selected S2 bands [R, G, B, NIR] as uint16 and the 2 S1 bands [VV, VH] as fp32")
+            want("raw_s2", torch.uint16, (B, 4, H, W))
+            want("raw_s1", torch.float32, (B, 2, H, W))
             io.data_kind, io.data, io.data2 = L.PC_DATA_SPLIT, s["raw_s2"].data_ptr(), s["raw_s1"].data_ptr()
         elif dk == ("raw",):
+            want("raw", torch.float32)
             io.data_kind, io.data, io.craw = L.PC_DATA_RAW, s["raw"].data_ptr(), s["raw"].shape[1]
         else:
             if s["input"].shape[1] != 6 or s["input"].dtype != torch.float32:
                 raise ValueError("input must be a (B, 6, H, W) fp32 tensor")
+            want("input", torch.float32, (B, 6, H, W))
             io.data_kind, io.data = L.PC_DATA_INPUT, s["input"].data_ptr()
+        want("census_idx", torch.int64, (B,))
+        want("y", torch.float32, (B,))
+        want("admin_mask", torch.float32, (B, H, W))
         io.admin_mask, io.census_idx, io.y = s["admin_mask"].data_ptr(), s["census_idx"].data_ptr(), s["y"].data_ptr()
         if sel.is_cuda:
             io.sel = sel.data_ptr()
@@ -429,8 +451,8 @@ class FusedTrainStep:
             if self._arena is not None:
                 io.arena, io.arena_bytes = self._arena.data_ptr(), self._arena.numel()
             rc = lib.pc_train_step(h, C.byref(io), phases, stream)
-            if rc != L.PC_ENOMEM:
-                break
+            if rc != L.PC_ENOMEM or not (phases & L.PC_STEP_FWD):
+                break               # (a backward / update phase never grows the arena: the forward's activations live in it)
             # the arena grows to what this geometry takes (+ 1/8: the next region is a little larger more often than not); the old one is
             # released to torch's stream-ordered allocator, so work still in flight on it finishes first
             self._arena = None

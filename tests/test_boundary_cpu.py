@@ -130,7 +130,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in popcorn_hip.h but not exported"
-    assert lib.pc_abi_version() == L.PC_ABI_VERSION == 8
+    assert lib.pc_abi_version() == L.PC_ABI_VERSION == 9
     assert isinstance(lib.pc_device_count(), int)
     assert lib.pc_error_string(-1).decode().startswith("invalid")
     # struct layouts agree with the header (sizes of the C structs, from the compiler)

@@ -3,8 +3,8 @@
 The composed ``Up`` convolutions re-associate the feature map by ~3e-7, which on the golden trajectory (fixture g5) flips one hidden
 unit of the head and puts one gradient tensor at 2.04e-4: the default path passes that fixture through the tie adjudication.  The
 LAYER-BY-LAYER path (``COMPOSED_UP = 0, FUSED_LEVEL2 = 0``: one launch per reference layer, same summation structure as the
-reference; with ``pc_set_head_split(0)`` = the head on fp32 MFMA fma chains too -- the default head kernels multiply through exact
-3-way bf16 operand splits, another association of the same sums) has no such tie on g5, so it is held to the FLAT bar here: 2e-4 on all 56 gradients and 1e-6 on the post-Adam
+reference; with ``pc_set_head_split(0)`` / ``pc_set_conv_split(0)`` = the head and the fused conv backward on fp32 MFMA fma chains too -- the default
+kernels multiply through exact 3-way bf16 operand splits, another association of the same sums) has no such tie on g5, so it is held to the FLAT bar here: 2e-4 on all 56 gradients and 1e-6 on the post-Adam
 parameters, no adjudication.  The same for BASELINE config[2] at full size (B = 64) against the oracle, and for the remaining
 corners of the switch matrix (``PADDED_INPUT = 0``, ``COMPOSED_UP = 0`` alone, ``FUSED_CONV_BWD = 0``) on a small training step."""
 import os
@@ -21,6 +21,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 class _HeadSplitState:
     pending = []
+    pending_conv = []
 
 
 @pytest.fixture(autouse=True)
@@ -29,6 +30,8 @@ def _restore_head_split():
     from popcorn_amd import _lib as L
     while _HeadSplitState.pending:
         L.lib().pc_set_head_split(_HeadSplitState.pending.pop())
+    while _HeadSplitState.pending_conv:
+        L.lib().pc_set_conv_split(_HeadSplitState.pending_conv.pop())
 
 
 def _switches(monkeypatch, **kw):
@@ -40,6 +43,8 @@ def _switches(monkeypatch, **kw):
     kw = dict(kw)
     if "HEAD_SPLIT" in kw:          # the head kernels' multiplication form (popcorn_hip.h: pc_set_head_split); restored by the autouse fixture
         _HeadSplitState.pending.append(L.lib().pc_set_head_split(int(kw.pop("HEAD_SPLIT"))))
+    if "CONV_SPLIT" in kw:          # ... and the fused conv backward's (pc_set_conv_split, round 6)
+        _HeadSplitState.pending_conv.append(L.lib().pc_set_conv_split(int(kw.pop("CONV_SPLIT"))))
     for k, v in kw.items():
         mod = E if hasattr(E, k) else T
         assert hasattr(mod, k)
@@ -51,7 +56,7 @@ def test_g5_reference_gradients_and_adam_on_the_layerwise_path_flat_bar(monkeypa
     from torch.nn.utils import clip_grad_norm_
     from popcorn_amd.model import POPCORN
     from popcorn_amd.utils.losses import get_loss
-    _switches(monkeypatch, COMPOSED_UP=False, FUSED_LEVEL2=False, HEAD_SPLIT=False)
+    _switches(monkeypatch, COMPOSED_UP=False, FUSED_LEVEL2=False, HEAD_SPLIT=False, CONV_SPLIT=False)
     g = np.load(os.path.join(G, "g5_train.npz"))
     torch.manual_seed(1600)
     m = POPCORN(input_channels=6, feature_extractor="DDA", occupancymodel=True, pretrained=True, biasinit=0.9407,
@@ -94,7 +99,7 @@ def test_g5_reference_gradients_and_adam_on_the_layerwise_path_flat_bar(monkeypa
 def test_config3_batch64_gradients_vs_oracle_on_the_layerwise_path_flat_bar(monkeypatch):
     from popcorn_amd.data.synthetic import make_raw_batch
     from tests.test_gpu_sizes import _fresh_trainer
-    _switches(monkeypatch, COMPOSED_UP=False, FUSED_LEVEL2=False, HEAD_SPLIT=False)
+    _switches(monkeypatch, COMPOSED_UP=False, FUSED_LEVEL2=False, HEAD_SPLIT=False, CONV_SPLIT=False)
     batch = make_raw_batch(64, 100, 100, seed=1603, region="disc")
     x = O.select_normalize(batch["raw"])
     cpu = {"input": x, "admin_mask": batch["admin_mask"], "census_idx": batch["census_idx"], "y": batch["y"]}
@@ -118,6 +123,8 @@ def test_config3_batch64_gradients_vs_oracle_on_the_layerwise_path_flat_bar(monk
                                     dict(NATIVE_STEP=False),              # every engine switch at its default, per-launch engine
                                     dict(HEAD_SPLIT=False),               # the head kernels on fp32 MFMA (native executor)
                                     dict(HEAD_SPLIT=False, NATIVE_STEP=False),
+                                    dict(CONV_SPLIT=False),               # the fused conv backward on fp32 MFMA, down1 as four launches
+                                    dict(CONV_SPLIT=False, HEAD_SPLIT=False, NATIVE_STEP=False),
                                     dict()])                              # ... and the native executor (pc_train_step)
 @pytest.mark.parametrize("shape", [(3, 100, 100), (2, 64, 48)])
 def test_training_step_under_every_engine_switch_vs_oracle(monkeypatch, switch, shape):

@@ -67,7 +67,7 @@ def parse():
                          "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
     ap.add_argument("--extras-multi", action="store_true",
                     help="N > 1: also run the `bf16` and `h2d` legs (default: skipped, the multi-GPU run stays under two minutes)")
-    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `grad_parity`, `config3_regions`, `config5`")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `grad_parity`, `config3_regions`, `config3_epoch`, `config5`")
     ap.add_argument("--soak-steps", type=int, default=1500)
     ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed steps in front of the W warm-up steps until this much wall time has passed: the part's clocks settle "
@@ -250,8 +250,9 @@ def _head_bwd_in_replayed_step(torch, trainer, sample, reps):
     return statistics.median([e0.elapsed_time(e1) for e0, e1 in ev[3:]]) * 1e-3
 
 
-def dominant_kernel_roofline(torch, trainer, sample, reps=10):
-    """`head_bwd_pc_kernel`, the kernel with the largest share of the step (profiles/r*_kernel_stats.csv): backward of the
+def head_bwd_roofline(torch, trainer, sample, reps=10):
+    """`roofline_head` (round 6: `roofline` is the fused conv backward, the top row of the tracked kernel stats by share).
+    `head_bwd_pc_kernel`, the largest SINGLE launch of the step (profiles/r*_kernel_stats.csv): backward of the
     sparse 16-64-64-64-1 head.  Timed live between two events on the launch stream, inside `reps` eager train steps on the
     step's real tensors (the call = weight-image pack + the kernel + its small reduce launch).  ALGORITHMIC flops per launch = 37,376 per
     selected pixel (data + weight gradients).  The kernel also recomputes the forward chain in registers
@@ -327,29 +328,127 @@ def dominant_kernel_roofline(torch, trainer, sample, reps=10):
         pmc = (_pmc("r5_pmc_head_bwd_bf16.json") or _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or
                _pmc("r2_pmc_head_bwd_bf16.json"))
         traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
-    return {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call",
-            "achieved": round(achieved, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic,
+    base = {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call", "unit": "TFLOP/s", "traffic": traffic,
             "launch_us": round(dur * 1e6, 2), "launch_us_eager_step": round(dur_eager * 1e6, 2),
             # STATIC fields: the tracked rocprofv3 average of this kernel, reported only when the tracked profile was collected from THIS
             # tree's kernel sources (stamp); the live measurement of the run is `launch_us` / `frac`
             "rocprof_us": rp_us, "rocprof_file": rp_file, "rocprof_stamp_matches_tree": rp_match,
-            "rocprof_frac": (round(flops / (rp_us * 1e-6) / peak, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
             "timed": ("graph replay of the step split at the call (events around the middle graph)" if dur_graph else
                       "eager steps, events around the call behind a device-side spin"),
             "alg_flop_per_launch": flops, "units_per_launch": nsel,
             "unit_def": f"selected pixel, {FLOP_HEAD_BWD_PX} flop (SURVEY.md 8d head backward)",
-            "executed_mfma_view": ({"flop_per_unit": 6 * (FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX),
-                                    "achieved_tflops": round(6 * issued / dur / 1e12, 3), "peak": BF16_MATRIX_PEAK / 1e12,
-                                    "frac": round(6 * issued / dur / BF16_MATRIX_PEAK, 4),
-                                    "note": "what the bf16 matrix pipe executes: six bf16 partial products per fp32 product, the forward chain "
-                                            "recomputed in registers included -- against the bf16 peak; `frac` above is the ALGORITHMIC fp32 work "
-                                            "against the fp32 matrix peak (the arithmetic type of the results)"} if split else
-                                   {"flop_per_unit": FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX,
-                                    "achieved_tflops": round(issued / dur / 1e12, 3),
-                                    "frac": round(issued / dur / peak, 4),
-                                    "note": "includes the forward chain recomputed in registers (not algorithmic work)"}),
             "alg_bytes_per_launch": nsel * (16 * esz + 4 + 4 + 1) + B * 16 * (H + 28) * (W + 28) * esz}
+    if split:
+        # The split form runs on the bf16 matrix pipe: `achieved` / `peak` / `frac` are what THAT pipe executes (six bf16 partial products
+        # per fp32 product, the forward chain recomputed in registers included) against ITS dense peak -- never a figure above 1 against a
+        # peak the kernel does not run on.  The algorithmic fp32 work is reported beside it, against the method's
+        # own ceiling (bf16 peak / 6) and, for continuity with rounds 1-5, against the fp32 matrix peak.
+        executed = 6 * issued
+        base.update({"pipe": "bf16", "achieved": round(executed / dur / 1e12, 3), "peak": BF16_MATRIX_PEAK / 1e12,
+                     "frac": round(executed / dur / BF16_MATRIX_PEAK, 4), "pipe_frac": round(executed / dur / BF16_MATRIX_PEAK, 4),
+                     "executed_flop_per_launch": executed,
+                     "alg_tflops": round(achieved, 3), "alg_ceiling_tflops": round(BF16_MATRIX_PEAK / 6 / 1e12, 1),
+                     "alg_frac_of_ceiling": round(achieved * 1e12 / (BF16_MATRIX_PEAK / 6), 4),
+                     "alg_frac_of_fp32_matrix_peak": round(achieved * 1e12 / FP32_MATRIX_PEAK, 4),
+                     "rocprof_frac": (round(executed / (rp_us * 1e-6) / BF16_MATRIX_PEAK, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
+                     "rocprof_alg_frac_of_fp32_matrix_peak": (round(flops / (rp_us * 1e-6) / FP32_MATRIX_PEAK, 4)
+                                                               if rp_us and (B, H, W) == (64, 100, 100) else None)})
+    else:
+        base.update({"pipe": "bf16" if bf else "fp32", "achieved": round(achieved, 3), "peak": peak / 1e12,
+                     "frac": round(achieved * 1e12 / peak, 4),
+                     "rocprof_frac": (round(flops / (rp_us * 1e-6) / peak, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
+                     "executed_mfma_view": {"flop_per_unit": FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX, "achieved_tflops": round(issued / dur / 1e12, 3),
+                                            "frac": round(issued / dur / peak, 4),
+                                            "note": "includes the forward chain recomputed in registers (not algorithmic work)"}})
+    return base
+
+
+def fused_conv_bwd_roofline(torch, trainer, sample, reps=8):
+    """`roofline` (fp32 line, round 6): the kernel with the LARGEST SHARE of the step in the tracked rocprofv3 summary --
+    `conv3x3_bwd_s3_kernel<8, false>`, data + weight + bias gradient of an 8 -> 8 conv layer in one launch (five launches per step: up1b,
+    the skip block of up1a, inc2 at 128 x 128, up2b and the two skip halves of up2a at 64 x 64; networks.py:259-266,318 backward).  With its
+    operands split into three bf16 planes (6 x 16 matrix cycles per 32 K-slots) the kernel sits BELOW the ridge of the pipe it runs on
+    (24 flop per byte against 2517 / 6 / 8 = 52): bound = hbm.  `achieved` = ALGORITHMIC bytes of the step's five launches (every distinct
+    gradient / input / output tensor once) / their summed durations, timed live: eager train steps through the per-launch engine (same
+    kernels as the captured step), two events around every launch behind a device-side spin.  `mfma_view`: the same launches as matrix
+    work (executed = 6 partial products per product + the bias-gradient column, against the bf16 dense peak; algorithmic against the
+    method's ceiling bf16 / 6)."""
+    from popcorn_amd import ops, _lib as L
+    if trainer.model.precision != "fp32" or not L.lib().pc_get_conv_split():
+        return None
+    spin = _spin_cycles(torch)
+    rec = []
+    orig = ops.WgradBatch.conv3x3_bwd_group
+
+    def timed(self, problems, cin_total, c0, accumulate=False):
+        g0 = problems[0]["g"]
+        mine = g0.shape[1] == 8 and problems[0].get("pool_act") is None and g0.dtype == torch.float32
+        if not mine:
+            return orig(self, problems, cin_total, c0, accumulate=accumulate)
+        uniq = {}
+        for pr in problems:
+            for k in ("g", "x", "out"):
+                uniq[pr[k].data_ptr()] = pr[k].numel() * 4
+        B, _, H, W = g0.shape
+        torch.cuda._sleep(spin)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        r = orig(self, problems, cin_total, c0, accumulate=accumulate)
+        t1.record()
+        rec.append((t0, t1, sum(uniq.values()), len(problems) * B * H * W, f"{len(problems)}x{B}x{H}x{W}"))
+        return r
+    saved_graph, saved_reducer = trainer.use_graph, trainer.reducer
+    snap = (trainer.flat_p.clone(), trainer.m.clone(), trainer.v.clone(), trainer.step_count.clone())
+    ops.WgradBatch.conv3x3_bwd_group = timed
+    trainer.use_graph = False
+    trainer.reducer = _LocalReducer()
+    trainer._native_ok = lambda s: False      # the per-launch engine (same kernels, same order as the native executor)
+    try:
+        for r in range(reps + 2):
+            torch.manual_seed(1)
+            trainer.step(sample)
+        torch.cuda.synchronize()
+    finally:
+        ops.WgradBatch.conv3x3_bwd_group = orig
+        del trainer._native_ok
+        trainer.use_graph, trainer.reducer = saved_graph, saved_reducer
+        trainer.flat_p.copy_(snap[0]); trainer.m.copy_(snap[1]); trainer.v.copy_(snap[2]); trainer.step_count.copy_(snap[3])
+    per_step = len(rec) // (reps + 2)
+    if per_step == 0:
+        return None
+    rec = rec[2 * per_step:]
+    steps = [rec[i * per_step:(i + 1) * per_step] for i in range(reps)]
+    tot = [sum(t0.elapsed_time(t1) for t0, t1, *_ in st) * 1e-3 for st in steps]
+    dur = statistics.median(tot)                                      # seconds for the step's launches of this kernel
+    nbytes = float(sum(b for _, _, b, _, _ in steps[0]))
+    px = float(sum(n for *_, n, _ in steps[0]))
+    alg_flop = px * 2.0 * (2 * 9 * 8 * 8)                             # data + weight gradient, 2 flop per MAC
+    # executed on the bf16 pipe per 128-pixel strip: 150 instructions of 16 x 16 x 32 (72 data gradient incl. the zero tap plane, 72 weight
+    # gradient, 6 bias column) = 150 * 16384 flop
+    executed = px / 128.0 * 150.0 * 16384.0
+    pmc = _pmc("r6_pmc_conv_bwd.json")
+    B, _, H, W = sample["input"].shape
+    traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
+    rp_us, rp_file, rp_match = _rocprof_avg_us("conv3x3_bwd_s3_kernel<8, false>", "fp32")
+    n = per_step
+    return {"bound": "hbm",
+            "kernel": "conv3x3_bwd_s3_kernel<8, false> (data + weight + bias gradient of an 8 -> 8 conv layer in one launch; fp32 tensors, operands "
+                      "split exactly into three bf16 planes once per strip while it is staged into LDS, six partial products per product on "
+                      "v_mfma_f32_16x16x32_bf16, fp32 accumulation) -- the top row of the tracked kernel stats by share: "
+                      f"{n} launches per step ({', '.join(lbl for *_, lbl in steps[0])})",
+            "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
+            "traffic": traffic, "launches_per_step": n,
+            "launch_us": round(dur / n * 1e6, 2), "alg_bytes_per_launch": nbytes / n, "alg_flop_per_launch": alg_flop / n,
+            "units_per_launch": px / n, "unit_def": "pixel of an 8 <-> 8 layer: 96 algorithmic bytes (gradient + input + data gradient, 8 fp32 "
+                                                    "channels each), 2,304 flop (SURVEY.md 8d: 1,152 per pixel and pass)",
+            "rocprof_us": rp_us, "rocprof_file": rp_file, "rocprof_stamp_matches_tree": rp_match,
+            "rocprof_frac": (round(nbytes / n / (rp_us * 1e-6) / HBM_PEAK, 4) if rp_us and (B, H, W) == (64, 100, 100) else None),
+            "timed": "eager steps of the per-launch engine, events around every launch of the kernel behind a device-side spin; mean launch of the step",
+            "mfma_view": {"pipe": "bf16", "executed_tflops": round(executed / dur / 1e12, 2), "peak": BF16_MATRIX_PEAK / 1e12,
+                          "pipe_frac": round(executed / dur / BF16_MATRIX_PEAK, 4), "alg_tflops": round(alg_flop / dur / 1e12, 2),
+                          "alg_ceiling_tflops": round(BF16_MATRIX_PEAK / 6 / 1e12, 1),
+                          "alg_frac_of_ceiling": round(alg_flop / dur / (BF16_MATRIX_PEAK / 6), 4),
+                          "flop_per_byte": round(alg_flop / nbytes, 1), "ridge_flop_per_byte": round(BF16_MATRIX_PEAK / 6 / HBM_PEAK, 1)}}
 
 
 def conv_kernel_roofline(torch, B, reps=5, nsets=4):
@@ -876,6 +975,62 @@ def config3_regions_leg(torch, margs, dev, steps=10, blocks=5):
             "frac_of_fp32_mfma_peak": round(tot_fl / tot_t / FP32_MATRIX_PEAK, 4), "peak_hbm_gib": round(peak, 2), "batches": rows}
 
 
+def config3_epoch_leg(torch, dev, regions=256, hw=(150, 700), workers=0):
+    """BASELINE config 3 END TO END: the trainer counterpart's own loop (popcorn_amd.cli.Trainer.train = run_train.py:146-269) over
+    `regions` synthetic census regions through the DataLoader -- collate (zero-padding to the batch maximum), pinned staging, the
+    one-batch-ahead copy stream (data/feed.py: RegionFeed), the one-launch augmentation (pc_augment_raw, coins drawn with the reference's
+    generators), the native executor with the normalisation inside its ingest -- timed over a whole epoch (the epoch before it is untimed:
+    worker start-up, per-worker sample caches, arena growth), next to the SAME batches already prepared and resident on the device."""
+    import tempfile
+    from popcorn_amd.cli import Trainer, limit_regime, prepare_sample_fused, train_parser
+    from popcorn_amd.data.feed import RegionFeed
+    tmp = tempfile.mkdtemp(prefix="pc_epoch_")
+    argv = (f"-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-4 --synthetic_regions {regions} -wb 2 --save_dir {tmp} "
+            f"-lt 1000000 -val 1000000 -e 1 --synthetic_hw_range {hw[0]} {hw[1]} --save-model no -w {workers}").split()
+    t = Trainer(train_parser().parse_args(argv))
+    a = t.args
+    t.train()                                   # epoch 0: untimed
+    torch.cuda.synchronize()
+    a.num_epochs = 2
+    native0, it0 = t.fused.native_steps, t.info["iter"]
+    t0 = time.perf_counter()
+    t.train()                                   # epoch 1: timed, loader -> collate -> feed -> augment -> step
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = t.info["iter"] - it0
+    # the same epoch's batches, prepared and resident: what the executor alone takes on this geometry mix
+    staged, px = [], 0
+    for smp in RegionFeed(t.loader, dev):
+        s = prepare_sample_fused(smp, t.data_transform)
+        n = s["raw"].shape[0] * s["raw"].shape[2] * s["raw"].shape[3]
+        staged.append((s, limit_regime(n, a.limit1, a.limit2, a.limit3)))
+        px += n
+    for s, (e, u, k) in staged[:3]:
+        t.fused.step(s, encoder_no_grad=e, unet_no_grad=u)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for s, (e, u, k) in staged:
+        if not k:
+            t.fused.step(s, encoder_no_grad=e, unet_no_grad=u)
+    torch.cuda.synchronize()
+    dr = time.perf_counter() - t1
+    loss = float(t.fused.loss_out[0].item())
+    if not (loss == loss) or abs(loss) == float("inf"):
+        raise SystemExit("config3_epoch: non-finite loss")
+    res = {"workload": f"Trainer.train() (run_train.py loop counterpart) over {regions} synthetic census regions of {hw[0]}..{hw[1]} px sides, "
+                       f"weak_batch_size 2, augmentations on, DataLoader (num_workers = {workers}) pulled by the feed's producer thread, pinned staging ring, copy "
+                       "stream, one-launch augmentation, native executor (raw input form: normalisation inside the step); second epoch timed",
+           "steps": steps, "native_executor_steps": t.fused.native_steps - native0, "regions_per_s": round(2 * steps / dt, 1),
+           "Mpx_per_s": round(px / dt / 1e6, 1), "ms_per_step": round(dt / max(steps, 1) * 1e3, 3),
+           "resident": {"ms_per_step": round(dr / max(len(staged), 1) * 1e3, 3), "Mpx_per_s": round(px / dr / 1e6, 1)},
+           "ratio_to_resident": round(dr / dt, 3)}
+    if getattr(t.loader, "_iterator", None) is not None:
+        t.loader._iterator._shutdown_workers()
+    del t, staged
+    torch.cuda.empty_cache()
+    return res
+
+
 def h2d_leg(torch, trainer, sample, batch, band_sel, nsteps, label):
     """The train step with every batch coming from PINNED HOST memory.  The loader owns TWO static sets of the trainer
     (`static_buffers(slot=0 / 1)`: raw tile + one packed buffer {admin_mask, y, census_idx}), each captured into its own graph: a copy
@@ -1201,7 +1356,10 @@ def main():
         }
         from popcorn_amd import _lib as L
         with L.precision(args.precision):
-            res["roofline"] = dominant_kernel_roofline(torch, trainer, sample)
+            res["roofline_head"] = head_bwd_roofline(torch, trainer, sample)
+            # `roofline` = the kernel with the largest share of the step in the tracked rocprofv3 summary: the fused conv backward in the
+            # fp32 step; in bf16 mode (and with the split form switched off) the head backward, as before
+            res["roofline"] = fused_conv_bwd_roofline(torch, trainer, sample) or res["roofline_head"]
             res["roofline_conv"] = conv_kernel_roofline(torch, B)
         if world == 1 and not args.no_class_sweep:
             res["roofline_conv_class"] = conv_class_sweep(torch, trainer, sample)
@@ -1218,6 +1376,7 @@ def main():
             del trainer, model
             torch.cuda.empty_cache()
             res["config3_regions"] = config3_regions_leg(torch, margs, dev)
+            res["config3_epoch"] = config3_epoch_leg(torch, dev)
             res["config5"] = config5_leg(torch, margs, dev)
     else:
         res = None

@@ -8,7 +8,10 @@
  * entry point below cites the reference op it replaces.  Conventions:
  *   - plain C, device pointers + sizes only, no torch types;
  *   - every function enqueues on the hipStream_t passed as `void* stream` (0 = the null stream),
- *     never synchronises, and returns 0 or a hipError_t / negative PC_E* code;
+ *     never synchronises, and returns 0 or a hipError_t / negative PC_E* code -- with ONE exception: pc_train_step, the eager
+ *     whole-step executor, measures on its FIRST call per caller stream which of its side streams runs beside that stream (one host
+ *     synchronisation, ~3 ms, cached per stream) and forks / joins through events of its own; it cannot be called while `stream` is
+ *     being captured (PC_ENOTSUP) -- captured steps are built from the per-launch entry points;
  *   - tensors are NCHW, described by pc_src / pc_dst (strides in ELEMENTS; element type = `dtype`: fp32, or bf16 for the
  *     activation / activation-gradient tensors of PC_PREC_BF16); parameters, weight gradients and scalars are always fp32;
  *   - pointers are borrowed for the duration of the enqueued work only.
@@ -540,6 +543,16 @@ int pc_adam_clip_step_fused(float* p, const float* g, float* m, float* v, int n,
 int pc_select_normalize(const float* raw, int Craw, const int* band6, const float* mean6, const float* std6,
                         float* out, int B, int H, int W, void* stream);
 
+/* The trainer's augmentations applied in ONE pass while the raw 6-channel tile is assembled (run_train.py:386-402, utils/transform.py:
+ * RandomBrightness / RandomGamma on the 4 Sentinel-2 bands, then vertical flip, horizontal flip and a rotation by rot quarter turns
+ * counter-clockwise, jointly on input and admin_mask; one coin per batch, drawn by the caller with the reference's generators):
+ *   raw[b] = rot90^rot(hflip(vflip(cat[aug(s2[b]), s1[b]]))),   admin_out[b] = the same geometric map of admin[b]
+ * s2 (B, 4, H, W) digital numbers, s1 (B, 2, H, W), admin (B, H, W), all fp32; raw (B, 6, Ho, Wo), admin_out (B, Ho, Wo) with
+ * (Ho, Wo) = (W, H) for odd rot.  bright / gam: apply x -> clamp(x / 1e4 * beta, 0, 1) * 1e4, then x -> clamp((max(x, 0) / 1e4)^gamma, 0, 1) * 1e4.
+ * Replaces apply_transformations_and_normalize's augmentation half (utils/utils.py:130-214); the normalisation is the step's ingest. */
+int pc_augment_raw(const float* s2, const float* s1, const float* admin, float* raw, float* admin_out, int B, int H, int W,
+                   int vflip, int hflip, int rot, int bright, float beta, int gam, float gamma, void* stream);
+
 /* ---- native executor of ONE training step: the body of the reference's inner loop (run_train.py:186-238) as one call -----------
  *   forward(train, padding=False, sparse=True) (popcorn.py:100-193) -> get_loss (utils/losses.py:49-76) -> x lam_weak -> backward
  *   -> clip_grad_norm_ -> Adam step -> zero_grad
@@ -639,6 +652,11 @@ int pc_census_adjust(float* pred, const int32_t* boundary, int64_t n, int num_id
 int pc_stitch_accumulate(const float* popdense, const float* scale, int M, int ps_y, int ps_x, int overlap, int yl, int xl,
                          float* out_sum, float* out_sq, float* scale_sum, float* scale_sq, int16_t* count, int H, int W,
                          void* stream);
+/* The visit counts of nwin windows that OTHER ranks computed (sharded sliding-window inference: every rank needs the complete count map,
+ * run_eval.py:140-154), in one pass: count[r][c] += M for every window whose interior rows [x0, x1) x columns [y0, y1) cover (r, c).
+ * win: DEVICE array of nwin x {x0, x1, y0, y1} (already clipped to the raster); overlapping interiors (the catch-up windows at the bottom /
+ * right edge) add up.  No scratch plane, no atomics on the map. */
+int pc_stitch_count_windows(const int32_t* win, int nwin, int M, int16_t* count, int H, int W, void* stream);
 /* run_eval.py:140-154: where count > 1: sum -> mean, sq -> unbiased std; pixels visited once keep their raw values. */
 int pc_stitch_finalize(float* out_sum, float* out_sq, float* scale_sum, float* scale_sq, const int16_t* count, int64_t n,
                        void* stream);

@@ -22,6 +22,7 @@ from . import ops
 from .data import stats
 from .data.collate import Population_Dataset_collate_fn
 from .data.dataset import SyntheticTestRaster, SyntheticWeaksupDataset
+from .data.feed import RegionFeed
 from .distributed import FlatReducer, init_from_env
 from .model import get_model_kwargs, model_dict
 from .utils.transform import default_train_transform
@@ -152,6 +153,23 @@ def normalize_sample(sample, device, transform=None):
     return out
 
 
+def prepare_sample_fused(sample, transform=None):
+    """The fast form of ``normalize_sample`` for the fused step (round 6): ``sample`` holds DEVICE tensors (``data.feed.RegionFeed``); the
+    augmentation parameters are drawn on the host with the reference's generator consumption (``draw_fused_params``), ONE launch
+    (``ops.augment_raw``) applies them while it assembles the raw [S2 | S1] tile, and the normalisation happens inside the step's ingest
+    (the executor's ``raw`` input form) -- no ``.float()`` / ``torch.cat`` / normalise / flip / rot90 launches, no synchronous copy.
+    Returns None when ``transform`` is not the reference trainer's set (the caller then takes ``normalize_sample``)."""
+    from .utils.transform import draw_fused_params
+    s2, s1, admin = sample["S2"], sample["S1"], sample["admin_mask"]
+    if not (s2.is_cuda and s2.dtype == torch.float32 and s1.dtype == torch.float32 and s2.shape[1] == 4 and s1.shape[1] == 2):
+        return None
+    params = draw_fused_params(transform)
+    if params is None:
+        return None
+    raw, adm = ops.augment_raw(s2.contiguous(), s1.contiguous(), admin.float().contiguous(), params)
+    return {"raw": raw, "admin_mask": adm, "census_idx": sample["census_idx"].contiguous(), "y": sample["y"].float().contiguous()}
+
+
 def limit_regime(num_pix, limit1, limit2, limit3):
     """The memory-driven truncation of the backward pass by batch size in pixels (run_train.py:191-198; defaults
     arguments/train.py:34-36: 9e6 / 9e6 / 13e6): (encoder_no_grad, unet_no_grad, skip the batch).  The limits nest like the
@@ -190,7 +208,8 @@ class Trainer:
                                                                            shuffle=True, seed=args.seed, drop_last=True)
         self.loader = torch.utils.data.DataLoader(ds, batch_size=args.weak_batch_size, num_workers=args.num_workers,
                                                   shuffle=self.sampler is None, sampler=self.sampler,
-                                                  collate_fn=Population_Dataset_collate_fn, drop_last=True)
+                                                  collate_fn=Population_Dataset_collate_fn, drop_last=True,
+                                                  persistent_workers=args.num_workers > 0)
         # weak validation set (run_train.py:410-414: a second Population_Dataset in weaksup mode, batch size -wvb)
         self.val_loader = torch.utils.data.DataLoader(
             SyntheticWeaksupDataset(args.synthetic_val_regions, min_hw=args.synthetic_hw_range[0], max_hw=args.synthetic_hw_range[1],
@@ -218,10 +237,13 @@ class Trainer:
             self.fused = None
         else:
             from .train import FusedTrainStep
+            # raw_norm: the feed hands the step the loader's own 6 bands [S2 R G B NIR | S1 VV VH] un-normalised (prepare_sample_fused);
+            # band j of that tile IS model channel j
             self.fused = FusedTrainStep(self.model, lr=args.learning_rate, weight_decay=args.weightdecay,
                                         gradient_clip=args.gradient_clip, loss=args.loss, lam=args.lam,
                                         scale_regularization=args.scale_regularization, lam_weak=args.lam_weak,
-                                        reducer=self.reducer, use_graph=args.fixed_hw is not None)
+                                        reducer=self.reducer, use_graph=args.fixed_hw is not None,
+                                        raw_norm=(tuple(range(6)), stats.MEAN6, stats.STD6))
         if args.resume:
             self.resume(args.resume)
 
@@ -278,8 +300,14 @@ class Trainer:
     # ---- loop ------------------------------------------------------------------------------------------------------
     def train_step(self, sample):
         a = self.args
-        s = normalize_sample(sample, self.device, self.data_transform)
-        num_pix = s["input"].shape[0] * s["input"].shape[2] * s["input"].shape[3]
+        s = None
+        if self.fused is not None and torch.is_tensor(sample.get("S2")) and sample["S2"].is_cuda:
+            # a batch staged by the feed: augmentation + assembly in one launch, normalisation inside the step (raw input form)
+            s = prepare_sample_fused(sample, self.data_transform)
+        if s is None:
+            s = normalize_sample(sample, self.device, self.data_transform)
+        dk = "raw" if "raw" in s else "input"
+        num_pix = s[dk].shape[0] * s[dk].shape[2] * s[dk].shape[3]
         if self.world > 1 and a.fixed_hw is None:
             # variable tile sizes: ranks must take the same regime (and skip together), or their collective counts
             # diverge and the job hangs.  The largest rank decides.
@@ -375,7 +403,10 @@ class Trainer:
             if self.sampler is not None:
                 self.sampler.set_epoch(epoch)                              # a fresh shuffle per epoch on every rank
             losses = []
-            for i, sample in enumerate(self.loader):
+            # the fused step is fed one batch ahead through pinned memory and a copy stream (data/feed.py: RegionFeed); the torch-optimizer
+            # recipe keeps the reference's synchronous loop
+            feed = RegionFeed(self.loader, self.device) if self.fused is not None else self.loader
+            for i, sample in enumerate(feed):
                 loss = self.train_step(sample)
                 if loss is not None:
                     losses.append(loss)

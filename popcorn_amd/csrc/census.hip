@@ -142,6 +142,45 @@ __global__ __launch_bounds__(256) void census_zero_kernel(double* sums, int32_t*
     }
 }
 
+// visit counts of MANY windows in one pass (windows other ranks computed: only their count, no data).  One workgroup per (row, 1024-column
+// segment): the windows whose interior covers the row are collected into LDS once (wave-uniform test), every thread then tests its four
+// columns against that short list -- no atomics on the count map, no scratch plane, any overlap between windows (catch-up windows).
+constexpr int CW_CAP = 1024;
+__global__ __launch_bounds__(256) void stitch_count_windows_kernel(const int32_t* __restrict__ win, int nwin, int M, int16_t* __restrict__ count,
+                                                                   int H, int W) {
+    __shared__ int ly0[CW_CAP], ly1[CW_CAP];
+    __shared__ int ln;
+    const int c0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    for (int r = blockIdx.y; r < H; r += gridDim.y) {
+    int acc[4] = {0, 0, 0, 0};
+    for (int base = 0; base < nwin; base += CW_CAP) {
+        if (threadIdx.x == 0) ln = 0;
+        __syncthreads();
+        for (int k = base + threadIdx.x; k < nwin && k < base + CW_CAP; k += 256) {
+            const int x0 = win[4 * k], x1 = win[4 * k + 1], y0 = win[4 * k + 2], y1 = win[4 * k + 3];
+            if (x0 <= r && r < x1 && y1 > y0) {
+                const int slot = atomicAdd(&ln, 1);
+                ly0[slot] = y0; ly1[slot] = y1;
+            }
+        }
+        __syncthreads();
+        const int n = ln;
+        for (int k = 0; k < n; ++k) {
+            const int y0 = ly0[k], y1 = ly1[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (y0 <= c0 + e && c0 + e < y1) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c0 + e < W && acc[e]) {
+            int16_t* p = count + (int64_t)r * W + c0 + e;
+            *p = (int16_t)(*p + M * acc[e]);
+        }
+    }
+}
+
 int stream_grid(int64_t n, int per_thread = 4) {
     int64_t g = (n / per_thread + 255) / 256;
     if (g > 4096) g = 4096;
@@ -194,6 +233,14 @@ extern "C" int pc_stitch_finalize(float* out_sum, float* out_sq, float* scale_su
     if (!out_sum || !out_sq || !count) return PC_EINVAL;
     hipLaunchKernelGGL(stitch_finalize_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, out_sum, out_sq,
                        scale_sum, scale_sq, count, n);
+    PC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pc_stitch_count_windows(const int32_t* win, int nwin, int M, int16_t* count, int H, int W, void* stream) {
+    if (!win || !count || nwin < 0 || H < 1 || W < 1) return PC_EINVAL;
+    if (nwin == 0) return 0;
+    hipLaunchKernelGGL(stitch_count_windows_kernel, dim3((W + 1023) / 1024, H < 65535 ? H : 65535), dim3(256), 0, (hipStream_t)stream, win, nwin, M, count, H, W);
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -27,19 +27,6 @@ extern int g_pc_precision;      // api.hip: pc_set_precision()
 // a = a1 + a2 + a3 exactly, with a1 = rn_bf16(a), a2 = rn_bf16(a - a1), a3 = a - a1 - a2 (8 + 8 + 8 mantissa bits, every difference exact
 // in fp32).  One PAIR of fp32 values -> the three packed bf16 pairs of its split (lo half = x0): 11 VALU instructions.
 __device__ __forceinline__ void pc_split_pair(float x0, float x1, unsigned& q1, unsigned& q2, unsigned& q3) {
-#ifdef POPCORN_SPLIT_TRUNC
-    // experiment: truncating split (and + sub + v_perm_b32, no conversions)
-    {
-        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-        q1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-        q2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-        q3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-        return;
-    }
-#endif
     q1 = pc_pack_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(q1 << 16), r1 = x1 - __uint_as_float(q1 & 0xffff0000u);
     q2 = pc_pack_bf16(r0, r1);

@@ -182,13 +182,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // i.e. an s_waitcnt right behind the load and no overlap with the MFMA phase.
     f32x4 R[NIT];
     int rvalid = 0;                                       // how many of the segment's 4 pixels are inside the image (0 .. 4)
+    // the sources' extents, pinned in scalar registers: read from the descriptor inside issue() they were three DEPENDENT scalar-memory
+    // round trips (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS queue) in front of every strip's prefetch (round 6)
+    int aW = q.a.W, aH = q.a.H, bW = q.b.W, bH = q.b.H, pW = p.W, pH = p.H;
+    asm volatile("" : "+s"(aW), "+s"(aH), "+s"(bW), "+s"(bH), "+s"(pW), "+s"(pH));
     auto issue = [&](int ch, int b, int y0, int x0) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         // DIRECT: a source placed at (0, 0) may be SMALLER than the conv domain -- the up-sampled half of an Up block's concatenated input
         // when the skip map has an odd extent (zero F.pad on the bottom / right, networks.py:309-312): rows / columns beyond the extent of
         // the chunk's own source are zeros.  (A chunk never straddles the two sources: the first one has 8 or 16 channels.)
-        const int sW = LD == LD_DIRECT ? (ch * CHUNK < CA ? q.a.W : q.b.W) : p.W;
-        const int sH = LD == LD_DIRECT ? (ch * CHUNK < CA ? q.a.H : q.b.H) : p.H;
+        const int sW = LD == LD_DIRECT ? (ch * CHUNK < CA ? aW : bW) : pW;
+        const int sH = LD == LD_DIRECT ? (ch * CHUNK < CA ? aH : bH) : pH;
         const bool ok = l_act && xg >= 0 && xg < sW && (unsigned)y < (unsigned)sH;
         // a row whose width is not a multiple of 4 ends inside a segment: the tail of that segment is read (the row stride is a
         // multiple of 4, so the 16 bytes exist) and masked per pixel when it is written to LDS
@@ -282,10 +286,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
 
     // strips: tile-major so that the 4 waves of a workgroup take the 4 strips of one 32 x 16 tile (shared halo rows
     // hit in L1/L2); workgroups walk the tiles in the XCD-aware order.
-    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    int gdim = (int)gridDim.x;                           // (pinned: read from the dispatch packet inside the loop it was one more scalar round trip per strip)
+    asm volatile("" : "+s"(gdim));
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / gdim + 1 : 0;
     const int nstages = my_tiles * NST;
     auto strip_coords = [&](int stage, int& b, int& y0, int& x0) {
-        const int t = blockIdx.x + (stage / NST) * gridDim.x;
+        const int t = blockIdx.x + (stage / NST) * gdim;
         const int tile = pc_xcd_remap(t, p.ntiles);
         b = (int)pc_div((uint32_t)tile, p.div_tpi);
         const int rem = tile - b * p.tiles_x * p.tiles_y;

@@ -639,16 +639,6 @@ __device__ long long g_bwd_prof[4096 * 8];
 #define BQ_DUMP
 #endif
 
-// wave priority of the matrix phases (build-time experiment: -DPOPCORN_BWD_PRIO=n)
-#ifndef POPCORN_BWD_PRIO
-#define POPCORN_BWD_PRIO 0
-#endif
-#if POPCORN_BWD_PRIO
-#define S3_PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define S3_PRIO(n)
-#endif
-
 template <int GC>
 struct S3Cfg {
     static constexpr int NG = GC / 8;
@@ -764,9 +754,10 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                 }
             }
     };
-    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int gdim = s3_pin((int)gridDim.x), ntl = s3_pin(p.ntiles);
+    const int my_tiles = ntl > (int)blockIdx.x ? (ntl - 1 - (int)blockIdx.x) / gdim + 1 : 0;
     auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
-        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
+        const int tile = pc_xcd_remap(blockIdx.x + k * gdim, ntl);
         b = (int)pc_div((uint32_t)tile, p.div_tpi);
         const int rem = tile - b * p.tiles_x * p.tiles_y;
         const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
@@ -869,7 +860,6 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
         f32x4 acc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        S3_PRIO(POPCORN_BWD_PRIO);
         if (!(dbg & 2))
 #pragma unroll
         for (int gc = 0; gc < NG; ++gc)
@@ -890,7 +880,6 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                         for (int u = 0; u < 4; ++u)
                             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[pa][u], wq[pw][gc][dx], acc[u], 0, 0, 0);
             }
-        S3_PRIO(0);
 #ifdef POPCORN_BWD_PROF
         asm volatile("" : : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #endif
@@ -984,7 +973,6 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
         BQ_CLOSE(bq4);
         // ---- weight gradient of the strip: D_dx[(s,co)][(v,ci)] += sum_x g[co][y0+2rpi+s][x] * x[ci][y0+2rpi+v-1][x+dx-1]
         //      three accumulator blocks (the dx of one half of x's channels) take turns: no instruction waits for its predecessor
-        S3_PRIO(POPCORN_BWD_PRIO);
         if (!(dbg & 4))
 #pragma unroll
         for (int rpi = 0; rpi < 2; ++rpi) {
@@ -1023,7 +1011,6 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                                 wacc[mb][dx * 2 + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][pg], bv[dx][px], wacc[mb][dx * 2 + nb], 0, 0, 0);
             }
         }
-        S3_PRIO(0);
 #ifdef POPCORN_BWD_PROF
 #pragma unroll
         for (int mb = 0; mb < NG; ++mb)

@@ -3363,8 +3363,7 @@ extern "C" int pc_head_bwd(const pc_src* feat, int py, int px, const float* cons
     }
     hipStream_t st = (hipStream_t)stream;
     if ((reinterpret_cast<uintptr_t>(g_feat->ptr) & 15) != 0) return PC_EINVAL;
-    const char* zv = getenv("POPCORN_HEAD_ZERO_FILL");            // A/B switch: 1 = the round-1 separate zero-fill launch
-    const bool zero_launch = !bfmode && (!use_pc || (zv && zv[0] == '1'));
+    const bool zero_launch = !bfmode && !use_pc;                  // (the single-role debug kernel only: the product kernels zero in-kernel)
     if (zero_launch) {
         // zero fill by a kernel, not a memset node (see zero_fill_kernel)
         const int64_t n4 = (int64_t)B * 16 * Hp * Wp / 4, rem = (int64_t)B * 16 * Hp * Wp - 4 * n4;

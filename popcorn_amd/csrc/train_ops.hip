@@ -307,3 +307,69 @@ extern "C" int pc_select_normalize(const float* raw, int Craw, const int* band6,
     PC_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- the trainer's augmentations in ONE pass (round 6) ----------------------------------------------------------------------------------
+// run_train.py:386-402 / utils/transform.py: RandomBrightness -> RandomGamma on the raw Sentinel-2 digital numbers, then (after the
+// concatenation [S2, S1]) RandomVerticalFlip -> RandomHorizontalFlip -> RandomRotationTransform(90 / 180 / 270) jointly on input and
+// admin_mask, all with ONE coin per batch.  The coins and factors are drawn on the host with the reference's generators in its order
+// (popcorn_amd/utils/transform.py: draw_fused_params); this kernel applies them while it assembles the 6-channel raw tile the step's ingest
+// normalises -- one launch instead of ~35 elementwise / flip / rot90 / cat launches per step.  Per element the S2 arithmetic is the
+// reference's, operation by operation in fp32: x / 10000 * beta clamped to [0, 1] * 10000; max(x, 0) / 10000 to the power gamma clamped * 10000.
+namespace {
+struct AugArgs {
+    const float* s2; const float* s1; const float* admin;
+    float* raw; float* admin_out;
+    int B, H, W, Ho, Wo;
+    int vflip, hflip, rot;             // rot = number of counter-clockwise quarter turns (torch.rot90 k)
+    int bright, gam;
+    float beta, gamma;
+};
+__global__ __launch_bounds__(256) void augment_raw_kernel(const AugArgs a) {
+    const int64_t npx = (int64_t)a.Ho * a.Wo;
+    const int64_t n = (int64_t)a.B * npx;
+    const int64_t hw = (int64_t)a.H * a.W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int b = (int)(idx / npx);
+        const int64_t r = idx - (int64_t)b * npx;
+        const int i = (int)(r / a.Wo), j = (int)(r - (int64_t)i * a.Wo);
+        // out = rot90^k(hflip(vflip(in))): undo the rotation, then the flips
+        int y, x;
+        switch (a.rot & 3) {
+            case 1: y = j; x = a.W - 1 - i; break;
+            case 2: y = a.H - 1 - i; x = a.W - 1 - j; break;
+            case 3: y = a.H - 1 - j; x = i; break;
+            default: y = i; x = j; break;
+        }
+        if (a.hflip) x = a.W - 1 - x;
+        if (a.vflip) y = a.H - 1 - y;
+        const int64_t src = (int64_t)y * a.W + x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = a.s2[((int64_t)b * 4 + c) * hw + src];
+            if (a.bright) v = fminf(fmaxf(__fmul_rn(__fdiv_rn(v, 10000.f), a.beta), 0.f), 1.f) * 10000.f;
+            if (a.gam) v = fminf(fmaxf(powf(__fdiv_rn(fmaxf(v, 0.f), 10000.f), a.gamma), 0.f), 1.f) * 10000.f;
+            a.raw[((int64_t)b * 6 + c) * npx + r] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) a.raw[((int64_t)b * 6 + 4 + c) * npx + r] = a.s1[((int64_t)b * 2 + c) * hw + src];
+        a.admin_out[(int64_t)b * npx + r] = a.admin[(int64_t)b * hw + src];
+    }
+}
+}  // namespace
+
+extern "C" int pc_augment_raw(const float* s2, const float* s1, const float* admin, float* raw, float* admin_out, int B, int H, int W,
+                              int vflip, int hflip, int rot, int bright, float beta, int gam, float gamma, void* stream) {
+    if (!s2 || !s1 || !admin || !raw || !admin_out || B < 1 || H < 1 || W < 1 || rot < 0 || rot > 3) return PC_EINVAL;
+    AugArgs a{};
+    a.s2 = s2; a.s1 = s1; a.admin = admin; a.raw = raw; a.admin_out = admin_out;
+    a.B = B; a.H = H; a.W = W;
+    a.Ho = (rot & 1) ? W : H; a.Wo = (rot & 1) ? H : W;
+    a.vflip = vflip; a.hflip = hflip; a.rot = rot; a.bright = bright; a.gam = gam; a.beta = beta; a.gamma = gamma;
+    const int64_t n = (int64_t)B * H * W;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(augment_raw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    PC_CHECK_LAUNCH();
+    return 0;
+}

@@ -42,6 +42,52 @@ def Population_Dataset_collate_fn(batch):
     return out
 
 
+def collate_into(batch, alloc):
+    """``Population_Dataset_collate_fn`` with the output tensors taken from ``alloc(key, shape, dtype)`` (the feed's pinned staging ring:
+    the batch is assembled where the H2D copy reads it, one pass over the items instead of collate + a second copy) and only the PADDING
+    filled (zeros; -1 for ``admin_mask``) instead of whole tensors.  Same keys, shapes and values as the plain collate."""
+    max_x = max_y = 0
+    for key in ("S2", "S1", "building_counts"):
+        if key in batch[0]:
+            max_x = max(item[key].shape[1] for item in batch)
+            max_y = max(item[key].shape[2] for item in batch)
+    n = len(batch)
+    out = {}
+    for key in ("S2", "S1", "building_counts"):
+        if key in batch[0]:
+            t = alloc(key, (n, 1 if key == "building_counts" else batch[0][key].shape[0], max_x, max_y), torch.float32)
+            for i, item in enumerate(batch):
+                xs, ys = item[key].shape[1], item[key].shape[2]
+                t[i, :, :xs, :ys] = item[key]
+                if xs < max_x:
+                    t[i, :, xs:, :] = 0
+                if ys < max_y:
+                    t[i, :, :xs, ys:] = 0
+            out[key] = t
+    admin = alloc("admin_mask", (n, max_x, max_y), torch.float32)
+    y = alloc("y", (n,), torch.float32)
+    for i, item in enumerate(batch):
+        xs, ys = item["admin_mask"].shape[0], item["admin_mask"].shape[1]
+        admin[i, :xs, :ys] = item["admin_mask"]
+        if xs < max_x:
+            admin[i, xs:, :] = -1
+        if ys < max_y:
+            admin[i, :xs, ys:] = -1
+        y[i] = item["y"]
+    cidx = torch.cat([item["census_idx"] for item in batch])
+    ci = alloc("census_idx", tuple(cidx.shape), cidx.dtype)
+    ci.copy_(cidx)
+    out.update({
+        "admin_mask": admin,
+        "y": y,
+        "img_coords": [item["img_coords"] for item in batch],
+        "valid_coords": [item["valid_coords"] for item in batch],
+        "season": torch.tensor([item["season"] for item in batch]),
+        "census_idx": ci,
+    })
+    return out
+
+
 def augment_geometric(inp, admin_mask, generator=None, p_flip=0.5, p_rot=0.75):
     """The joint geometric augmentation of the reference (utils/transform.py:54-200: RandomVerticalFlip /
     RandomHorizontalFlip (per sample) and RandomRotationTransform([90,180,270], p=.75) with expand=True), restated with

@@ -133,3 +133,142 @@ class HostFeed:
 
     def flush(self, **kw):
         return self._run(**kw) if self.n_run < self.n_in else None
+
+
+class RegionFeed:
+    """Variable-size census-region batches from a ``DataLoader`` to the device, AHEAD of the training step (round 6; the reference's loop
+    copies every batch synchronously and then runs ~35 small launches of augmentation / normalisation on it: run_train.py:185-187,
+    utils/utils.py:22-43,130-214).
+
+        for sample in RegionFeed(loader, device):      # dicts like the loader's, tensors already on the device
+            trainer.train_step(sample)
+
+    A producer THREAD pulls the batches (with ``num_workers = 0`` the dataset access and the collate run in it: torch's copies release the
+    GIL; worker processes cost more in IPC than an in-memory collate takes -- tools/feed_probe.py: 2.7 - 5.2 ms per batch through 8 workers
+    with / without the loader's pinning thread against 0.7 ms for the collate itself), stages their tensors in a ring of pinned host
+    buffers (grow-only) and enqueues the copies on a copy stream that does not share a hardware queue with the compute stream
+    (``pick_copy_stream``); the consumer waits on the copy's event and steps.  Region shapes never recur, so the device tensors come from
+    torch's caching allocator (``record_stream`` keeps a block alive until the step that reads it has run).  Non-tensor items pass
+    through.  Determinism: the FIRST batch is pulled on the caller's thread -- that is where a shuffling sampler draws its seed from the
+    global generator -- so the producer never touches the generators the augmentation coins and selection grids come from."""
+
+    TENSOR_KEYS = ("S2", "S1", "admin_mask", "y", "census_idx", "building_counts")
+    DEPTH = 3                       # staged batches in flight (ring slots of pinned memory)
+
+    def __init__(self, loader, device, copy_stream=None):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.cs = copy_stream if copy_stream is not None else pick_copy_stream(self.device)
+        self._pin = [{} for _ in range(self.DEPTH)]      # per slot: key -> pinned staging tensor (grow-only)
+        self._done = [None] * self.DEPTH                 # per slot: event behind the slot's last copy
+        self._n = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _slot(self):
+        slot = self._n % self.DEPTH
+        self._n += 1
+        if self._done[slot] is not None:
+            self._done[slot].synchronize()             # DEPTH batches back: guards the staging buffers of this slot
+        return slot
+
+    def _alloc(self, slot):
+        """(key, shape, dtype) -> a view of this slot's pinned staging buffer of that key (grow-only)."""
+        def alloc(key, shape, dtype):
+            n = 1
+            for d in shape:
+                n *= int(d)
+            buf = self._pin[slot].get(key)
+            if buf is None or buf.numel() < n or buf.dtype != dtype:
+                buf = self._pin[slot][key] = torch.empty(max(int(n * 1.25), 1), dtype=dtype).pin_memory()
+            return buf[:n].view(shape)
+        return alloc
+
+    def _stage(self, batch, consumer_stream, slot=None):
+        if slot is None:
+            slot = self._slot()
+        dev, host = {}, {}
+        for k, v in batch.items():
+            if not (torch.is_tensor(v) and k in self.TENSOR_KEYS):
+                host[k] = v
+                continue
+            if k in ("admin_mask", "y") and v.dtype != torch.float32:
+                v = v.float()
+            if not v.is_pinned():
+                p = self._alloc(slot)(k, tuple(v.shape), v.dtype)
+                p.copy_(v)
+                v = p
+            host[k] = v
+        with torch.cuda.stream(self.cs):
+            for k in self.TENSOR_KEYS:
+                if k in host and torch.is_tensor(host[k]):
+                    t = host.pop(k).to(self.device, non_blocking=True)
+                    t.record_stream(consumer_stream)
+                    dev[k] = t
+            ev = torch.cuda.Event()
+            ev.record(self.cs)
+        self._done[slot] = ev
+        return dev, host, ev
+
+    def __iter__(self):
+        import queue
+        import threading
+        from .collate import Population_Dataset_collate_fn, collate_into
+        it = iter(self.loader)
+        # Fast path (in-process loader with the standard collate): the index batches come from the loader's OWN iterator (same generator
+        # consumption, same order), the items are assembled straight into the pinned staging slot (collate_into) -- one pass over the
+        # data instead of collate + staging copy.  Anything else (worker processes, another collate): the loader's batches as they come.
+        direct = (getattr(self.loader, "num_workers", 1) == 0 and getattr(self.loader, "collate_fn", None) is Population_Dataset_collate_fn and
+                  hasattr(it, "_next_index") and getattr(self.loader, "batch_sampler", None) is not None)
+        ds = self.loader.dataset
+
+        def pull():
+            if not direct:
+                return next(it, None)
+            try:
+                return it._next_index()
+            except StopIteration:
+                return None
+        first = pull()                                  # on the caller's thread: the sampler's seed draw (see the class docstring)
+        if first is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        q = queue.Queue(maxsize=self.DEPTH - 1)
+        stop = threading.Event()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def produce():
+            try:
+                torch.cuda.set_device(dev_index)
+                batch = first
+                while batch is not None and not stop.is_set():
+                    if direct:
+                        slot = self._slot()
+                        q.put(self._stage(collate_into([ds[i] for i in batch], self._alloc(slot)), cur, slot))
+                    else:
+                        q.put(self._stage(batch, cur))
+                    batch = pull()
+                q.put(None)
+            except BaseException as ex:                 # surfaces in the consumer
+                q.put(ex)
+        th = threading.Thread(target=produce, name="popcorn-region-feed", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                dev, host, ev = item
+                cur.wait_event(ev)
+                yield {**host, **dev}
+        finally:
+            stop.set()
+            while th.is_alive():                        # a consumer that stops early: drain so that the producer can finish
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()

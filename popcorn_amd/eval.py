@@ -87,34 +87,25 @@ class Stitcher:
             self.count[x0:x1, y0:y1] += M
 
     def add_counts_only(self, windows, M, ps, overlap=OVERLAP):
-        """The visit counts of MANY windows other ranks computed, in one pass: a 2-D difference array (4 scatter-adds per window, one
-        ``index_put_``) and two prefix sums over the raster instead of one slice-add per window from the host loop.  windows: iterable of
-        (row origin, column origin)."""
+        """The visit counts of MANY windows other ranks computed, in ONE launch of ``census.hip`` (pc_stitch_count_windows) instead of one
+        slice-add per window from the host loop.  windows: iterable of (row origin, column origin)."""
         ws = [(int(x), int(y)) for x, y in windows]
         if not ws:
             return
-        dev = self.count.device
-        xy = torch.tensor(ws, dtype=torch.int64, device=dev)
-        x0 = (xy[:, 0] + overlap).clamp(max=self.h)
-        x1 = (xy[:, 0] + ps - overlap).clamp(max=self.h)
-        y0 = (xy[:, 1] + overlap).clamp(max=self.w)
-        y1 = (xy[:, 1] + ps - overlap).clamp(max=self.w)
-        keep = (x1 > x0) & (y1 > y0)
-        x0, x1, y0, y1 = x0[keep], x1[keep], y0[keep], y1[keep]
-        # ONE transient int32 plane, prefix sums in place, added to the counts band by band: 4 B/px of scratch (+ a band) instead of the
-        # 12 B/px of a fresh cumsum result per pass and an int16 copy -- at country scale (1e9 px) that was > 10 GB next to the 16 B/px
-        # of accumulators, in exactly the multi-GPU path meant for the largest rasters (ADVICE round 4)
-        diff = torch.zeros(self.h + 1, self.w + 1, dtype=torch.int32, device=dev)
-        m = torch.full((x0.numel(),), int(M), dtype=torch.int32, device=dev)
-        for xs, ys, sgn in ((x0, y0, 1), (x0, y1, -1), (x1, y0, -1), (x1, y1, 1)):
-            diff.index_put_((xs, ys), m * sgn, accumulate=True)
-        diff.cumsum_(0)
-        diff.cumsum_(1)
-        band = max(1, (1 << 26) // max(self.w, 1))               # rows per band: 64 M elements of int16 conversion scratch at most
-        for r0 in range(0, self.h, band):
-            r1 = min(self.h, r0 + band)
-            self.count[r0:r1] += diff[r0:r1, :self.w].to(self.count.dtype)
-        del diff
+        # clipped interiors {x0, x1, y0, y1} of all windows as ONE small device array; census.hip counts them into the map in one launch
+        # (round 6: the difference-array form did this bookkeeping with stock torch ops -- index_put_, two cumsum_, a banded int16
+        # conversion -- and a transient int32 plane of the raster's size)
+        rows = []
+        for x, y in ws:
+            x0, x1 = min(x + overlap, self.h), min(x + ps - overlap, self.h)
+            y0, y1 = min(y + overlap, self.w), min(y + ps - overlap, self.w)
+            if x1 > x0 and y1 > y0:
+                rows.append((x0, x1, y0, y1))
+        if not rows:
+            return
+        win = torch.tensor(rows, dtype=torch.int32).to(self.count.device)
+        L.check(L.lib().pc_stitch_count_windows(L.ptr(win), len(rows), int(M), L.ptr(self.count), self.h, self.w, L.stream_ptr()),
+                "pc_stitch_count_windows")
 
     def all_reduce(self, reducer: FlatReducer):
         """Multi-GPU, simple form: sum the full accumulators on every rank (interiors of regular windows are disjoint, the

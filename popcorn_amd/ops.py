@@ -652,6 +652,33 @@ def select_normalize(raw, band6, mean6, std6, out=None):
     return out
 
 
+def augment_raw(s2, s1, admin_mask, params, out=None, admin_out=None):
+    """The trainer's augmentations (run_train.py:386-402) with parameters drawn on the host (utils/transform.py: draw_fused_params), applied
+    while the raw 6-channel tile [S2 | S1] is assembled -- ONE launch (pc_augment_raw).  s2 (B, 4, H, W) digital numbers, s1 (B, 2, H, W),
+    admin_mask (B, H, W), fp32 device tensors; returns (raw (B, 6, Ho, Wo), admin (B, Ho, Wo)); params None = no augmentation."""
+    L.require_device(s2, s1, admin_mask)
+    B, c2, H, W = s2.shape
+    if c2 != 4 or tuple(s1.shape) != (B, 2, H, W) or tuple(admin_mask.shape) != (B, H, W):
+        raise ValueError(f"augment_raw: S2 (B, 4, H, W), S1 (B, 2, H, W), admin_mask (B, H, W); got {tuple(s2.shape)}, {tuple(s1.shape)}, "
+                         f"{tuple(admin_mask.shape)}")
+    for t in (s2, s1, admin_mask):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("augment_raw: contiguous fp32 tensors")
+    pr = params or {}
+    k = int(pr.get("rot", 0)) & 3
+    Ho, Wo = (W, H) if k & 1 else (H, W)
+    if out is None:
+        out = torch.empty(B, 6, Ho, Wo, device=s2.device, dtype=torch.float32)
+    if admin_out is None:
+        admin_out = torch.empty(B, Ho, Wo, device=s2.device, dtype=torch.float32)
+    beta, gamma = pr.get("beta"), pr.get("gamma")
+    L.check(L.lib().pc_augment_raw(L.ptr(s2), L.ptr(s1), L.ptr(admin_mask), L.ptr(out), L.ptr(admin_out), B, H, W,
+                                   int(bool(pr.get("vflip"))), int(bool(pr.get("hflip"))), k, int(beta is not None),
+                                   C.c_float(beta if beta is not None else 1.0), int(gamma is not None),
+                                   C.c_float(gamma if gamma is not None else 1.0), L.stream_ptr()), "pc_augment_raw")
+    return out, admin_out
+
+
 def loss_fwd_bwd(popcount, y, stats, lam4, scale_regularization, lam_weak, inv_B, loss_out, g_popcount, g_scale_const):
     L.require_device(popcount, y)
     L.check(L.lib().pc_loss_fwd_bwd(L.ptr(popcount), L.ptr(y), L.ptr(stats), (C.c_float * 4)(*lam4),

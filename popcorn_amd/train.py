@@ -26,9 +26,9 @@ from . import ops
 from .distributed import FlatReducer
 from .model.popcorn import pad_geometry
 
-# A/B switch: 0 = the head backward reduces its own weight-gradient partials (one launch more per step) instead of handing them to the
-# U-Net backward's batched reduction
-DEFER_HEAD_REDUCE = os.environ.get("POPCORN_DEFER_HEAD_REDUCE", "1") != "0"
+# The head backward hands its weight-gradient partials to the U-Net backward's batched reduction (False: it reduces them itself, one launch
+# more per step -- what the head-only regime does anyway).  A test hook, not an environment switch any more (round 6).
+DEFER_HEAD_REDUCE = True
 
 # Eager steps (no captured graph: the reference's variable-size census regions, run_train.py:186-202) go through the native executor --
 # ONE C-ABI call per step (pc_train_step: geometry, arena, descriptors and all launches in C++) instead of ~45 ctypes calls.

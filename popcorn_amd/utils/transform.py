@@ -153,3 +153,42 @@ def default_train_transform():
         "S2": OwnCompose([RandomBrightness(p=0.9, beta_limit=(0.666, 1.5)), RandomGamma(p=0.9, gamma_limit=(0.6666, 1.5))]),
         "S1": Compose([]),
     }
+
+
+def draw_fused_params(transform):
+    """The parameters of one batch's augmentation, drawn with EXACTLY the generator consumption of applying ``transform`` the way the
+    trainer does (utils/utils.py:130-214: the S2 transforms first, then the joint geometric ones) -- ``torch.rand(1)`` per coin, Python's
+    ``random`` for the factors / the angle, in the same order -- for ``ops.augment_raw`` (one HIP launch instead of the per-op torch
+    launches).  Returns ``{"beta", "gamma", "vflip", "hflip", "rot"}`` (None / False / 0 = not applied) or ``None`` when ``transform`` is
+    not the reference trainer's set (per-sample coins, other transforms): the caller then applies the classes themselves."""
+    if transform is None:
+        return {"beta": None, "gamma": None, "vflip": False, "hflip": False, "rot": 0}
+    s2 = transform.get("S2")
+    gen = transform.get("general")
+    s1 = transform.get("S1")
+    s2t = list(getattr(s2, "transforms", [])) if s2 is not None else []
+    gt = list(getattr(gen, "transforms", [])) if gen is not None else []
+    if s1 is not None and list(getattr(s1, "transforms", [None])):
+        return None
+    if [type(t) for t in s2t] not in ([], [RandomBrightness, RandomGamma]):
+        return None
+    if [type(t) for t in gt] not in ([], [RandomVerticalFlip, RandomHorizontalFlip, RandomRotationTransform]):
+        return None
+    if gt and not (gt[0].allsame and gt[1].allsame and all(a % 90 == 0 for a in gt[2].angles)):
+        return None
+    if s2t and (s2t[0].s2_max != 10000 or s2t[1].s2_max != 10000):
+        return None
+    out = {"beta": None, "gamma": None, "vflip": False, "hflip": False, "rot": 0}
+    if s2t:
+        br, ga = s2t
+        if torch.rand(1) < br.p:
+            out["beta"] = random.uniform(br.beta_limit[0], br.beta_limit[1])
+        if torch.rand(1) < ga.p:
+            out["gamma"] = random.uniform(ga.gamma_limit[0], ga.gamma_limit[1])
+    if gt:
+        vf, hf, ro = gt
+        out["vflip"] = bool(torch.rand(1) < vf.p)
+        out["hflip"] = bool(torch.rand(1) < hf.p)
+        if torch.rand(1) < ro.p:
+            out["rot"] = (random.choice(ro.angles) // 90) % 4
+    return out

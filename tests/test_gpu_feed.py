@@ -102,3 +102,67 @@ def test_host_feed_equals_resident_steps_bit_for_bit(kind):
     assert feed.flush() is None
     assert got == want
     assert torch.equal(tr.flat_p, ref.flat_p)
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 52), (1, 64, 64), (3, 20, 33)])
+def test_augment_raw_equals_the_transform_classes_and_their_generator_consumption(shape):
+    """pc_augment_raw + draw_fused_params against the reference-named classes applied the way the trainer applies them
+    (utils/utils.py:130-214: S2 transforms on the digital numbers, cat, normalise, joint geometric transform of input and admin_mask):
+    over 24 seeds (every flip / rotation / brightness / gamma combination occurs) the raw tile normalises to the same input (the power
+    function differs by an ulp between torch and the kernel), the admin mask is identical, and BOTH generators (torch's and Python's)
+    end in the same state."""
+    import random
+    from popcorn_amd import ops
+    from popcorn_amd.cli import normalize_sample, prepare_sample_fused
+    from popcorn_amd.data import stats
+    from popcorn_amd.utils.transform import default_train_transform
+    B, H, W = shape
+    tr = default_train_transform()
+    seen = set()
+    for seed in range(24):
+        g = torch.Generator().manual_seed(seed)
+        smp = {"S2": torch.randint(0, 10000, (B, 4, H, W), generator=g).float(), "S1": torch.randn(B, 2, H, W, generator=g) * 4 - 12,
+               "admin_mask": torch.randint(0, 7, (B, H, W), generator=g).float(), "y": torch.rand(B, generator=g),
+               "census_idx": torch.arange(1, B + 1)}
+        torch.manual_seed(100 + seed)
+        random.seed(100 + seed)
+        ref = normalize_sample({k: v.clone() for k, v in smp.items()}, torch.device("cuda"), tr)
+        end_t, end_r = torch.get_rng_state(), random.getstate()
+        torch.manual_seed(100 + seed)
+        random.seed(100 + seed)
+        fast = prepare_sample_fused({k: v.cuda() for k, v in smp.items()}, tr)
+        assert torch.equal(torch.get_rng_state(), end_t) and random.getstate() == end_r
+        x = ops.select_normalize(fast["raw"], tuple(range(6)), stats.MEAN6, stats.STD6)
+        assert x.shape == ref["input"].shape
+        torch.testing.assert_close(x, ref["input"], rtol=2e-6, atol=2e-5)
+        assert torch.equal(fast["admin_mask"], ref["admin_mask"])
+        assert torch.equal(fast["census_idx"], ref["census_idx"]) and torch.equal(fast["y"], ref["y"])
+        seen.add(tuple(x.shape[2:]) == (H, W))
+    assert seen == {True, False} or H == W
+
+
+def test_trainer_fed_one_batch_ahead_takes_the_reference_order_steps(tmp_path):
+    """Trainer.train() through RegionFeed (pinned loader, copy stream, one-launch augmentation, raw input form) against the same trainer
+    stepped the reference's way (synchronous copy, per-op augmentation launches, normalised input): same seeds -> same batches, same
+    coins, same selection grids; after an epoch of variable-size regions the parameters agree to the rounding of the differing power
+    function (1e-5 relative on the flat parameter vector; the two runs take identical optimisation decisions)."""
+    import random
+    from popcorn_amd.cli import Trainer, normalize_sample, train_parser, limit_regime
+    argv = ("-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-4 --synthetic_regions 12 -wb 2 "
+            f"--save_dir {tmp_path} -lt 100 -val 100 -e 1 --synthetic_hw_range 90 200 --save-model no").split()
+    ta = Trainer(train_parser().parse_args(argv))
+    ta.train()
+    torch.cuda.synchronize()
+    tb = Trainer(train_parser().parse_args(argv))
+    tb.model.train()
+    a = tb.args
+    for sample in tb.loader:                       # the pre-round-6 loop body
+        s = normalize_sample(sample, tb.device, tb.data_transform)
+        n = s["input"].shape[0] * s["input"].shape[2] * s["input"].shape[3]
+        e, u, k = limit_regime(n, a.limit1, a.limit2, a.limit3)
+        tb.fused.step(s, encoder_no_grad=e, unet_no_grad=u)
+    torch.cuda.synchronize()
+    assert ta.fused.native_steps == 6 and int(ta.fused.step_count[0].item()) == int(tb.fused.step_count[0].item()) == 6
+    pa, pb = ta.fused.flat_p, tb.fused.flat_p
+    assert torch.isfinite(pa).all()
+    assert (pa - pb).abs().max().item() <= 1e-5 * pb.abs().max().item()

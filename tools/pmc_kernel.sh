@@ -24,4 +24,17 @@ for f in glob.glob("gpurun_out/pmck_*/**/*counter_collection.csv", recursive=Tru
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:32s} n={len(v):3d} mean {sum(v) / len(v):16.1f}")
+import json, os
+if os.environ.get("PMCK_JSON"):
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    d = {"kernel_substring": sys.argv[1], "launches_per_counter": {k: len(v) for k, v in acc.items()}, "mean_per_launch": m}
+    # SQ counters are summed over the chip: ratios are what is comparable between kernels
+    if m.get("SQ_WAVE_CYCLES"):
+        d["wait_inst_any_over_wave_cycles"] = m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
+    if m.get("SQ_BUSY_CYCLES") and m.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+        # SQ_BUSY_CYCLES counts per SE-level SQ; MFMA-busy per SIMD: normalise by the kernel's own duration in GRBM cycles over 1024 SIMDs
+        if m.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_per_simd_over_kernel_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+    d["note"] = os.environ.get("PMCK_NOTE", "")
+    json.dump(d, open(os.environ["PMCK_JSON"], "w"), indent=1)
 PY

@@ -47,6 +47,15 @@ for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kerne
         r["note"] = ("traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction for 16-byte-per-lane streams; an upper estimate "
                      "where loads are narrower); separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --no-graph, B=64 100x100")
         json.dump(r, open(f"{OUT}/{tag}_pmc_head_bwd{sfx}.json", "w"), indent=1)
+    cb = [r for r in rows if r["kernel"].startswith("conv3x3_bwd_s3_kernel<8, false>")]
+    if cb and prec == "fp32":
+        r = dict(cb[0])
+        r["alg_bytes_mean_launch"] = (3 * 2 * 64 * 128 * 128 * 24 * 4 + 2 * 64 * 64 * 64 * 24 * 4 + 2 * 64 * 64 * 64 * 40 * 4) / 5
+        r["note"] = ("roofline.traffic of the fp32 line (round 6): mean over the step's five launches of the fused conv backward (three at 128 x 128 x 2 "
+                     "streams, up2b at 64 x 64 x 2, the two skip halves of up2a at 64 x 64 x 4 problems); traffic = 2*FETCH_SIZE + WRITE_SIZE "
+                     "(gfx950 FETCH_SIZE correction for 16-byte-per-lane streams); separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 "
+                     "--no-graph, B=64 100x100")
+        json.dump(r, open(f"{OUT}/{tag}_pmc_conv_bwd.json", "w"), indent=1)
     conv = collections.defaultdict(dict)
     for d in glob.glob(f"{OUT}/pmcc_{prec}_*"):
         for n, cs in per_kernel(f"{d}/**/*counter_collection.csv").items():
@@ -59,5 +68,9 @@ for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kerne
             out = {"kernel": n, "counters": d, "traffic_bytes": (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024,
                    "alg_bytes": 4 * 64 * 128 * 128 * esz * 16,
                    "note": "grouped conv 8->8 @128x128 x4 (tools/ablate_conv_group.py 8 8 128, ABL_ONE=0), mean per launch; traffic = "
-                           "2*FETCH_SIZE + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (4 * GRBM_GUI_ACTIVE * 256 CUs) ~ MFMA pipe utilisation"}
+                           "2*FETCH_SIZE + WRITE_SIZE; MFMA pipe utilisation = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs): "
+                           "both counters are summed over the chip (VERDICT round 5: the earlier note divided by the summed GRBM cycles)",
+                   "mfma_busy_per_simd_over_kernel_cycles": (d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (d["GRBM_GUI_ACTIVE"] / 8.0)
+                                                              if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE") else None),
+                   "wait_inst_any_over_wave_cycles": (d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"] if d.get("SQ_WAVE_CYCLES") else None)}
             json.dump(out, open(f"{OUT}/{tag}_pmc_conv_8to8{sfx}.json", "w"), indent=1)

@@ -3,7 +3,7 @@
 # WRITE_SIZE PMC passes (separate runs, --kernel-trace only, eager dispatches) that feed `roofline.traffic`, for both modes.
 #   usage: tools/profile_round.sh r4 [quick]   -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
 #   quick: only the two kernel-stats runs + the source stamp (refresh after a kernel commit); full: + all PMC passes
-TAG=${1:-r5}
+TAG=${1:-r6}
 MODE=${2:-full}
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repository copy)}"
 export TMPDIR=/tmp

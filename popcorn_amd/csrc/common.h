@@ -36,6 +36,32 @@ __device__ __forceinline__ void pc_split_pair(float x0, float x1, unsigned& q1, 
 // conv kernels' multiplication form in PC_PREC_FP32 (api.hip: pc_set_conv_split): 1 = split-operand kernels where they exist
 int pc_conv_split_on();
 
+// ---- wave-uniform descriptor fields pinned in scalar registers (round 6) --------------------------------------------------------------------
+// Kernel arguments are read with s_load from the kernarg segment.  hipcc treats those loads as free to REMATERIALISE: under SGPR pressure it
+// re-issues them wherever a field is used -- inside the strip loops that meant up to 34 scalar-memory round trips per iteration
+// (s_load + s_waitcnt lgkmcnt(0), which also drains the wave's LDS queue; tools/isa_scalar_loads.py lists them per kernel), 1,800 of
+// 10,000 cycles per strip in the first version of conv3x3_bwd_s3_kernel.  A value that went through an empty asm is opaque to that: it
+// stays in an SGPR (or is spilled to a VGPR lane, a v_readlane away).  Pointers come back GLOBAL (through an address_space(1) cast): a
+// pointer that lost its provenance would be dereferenced with flat_load, which counts on vmcnt AND lgkmcnt.
+__device__ __forceinline__ void pc_pin(int& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pc_pin(unsigned& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pc_pin(int64_t& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pc_pin(float& v) { asm volatile("" : "+s"(v)); }
+template <typename T>
+__device__ __forceinline__ T* pc_pin_ptr(T* ptr) {
+    uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    asm volatile("" : "+s"(v));
+    return (T*)(__attribute__((address_space(1))) T*)v;
+}
+__device__ __forceinline__ void pc_pin(pc_src& s) {
+    s.ptr = pc_pin_ptr(s.ptr);
+    pc_pin(s.bstride); pc_pin(s.cstride); pc_pin(s.rstride); pc_pin(s.xstride); pc_pin(s.H); pc_pin(s.W); pc_pin(s.oy); pc_pin(s.ox); pc_pin(s.C);
+}
+__device__ __forceinline__ void pc_pin(pc_dst& d) {
+    d.ptr = pc_pin_ptr(d.ptr);
+    pc_pin(d.bstride); pc_pin(d.cstride); pc_pin(d.rstride); pc_pin(d.xstride);
+}
+
 // ---- element access for fp32 / bf16 containers (bf16 = unsigned short bits) -------------------------------------------------
 typedef unsigned short pc_bf16_t;
 __device__ __forceinline__ float pc_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -117,6 +143,7 @@ static inline int pc_resident_workgroups(int regs, size_t lds) {
 struct pc_fastdiv {
     uint32_t d, m;
 };
+__device__ __forceinline__ void pc_pin(pc_fastdiv& f) { pc_pin(f.d); pc_pin(f.m); }
 static inline pc_fastdiv pc_make_fastdiv(uint32_t d) {
     pc_fastdiv f;
     f.d = d ? d : 1;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs p) {
     // the sources' extents, pinned in scalar registers: read from the descriptor inside issue() they were three DEPENDENT scalar-memory
     // round trips (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS queue) in front of every strip's prefetch (round 6)
     int aW = q.a.W, aH = q.a.H, bW = q.b.W, bH = q.b.H, pW = p.W, pH = p.H;
-    asm volatile("" : "+s"(aW), "+s"(aH), "+s"(bW), "+s"(bH), "+s"(pW), "+s"(pH));
+    pc_pin(aW); pc_pin(aH); pc_pin(bW); pc_pin(bH); pc_pin(pW); pc_pin(pH);
     auto issue = [&](int ch, int b, int y0, int x0) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         // DIRECT: a source placed at (0, 0) may be SMALLER than the conv domain -- the up-sampled half of an Up block's concatenated input
@@ -955,11 +955,22 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     constexpr int NIT = CIN < 8 ? CIN : 1;               // REFLECT loader: planar fp32 rows, one 16-byte segment per channel
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const ConvProb& q = p.pr[blockIdx.y];
+    // the problem's descriptor and the launch geometry, pinned in scalar registers (common.h: pc_pin -- read from the kernel arguments
+    // inside the strip loop they were 15 - 32 scalar-memory round trips per strip, round 6)
+    ConvProb q = p.pr[blockIdx.y];
+    pc_pin(q.a); pc_pin(q.b); pc_pin(q.out);
+    q.act = pc_pin_ptr(q.act); pc_pin(q.act_bstride); pc_pin(q.act_rstride); pc_pin(q.act_xstride);
+    if constexpr (EPI == EPI_POOL) pc_pin(q.pool_out);
+    if constexpr (EPI == EPI_DOT) { q.dot_w = pc_pin_ptr(q.dot_w); pc_pin(q.dot_out); }
+    if constexpr (EPI == EPI_UPT) pc_pin(q.upt_out);
+    int pH = p.H, pW = p.W, prelu = p.relu, paccum = p.accumulate, pdbg = p.dbg, ntl = p.ntiles, tlx = p.tiles_x, tly = p.tiles_y, gdim = (int)gridDim.x;
+    pc_pin(pH); pc_pin(pW); pc_pin(prelu); pc_pin(paccum); pc_pin(pdbg); pc_pin(ntl); pc_pin(tlx); pc_pin(tly); pc_pin(gdim);
+    pc_fastdiv dtx = p.div_tx, dtpi = p.div_tpi;
+    pc_pin(dtx); pc_pin(dtpi);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    if (p.dbg & 8) return;
+    if (pdbg & 8) return;
     u32x4* const wl = reinterpret_cast<u32x4*>(lds) + wave * (SROWS * BSLOTS);       // this wave's strip: [6 rows][48 slots]
 
     // ---- loader: piece id = lane + 64 * i -> (strip row, pixel of the 34-pixel row)
@@ -982,7 +993,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
             rvalid = lane < 60 ? 1u : 0u;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                RF[it] = lane < 60 ? pc_fetch_reflect_seg(q.a, b, it, y0 - 1 + r_r, x0 - 4 + 4 * r_seg, p.H, p.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+                RF[it] = lane < 60 ? pc_fetch_reflect_seg(q.a, b, it, y0 - 1 + r_r, x0 - 4 + 4 * r_seg, pH, pW) : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const bool useb = LD == LD_DIRECT && 8 * ch >= CA;
             const pc_src& s = useb ? q.b : q.a;
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int y = y0 - 1 + l_r[i], x = x0 - 1 + l_px[i];
-                bool ok = l_slot[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                bool ok = l_slot[i] >= 0 && (unsigned)y < (unsigned)pH && (unsigned)x < (unsigned)pW;
                 if constexpr (LD == LD_DIRECT) {
                     const int ys = y - s.oy, xq = x - s.ox;
                     ok = ok && (unsigned)ys < (unsigned)s.H && (unsigned)xq < (unsigned)s.W;
@@ -1038,21 +1049,21 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
         }
     };
 
-    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int my_tiles = ntl > (int)blockIdx.x ? (ntl - 1 - (int)blockIdx.x) / gdim + 1 : 0;
     const int nstages = my_tiles * NCHUNK;
     auto strip_coords = [&](int stage, int& b, int& y0, int& x0) {
-        const int t = blockIdx.x + (stage / NCHUNK) * gridDim.x;
-        const int tile = pc_xcd_remap(t, p.ntiles);
-        b = (int)pc_div((uint32_t)tile, p.div_tpi);
-        const int rem = tile - b * p.tiles_x * p.tiles_y;
-        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
-        x0 = (rem - ty * p.tiles_x) * TW;
+        const int t = blockIdx.x + (stage / NCHUNK) * gdim;
+        const int tile = pc_xcd_remap(t, ntl);
+        b = (int)pc_div((uint32_t)tile, dtpi);
+        const int rem = tile - b * tlx * tly;
+        const int ty = (int)pc_div((uint32_t)rem, dtx);
+        x0 = (rem - ty * tlx) * TW;
         y0 = ty * TH + 4 * wave;
     };
     int b = 0, y0 = 0, x0 = 0;
     if (nstages > 0) {
         strip_coords(0, b, y0, x0);
-        if (!(p.dbg & 1)) issue(0, b, y0, x0);
+        if (!(pdbg & 1)) issue(0, b, y0, x0);
     }
 
     // ---- weight image [dy plane 0..3][co][chunk][dx][8 ci] bf16 (plane 3 all zero), as in the planar bf16 path; a lane's
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int y = ey0 + 2 * (u >> 1) + e_s, x = ex0 + (u & 1) * 16 + li;
-            const bool ok = y < p.H && x < p.W;
+            const bool ok = y < pH && x < pW;
             if constexpr (MODE == MODE_FWD) {
                 float dsum = 0.f;
 #pragma unroll
@@ -1170,7 +1181,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float o = v[r] * e_scale[nb][r] + e_shift[nb][r];
-                        v[r] = pc_bf16r(p.relu ? fmaxf(o, 0.f) : o);
+                        v[r] = pc_bf16r(prelu ? fmaxf(o, 0.f) : o);
                     }
                     if (EPI == EPI_DOT && q.dot_w) {
 #pragma unroll
@@ -1190,7 +1201,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
                         for (int sr = 0; sr < 2; ++sr) {
                             const int ys = ey0 + 2 * (u >> 1) + sr;
-                            const bool oks = ys < p.H && x < p.W;
+                            const bool oks = ys < pH && x < pW;
 #pragma unroll
                             for (int a = 0; a < 2; ++a) {
                                 f32x4 ua = f32x4{upt_bias[0], upt_bias[1], upt_bias[2], upt_bias[3]};
@@ -1230,7 +1241,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb][r] : 0.f;
                     }
-                    if (p.accumulate) {
+                    if (paccum) {
                         const f32x4 o4 = pc_ld4(op);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += o4[r];
@@ -1269,14 +1280,14 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
     f32x4 acc[4][NB];
     for (int stage = 0; stage < nstages; ++stage) {
         const int ch = stage % NCHUNK;
-        if (!(p.dbg & 1)) commit();
+        if (!(pdbg & 1)) commit();
         int nb_ = b, ny0 = y0, nx0 = x0;
         if (stage + 1 < nstages) {
             if ((stage + 1) % NCHUNK == 0) strip_coords(stage + 1, nb_, ny0, nx0);
-            if (!(p.dbg & 1)) issue((stage + 1) % NCHUNK, nb_, ny0, nx0);
+            if (!(pdbg & 1)) issue((stage + 1) % NCHUNK, nb_, ny0, nx0);
         }
         if (have_prev) {
-            if (!(p.dbg & 4)) epilogue();
+            if (!(pdbg & 4)) epilogue();
             have_prev = false;
         }
         if (ch == 0) {
@@ -1285,7 +1296,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[u][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!(p.dbg & 2)) {
+        if (!(pdbg & 2)) {
             load_bwh(ch);
             const u32x4* lrow = wl + lk * BSLOTS + (COL0 - 1) + li;
 #pragma unroll
@@ -1311,7 +1322,7 @@ __global__ __launch_bounds__(256) void conv3x3_cl_kernel(const ConvArgs p) {
         }
         b = nb_; y0 = ny0; x0 = nx0;
     }
-    if (have_prev && !(p.dbg & 4)) epilogue();
+    if (have_prev && !(pdbg & 4)) epilogue();
 }
 
 template <int CIN, int COUT, int MODE, int LD, int EPI>

@@ -69,7 +69,15 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
     using Cfg = BwdCfg<GC, XC>;
     constexpr int NG = Cfg::NG, NX = Cfg::NX, NBP = Cfg::NBP, NBLK = Cfg::NBLK, EC = Cfg::EC;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    const BwdProb& q = p.pr[blockIdx.y];
+    // the problem's descriptor and the launch geometry, pinned in scalar registers (common.h: pc_pin -- read from the kernel arguments
+    // inside the strip loop they were ~30 scalar-memory round trips per strip, round 6)
+    BwdProb q = p.pr[blockIdx.y];
+    pc_pin(q.g); pc_pin(q.x); pc_pin(q.out); pc_pin(q.mask);
+    if constexpr (POOL) pc_pin(q.pool_act);
+    int pH = p.H, pW = p.W, pacc = p.accumulate, ntl = p.ntiles, tlx = p.tiles_x, tly = p.tiles_y, gdim = (int)gridDim.x;
+    pc_pin(pH); pc_pin(pW); pc_pin(pacc); pc_pin(ntl); pc_pin(tlx); pc_pin(tly); pc_pin(gdim);
+    pc_fastdiv dtx = p.div_tx, dtpi = p.div_tpi;
+    pc_pin(dtx); pc_pin(dtpi);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     unsigned char* const wimg = ldsb + wave * Cfg::WAVE_B;
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = y0 - 1 + l_r[i], x = x0 - 1 + l_px[i];
-            const bool in = l_slot[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const bool in = l_slot[i] >= 0 && (unsigned)y < (unsigned)pH && (unsigned)x < (unsigned)pW;
             const pc_bf16_t* gp = gptr + b * q.g.bstride + (in ? (int64_t)y * q.g.rstride + (int64_t)x * q.g.xstride : 0);
 #pragma unroll
             for (int c = 0; c < NG; ++c) RG[c][i] = *reinterpret_cast<const u32x4*>(gp + 8 * c);
@@ -119,13 +127,13 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
                 for (int c = 0; c < NX; ++c) ix[c * SROWS * BSLOTS + l_slot[i]] = ((xvalid >> i) & 1u) ? RX[c][i] : u32x4{0u, 0u, 0u, 0u};
             }
     };
-    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int my_tiles = ntl > (int)blockIdx.x ? (ntl - 1 - (int)blockIdx.x) / gdim + 1 : 0;
     auto strip_coords = [&](int k, int& b, int& y0, int& x0) {
-        const int tile = pc_xcd_remap(blockIdx.x + k * gridDim.x, p.ntiles);
-        b = (int)pc_div((uint32_t)tile, p.div_tpi);
-        const int rem = tile - b * p.tiles_x * p.tiles_y;
-        const int ty = (int)pc_div((uint32_t)rem, p.div_tx);
-        x0 = (rem - ty * p.tiles_x) * TW;
+        const int tile = pc_xcd_remap(blockIdx.x + k * gdim, ntl);
+        b = (int)pc_div((uint32_t)tile, dtpi);
+        const int rem = tile - b * tlx * tly;
+        const int ty = (int)pc_div((uint32_t)rem, dtx);
+        x0 = (rem - ty * tlx) * TW;
         y0 = ty * TH + 4 * wave;
     };
     int b = 0, y0 = 0, x0 = 0;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int y = y0 + 2 * (u >> 1) + e_s, x = x0 + (u & 1) * 16 + li;
-            if (y < p.H && x < p.W) {
+            if (y < pH && x < pW) {
                 if constexpr (POOL) {
                     const pc_bf16_t* const actp = reinterpret_cast<const pc_bf16_t*>(q.pool_act.ptr);
                     const int a_rs = q.pool_act.rstride, a_xs = q.pool_act.xstride, o_rs = q.out.rstride, o_xs = q.out.xstride;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_cl_kernel(const BwdArgs p) {
                         for (int r = 0; r < 4; ++r) v[r] = a4[r] > 0.f ? v[r] * e_scale[nb][r] : 0.f;
                     }
                     pc_bf16_t* op = outp + b * q.out.bstride + (int64_t)y * q.out.rstride + (int64_t)x * q.out.xstride + nb * 8 + c4;
-                    if (p.accumulate) {
+                    if (pacc) {
                         const f32x4 o4 = pc_ld4(op);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += o4[r];

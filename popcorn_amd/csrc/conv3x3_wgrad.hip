@@ -190,9 +190,27 @@ struct WgradGroup {
     WgradArgs pr[PC_MAX_GROUP];      // problems of identical geometry and loader kind: blockIdx.z selects
 };
 
+// the problem's descriptor, pinned in scalar registers (common.h: pc_pin; round 6: the strip loops re-loaded its fields from the kernel
+// arguments 26 - 78 times per iteration).  The REFLECT loader indexes the source's channel map per lane: that instantiation keeps the
+// reference into the kernel arguments.
+template <int LD>
+__device__ __forceinline__ const WgradArgs& wgrad_pinned(const WgradArgs& in, WgradArgs& local) {
+    if constexpr (LD == 3) {
+        return in;
+    } else {
+        local = in;
+        pc_pin(local.a); pc_pin(local.b); pc_pin(local.g);
+        local.partial = pc_pin_ptr(local.partial);
+        pc_pin(local.ci0); pc_pin(local.B); pc_pin(local.H); pc_pin(local.W); pc_pin(local.tiles_x); pc_pin(local.tiles_y); pc_pin(local.ntiles);
+        pc_pin(local.div_tx); pc_pin(local.div_tpi);
+        return local;
+    }
+}
+
 template <int CINC, int COUT, int LD>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_wave_kernel(const WgradGroup grp_) {
-    const WgradArgs& p = grp_.pr[blockIdx.z];
+    WgradArgs p_local;
+    const WgradArgs& p = wgrad_pinned<LD>(grp_.pr[blockIdx.z], p_local);
     using Cfg = WgradCfg<CINC, COUT>;
     constexpr int NBLK = Cfg::NBLK, MB = Cfg::MB;
     constexpr int NIT = CINC;
@@ -440,7 +458,8 @@ struct WgradClCfg {
 
 template <int CINC, int COUT, int LD>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_cl_kernel(const WgradGroup grp_) {
-    const WgradArgs& p = grp_.pr[blockIdx.z];
+    WgradArgs p_local;
+    const WgradArgs& p = wgrad_pinned<LD>(grp_.pr[blockIdx.z], p_local);
     using Cfg = WgradCfg<CINC, COUT>;
     using Cl = WgradClCfg<CINC, COUT>;
     constexpr int MB = Cl::MB, NCH = Cl::NCH, NBP = Cl::NBP, NBLK = Cl::NBLK;

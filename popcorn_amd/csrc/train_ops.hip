@@ -356,6 +356,55 @@ __global__ __launch_bounds__(256) void augment_raw_kernel(const AugArgs a) {
         a.admin_out[(int64_t)b * npx + r] = a.admin[(int64_t)b * hw + src];
     }
 }
+// odd rotations: a 32 x 32 tile of the output is a 32 x 32 tile of the source read ACROSS its rows -- staged through LDS so that both the
+// reads (along source rows) and the writes (along output rows) are coalesced (the direct form above touches one cache line per thread)
+__global__ __launch_bounds__(256) void augment_raw_transposed_kernel(const AugArgs a) {
+    __shared__ float tile[7][32][33];
+    const int tiles_j = (a.Wo + 31) / 32, tiles_i = (a.Ho + 31) / 32;
+    const int64_t hw = (int64_t)a.H * a.W, npx = (int64_t)a.Ho * a.Wo;
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;            // 32 x 8 threads, four rows each
+    for (int t = blockIdx.x; t < a.B * tiles_i * tiles_j; t += gridDim.x) {
+        const int b = t / (tiles_i * tiles_j), r = t - b * tiles_i * tiles_j;
+        const int i0 = (r / tiles_j) * 32, j0 = (r % tiles_j) * 32;
+        // source coordinates of output (i, j): rot 1: (y, x) = (j, W - 1 - i); rot 3: (H - 1 - j, i); then the flips.  Along a source ROW x
+        // follows i: the tile is read with tx -> i (x direction), ty -> j (y direction)
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dj = ty0 + 8 * q, di = tx;
+            const int i = i0 + di, j = j0 + dj;
+            if (i < a.Ho && j < a.Wo) {
+                int y, x;
+                if ((a.rot & 3) == 1) { y = j; x = a.W - 1 - i; } else { y = a.H - 1 - j; x = i; }
+                if (a.hflip) x = a.W - 1 - x;
+                if (a.vflip) y = a.H - 1 - y;
+                const int64_t src = (int64_t)y * a.W + x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = a.s2[((int64_t)b * 4 + c) * hw + src];
+                    if (a.bright) v = fminf(fmaxf(__fmul_rn(__fdiv_rn(v, 10000.f), a.beta), 0.f), 1.f) * 10000.f;
+                    if (a.gam) v = fminf(fmaxf(powf(__fdiv_rn(fmaxf(v, 0.f), 10000.f), a.gamma), 0.f), 1.f) * 10000.f;
+                    tile[c][dj][di] = v;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) tile[4 + c][dj][di] = a.s1[((int64_t)b * 2 + c) * hw + src];
+                tile[6][dj][di] = a.admin[(int64_t)b * hw + src];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int di = ty0 + 8 * q, dj = tx;                 // output row i0 + di, column j0 + dj: tx along the output row
+            const int i = i0 + di, j = j0 + dj;
+            if (i < a.Ho && j < a.Wo) {
+                const int64_t o = (int64_t)i * a.Wo + j;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a.raw[((int64_t)b * 6 + c) * npx + o] = tile[c][dj][di];
+                a.admin_out[(int64_t)b * npx + o] = tile[6][dj][di];
+            }
+        }
+    }
+}
 }  // namespace
 
 extern "C" int pc_augment_raw(const float* s2, const float* s1, const float* admin, float* raw, float* admin_out, int B, int H, int W,
@@ -369,7 +418,13 @@ extern "C" int pc_augment_raw(const float* s2, const float* s1, const float* adm
     const int64_t n = (int64_t)B * H * W;
     int grid = (int)((n + 255) / 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(augment_raw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (rot & 1) {
+        int tiles = B * ((a.Ho + 31) / 32) * ((a.Wo + 31) / 32);
+        if (tiles > 8192) tiles = 8192;
+        hipLaunchKernelGGL(augment_raw_transposed_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(augment_raw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    }
     PC_CHECK_LAUNCH();
     return 0;
 }

@@ -54,10 +54,17 @@ struct UbArgs { UbProb pr[PC_MAX_GROUP]; int H, W, ntx, nblocks, blocks_per_img;
 template <int C, int W>
 __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const UbProb& q = a.pr[blockIdx.y];
+    // the problem's descriptor and the launch geometry, pinned in scalar registers (common.h: pc_pin; round 6: 14 - 24 re-loads per block)
+    UbProb q = a.pr[blockIdx.y];
+    q.g = pc_pin_ptr(q.g); pc_pin(q.g_bs); pc_pin(q.g_cs); pc_pin(q.g_rs);
+    q.z = pc_pin_ptr(q.z); pc_pin(q.z_bs); pc_pin(q.z_cs); pc_pin(q.z_rs);
+    q.gz = pc_pin_ptr(q.gz); pc_pin(q.gz_bs); pc_pin(q.gz_cs); pc_pin(q.gz_rs);
+    q.part = pc_pin_ptr(q.part);
+    int aH = a.H, aW = a.W, a_ntx = a.ntx, a_nblocks = a.nblocks, a_bpi = a.blocks_per_img, gdim = (int)gridDim.x;
+    pc_pin(aH); pc_pin(aW); pc_pin(a_ntx); pc_pin(a_nblocks); pc_pin(a_bpi); pc_pin(gdim);
     constexpr int w = W / 2, W4 = W / 4, w4 = w / 4;
-    const int H = a.H, h = H >> 1;
-    const int WI = a.W, wI = WI >> 1;                        // image width (full / low resolution)
+    const int H = aH, h = H >> 1;
+    const int WI = aW, wI = WI >> 1;                        // image width (full / low resolution)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     constexpr int GRS = W + 8;                               // G row: data at cols 4 .. W + 3, halo cols 3 and W + 4
@@ -95,10 +102,10 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
     const int hg_side = tid & 1, hg_row = (tid >> 1) % UB_GROWS, hg_co = (tid >> 1) / UB_GROWS;
     const int hz_side = tid & 1, hz_row = (tid >> 1) % (UB_RB + 2), hz_ci = (tid >> 1) / (UB_RB + 2);
     auto decode = [&](int blk, int& b, int& i0, int& X0) {
-        b = blk / a.blocks_per_img;
-        const int r = blk - b * a.blocks_per_img, rb = r / a.ntx;
+        b = blk / a_bpi;
+        const int r = blk - b * a_bpi, rb = r / a_ntx;
         i0 = rb * UB_RB;
-        X0 = (r - rb * a.ntx) * W;
+        X0 = (r - rb * a_ntx) * W;
     };
     auto fetch = [&](int blk) {
         int b, i0, X0;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
             const int x = x0 + 4 * seg;
             RZ[k] = ci < C ? *reinterpret_cast<const f32x4*>(zp + ci * q.z_cs + (int64_t)Ic * q.z_rs + (x < wI ? x : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (a.ntx > 1) {
+        if (a_ntx > 1) {
             if (tid < 8 * UB_GROWS * 2) {
                 const int Y = 2 * i0 - 1 + hg_row, Yc = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
                 const int X = hg_side ? X0 + W : X0 - 1;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
             const int I = i0 - 1 + row;
             if (ci < C) *reinterpret_cast<f32x4*>(zimg + ci * ZCS + row * ZRS + 4 + 4 * seg) = ((unsigned)I < (unsigned)h && x0 + 4 * seg < wI) ? RZ[k] : zero;
         }
-        if (a.ntx > 1) {
+        if (a_ntx > 1) {
             if (tid < 8 * UB_GROWS * 2) {
                 const int Y = 2 * i0 - 1 + hg_row, X = hg_side ? X0 + W : X0 - 1;
                 gimg[hg_co * GCS + hg_row * GRS + (hg_side ? W + 4 : 3)] = ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)WI) ? RGh : 0.f;
@@ -175,14 +182,14 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const UbArgs a) {
         for (int c = 0; c < 4; ++c) sg[k][c] = 0.f;
 
     int blk = blockIdx.x;
-    if (blk < a.nblocks) fetch(blk);
-    for (; blk < a.nblocks; blk += gridDim.x) {
+    if (blk < a_nblocks) fetch(blk);
+    for (; blk < a_nblocks; blk += gdim) {
         int b, i0, X0;
         decode(blk, b, i0, X0);
         const int x0 = X0 >> 1;
         __syncthreads();                             // the previous block's MFMA reads of the images are done
         commit(blk);
-        if (blk + (int)gridDim.x < a.nblocks) fetch(blk + gridDim.x);
+        if (blk + gdim < a_nblocks) fetch(blk + gdim);
         __syncthreads();
 
         // ---- data gradient: units (low-res row il, 16-column block jb), round-robin over the waves

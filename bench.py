@@ -67,7 +67,7 @@ def parse():
                          "1500-step block) and `h2d` (the step fed from pinned host memory through a copy stream)")
     ap.add_argument("--extras-multi", action="store_true",
                     help="N > 1: also run the `bf16` and `h2d` legs (default: skipped, the multi-GPU run stays under two minutes)")
-    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `grad_parity`, `config3_regions`, `config3_epoch`, `config5`")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the N = 1 legs `fwd_parity`, `grad_parity`, `batch16`, `config3_regions`, `config3_epoch`, `config5`")
     ap.add_argument("--soak-steps", type=int, default=1500)
     ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed steps in front of the W warm-up steps until this much wall time has passed: the part's clocks settle "
@@ -975,6 +975,41 @@ def config3_regions_leg(torch, margs, dev, steps=10, blocks=5):
             "frac_of_fp32_mfma_peak": round(tot_fl / tot_t / FP32_MATRIX_PEAK, 4), "peak_hbm_gib": round(peak, 2), "batches": rows}
 
 
+def small_batch_leg(torch, margs, dev, B=16, steps=60, blocks=5):
+    """The headline step at B = 16 tiles (captured graph, raw 15-band tiles resident): the batch size at which per-launch fixed costs weigh
+    four times as much as at B = 64 (reported on the driver's line instead of only in DESIGN.md)."""
+    from popcorn_amd.data.synthetic import make_raw_batch
+    from popcorn_amd.model import get_model_kwargs, model_dict
+    from popcorn_amd.train import FusedTrainStep
+    torch.manual_seed(1600)
+    model = model_dict["POPCORN"](**get_model_kwargs(margs, "POPCORN")).to(dev)
+    tr = FusedTrainStep(model, lr=1e-4, weight_decay=1e-5, gradient_clip=0.01, loss=("log_l1_loss",), lam=(1.0,), scale_regularization=0.01,
+                        lam_weak=100.0, reducer=_LocalReducer(), use_graph=True)
+    batch = make_raw_batch(B, 100, 100, seed=1616, device=dev)
+    smp = tr.static_buffers(B, 100, 100, raw_channels=batch["raw"].shape[1])
+    smp["raw"].copy_(batch["raw"]); smp["admin_mask"].copy_(batch["admin_mask"]); smp["census_idx"].copy_(batch["census_idx"]); smp["y"].copy_(batch["y"])
+    torch.manual_seed(1616)
+    for _ in range(200):
+        tr.step(smp)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(smp)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) / steps * 1e3)
+    lv = float(loss[0].item())
+    if not (lv == lv) or abs(lv) == float("inf"):
+        raise SystemExit("small_batch: non-finite loss")
+    m = statistics.median(ms)
+    del tr, model
+    torch.cuda.empty_cache()
+    return {"batch": B, "value": round(B / m * 1e3, 1), "unit": "patches/s", "ms_per_step": round(m, 4), "ms_per_step_blocks": [round(v, 4) for v in ms],
+            "step_frac_of_fp32_mfma_peak": round(B / m * 1e3 * FLOP_TRAIN_PER_TILE / FP32_MATRIX_PEAK, 4),
+            "workload": f"the headline step at B = {B} tiles (captured graph, raw 15-band tiles resident, every pixel selected)"}
+
+
 def config3_epoch_leg(torch, dev, regions=256, hw=(150, 700), workers=0):
     """BASELINE config 3 END TO END: the trainer counterpart's own loop (popcorn_amd.cli.Trainer.train = run_train.py:146-269) over
     `regions` synthetic census regions through the DataLoader -- collate (zero-padding to the batch maximum), pinned staging, the
@@ -987,16 +1022,18 @@ def config3_epoch_leg(torch, dev, regions=256, hw=(150, 700), workers=0):
     tmp = tempfile.mkdtemp(prefix="pc_epoch_")
     argv = (f"-S2 -NIR -S1 -occmodel -senbuilds -pret -wd 1e-5 --biasinit 0.9407 -lr 1e-4 --synthetic_regions {regions} -wb 2 --save_dir {tmp} "
             f"-lt 1000000 -val 1000000 -e 1 --synthetic_hw_range {hw[0]} {hw[1]} --save-model no -w {workers}").split()
+    import contextlib
     t = Trainer(train_parser().parse_args(argv))
     a = t.args
-    t.train()                                   # epoch 0: untimed
-    torch.cuda.synchronize()
-    a.num_epochs = 2
-    native0, it0 = t.fused.native_steps, t.info["iter"]
-    t0 = time.perf_counter()
-    t.train()                                   # epoch 1: timed, loader -> collate -> feed -> augment -> step
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with contextlib.redirect_stdout(sys.stderr):        # (the trainer's "Training finished" line: stdout carries the ONE JSON line)
+        t.train()                               # epoch 0: untimed
+        torch.cuda.synchronize()
+        a.num_epochs = 2
+        native0, it0 = t.fused.native_steps, t.info["iter"]
+        t0 = time.perf_counter()
+        t.train()                               # epoch 1: timed, loader -> collate -> feed -> augment -> step
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     steps = t.info["iter"] - it0
     # the same epoch's batches, prepared and resident: what the executor alone takes on this geometry mix
     staged, px = [], 0
@@ -1306,6 +1343,24 @@ def main():
     extras = {}
     if not args.no_extras and (world == 1 or args.extras_multi):
         extras = extra_legs(torch, dist, args, world, rank, dev, B, batch, trainer, sample, step, build, run_blocks, timed_block)
+    elif not args.no_extras:
+        # N > 1 (round 6): the scaling run shows the one limit SURVEY 8e predicted -- N ranks fed through one host -- by default: ONE host-feed
+        # leg with the narrowest feed (S2 as uint16 digital numbers + S1 fp32, 160 KB per tile: 8 ranks need 49 GB/s of pinned H2D against
+        # 52.5 measured on the one-link test box; the fp32 6-band feed needs 73.6), reported next to the resident `value` as `value_fed`
+        torch.cuda.synchronize()
+        dist.barrier()
+        nfeed = max(args.steps * 4, 100)
+        leg, dtf = h2d_leg(torch, trainer, sample, batch, "split", nfeed, "6 pre-selected bands, S2 as uint16 digital numbers + S1 fp32 (160 KB / tile)")
+        tt = torch.tensor([dtf], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dtf = tt.item()
+        leg["ms_per_step"] = round(dtf / nfeed * 1e3, 4)
+        leg["value"] = round(B * world * nfeed / dtf, 1)
+        extras = {"value_fed": leg["value"],
+                  "h2d": {"unit": "patches/s", "precision": args.precision, "legs": [leg], "default_feed": leg["feed"],
+                          "h2d_gbps_per_rank_sustained": leg["h2d_gbps_sustained"],
+                          "note": "whole job, max over ranks: every rank feeds its own batches from pinned host memory on its measured copy stream; "
+                                  "`value` (the headline) keeps its inputs resident in HBM"}}
 
     # which devices took part (one entry per rank: "<rank>:<device ordinal>:<bus id>"), gathered through the job's own backend
     dp = {"ranks_seen": 1, "devices": None, "capture_failed": False}
@@ -1375,6 +1430,7 @@ def main():
             res["grad_parity"] = grad_parity(torch, margs, sd_cpu, batch, dev)
             del trainer, model
             torch.cuda.empty_cache()
+            res["batch16"] = small_batch_leg(torch, margs, dev, 16)
             res["config3_regions"] = config3_regions_leg(torch, margs, dev)
             res["config3_epoch"] = config3_epoch_leg(torch, dev)
             res["config5"] = config5_leg(torch, margs, dev)

@@ -321,7 +321,11 @@ class Trainer:
         if self.fused is not None:
             # loss_out is one device buffer overwritten by every step: keep a copy for the running log mean
             loss = self.fused.step(s, encoder_no_grad=enc_ng, unet_no_grad=unet_ng)[0].clone()
-            self._buffer_r2(self.fused.last["popcount"], s["y"])
+            # the R2 buffers hold the last 300 samples and are read at log steps only: a step whose samples will have left the window
+            # by the next log step does not copy them (two launches per step on the smallest regions)
+            to_log = a.logstep_train - (self.info["iter"] % a.logstep_train)
+            if to_log * s["y"].numel() <= 300 + s["y"].numel():
+                self._buffer_r2(self.fused.last["popcount"], s["y"])
             return loss
         from torch.nn.utils import clip_grad_norm_
         from .utils.losses import get_loss

@@ -35,11 +35,21 @@ struct CtGroup {
     CtArgs pr[PC_MAX_GROUP];
 };
 
+// the problem's descriptor, pinned in scalar registers (common.h: pc_pin; round 6: the group loops re-loaded its fields from the kernel
+// arguments 10 - 34 times per iteration)
+__device__ __forceinline__ void ct_pin(CtArgs& p) {
+    pc_pin(p.x); pc_pin(p.g); pc_pin(p.out);
+    p.w = pc_pin_ptr(p.w); p.bias = pc_pin_ptr(p.bias); p.act = pc_pin_ptr(p.act); p.partial = pc_pin_ptr(p.partial);
+    pc_pin(p.act_bstride); pc_pin(p.act_cstride); pc_pin(p.act_rstride); pc_pin(p.act_xstride);
+    pc_pin(p.B); pc_pin(p.H); pc_pin(p.W); pc_pin(p.groups_x); pc_pin(p.ngroups); pc_pin(p.div_gx); pc_pin(p.div_gimg);
+}
+
 // fp32 kernels (planar tensors); the channels-last bf16 kernels of PC_PREC_BF16 follow below
 template <int C>
 __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
     using act_t = float;
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     constexpr int KS = C / 4, NBK = C / 4;
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -107,7 +117,8 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const CtGroup grp_) {
 template <int C>
 __global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const CtGroup grp_) {
     using act_t = float;
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -189,7 +200,8 @@ typedef unsigned ct_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ short ct_bf(float x) { return (short)pc_f2bf(x); }
 template <int C>
 __global__ __launch_bounds__(256) void convt2x2_fwd_cl_kernel(const CtGroup grp_) {
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     constexpr int NT = C / 4;                 // M tiles of the (a, b, co) space: C = 8: tile = a, m = b*8 + co;  C = 16: tile = (a, b), m = co
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -238,7 +250,8 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_cl_kernel(const CtGroup grp_
 
 template <int C>
 __global__ __launch_bounds__(256) void convt2x2_dgrad_cl_kernel(const CtGroup grp_) {
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     constexpr int NH = C / 8;                 // 8-channel halves of co = MFMAs per group
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -298,7 +311,8 @@ __device__ __forceinline__ ct_s4 ct_tr(const unsigned char* p) {
 // the pixel operand = one 16-byte slot of the g image, the ReLU mask of x's producer from the x image.
 template <int C, bool DG>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_cl_kernel(const CtGroup grp_) {
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     constexpr int NBK = C / 4, NT = C / 4;    // N tiles: C = 8: tile = a, n = b*8 + co;  C = 16: tile = (a, b), n = co
     constexpr int PB = 2 * C;                 // bytes per pixel
     constexpr int XB = 32 * PB, GB = 2 * 64 * PB, WB = XB + GB;
@@ -466,7 +480,8 @@ constexpr int CT_GLRS = 36;
 template <int C, bool VEC, bool DG>
 __global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const CtGroup grp_) {
     using act_t = float;
-    const CtArgs& p = grp_.pr[blockIdx.y];
+    CtArgs p = grp_.pr[blockIdx.y];
+    ct_pin(p);
     constexpr int NBK = C / 4;
     using Cfg = CtWgradCfg<C>;
     constexpr int GLW = C * 2 * CT_GLRS;                   // floats of a wave's gradient image (DG)

@@ -119,8 +119,29 @@ def test_live_two_rank_bench_line_on_one_gpu_through_gloo():
     assert c["collectives"] is True and c["collectives_per_step"] == 2 and c["dp_graph"] == "split" and c["ranks_seen"] == 2
     assert c["dp_capture_failed"] is False and len(d["per_rank_ms_per_step"]) == 2
     assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
-    assert "bf16" not in d and "h2d" not in d and "soak" not in d          # N > 1: the extra legs are skipped (run stays short)
+    assert "bf16" not in d and "soak" not in d                             # N > 1: the long extra legs are skipped (run stays short) ...
+    # ... but ONE host-feed leg runs by default (round 6: the narrowest feed, uint16 S2 + fp32 S1) and the line carries the fed rate
+    # next to the resident one -- the limit a scaling run through one host is expected to show
+    assert d["value_fed"] > 0 and len(d["h2d"]["legs"]) == 1 and "uint16" in d["h2d"]["default_feed"]
+    assert abs(d["value_fed"] - d["h2d"]["legs"][0]["value"]) < 1e-6 and d["h2d"]["legs"][0]["host_bytes_per_step"] < 64 * 100 * 100 * 21
     assert d["cpu_baseline"] is None and "config3_regions" not in d
+
+
+@pytest.mark.gpu
+def test_scale_preflight_runs_on_two_gloo_ranks_of_one_gpu():
+    """tools/scale_preflight.py (what to run on the N-GPU node before the scaling bench): rank census, the two collectives alone, one-graph
+    vs three-graph data-parallel steps against the single-process trajectory -- as a functional run with two gloo ranks on the one test
+    GPU (the one-graph form needs RCCL: on gloo both settings take the split form and must reproduce the single-process parameters)."""
+    env = dict(os.environ, POPCORN_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "tools", "scale_preflight.py"), "--steps", "12", "--batch", "4"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["ok"] is True and d["world"] == 2 and d["ranks_seen"] == 2 and d["rccl_ranks_seen"] is None
+    assert set(d["collectives_us"]) == {"grad_allreduce_157KB", "stats_allreduce_16B"}
+    for v in d["dp_graph_ab"].values():
+        assert v["graph_form"] == "split" and v["max_rel_param_distance_to_single_process"] <= 1e-4
 
 
 @pytest.mark.gpu

@@ -45,8 +45,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--step-ms", type=float, default=1.67, help="resident step time: what one rank's feed must keep up with")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--feed", choices=["fp32", "split"], default="fp32",
+                    help="split: S2 as uint16 digital numbers + S1 fp32 (160 KB per tile, the default feed of bench.py --gpus N since round 6)")
     a = ap.parse_args()
-    nbytes = 64 * 6 * 100 * 100 * 4
+    nbytes = 64 * 6 * 100 * 100 * 4 if a.feed == "fp32" else 64 * 100 * 100 * (4 * 2 + 2 * 4)
     res = {}
     for n in sorted({1, a.ranks}):
         ctx = mp.get_context("spawn")
@@ -61,7 +63,8 @@ def main():
     need1 = nbytes / (a.step_ms * 1e-3) / 1e9
     res["needed_per_rank_gbps"] = round(need1, 2)
     res[f"needed_{a.ranks}_ranks_gbps"] = round(need1 * a.ranks, 2)
-    res["feed"] = f"fp32 6-band, B = 64 tiles of 100 x 100: {nbytes / 1e6:.1f} MB per step, step {a.step_ms} ms"
+    res["feed"] = (f"{'fp32 6-band' if a.feed == 'fp32' else 'uint16 S2 (4 bands) + fp32 S1 (2 bands)'}, B = 64 tiles of 100 x 100: "
+                   f"{nbytes / 1e6:.1f} MB per step, step {a.step_ms} ms")
     res["note"] = "all ranks share the ONE PCIe link of the single-GPU box: a lower bound for N links"
     print(json.dumps(res))
     if a.out:

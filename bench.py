@@ -1387,10 +1387,13 @@ def main():
                        "global_batch": B * world, "tile": "15x100x100 -> 6x100x100 (128x128 internal)",
                        "parallelism": f"dp{world}", "graph": not args.no_graph,
                        # fp32 mode: the sparse head's products are exact 3-way bf16 operand splits on the bf16 matrix pipe, accumulated in
-                       # fp32 (popcorn_hip.h: pc_set_head_split; fp32 accuracy measured against float64 in tests/test_gpu_convt_head.py);
-                       # every other kernel of the fp32 step is v_mfma_f32_16x16x4_f32
+                       # fp32 (popcorn_hip.h: pc_set_head_split; fp32 accuracy measured against float64 in tests/test_gpu_convt_head.py)
                        "head_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_head_split() else "fp32_mfma") if args.precision == "fp32"
                                          else "bf16"),
+                       # ... and so does the fused conv backward (round 6: popcorn_hip.h: pc_set_conv_split; 7 of the step's 33 launches); the
+                       # other conv kernels of the fp32 step are v_mfma_f32_16x16x4_f32
+                       "conv_bwd_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_conv_split() else "fp32_mfma") if args.precision == "fp32"
+                                             else "bf16"),
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "collectives": bool(trainer.reducer.active),
                        "collectives_per_step": 2 if trainer.reducer.active else 0,

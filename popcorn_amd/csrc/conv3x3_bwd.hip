@@ -650,7 +650,7 @@ __device__ long long g_bwd_prof[4096 * 8];
 template <int GC>
 struct S3Cfg {
     static constexpr int NG = GC / 8;
-    static constexpr int BSL = 35;                             // slots per strip row: slot s = pixel x0 - 1 + s (34 used)
+    static constexpr int BSL = 34;                             // slots per strip row: logical slot s = pixel x0 - 1 + s, stored at s3_sl(s)
     static constexpr int IMG = SROWS * BSL * 16;               // bytes of one 8-channel plane image
     static constexpr int PLANE = (NG + 1) * IMG;               // one split plane of a wave: NG images of g, one of x
     static constexpr int WAVE_B = 3 * PLANE;
@@ -663,6 +663,13 @@ struct S3Cfg {
     static_assert(3 * WPL <= 4 * WAVE_B, "the prologue's weight image overlays the strip images");
     static constexpr int WAVES_PER_SIMD = (size_t)2 * LDS_B <= 160 * 1024 ? 2 : 1;
 };
+
+// Physical slot of logical slot s inside a strip row: an XOR swizzle of the low two bits with the 8-slot block index.  With the plain
+// layout the 8 lanes of a ds_write_b128 group (segments 4 slots apart) hit 2 of 8 bank groups (4-way conflict) and the two strip rows of a
+// 16-lane ds_read_b128 group overlap (2-way): SQ_LDS_BANK_CONFLICT was 11.1 M of 18.0 M LDS-active cycles per launch, the LDS 70 % busy
+// (profiles/r6_pmc_conv_bwd_after.json).  A bank simulator over row strides, per-row rotations and XOR swizzles (tools/lds_bank_sim.py) puts
+// this one at 996 LDS cycles per strip against 1,368 (conflict-free: 504; that needs a 48-slot stride = one workgroup per CU).
+__device__ __forceinline__ int s3_sl(int s) { return s ^ ((s >> 3) & 3); }
 
 // a wave-uniform value the compiler must keep in a scalar register: without this hipcc re-loads kernel-argument fields (descriptor
 // pointers, strides, flags) with s_load + s_waitcnt at every use inside the strip loop -- four dependent scalar-memory round trips per
@@ -713,6 +720,12 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
     const bool l_act = lane < 60;
     f32x4 RG[GC], RX[8];
     bool rvalid = false;
+    int c_sl[4];                                                             // physical slots of the lane's four pixels (commit)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sl = 4 * l_seg + e - 3;
+        c_sl[e] = s3_sl(sl < 0 ? 0 : (sl > 33 ? 33 : sl));
+    }
     auto issue = [&](int b, int y0, int x0) {
         const int xg = x0 - 4 + 4 * l_seg, y = y0 - 1 + l_r;
         const bool ok = l_act && xg >= 0 && xg < W && (unsigned)y < (unsigned)H;
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) RX[it][e] = rvalid ? RX[it][e] : 0.f;
         }
-        u32x4* const d0 = reinterpret_cast<u32x4*>(wimg) + l_r * BSL + 4 * l_seg - 3;
+        u32x4* const d0 = reinterpret_cast<u32x4*>(wimg) + l_r * BSL;
 #pragma unroll
         for (int c = 0; c < NG + 1; ++c)
 #pragma unroll
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                 // e = 3 exists in every segment but the last, e = 0 in every segment but the first, e = 1, 2 in the inner ones
                 const bool w_ok = l_act && (e == 3 ? l_seg < 9 : (e == 0 ? l_seg > 0 : (l_seg > 0 && l_seg < 9)));
                 if (w_ok) {
-                    u32x4* d = d0 + c * (IMG / 16) + e;
+                    u32x4* d = d0 + c * (IMG / 16) + c_sl[e];
                     d[0] = q1;
                     d[PLANE / 16] = q2;
                     d[2 * (PLANE / 16)] = q3;
@@ -826,8 +839,18 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
 
     // ---- weight-gradient reads (conv3x3_bwd_cl_kernel's): lane supplies pixel row j = li >> 2 and column quad tq = li & 3
     const int t_j = li >> 2, t_q = li & 3;
-    const int a_off = ((1 + (t_q >> 1)) * BSL + SL0 + 8 * lk + t_j) * 16 + 8 * (t_q & 1);
-    const int b_off = (t_q * BSL + (SL0 - 1) + 8 * lk + t_j) * 16;
+    int a_off[2], b_off[3][2];                                               // [.., hi]: the second transposing read sits 4 pixels on
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        a_off[hi] = ((1 + (t_q >> 1)) * BSL + s3_sl(SL0 + 8 * lk + t_j + 4 * hi)) * 16 + 8 * (t_q & 1);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) b_off[dx][hi] = (t_q * BSL + s3_sl((SL0 - 1) + 8 * lk + t_j + dx + 4 * hi)) * 16;
+    }
+    int dg_sl[3][2];                                                         // data gradient: the lane's pixel slot per (dx, half of the strip row)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dg_sl[dx][h] = s3_sl((SL0 - 1) + li + dx + 16 * h);
     f32x4 wacc[NG][NBLK], bacc[NG];
     const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 #pragma unroll
@@ -838,7 +861,12 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
     }
     const unsigned char* const ixb = wimg + NG * IMG;                       // plane 0 of the x image
     // sign of the layer's input at the lane's output pixels: first split plane of the x image (rn_bf16 keeps sign and zero)
-    const unsigned short* const xs0 = reinterpret_cast<const unsigned short*>(ixb + ((1 + s_row) * BSL + SL0 + 4 * lk) * 16) + col;
+    const unsigned short* const xs0 = reinterpret_cast<const unsigned short*>(ixb + ((1 + s_row) * BSL) * 16) + col;
+    int m_sl[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m_sl[h][r] = s3_sl(SL0 + 16 * h + 4 * lk + r);
 
     BQ_DECL;
     BQ_START;
@@ -861,7 +889,7 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xm[4 * u + r] = xs0[((u >> 1) * 2 * BSL + (u & 1) * 16 + r) * 8];
+                    for (int r = 0; r < 4; ++r) xm[4 * u + r] = xs0[((u >> 1) * 2 * BSL + m_sl[u & 1][r]) * 8];
             }
         }
         // ---- data gradient: a 3x3 conv over g, K = 4 rows x 8 channels per instruction, six partial products per K-step
@@ -876,9 +904,9 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                 bf16x8 av[3][4];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const u32x4* lrow = reinterpret_cast<const u32x4*>(wimg + pl * PLANE + gc * IMG) + lk * BSL + (SL0 - 1) + li + dx;
+                    const u32x4* lrow = reinterpret_cast<const u32x4*>(wimg + pl * PLANE + gc * IMG) + lk * BSL;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) av[pl][u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSL + (u & 1) * 16]);
+                    for (int u = 0; u < 4; ++u) av[pl][u] = __builtin_bit_cast(bf16x8, lrow[(u >> 1) * 2 * BSL + dg_sl[dx][u & 1]]);
                 }
 #pragma unroll
                 for (int pw = 2; pw >= 0; --pw)               // weight split index; pixel split indices 2 - pw .. 0: smallest products first
@@ -989,8 +1017,8 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
             for (int mb = 0; mb < NG; ++mb)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned char* ga = wimg + pl * PLANE + mb * IMG + 2 * rpi * BSL * 16 + a_off;
-                    av[mb][pl] = bw_pair(bw_tr(ga), bw_tr(ga + 4 * 16));
+                    const unsigned char* ga = wimg + pl * PLANE + mb * IMG + 2 * rpi * BSL * 16;
+                    av[mb][pl] = bw_pair(bw_tr(ga + a_off[0]), bw_tr(ga + a_off[1]));
                 }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -999,8 +1027,8 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned char* xb = ixb + pl * PLANE + 2 * rpi * BSL * 16 + b_off + dx * 16 + 8 * nb;
-                        bv[dx][pl] = bw_pair(bw_tr(xb), bw_tr(xb + 4 * 16));
+                        const unsigned char* xb = ixb + pl * PLANE + 2 * rpi * BSL * 16 + 8 * nb;
+                        bv[dx][pl] = bw_pair(bw_tr(xb + b_off[dx][0]), bw_tr(xb + b_off[dx][1]));
                     }
                 if (nb == 0) {
 #pragma unroll

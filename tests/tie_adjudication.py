@@ -115,7 +115,8 @@ def head_near_ties(sd, feats, mask, rel_eps=3e-6):
     return [(i, u, c) for _, i, u, c in sorted(out)]
 
 
-def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, head_flips=(), search_head=True, bar=1e-4, **flags):
+def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, head_flips=(), search_head=True, bar=1e-4,
+                             max_flip_rate=2e-5, margin_bar=1e-4, **flags):
     """Worst relative distance between the HIP gradients and the CPU oracle's when the oracle takes the HIP side's decisions: at EVERY
     ReLU mask and pooling arg-max of the trainable U-Net they come from the HIP forward's saved activations (``O.ForceDecisions``);
     the head's hidden activations live in registers, so if the distance is still above ``bar`` the head's decisions are looked for
@@ -123,7 +124,12 @@ def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, 
     the distance down by more than half (at most 3 units).  No tie is then left to flip between the two sides and the distance is
     rounding only -- whatever the unforced comparison showed.  ``fp64``: the oracle in double precision (the exact gradients of that
     decision set).  Returns (worst, name of the worst tensor, {"relu", "pool": sites where the oracle alone decides differently,
-    "head": inverted head units}, loss)."""
+    "head": inverted head units}, loss).
+
+    The forced oracle takes its decisions from the implementation under test, so it must not be able to adopt a WRONG mask: the number of
+    overridden sites is bounded (``max_flip_rate`` of all decision sites, at least 8) and every overridden site must be within rounding of
+    a tie in the oracle's own values (``margin_bar``: |pre-activation| or top-2 gap relative to the layer's mean magnitude) -- a kernel
+    regression that corrupts masks or arg-maxes fails here instead of being adopted."""
     acts, pools, hip_feats = hip_decision_sites(sd, x_dev, bool(flags.get("encoder_no_grad")))
     if flags.get("unet_no_grad"):
         acts, pools = [], []                      # nothing in the U-Net carries gradient: only the head has decisions
@@ -137,6 +143,10 @@ def forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, fp64=True, 
         with O.ForceDecisions(acts, pools, hf) as f:
             loss, out, g, _ = O.train_step_grads(sd, dict(cpu_sample), **flags)
         assert f.i == len(acts) and f.j == len(pools), (f.i, len(acts), f.j, len(pools))
+        for kind in ("relu", "pool"):
+            assert f.flips[kind] <= max(8, max_flip_rate * f.sites[kind]), \
+                (kind, "overridden decisions", f.flips[kind], "of", f.sites[kind], ": more than rounding explains")
+            assert f.margin[kind] <= margin_bar, (kind, "an overridden decision is not a near-tie in the oracle's own values", f.margin[kind])
         errs = {n: rel(hip_grads[n], g[n]) for n in g}
         worst = max(errs, key=errs.get)
         return errs[worst], worst, dict(f.flips), loss

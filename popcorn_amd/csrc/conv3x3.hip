@@ -26,6 +26,7 @@
 // Up to PC_MAX_GROUP independent problems of identical geometry (e.g. the SAR and optical streams, or the frozen
 // building extractor next to the trainable U-Net) share one launch: blockIdx.y selects the problem.
 #include "common.h"
+#include <type_traits>
 #include "tile_loader.h"
 
 static int g_conv_dbg = 0, g_conv_max_grid = 0;
@@ -919,6 +920,8 @@ int launch_conv_po(ConvArgs& p, int nprob, hipStream_t stream) {
     return 0;
 }
 
+#include "conv3x3_fwd_s3.h"
+
 
 // =====================================================================================================================
 // Channels-last bf16 kernel (PC_PREC_BF16).  Activations / gradients are bf16 tensors with the channels of a pixel
@@ -1414,6 +1417,20 @@ int launch_conv_bf16(ConvArgs& p, int nprob, hipStream_t stream) {
 
 template <int CIN, int COUT, int MODE, int LD>
 int launch_conv_ld(ConvArgs& p, int nprob, hipStream_t stream) {
+    if constexpr (MODE == MODE_FWD && LD == LD_DIRECT && (CIN == 8 || CIN == 16) && (COUT == 8 || COUT == 16)) {
+        // split-operand form (conv3x3_fwd_s3.h): every 8- / 16-channel layer whose tensors are aligned
+        if (fwd_s3_ok<CIN, COUT>(p, nprob, 0)) {
+            bool po = false, dot = false;
+            for (int i = 0; i < nprob; ++i) {
+                po = po || p.pr[i].pool_out.ptr != nullptr;
+                dot = dot || p.pr[i].dot_w != nullptr;
+            }
+            if constexpr (CIN == 8 && COUT == 8) {
+                if (dot) return launch_fwd_s3<CIN, COUT, EPI_DOT, 0>(p, nprob, stream);
+            }
+            return po ? launch_fwd_s3<CIN, COUT, EPI_POOL, 0>(p, nprob, stream) : launch_fwd_s3<CIN, COUT, EPI_NONE, 0>(p, nprob, stream);
+        }
+    }
     if constexpr (MODE == MODE_FWD && CIN >= 8) {       // the layers in front of a Down block: inc.conv.3 (8->8), down1 conv.3 (16->16)
         bool po = false;
         for (int i = 0; i < nprob; ++i) po = po || p.pr[i].pool_out.ptr != nullptr;
@@ -1819,6 +1836,10 @@ extern "C" int pc_conv3x3_up_fwd_group(int n, const pc_conv_up_fwd_desc* d, int 
     p.div_tpi = pc_make_fastdiv(p.tiles_x * p.tiles_y);
     p.dbg = g_conv_dbg;
     p.ts = g_conv_ts;
-    if (Cs == 8) return launch_conv_po<8, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 8>(p, n, st);
+    if (Cs == 8) {
+        if (fwd_s3_ok<8, 8>(p, n, 8)) return launch_fwd_s3<8, 8, EPI_NONE, 8>(p, n, st);
+        return launch_conv_po<8, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 8>(p, n, st);
+    }
+    if (fwd_s3_ok<16, 8>(p, n, 16)) return launch_fwd_s3<16, 8, EPI_NONE, 16>(p, n, st);
     return launch_conv_po<16, 8, MODE_FWD, LD_DIRECT, EPI_NONE, 16>(p, n, st);
 }

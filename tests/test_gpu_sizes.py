@@ -184,7 +184,7 @@ def test_config3_batch64_train_step_is_deterministic_and_graph_equals_eager():
 def test_config3_batch64_fused_step_gradients_vs_oracle():
     """BASELINE config[2] at its full size (B=64 tiles of 100x100, rwa recipe): loss, popcount and all 56 gradients of ONE
     fused step against the CPU oracle's autograd (~10 s of CPU), <= 2e-4 relative -- the same bar as the B=3 reference
-    fixture g5."""
+    fixture g5 (and the same adjudication of a mismatch above it: a proven decision flip + the shared-decision distance)."""
     from popcorn_amd.data.synthetic import make_raw_batch
     batch = make_raw_batch(64, 100, 100, seed=1603, region="disc")
     x = O.select_normalize(batch["raw"])
@@ -199,9 +199,16 @@ def test_config3_batch64_fused_step_gradients_vs_oracle():
     assert abs(loss[0].item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
     torch.testing.assert_close(tr.last["popcount"].cpu(), ref_out["popcount"], rtol=1e-4, atol=1e-3)
     assert set(ref_grads) == set(tr.grads)
-    for n, r in ref_grads.items():
-        e = (tr.grads[n].cpu() - r).abs().max().item()
-        assert e <= 2e-4 * max(r.abs().max().item(), 1e-3), (n, e, r.abs().max().item())
+    worst = max((tr.grads[n].cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-3) for n, r in ref_grads.items())
+    if worst > 2e-4:
+        # 640 k pixels x 20 layers of decisions: above the bar only through a PROVEN ReLU / arg-max tie flip (tests/tie_adjudication.py),
+        # and the fp64 oracle on the HIP side of every decision must then be the HIP gradients' neighbour
+        from tests.tie_adjudication import assert_tie_flip, forced_decision_distance
+        assert worst < 5e-3, worst
+        hip_g = {n: tr.grads[n].cpu().clone() for n in ref_grads}
+        assert_tie_flip(sd, cpu, x.cuda(), hip_g, {n: r.clone() for n, r in ref_grads.items()}, 5, worst)
+        wf, wname, flips, _ = forced_decision_distance(sd, cpu, x.cuda(), hip_g, 5)
+        assert wf < 1e-4, (wf, wname, flips)
 
 
 def test_graph_replay_equals_eager_over_many_steps_with_static_buffers():

@@ -7,7 +7,9 @@ activation within fp32 rounding of a tie flips one of them in one of two fp32 ev
   1. at least one decision differs between the HIP forward and the fp32 CPU oracle, compared site by site: the ReLU masks and pooling
      arg-maxes of the trainable U-Net (``O.TieProbe`` against the HIP forward's saved activations) and the ReLU masks of the head's
      three hidden layers and of the final ``relu(out[:, 0])`` on the selected pixels (the head evaluated on either side's features:
-     a feature difference of a few 1e-7 is enough to move a hidden unit across zero);
+     a feature difference of a few 1e-7 is enough to move a hidden unit across zero) -- or, when that comparison finds none (the head
+     kernel's own hidden units are not observable), the shared-decision comparison below finds the differing site AND brings the
+     distance under 1e-4;
   2. ONE of the two fp32 gradient sets is the neighbour of the exact (fp64 oracle) gradients (<= 2e-4) and the other is no further
      than one flipped decision explains (< 5e-3);
   3. (checked by the callers) the forward results / losses agree to rounding.
@@ -84,7 +86,18 @@ def assert_tie_flip(sd, cpu_sample, x_dev, hip_grads, ref_grads, seed, worst, **
     ref_feats = fo["features"][:, :, pt:pt + H, pl:pl + W]
     for a, b in zip(head_decisions(sd, ref_feats, fo["mask"]), head_decisions(sd, hip_feats, fo["mask"])):
         flips += int((a != b).sum())
-    assert flips > 0, ("no differing decision between the HIP forward and the fp32 oracle: a real mismatch", worst)
+    proof = "site by site"
+    if flips == 0:
+        # The head's hidden activations live in registers: a unit within rounding of zero can take the other side INSIDE the head kernel while
+        # the head re-evaluated above on the HIP features agrees with the oracle (round 6: with the split-operand forward convs the HIP
+        # features sit closer to the oracle's than the head's own arithmetic does).  The proof is then the stronger one: the fp64 oracle made
+        # to take the HIP side of every decision -- U-Net sites from the saved activations, head units searched among the near-ties, every
+        # overridden site bounded in number and in its distance from a tie -- must be the HIP gradients' neighbour, with at least one site
+        # actually differing.
+        wf, wname, fsites, _ = forced_decision_distance(sd, cpu_sample, x_dev, hip_grads, seed, **flags)
+        flips = int(fsites.get("relu", 0)) + int(fsites.get("pool", 0)) + len(fsites.get("head", ()))
+        assert flips > 0 and wf < 1e-4, ("no differing decision between the HIP side and the oracle explains the mismatch", worst, wf, wname, fsites)
+        proof = f"shared decisions ({wf:.1e})"
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     cpu64 = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_sample.items()}
     torch.manual_seed(seed)
@@ -92,7 +105,7 @@ def assert_tie_flip(sd, cpu_sample, x_dev, hip_grads, ref_grads, seed, worst, **
     w_hip = max(rel(hip_grads[n], g64[n]) for n in g64)
     w_ref = max(rel(ref_grads[n], g64[n]) for n in g64)
     import os
-    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "worst": worst, "flips": flips, "w_hip": w_hip, "w_ref": w_ref}
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "worst": worst, "flips": flips, "w_hip": w_hip, "w_ref": w_ref, "proof": proof}
     print(f"\n[tie adjudication] {rec['test']}: HIP-vs-fp32-reference {worst:.2e} above the 2e-4 bar; differing decisions (flips) = {flips}; "
           f"vs the fp64 oracle: w_hip = {w_hip:.2e}, w_ref = {w_ref:.2e}")
     assert min(w_hip, w_ref) < 2e-4 and max(w_hip, w_ref) < 5e-3, (worst, flips, w_hip, w_ref)

@@ -314,7 +314,7 @@ def head_bwd_roofline(torch, trainer, sample, reps=10):
     flops = float(FLOP_HEAD_BWD_PX) * nsel
     issued = float(FLOP_HEAD_BWD_PX + FLOP_HEAD_FWD_PX) * nsel
     achieved = flops / dur / 1e12
-    pmc = _pmc("r5_pmc_head_bwd.json") or _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
+    pmc = _pmc("r6_pmc_head_bwd.json") or _pmc("r5_pmc_head_bwd.json") or _pmc("r4_pmc_head_bwd.json") or _pmc("r3_pmc_head_bwd.json") or _pmc("r2_pmc_head_bwd.json")
     traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     split = (not bf) and bool(L.lib().pc_get_head_split())
     rp_us, rp_file, rp_match = _rocprof_avg_us("head_bwd_bf16_coop4_kernel" if bf else ("head_bwd_pc_kernel<0, true>" if split else "head_bwd_pc_kernel<0, false>"),
@@ -325,7 +325,7 @@ def head_bwd_roofline(torch, trainer, sample, reps=10):
               "against float64 at the accuracy of the fp32-MFMA form, tests/test_gpu_convt_head.py)" if split else
               "head_bwd_pc_kernel<0, false> (sparse head backward, producer/consumer waves, fp32 MFMA 16x16x4)"))
     if bf:
-        pmc = (_pmc("r5_pmc_head_bwd_bf16.json") or _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or
+        pmc = (_pmc("r6_pmc_head_bwd_bf16.json") or _pmc("r5_pmc_head_bwd_bf16.json") or _pmc("r4_pmc_head_bwd_bf16.json") or _pmc("r3_pmc_head_bwd_bf16.json") or
                _pmc("r2_pmc_head_bwd_bf16.json"))
         traffic = pmc["traffic_bytes"] if pmc and (B, H, W) == (64, 100, 100) else None
     base = {"bound": "mfma", "kernel": kname + " + the reduce launch of the same call", "unit": "TFLOP/s", "traffic": traffic,
@@ -490,10 +490,14 @@ def conv_kernel_roofline(torch, B, reps=5, nsets=4):
     dur = e0.elapsed_time(e1) * 1e-3 / (reps * nsets)
     nbytes = 4 * B * 128 * 128 * esz * (8 + 8)               # compulsory: read 8 channels, write 8 channels
     flops = 4 * B * 128 * 128 * 2 * 9 * 8 * 8
-    pmc = (_pmc("r5_pmc_conv_8to8_bf16.json" if esz == 2 else "r5_pmc_conv_8to8.json") or
+    pmc = (_pmc("r6_pmc_conv_8to8_bf16.json" if esz == 2 else "r6_pmc_conv_8to8.json") or
+           _pmc("r5_pmc_conv_8to8_bf16.json" if esz == 2 else "r5_pmc_conv_8to8.json") or
            _pmc("r4_pmc_conv_8to8_bf16.json" if esz == 2 else "r4_pmc_conv_8to8.json") or
            _pmc("r3_pmc_conv_8to8_bf16.json" if esz == 2 else "r3_pmc_conv_8to8.json"))
-    return {"bound": "hbm", "kernel": f"{'conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)' if esz == 2 else 'conv3x3_mfma_kernel<8,8,fwd> (fp32)'} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
+    split = esz == 4 and int(L.lib().pc_get_conv_split()) != 0
+    kname = ("conv3x3_cl_kernel<8,8,fwd> (channels-last bf16)" if esz == 2 else
+             ("conv3x3_fwd_s3_kernel<8,8> (fp32 tensors, split operands on the bf16 matrix pipe)" if split else "conv3x3_mfma_kernel<8,8,fwd> (fp32)"))
+    return {"bound": "hbm", "kernel": f"{kname} grouped x4 (3x3 conv + BN + ReLU, 8->8 @128x128)",
             "achieved": round(nbytes / dur / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nbytes / dur / HBM_PEAK, 4),
             "traffic": pmc["traffic_bytes"] if pmc and B == 64 else None, "launch_us": round(dur * 1e6, 2),
             "alg_bytes_per_launch": nbytes,
@@ -1390,9 +1394,12 @@ def main():
                        # fp32 (popcorn_hip.h: pc_set_head_split; fp32 accuracy measured against float64 in tests/test_gpu_convt_head.py)
                        "head_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_head_split() else "fp32_mfma") if args.precision == "fp32"
                                          else "bf16"),
-                       # ... and so does the fused conv backward (round 6: popcorn_hip.h: pc_set_conv_split; 7 of the step's 33 launches); the
-                       # other conv kernels of the fp32 step are v_mfma_f32_16x16x4_f32
+                       # ... and so do the fused conv backward (round 6: popcorn_hip.h: pc_set_conv_split; 7 of the step's 33 launches) and every
+                       # 8- / 16-channel forward conv (csrc/conv3x3_fwd_s3.h; 7 launches); still v_mfma_f32_16x16x4_f32: the first layers, the
+                       # 32 x 32 level, the composed Up backward
                        "conv_bwd_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_conv_split() else "fp32_mfma") if args.precision == "fp32"
+                                             else "bf16"),
+                       "conv_fwd_products": (("split3_bf16_fp32acc" if ops.L.lib().pc_get_conv_split() else "fp32_mfma") if args.precision == "fp32"
                                              else "bf16"),
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "collectives": bool(trainer.reducer.active),

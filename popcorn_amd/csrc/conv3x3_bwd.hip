@@ -709,7 +709,15 @@ __global__ __launch_bounds__(256, S3Cfg<GC>::WAVES_PER_SIMD) void conv3x3_bwd_s3
     const unsigned x_bs = s3_pin((unsigned)q.x.bstride), x_cs = s3_pin((unsigned)q.x.cstride * 4u), x_rs = s3_pin((unsigned)q.x.rstride);
     const unsigned o_bs = s3_pin((unsigned)q.out.bstride), o_cs = s3_pin((unsigned)q.out.cstride), o_rs = s3_pin((unsigned)q.out.rstride);
     const int H = s3_pin(p.H), W = s3_pin(p.W);
-    const int maskf = s3_pin(q.mask), accf = s3_pin(p.accumulate), dbg = s3_pin(p.dbg);
+    const int maskf = s3_pin(q.mask), accf = s3_pin(p.accumulate);
+    // ablation switches (pc_debug_conv_bwd; tools/time_conv_bwd.py --ablate) exist in -DPOPCORN_CONV_ABLATE builds only (tools/build_variant.sh):
+    // as run-time flags they made commit() conditional, and a path that may skip it leaves its loads pending -- the compiler then waits
+    // vmcnt(0) before it re-uses their registers for the next prefetch
+#ifdef POPCORN_CONV_ABLATE
+    const int dbg = s3_pin(p.dbg);
+#else
+    constexpr int dbg = 0;
+#endif
     const s3_gptr a_base = s3_pin_global(POOL ? q.pool_act.ptr : q.x.ptr);
     const unsigned a_bs = s3_pin((unsigned)(POOL ? q.pool_act.bstride : 0)), a_cs = s3_pin((unsigned)(POOL ? q.pool_act.cstride : 0)),
                    a_rs = s3_pin((unsigned)(POOL ? q.pool_act.rstride : 0));

@@ -26,7 +26,8 @@ struct FS3Cfg {
     static constexpr int NCH = CI / 8, NZ = ZC / 8, NST = NCH + NZ, NB = CO / 8;
     static constexpr int BSL = 34;                              // slots per strip row: logical slot s = pixel x0 - 1 + s
     static constexpr int ZSL = 18;                              // slots per row of the low-resolution piece: slot t = column x0 / 2 - 1 + t
-    static constexpr int IMG = SROWS * BSL * 16;                // bytes of one split plane of a wave's image
+    static constexpr int DUMMY = SROWS * BSL;                   // one more slot per plane: where a lane writes the pixels that are not part of the strip
+    static constexpr int IMG = (SROWS * BSL + 1) * 16;          // bytes of one split plane of a wave's image
     static constexpr int WAVE_B = 3 * IMG;
     static constexpr int BW_CO = NCH * 24, BW_DYS = CO * BW_CO, WPL = 3 * BW_DYS;    // weight image, bf16 elements: [dy 0..2][co][chunk][dx][8 ci]
     static constexpr int ZW_N = NZ * 32, ZW_V = 16 * ZW_N, ZPL = 3 * ZW_V;           // composed weights: [row v 0..2][n = (s, co)][chunk][2 tj + j][8 zci]
@@ -85,7 +86,15 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
     const fs3_gptr po_base = fs3_pin_global(has_po ? (const void*)q.pool_out.ptr : (const void*)q.out.ptr);
     const unsigned po_bs = fs3_pin((unsigned)(has_po ? q.pool_out.bstride : 0)), po_cs = fs3_pin((unsigned)(has_po ? q.pool_out.cstride : 0)),
                    po_rs = fs3_pin((unsigned)(has_po ? q.pool_out.rstride : 0));
-    const int H = fs3_pin(p.H), W = fs3_pin(p.W), relu = fs3_pin(p.relu), dbg = fs3_pin(p.dbg);
+    const int H = fs3_pin(p.H), W = fs3_pin(p.W), relu = fs3_pin(p.relu);
+    // ablation switches (pc_debug_conv; tools/time_conv_fwd.py --ablate) exist in -DPOPCORN_CONV_ABLATE builds only (tools/build_variant.sh): as
+    // run-time flags they made the commit conditional, and a path that may skip it leaves its loads pending -- the compiler then waits
+    // vmcnt(0) before it re-uses their registers for the next prefetch, i.e. behind the epilogue's stores
+#ifdef POPCORN_CONV_ABLATE
+    const int dbg = fs3_pin(p.dbg);
+#else
+    constexpr int dbg = 0;
+#endif
     // EPI_DOT: problems with dot_w write sum_co dot_w[co] * out[co] (the partial logit of the 1x1 out-conv that follows) instead of the map
     const bool has_dot = EPI == EPI_DOT && q.dot_w != nullptr;
     const fs3_gptr d_base = fs3_pin_global(has_dot ? (const void*)q.dot_out.ptr : (const void*)q.out.ptr);
@@ -104,16 +113,17 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
     const bool z_act = ZC > 0 && lane < 24;
     f32x4 R[8];
     bool rvalid = false;
-    int c_sl[4], c_okm = 0, cz_sl[4], cz_okm = 0;              // physical slots of the lane's four pixels; bit e: the pixel is part of the image
+    // slot (relative to the wave's image) of each of the lane's four pixels.  Pixels that are not part of the strip (the outer three of the
+    // first and last segment, idle lanes) go to a dummy slot: the LDS writes are UNCONDITIONAL, so every path consumes all eight loaded
+    // registers and the compiler knows no load is pending when the next prefetch is issued (with predicated writes it waited vmcnt(0) there
+    // -- behind the epilogue's stores)
+    int c_sl[4], cz_sl[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int sl = 4 * l_seg + e - 3;
-        const int cl = sl < 0 ? 0 : (sl > 33 ? 33 : sl);
-        c_sl[e] = P2 ? fs3_sl_p2(cl) : fs3_sl(cl);
-        if (l_act && sl >= 0 && sl <= 33) c_okm |= 1 << e;
+        c_sl[e] = (l_act && sl >= 0 && sl <= 33) ? l_r * BSL + (P2 ? fs3_sl_p2(sl) : fs3_sl(sl)) : Cfg::DUMMY;
         const int t = 4 * z_s + e - 3;
-        cz_sl[e] = t < 0 ? 0 : (t > 17 ? 17 : t);
-        if (z_act && t >= 0 && t <= 17) cz_okm |= 1 << e;
+        cz_sl[e] = (z_act && t >= 0 && t <= 17) ? z_r * ZSL + t : Cfg::DUMMY;
     }
     auto issue = [&](auto CH, int b, int y0, int x0) {
         constexpr int ch = decltype(CH)::value;
@@ -144,8 +154,7 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) R[it][e] = rvalid ? R[it][e] : 0.f;
         }
-        u32x4* const d0 = reinterpret_cast<u32x4*>(wimg) + (isz ? z_r * ZSL : l_r * BSL);
-        const int okm = isz ? cz_okm : c_okm;
+        u32x4* const d0 = reinterpret_cast<u32x4*>(wimg);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             u32x4 q1, q2, q3;
@@ -155,12 +164,10 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
                 pc_split_pair(R[2 * d][e], R[2 * d + 1][e], a1, a2, a3);
                 q1[d] = a1; q2[d] = a2; q3[d] = a3;
             }
-            if (okm & (1 << e)) {
-                u32x4* d = d0 + (isz ? cz_sl[e] : c_sl[e]);
-                d[0] = q1;
-                d[IMG / 16] = q2;
-                d[2 * (IMG / 16)] = q3;
-            }
+            u32x4* d = d0 + (isz ? cz_sl[e] : c_sl[e]);
+            d[0] = q1;
+            d[IMG / 16] = q2;
+            d[2 * (IMG / 16)] = q3;
         }
     };
     const int gdim = fs3_pin((int)gridDim.x), ntl = fs3_pin(p.ntiles);
@@ -383,9 +390,17 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
         }
     };
 
-    auto epilogue = [&](int eb, int ey0, int ex0) {
-        // lane holds (co = nb*8 + col, y = ey0 + 2*(u>>1) + s_row, x = ex0 + xu(u) + r), r = 0..3
-        f32x4 pacc[4][NB];
+    // Deferred epilogue: finish() turns the accumulators of strip k into final values (pacc), store_prev() writes them in strip k + 1,
+    // BETWEEN its first commit and the prefetch it issues.  With the stores at the end of their own strip they sat behind the prefetch in
+    // the memory queue; they are predicated (execz branches), so the compiler cannot count them and the commit's wait for the prefetched
+    // loads became s_waitcnt vmcnt(0) -- a store round trip in series with every strip (conv3x3_mfma_kernel defers for the same reason).
+    f32x4 pacc[4][NB];
+    int eb = 0, ey0 = 0, ex0 = 0;
+    bool have_prev = false;
+    auto finish = [&](int fb, int fy0, int fx0) {
+        // lane holds (co = nb*8 + col, y = fy0 + 2*(u>>1) + s_row, x = fx0 + xu(u) + r), r = 0..3
+        eb = fb; ey0 = fy0; ex0 = fx0;
+        have_prev = true;
         if constexpr (P2) {
             // acc[rp*2 + j][r] = pixel 2 (4 lk + r) + j  ->  pacc[rp*2 + h][e] = pixel 8 lk + 4 h + e
 #pragma unroll
@@ -414,17 +429,23 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
                 for (int nb = 0; nb < NB; ++nb) pacc[u][nb] = acc[u][nb];
         }
 #pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = pacc[u][nb][r] * e_scale[nb] + e_shift[nb];
+                    pacc[u][nb][r] = relu ? fmaxf(o, 0.f) : o;
+                }
+    };
+    auto store_prev = [&]() {
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int y = ey0 + 2 * (u >> 1) + s_row, x = ex0 + (P2 ? 8 * lk + 4 * (u & 1) : (u & 1) * 16 + 4 * lk);
             const bool in = y < H && x < W;                     // W % 4 == 0: a 4-pixel piece is inside or outside as a whole
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                f32x4 v = pacc[u][nb];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float o = v[r] * e_scale[nb] + e_shift[nb];
-                    v[r] = relu ? fmaxf(o, 0.f) : o;
-                }
+                const f32x4 v = pacc[u][nb];
                 if constexpr (EPI == EPI_DOT) {
                     if (has_dot) {
                         // sum over the 8 channels = the 8 lanes `col` of a 16-lane group half (they hold the same pixels); lane col == 0 stores
@@ -463,6 +484,12 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
         auto stage = [&](auto CH) {
             constexpr int ch = decltype(CH)::value;
             if (!(dbg & (1 | 32))) commit(CH);                  // ablation (pc_debug_conv): 1 no loads / LDS writes, 32 no split + LDS writes, 64 no loads,
+            if constexpr (ch == 0) {
+                // (fences: the scheduler otherwise hoists the stores between the commit's per-pixel blocks, whose waits then cover them)
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_prev && !(dbg & 4)) store_prev();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (ch + 1 < NST) {                       //                           2 no matrix phase, 4 no epilogue
                 if (!(dbg & (1 | 64))) issue(fs3_int<ch + 1>{}, b, y0, x0);
             } else {
@@ -474,9 +501,10 @@ __global__ __launch_bounds__(256, (FS3Cfg<CI, CO, ZC>::WAVES_PER_SIMD)) void con
         if constexpr (NST > 1) stage(fs3_int<1>{});
         if constexpr (NST > 2) stage(fs3_int<2>{});
         if constexpr (NST > 3) stage(fs3_int<3>{});
-        if (!(dbg & 4)) epilogue(b, y0, x0);
+        finish(b, y0, x0);
         b = nb_; y0 = ny0; x0 = nx0;
     }
+    if (have_prev && !(dbg & 4)) store_prev();
 }
 
 // every problem of the group qualifies for the split-form kernel: one aligned planar fp32 source of exactly the conv domain, aligned planar

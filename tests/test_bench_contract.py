@@ -43,6 +43,7 @@ def test_committed_final_bench_line_keeps_the_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32"
     assert d["value"] >= 44000.0 and d["ms_per_step"] <= 1.45          # step <= 1.42 ms on the driver's box (builder's boxes +-2 %)
     assert d["config"]["head_products"] == "split3_bf16_fp32acc" and d["config"]["conv_bwd_products"] == "split3_bf16_fp32acc"
+    assert d["config"]["conv_fwd_products"] == "split3_bf16_fp32acc"
     # the metric's second half and the other configurations ride on the same line
     fp = d["fwd_parity"]
     assert fp["ok"] is True and fp["max_rel"] <= 1e-4 and {"popdensemap", "popcount", "scale"} <= set(fp)

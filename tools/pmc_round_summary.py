@@ -24,7 +24,7 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kernel", "conv3x3_mfma_kernel", 4),
+for prec, sfx, head_kernel, conv_kernel, esz in (("fp32", "", "head_bwd_pc_kernel", ("conv3x3_fwd_s3_kernel", "conv3x3_mfma_kernel"), 4),
                                                  ("bf16", "_bf16", "head_bwd_bf16_coop4_kernel", "conv3x3_cl_kernel", 2)):
     step = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -127,8 +127,11 @@ int pc_get_precision(void);
 int pc_set_head_split(int on);
 int pc_get_head_split(void);
 
-/* fp32 mode only (round 6, ABI 9): how the 3x3 convolution kernels that have a split-operand form multiply (today: the fused
- * data + weight gradient pc_conv3x3_bwd_group; networks.py:259-266 backward).  Same arithmetic as pc_set_head_split:
+/* fp32 mode only (round 6, ABI 9): how the 3x3 convolution kernels that have a split-operand form multiply: the fused data + weight
+ * gradient pc_conv3x3_bwd_group (networks.py:259-266 backward) and the forward convs pc_conv3x3_bn_relu_fwd[_group] /
+ * pc_conv3x3_up_fwd_group on aligned planar tensors with 8 or 16 channels (csrc/conv3x3_fwd_s3.h; results differ from the
+ * v_mfma_f32_16x16x4_f32 form by rounding only, both are measured against float64 in tests/test_gpu_conv_fwd_split.py).  Same arithmetic
+ * as pc_set_head_split:
  *   1 (default; POPCORN_CONV_SPLIT=0 in the environment starts with 0): operands are split exactly into three bf16 numbers when a strip is
  *     staged into LDS (once per strip, not per use), products are six bf16 x bf16 partial products accumulated in fp32 on
  *     v_mfma_f32_16x16x32_bf16; also opens the forms that exist only this way (16 gradient channels, the Down blocks' pool_act);
@@ -263,9 +266,12 @@ typedef struct pc_conv_bwd_desc {
 int pc_conv3x3_bwd_group(int n, const pc_conv_bwd_desc* d, int Cin_total, int c0, int accumulate, int B, int H, int W,
                          int* nwg_out, void* stream);
 /* ablation switches of the split-operand fused backward kernel (tools/time_conv_bwd.py --ablate; 0 = normal operation): 1 no split / LDS
- * writes, 2 no data-gradient matrix phase, 4 no weight-gradient matrix phase, 8 no prefetch loads, 16 no epilogue */
+ * writes, 2 no data-gradient matrix phase, 4 no weight-gradient matrix phase, 8 no prefetch loads, 16 no epilogue.  Honoured by builds with
+ * -DPOPCORN_CONV_ABLATE only (tools/build_variant.sh): as run-time flags they cost the shipped kernel its wait placement */
 void pc_debug_conv_bwd(int dbg);
-/* ablation switches for tools/ablate_conv.py (0,0 = normal operation) */
+/* ablation switches for tools/ablate_conv.py (0,0 = normal operation); the split-form forward kernel (tools/time_conv_fwd.py --ablate:
+ * 1 no loads / LDS writes, 2 no matrix phase, 4 no epilogue, 32 no split + LDS writes, 64 no loads) honours them in -DPOPCORN_CONV_ABLATE
+ * builds only */
 void pc_debug_conv(int dbg, int max_grid);
 /* debug: buffer of 8 x int64 per workgroup receiving wall-clock stamps of the conv kernels' phases (NULL = off; tools/conv_timeline.py) */
 void pc_debug_conv_ts(void* buf);

@@ -183,3 +183,48 @@ def test_forward_split_form_partial_logit_output():
         assert (logits[:, 1].cpu().double() - ref0).abs().max().item() < 5e-5, form
         assert torch.isnan(logits[:, 0]).all()
         assert (out1.cpu().double() - ref1).abs().max().item() < 2e-5, form
+
+
+def test_forward_split_form_fuzzed_geometries_and_views():
+    """40 seeded cases: random (B, H, W % 4 == 0), channel counts 8 / 16, inputs and outputs that are CHANNEL WINDOWS of larger tensors
+    (what the engine passes: feats[:, f0:f0 + 8], halves of a 16-channel map) and row-padded tensors (L.padded_rows), optional pooled
+    second output where the geometry allows it; split form against float64, and nothing outside the output window is written"""
+    import random
+    from popcorn_amd import _lib as L
+    from popcorn_amd import ops
+    rnd = random.Random(20261003)
+    for case in range(40):
+        cin, cout = rnd.choice([(8, 8), (8, 16), (16, 16), (16, 8)])
+        B = rnd.randint(1, 3)
+        H = rnd.randint(3, 70)
+        W = 4 * rnd.randint(1, 40)
+        g = torch.Generator().manual_seed(1000 + case)
+        x_full = torch.randn(B, cin + 8, H, W, generator=g)
+        c0 = rnd.choice([0, 8])
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+        p = _bn(cout, g)
+        ref = _ref_layer(x_full[:, c0:c0 + cin], w, p)
+        xd = x_full.cuda()
+        out_full = torch.full((B, cout + 16, H, W), float("nan"), device="cuda")
+        o0 = rnd.choice([0, 8, 16])
+        dp = [t.cuda() for t in p]
+        pr = {"a": xd[:, c0:c0 + cin], "w": w.cuda(), "bn": L.bn(dp[0], dp[1], dp[2], dp[3], dp[4], 1e-5), "out": out_full[:, o0:o0 + cout]}
+        want_pool = W % 32 == 0 and H % 4 == 0 and o0 == 0 and rnd.random() < 0.7
+        if want_pool:
+            # (the pooled copy needs a dense output tensor: ops.pool_out_like decides)
+            dense = torch.full((B, cout, H, W), float("nan"), device="cuda")
+            po = ops.pool_out_like(dense)
+            if po is not None:
+                pr["out"], pr["pool_out"] = dense, po
+        with _form(1):
+            ops.conv3x3_fwd_group([pr])
+            torch.cuda.synchronize()
+        got = pr["out"].cpu().double()
+        err = (got - ref).abs().max().item()
+        assert err < 2e-5, (case, cin, cout, B, H, W, err)
+        if "pool_out" in pr:
+            assert torch.equal(pr["pool_out"], F.max_pool2d(pr["out"], 2)), case
+        else:
+            rest = torch.ones(cout + 16, dtype=torch.bool)
+            rest[o0:o0 + cout] = False
+            assert torch.isnan(out_full[:, rest]).all(), (case, "wrote outside its channel window")

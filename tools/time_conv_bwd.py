@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--sets", type=int, default=3)
     ap.add_argument("--json", default=None)
-    ap.add_argument("--ablate", action="store_true", help="the 8<->8 @128x128 launch with phases of the split kernel switched off")
+    ap.add_argument("--ablate", action="store_true", help="the 8<->8 @128x128 launch with phases of the split kernel switched off (needs a -DPOPCORN_CONV_ABLATE build: tools/build_variant.sh ablate -DPOPCORN_CONV_ABLATE; POPCORN_HIP_LIB=ab/libpopcorn_ablate.so)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B = a.batch

@@ -1,6 +1,6 @@
 """Round 6: the fused conv backward (pc_conv3x3_bwd_group, fp32 mode) at the step's geometries (B = 64 tiles, two streams), in both
 multiplication forms (pc_set_conv_split 1 / 0), next to the data-gradient + weight-gradient launches the 16-channel forms replace.
-Every timed call runs on rotating buffer sets (cold Infinity Cache), HIP events around N back-to-back launches.
+Every timed call runs on rotating buffer sets (cold Infinity Cache), N launches captured into one HIP graph, HIP events around three replays.
 
     python3 tools/time_conv_bwd.py [--iters 20] [--json gpurun_out/conv_bwd.json]
 """
@@ -16,15 +16,26 @@ from popcorn_amd import ops, _lib as L  # noqa: E402
 
 
 def timed(fn, iters):
-    fn()
+    """us per launch: `iters` launches (rotating buffer sets) captured into ONE HIP graph and replayed (the Python side of a grouped call,
+    ~40 us of descriptor marshalling, would otherwise bound every launch shorter than that)"""
+    fn(0)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(iters):
-        fn(i)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(iters):
+                fn(i)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (3 * iters)
 
 
 def main():

@@ -1,10 +1,11 @@
 // conv3x3_fwd_s3.h -- PC_PREC_FP32 forward conv3x3 + BN + ReLU on the bf16 matrix pipe (round 6), included by conv3x3.hip inside its
 // anonymous namespace (it uses ConvArgs / ConvProb, the strip geometry and the EPI_* constants defined there).
 //
-// The forward counterpart of conv3x3_bwd_s3_kernel (conv3x3_bwd.hip), for the layers whose fp32-MFMA form is bound by the matrix pipe and
-// not by memory -- 16-channel inputs / outputs at 64 x 64 (Down.conv: networks.py:286-294) and the first conv of an Up block taken straight
-// from the low-resolution map (Up: networks.py:302-318; composed weights: compose_up_kernel above).  The plain 8 -> 8 layers at full
-// resolution already move their bytes at the strip pattern's rate and stay on conv3x3_mfma_kernel.
+// The forward counterpart of conv3x3_bwd_s3_kernel (conv3x3_bwd.hip) for every forward layer with 8 or 16 input and output channels on
+// aligned planar fp32 tensors: DoubleConv / Down.conv (networks.py:259-294) incl. the pooled second output and the partial 1x1 logit, and
+// the first conv of an Up block taken straight from the low-resolution map (Up: networks.py:302-318; composed weights: compose_up_kernel
+// above).  In the step (B = 64, 4 problems per launch) the 16-channel and composed layers were bound by the fp32 matrix pipe (-15 .. -25 %
+// each in this form); the plain 8 -> 8 layers move their bytes at the strip pattern's rate in either form and gain 10 - 20 %.
 //   * planar fp32 tensors at both ends; a strip (32 x 4 outputs, 6 x 34 inputs) of 8 input channels is loaded as one aligned 16-byte
 //     piece per lane and channel, prefetched one STAGE ahead, and split ONCE while it is written to LDS: every fp32 value is exactly the
 //     sum of three bf16 numbers (common.h: pc_split_pair), so a lane turns 4 pixels x 8 channels into 3 planes x 4 channels-last 16-byte

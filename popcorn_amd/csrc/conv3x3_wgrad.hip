@@ -1014,8 +1014,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
             const int e = (((ng >> 4) * 64) + (ci >> 2) * 16 + (ng & 15)) * 4 + (ci & 3);
             s0 = rb_sum(slice, q.nwg, [&](int w) { return q.partial[(int64_t)w * E + e]; });
         } else if (o < n_out) {
+            // bias gradient of a transposed conv: 16 elements of every partial.  Four partials per round (64 loads in flight; eight measured slower: 34 us): as one
+            // partial per round this tail was nwg / 8 = 64 dependent memory round trips of ONE workgroup -- 7 - 10 of the launch's 28 us in
+            // the bf16 step, whose four transposed-conv entries the fp32 step (composed Up blocks) does not have
             const int co = o - n_w;
-            for (int w = slice; w < q.nwg; w += RB_SL) {
+            auto at = [&](int w) {
                 const float* pq = q.partial + (int64_t)w * E + NBK * 256;
                 float t = 0.f;
 #pragma unroll
@@ -1024,8 +1027,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RbArgs a)
 #pragma unroll
                     for (int lk = 0; lk < 4; ++lk) t += pq[(ng >> 4) * 64 + lk * 16 + (ng & 15)];
                 }
-                s0 += t;
+                return t;
+            };
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            int w = slice;
+            for (; w + 3 * RB_SL < q.nwg; w += 4 * RB_SL) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s4[k] += at(w + RB_SL * k);
             }
+            for (; w < q.nwg; w += RB_SL) s4[0] += at(w);
+            s0 = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
     }
     red[tid] = s0;

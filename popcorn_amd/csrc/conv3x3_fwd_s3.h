@@ -19,7 +19,7 @@
 //     x parity j): the strip image stores even and odd pixels in two blocks of 17 slots so that every operand read is unit-stride;
 //   * A = pixels, B = weights: a lane ends with FOUR CONSECUTIVE PIXELS of one output channel = the planar fp32 epilogues of
 //     conv3x3_mfma_kernel (BN + ReLU, 16-byte stores, the 2 x 2 max-pooled second output, the transposed conv's bias through the taps).
-// The result differs from the fp32-MFMA form by the dropped partial products only (tests/test_gpu_conv3x3.py measures both against
+// The result differs from the fp32-MFMA form by the dropped partial products only (tests/test_gpu_conv_fwd_split.py measures both against
 // float64); pc_set_conv_split(0) selects the fp32-MFMA kernels everywhere.
 
 template <int CI, int CO, int ZC>
